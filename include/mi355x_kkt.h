@@ -1,0 +1,163 @@
+/*
+ * mi355x_kkt.h -- C ABI of the MI355X-native sparse symmetric-indefinite KKT solver
+ * (supernodal multifrontal LDL^T + triangular solves, hand-written HIP for gfx950).
+ *
+ * This is the drop-in boundary for Ipopt's linear-solver plug-in point.  Every entry
+ * point replaces one step of the reference's third-party-solver adapters:
+ *
+ *   mi355x_kkt_create / _destroy   <->  adapter ctor/dtor, e.g. Ma97SolverInterface
+ *                                       (reference src/Algorithm/LinearSolvers/IpMa97SolverInterface.cpp:277-301)
+ *   mi355x_kkt_analyse             <->  SparseSymLinearSolverInterface::InitializeStructure
+ *                                       (IpSparseSymLinearSolverInterface.hpp:139) -> ma97_analyse (IpMa97SolverInterface.cpp:567,674),
+ *                                       MUMPS job=1 (IpMumpsSolverInterface.cpp:385-446)
+ *   mi355x_kkt_values_buffer       <->  GetValuesArrayPtr (IpSparseSymLinearSolverInterface.hpp:155)
+ *   mi355x_kkt_factor              <->  the "new_matrix" half of MultiSolve (hpp:190): ma97_factor (IpMa97SolverInterface.cpp:707),
+ *                                       MUMPS job=2 (IpMumpsSolverInterface.cpp:448-541); returns inertia like INFOG(12)/info.num_neg
+ *   mi355x_kkt_solve               <->  the back-solve half of MultiSolve: ma97_solve (IpMa97SolverInterface.cpp:790,805),
+ *                                       MUMPS job=3 (IpMumpsSolverInterface.cpp:543-583)
+ *   mi355x_kkt_set_pivtol          <->  IncreaseQuality (hpp:220; u <- u^0.75, IpMa97SolverInterface.cpp:822-854)
+ *   mi355x_kkt_get_info            <->  struct ma97_info (hsl_ma97d.h:96-121) / MUMPS INFOG
+ *
+ * Conventions: plain pointers and sizes only, no C++ types, no exceptions cross this
+ * boundary, no global mutable state (re-entrant per handle).  Return value of every
+ * int function is a MI355X_KKT_* status that mirrors Ipopt's ESymSolverStatus
+ * (IpSymLinearSolver.hpp:19-33): 0 success, 1 singular, 2 wrong inertia (never produced
+ * here: the caller compares num_neg), 4 fatal.  All floating point is fp64, all
+ * indices int32 (Ipopt's Index), 64-bit counters where nnz(L)/flops can overflow.
+ *
+ * There is NO CPU fallback: factor/solve fail with MI355X_KKT_FATAL (and a message in
+ * mi355x_kkt_last_error) when no gfx950 device is usable.  Only _analyse (symbolic,
+ * host C++) and the query functions work without a GPU.
+ */
+#ifndef MI355X_KKT_H
+#define MI355X_KKT_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI355X_KKT_SUCCESS        0
+#define MI355X_KKT_SINGULAR       1
+#define MI355X_KKT_WRONG_INERTIA  2
+#define MI355X_KKT_CALL_AGAIN     3
+#define MI355X_KKT_FATAL          4
+
+/* input formats, cf. EMatrixFormat (IpSparseSymLinearSolverInterface.hpp:102-114) */
+#define MI355X_KKT_FMT_TRIPLET    0   /* (row[k],col[k]) k<nnz; either triangle; duplicates are summed */
+#define MI355X_KKT_FMT_CSR_UPPER  1   /* row = ia[n+1], col = ja[nnz]; upper-triangular CSR == lower CSC */
+
+typedef struct mi355x_kkt_handle_s* mi355x_kkt_handle;
+
+typedef struct mi355x_kkt_options {
+    int    device;          /* HIP device ordinal; -1 = current device                                  */
+    int    index_base;      /* 1 (Ipopt/Fortran numbering, default) or 0                                */
+    int    ordering;        /* 0 = nested dissection + minimum-degree leaves (default), 1 = MD only,    */
+                            /* 2 = natural (identity)                                                   */
+    int    matching;        /* 1 (default) = pre-pair zero-diagonal rows with a partner column so that  */
+                            /* the pair is one 2x2-capable supernode; 0 = off                           */
+    int    scaling;         /* 0 none, 1 (default) = symmetric Ruiz inf-norm equilibration on device    */
+    int    nd_leaf;         /* ND stops splitting below this many (compressed) nodes; default 96        */
+    int    nemin;           /* relaxed-supernode amalgamation: always merge below this #cols; default 8 */
+    int    max_sn_cols;     /* cap on columns of an amalgamated supernode; default 64                   */
+    double pivtol;          /* relative pivot threshold u (default 1e-8, cf. ma97_u)                    */
+    double pivtolmax;       /* upper bound for set_pivtol escalation (default 1e-4)                     */
+    double small;           /* |pivot| below this (after scaling) counts as zero (default 1e-20)        */
+    int    refine_steps;    /* internal iterative-refinement steps per solve (default 0; Ipopt has its  */
+                            /* own refinement loop, IpPDFullSpaceSolver.cpp:256-346)                    */
+    int    use_graph;       /* 1 (default) = replay factor/solve launch sequences as hipGraphs          */
+    int    nranks;          /* multi-GPU: number of ranks sharing one matrix (default 1)                */
+    int    rank;            /* multi-GPU: this rank                                                     */
+    int    verbose;         /* 0 silent                                                                 */
+    int    reserved[8];
+} mi355x_kkt_options;
+
+typedef struct mi355x_kkt_info {
+    int     n;
+    int     nnz_in;          /* entries handed to analyse                                               */
+    int     nnz_a;           /* distinct entries of one triangle (incl. diagonal)                       */
+    int64_t nnz_l;           /* entries in L incl. diagonal (sum over supernodes of trapezoid)          */
+    int64_t flops_factor;    /* sum_j (c_j-1)(c_j+2), c_j = column count of L             */
+    int64_t flops_solve;     /* 4 nnz(L) - 3 n per right-hand side                                      */
+    int64_t bytes_factor;    /* 12 nnz(A) + 8 nnz(L) + 4 sum(rows of supernodes)                        */
+    int64_t bytes_solve;     /* 2 (8 nnz(L) + 4 sum rows) + 24 n per right-hand side                    */
+    int64_t sum_sn_rows;     /* sum over supernodes of front order                                      */
+    int64_t cb_doubles;      /* doubles in the contribution-block arena                                 */
+    int     num_sn;          /* supernodes                                                              */
+    int     num_levels;      /* height of the assembly tree (launch waves per factorisation)            */
+    int     maxfront;        /* largest front order                                                     */
+    int     maxsupernode;    /* largest number of columns in a supernode                                */
+    int     num_pairs;       /* 2x2 pre-pairs from the matching                                         */
+    int     num_neg;         /* negative eigenvalues of the last factorisation                          */
+    int     num_zero;        /* zero pivots (=> singular) of the last factorisation                     */
+    int     num_two;         /* 2x2 pivots of the last factorisation                                    */
+    int     num_small;       /* pivots that failed the relative threshold test u (static pivoting:      */
+                             /* accepted, counted; the analogue of info.num_delay)                      */
+    int     num_big_fronts;  /* fronts handled by the blocked (global-memory, MFMA) path                */
+    double  time_analyse;    /* host seconds, last analyse                                              */
+    double  time_factor_ms;  /* device ms (hip events on the solver's stream), last factor              */
+    double  time_solve_ms;   /* device ms, last solve                                                   */
+    double  reserved[8];
+} mi355x_kkt_info;
+
+/* fill opts with the defaults documented above */
+void mi355x_kkt_default_options(mi355x_kkt_options* opts);
+
+/* create a solver instance; opts may be NULL (defaults) */
+int  mi355x_kkt_create(mi355x_kkt_handle* h, const mi355x_kkt_options* opts);
+void mi355x_kkt_destroy(mi355x_kkt_handle h);
+
+/* Symbolic analysis, once per sparsity structure.  `vals` (nnz doubles in the same order as
+ * row/col, or NULL) is used only to detect zero diagonals for the 2x2 pre-pairing; the
+ * Ipopt adapter therefore analyses lazily at the first MultiSolve, as the reference's
+ * MUMPS adapter does (IpMumpsSolverInterface.cpp:349-383).  row/col are copied. */
+int  mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, const int* col,
+                        int format, const double* vals);
+
+/* Pinned host staging buffer of nnz doubles the caller fills before every factor()
+ * (GetValuesArrayPtr contract, IpSparseSymLinearSolverInterface.hpp:155). */
+double* mi355x_kkt_values_buffer(mi355x_kkt_handle h);
+
+/* Numeric factorisation of the values currently in values_buffer (or, if dvals != NULL, of
+ * nnz doubles already resident in device memory).  Outputs may be NULL. */
+int  mi355x_kkt_factor(mi355x_kkt_handle h, const double* dvals, int* num_neg, int* num_zero);
+
+/* Re-factor the device-resident copy of the last values (after set_pivtol); cf. MA97/SPRAL
+ * adapters that refactor from their private val_ copy (IpMa97SolverInterface.cpp:623). */
+int  mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero);
+
+/* Solve A X = B in place for nrhs right-hand sides, rhs[irhs*ld + i], host memory. */
+int  mi355x_kkt_solve(mi355x_kkt_handle h, int nrhs, double* rhs_inout, int ld);
+/* Same with rhs/solution resident in device memory (nrhs columns, leading dimension ld). */
+int  mi355x_kkt_solve_device(mi355x_kkt_handle h, int nrhs, double* d_rhs_inout, int ld);
+
+int  mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u);
+int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
+const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
+
+/* ---- symbolic introspection (host logic tests, debugging; sizes via get_info) ---- */
+/* what: 0 perm[n] (new->old), 1 sn_colptr[num_sn+1], 2 sn_rowptr[num_sn+1], 3 sn_rows[sum_sn_rows],
+ *       4 sn_parent[num_sn], 5 sn_level[num_sn], 6 rel[sum_sn_rows] (position of each update row in the
+ *       parent's front, -1 for pivot rows), 7 aperm_colptr[n+1], 8 aperm_row[nnz_a] (permuted lower CSC),
+ *       9 trip2slot[nnz_in] (triplet -> permuted CSC slot), 10 pair_of[n] (old index of the 2x2 partner or -1),
+ *       11 sn_owner[num_sn] (multi-GPU rank owning the supernode, -1 = replicated top),
+ *       12 apos[nnz_a] (row + col*m position of each permuted-CSC slot inside its supernode panel),
+ *       13 level_ptr[num_levels*4+1], 14 level_sn[num_sn] (launch schedule: buckets (level, front class)) */
+int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t capacity);
+
+/* ---- multi-GPU (one process per GPU; subtrees sharded, top of the tree replicated) ---- */
+/* The top-of-tree fronts live in one contiguous device buffer ("top arena").  After
+ * factor_local() each rank holds its own subtrees' Schur contributions there; the caller
+ * sums the arena over ranks (RCCL all-reduce) and calls factor_top().  See DESIGN.md (e). */
+int  mi355x_kkt_factor_local(mi355x_kkt_handle h, const double* dvals);
+int  mi355x_kkt_top_arena(mi355x_kkt_handle h, double** dptr, int64_t* ndoubles);
+int  mi355x_kkt_factor_top(mi355x_kkt_handle h, int* num_neg_local, int* num_zero_local);
+int  mi355x_kkt_solve_fwd_local(mi355x_kkt_handle h, double* d_rhs);
+int  mi355x_kkt_top_rhs(mi355x_kkt_handle h, double** dptr, int64_t* ndoubles);
+int  mi355x_kkt_solve_top_and_bwd(mi355x_kkt_handle h, double* d_rhs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355X_KKT_H */

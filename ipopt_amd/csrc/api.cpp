@@ -1,0 +1,184 @@
+// api.cpp -- the C ABI of include/mi355x_kkt.h on top of Symbolic (host) + Numeric (HIP).
+// No exception may cross this boundary ("never let one cross our C ABI").
+#include "../../include/mi355x_kkt.h"
+#include "symbolic.h"
+#include "numeric.h"
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace mi355x;
+
+struct mi355x_kkt_handle_s {
+    mi355x_kkt_options opts;
+    Symbolic sym;
+    Numeric* num = nullptr;
+    bool analysed = false, numeric_ready = false, factored = false;
+    FactorStats last;
+    std::string err;
+    std::vector<double> host_vals_nodev;   // plain host staging buffer handed out when no device exists (values only, never computed on)
+};
+
+extern "C" {
+
+void mi355x_kkt_default_options(mi355x_kkt_options* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->device = -1; o->index_base = 1; o->ordering = 0; o->matching = 1; o->scaling = 1;
+    o->nd_leaf = 96; o->nemin = 8; o->max_sn_cols = 64;
+    o->pivtol = 1e-8; o->pivtolmax = 1e-4; o->small = 1e-20;
+    o->refine_steps = 0; o->use_graph = 1; o->nranks = 1; o->rank = 0; o->verbose = 0;
+}
+
+int mi355x_kkt_create(mi355x_kkt_handle* h, const mi355x_kkt_options* opts)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    try {
+        auto* p = new mi355x_kkt_handle_s();
+        if (opts) p->opts = *opts; else mi355x_kkt_default_options(&p->opts);
+        *h = p; return MI355X_KKT_SUCCESS;
+    } catch (...) { *h = nullptr; return MI355X_KKT_FATAL; }
+}
+
+void mi355x_kkt_destroy(mi355x_kkt_handle h)
+{
+    if (!h) return;
+    try { delete h->num; delete h; } catch (...) {}
+}
+
+const char* mi355x_kkt_last_error(mi355x_kkt_handle h) { return h ? h->err.c_str() : "null handle"; }
+
+int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, const int* col, int format, const double* vals)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    try {
+        h->analysed = false; h->numeric_ready = false; h->factored = false;
+        delete h->num; h->num = nullptr;
+        SymbolicOptions so;
+        so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
+        so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 96; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
+        so.max_sn_cols = h->opts.max_sn_cols > 1 ? h->opts.max_sn_cols : 64;
+        so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose;
+        if (!analyse(h->sym, so, n, nnz, row, col, format, vals)) { h->err = h->sym.error; return MI355X_KKT_FATAL; }
+        h->analysed = true;
+        // device setup is attempted right away so that values_buffer() can hand out pinned memory;
+        // without a GPU the symbolic result stays queryable and factor()/solve() fail loudly.
+        h->num = new Numeric();
+        NumericOptions no;
+        no.device = h->opts.device; no.scaling = h->opts.scaling; no.pivtol = h->opts.pivtol; no.small = h->opts.small;
+        no.refine_steps = h->opts.refine_steps; no.use_graph = h->opts.use_graph; no.rank = h->opts.rank; no.nranks = so.nranks;
+        no.verbose = h->opts.verbose;
+        h->numeric_ready = h->num->setup(h->sym, no);
+        if (!h->numeric_ready) h->err = h->num->error();
+        return MI355X_KKT_SUCCESS;
+    } catch (const std::bad_alloc&) { h->err = "analyse: out of host memory"; return MI355X_KKT_FATAL; }
+    catch (...) { h->err = "analyse: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
+double* mi355x_kkt_values_buffer(mi355x_kkt_handle h)
+{
+    if (!h || !h->analysed) return nullptr;
+    if (h->numeric_ready) return h->num->values_buffer();
+    try { h->host_vals_nodev.resize(h->sym.nnz_in > 0 ? h->sym.nnz_in : 1); return h->host_vals_nodev.data(); } catch (...) { return nullptr; }
+}
+
+static int do_factor(mi355x_kkt_handle h, const double* dvals, bool reuse, int* num_neg, int* num_zero)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->analysed) { h->err = "factor: analyse() has not been called"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { if (h->err.empty()) h->err = "factor: no usable HIP device (no CPU fallback)"; return MI355X_KKT_FATAL; }
+    try {
+        if (h->sym.n == 0) { h->last = FactorStats(); h->factored = true; if (num_neg) *num_neg = 0; if (num_zero) *num_zero = 0; return MI355X_KKT_SUCCESS; }
+        FactorStats st;
+        if (!h->num->factor(dvals, reuse, st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
+        h->last = st; h->factored = true;
+        if (num_neg) *num_neg = st.num_neg;
+        if (num_zero) *num_zero = st.num_zero;
+        return st.num_zero > 0 ? MI355X_KKT_SINGULAR : MI355X_KKT_SUCCESS;
+    } catch (...) { h->err = "factor: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
+int mi355x_kkt_factor(mi355x_kkt_handle h, const double* dvals, int* num_neg, int* num_zero) { return do_factor(h, dvals, false, num_neg, num_zero); }
+int mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero) { return do_factor(h, nullptr, true, num_neg, num_zero); }
+
+int mi355x_kkt_solve(mi355x_kkt_handle h, int nrhs, double* rhs, int ld)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->factored || !h->numeric_ready) { h->err = "solve: no factorisation available"; return MI355X_KKT_FATAL; }
+    if (h->sym.n == 0 || nrhs == 0) return MI355X_KKT_SUCCESS;
+    try { if (!h->num->solve_host(nrhs, rhs, ld)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; }
+    catch (...) { h->err = "solve: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
+int mi355x_kkt_solve_device(mi355x_kkt_handle h, int nrhs, double* drhs, int ld)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->factored || !h->numeric_ready) { h->err = "solve: no factorisation available"; return MI355X_KKT_FATAL; }
+    if (h->sym.n == 0 || nrhs == 0) return MI355X_KKT_SUCCESS;
+    try { if (!h->num->solve_device(nrhs, drhs, ld)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; }
+    catch (...) { h->err = "solve: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
+int mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!(u > 0.0) || u > 0.5) { h->err = "set_pivtol: u must be in (0, 0.5]"; return MI355X_KKT_FATAL; }
+    h->opts.pivtol = u;
+    if (h->num) h->num->set_pivtol(u);
+    return MI355X_KKT_SUCCESS;
+}
+
+int mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info)
+{
+    if (!h || !info) return MI355X_KKT_FATAL;
+    std::memset(info, 0, sizeof(*info));
+    const Symbolic& S = h->sym;
+    info->n = S.n; info->nnz_in = S.nnz_in; info->nnz_a = S.nnz_a; info->nnz_l = S.nnz_l;
+    info->flops_factor = S.flops_factor; info->flops_solve = 4 * S.nnz_l - 3 * (int64_t)S.n;
+    info->bytes_factor = 12 * (int64_t)S.nnz_a + 8 * S.nnz_l + 4 * S.sum_sn_rows;
+    info->bytes_solve = 2 * (8 * S.nnz_l + 4 * S.sum_sn_rows) + 24 * (int64_t)S.n;
+    info->sum_sn_rows = S.sum_sn_rows; info->cb_doubles = S.cb_doubles;
+    info->num_sn = S.num_sn; info->num_levels = S.num_levels; info->maxfront = S.maxfront; info->maxsupernode = S.maxsupernode;
+    info->num_pairs = S.num_pairs; info->num_big_fronts = S.num_big;
+    info->num_neg = h->last.num_neg; info->num_zero = h->last.num_zero; info->num_two = h->last.num_two; info->num_small = h->last.num_small;
+    info->time_analyse = S.time_analyse;
+    if (h->num) { info->time_factor_ms = h->num->last_factor_ms(); info->time_solve_ms = h->num->last_solve_ms(); }
+    return MI355X_KKT_SUCCESS;
+}
+
+int mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t cap)
+{
+    if (!h || !h->analysed || !out) return MI355X_KKT_FATAL;
+    const Symbolic& S = h->sym;
+    const std::vector<int>* v = nullptr;
+    switch (what) {
+        case 0: v = &S.perm; break;        case 1: v = &S.sn_colptr; break;  case 2: v = &S.sn_rowptr; break;
+        case 3: v = &S.sn_rows; break;     case 4: v = &S.sn_parent; break;  case 5: v = &S.sn_level; break;
+        case 6: v = &S.rel; break;         case 7: v = &S.acolptr; break;    case 8: v = &S.arow; break;
+        case 9: v = &S.trip2slot; break;   case 10: v = &S.pair_of; break;   case 11: v = &S.sn_owner; break;
+        case 12: v = &S.apos; break;       case 13: v = &S.level_ptr; break; case 14: v = &S.level_sn; break;
+        default: h->err = "get_symbolic: unknown selector"; return MI355X_KKT_FATAL;
+    }
+    if ((int64_t)v->size() > cap) { h->err = "get_symbolic: buffer too small"; return MI355X_KKT_FATAL; }
+    if (!v->empty()) std::memcpy(out, v->data(), v->size() * sizeof(int));
+    return MI355X_KKT_SUCCESS;
+}
+
+// ---- multi-GPU ----
+#define MG_GUARD if (!h) return MI355X_KKT_FATAL; if (!h->numeric_ready) { h->err = "multi-GPU call without a device"; return MI355X_KKT_FATAL; }
+int mi355x_kkt_factor_local(mi355x_kkt_handle h, const double* dvals) { MG_GUARD try { if (!h->num->factor_local(dvals)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
+int mi355x_kkt_top_arena(mi355x_kkt_handle h, double** d, int64_t* nd) { MG_GUARD try { if (!h->num->top_arena(d, nd)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
+int mi355x_kkt_factor_top(mi355x_kkt_handle h, int* nneg, int* nzero)
+{
+    MG_GUARD
+    try { FactorStats st; if (!h->num->factor_top(st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
+          h->last = st; h->factored = true; if (nneg) *nneg = st.num_neg; if (nzero) *nzero = st.num_zero; return 0; } catch (...) { return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_solve_fwd_local(mi355x_kkt_handle h, double* d) { MG_GUARD try { if (!h->num->solve_fwd_local(d)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
+int mi355x_kkt_top_rhs(mi355x_kkt_handle h, double** d, int64_t* nd) { MG_GUARD try { if (!h->num->top_rhs(d, nd)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
+int mi355x_kkt_solve_top_and_bwd(mi355x_kkt_handle h, double* d) { MG_GUARD try { if (!h->num->solve_top_and_bwd(d)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
+
+} // extern "C"

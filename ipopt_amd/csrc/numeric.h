@@ -1,0 +1,50 @@
+// numeric.h -- device-side numeric engine interface (implemented in numeric.hip).
+// Host code (api.cpp) owns a Numeric object per solver handle.
+#pragma once
+#include "symbolic.h"
+#include <cstdint>
+#include <string>
+
+namespace mi355x {
+
+struct NumericOptions {
+    int    device = -1;
+    int    scaling = 1;
+    double pivtol = 1e-8;
+    double small = 1e-20;
+    int    refine_steps = 0;
+    int    use_graph = 1;
+    int    rank = 0, nranks = 1;
+    int    verbose = 0;
+};
+
+struct FactorStats { int num_neg = 0, num_zero = 0, num_two = 0, num_small = 0; };
+
+class NumericImpl;
+
+class Numeric {
+public:
+    Numeric();
+    ~Numeric();
+    // false + error() on failure (e.g. no HIP device: there is NO CPU fallback)
+    bool   setup(const Symbolic& S, const NumericOptions& opt);
+    double* values_buffer();                         // pinned host buffer, nnz_in doubles
+    bool   factor(const double* dvals_or_null, bool reuse_device_values, FactorStats& st);
+    bool   solve_host(int nrhs, double* rhs, int ld);
+    bool   solve_device(int nrhs, double* drhs, int ld);
+    void   set_pivtol(double u);
+    double last_factor_ms() const;
+    double last_solve_ms() const;
+    const std::string& error() const;
+    // multi-GPU pieces
+    bool   factor_local(const double* dvals_or_null);
+    bool   top_arena(double** dptr, int64_t* ndoubles);
+    bool   factor_top(FactorStats& st);
+    bool   solve_fwd_local(double* drhs);
+    bool   top_rhs(double** dptr, int64_t* ndoubles);
+    bool   solve_top_and_bwd(double* drhs);
+private:
+    NumericImpl* p_;
+};
+
+} // namespace mi355x

@@ -1,0 +1,672 @@
+// numeric.hip -- hand-written HIP (gfx950 / CDNA4) numeric engine of the MI355X KKT solver:
+// value gather + equilibration, level-scheduled multifrontal LDL^T with Bunch-Kaufman
+// pivoting inside the fully-summed block of every front, inertia count, and
+// level-scheduled forward / diagonal / backward solves.
+//
+// This is the arithmetic the reference delegates to MUMPS / HSL / PARDISO behind
+// SparseSymLinearSolverInterface::MultiSolve (IpSparseSymLinearSolverInterface.hpp:190;
+// e.g. IpMumpsSolverInterface.cpp:448-583, IpMa97SolverInterface.cpp:611-820); the value
+// gather replaces TripletToCSRConverter::ConvertValues (IpTripletToCSRConverter.cpp:337-372).
+//
+// Design:
+//   * wave = 64 lanes; small fronts (order <= 32) get ONE wavefront each, fronts up to order
+//     128 one 256-thread workgroup; the whole front lives in LDS (<= 134 KiB of the 160 KiB/CU)
+//     from assembly to the write-back of L and of the contribution block, so HBM sees each
+//     A value, each child contribution block and each L entry exactly once.
+//   * column-major fronts with an ODD leading dimension: lanes walk rows => consecutive 8-byte
+//     LDS words (ds_read_b64 is conflict-free); the occasional row walk strides by an odd
+//     number of 8-byte banks.
+//   * pivot search / column maxima are wavefront shuffle reductions (DPP), one LDS hop across
+//     the 4 waves of a workgroup.
+//   * everything is launched on one HIP stream, one launch per (tree level, front class);
+//     the sequences are captured into hipGraphs and replayed (launch-bound regime).
+//   * larger fronts take the blocked global-memory path (panel kernels + v_mfma_f64_16x16x4
+//     trailing updates), see bigfront section.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include "numeric.h"
+
+namespace mi355x {
+
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
+    err_ = std::string(#call) + ": " + hipGetErrorString(e_); return false; } } while (0)
+
+static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
+static constexpr double PIV_PERT = 1e-10;                // replacement magnitude for a zero pivot
+
+// ------------------------------------------------------------------------------------------------
+// device-side view of the symbolic structure + numeric storage (passed by value to kernels)
+// ------------------------------------------------------------------------------------------------
+struct DevView {
+    // symbolic
+    const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
+    const int* child_ptr; const int* child_idx; const int* sn_owner;
+    const long long* panel_off; const long long* cb_off;
+    const int* acolptr; const int* apos; const int* arow; const int* acol;
+    const int* dup_ptr; const int* dup_src;
+    const int* level_sn;
+    const int* perm;
+    // numeric
+    const double* tvals;    // triplet values (device copy)
+    double* aval;           // summed + scaled values, permuted lower CSC order
+    double* scale;          // symmetric scaling, permuted numbering
+    unsigned long long* rowmax;  // scratch for equilibration (bit pattern of non-negative doubles)
+    double* L;              // panels
+    double* cb;             // contribution blocks
+    double* dinv; double* doff; int* ptype; int* lperm;
+    int4*   fstat;          // per front {neg, zero, two, small}
+    double* xw;             // work vector (permuted, scaled)
+    double* cvec;           // forward-solve contributions, aligned with sn_rows
+    // multi-GPU top arena (full m x m squares per replicated front), null on 1 GPU
+    double* arena; const long long* arena_off;
+    double* top_rhs; const long long* top_rhs_off;
+    // parameters
+    double pivtol, small;
+    int n, nnz_a, nsn;
+};
+
+// ------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------
+struct MaxIdx { double v; int i; };
+__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+
+template <int NT>
+__device__ __forceinline__ MaxIdx block_argmax(MaxIdx x, double* redv, int* redi)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { MaxIdx o; o.v = __shfl_xor(x.v, off); o.i = __shfl_xor(x.i, off); x = better(x, o); }
+    if (NT == 64) return x;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { redv[w] = x.v; redi[w] = x.i; }
+    __syncthreads();
+    MaxIdx r; r.v = redv[0]; r.i = redi[0];
+#pragma unroll
+    for (int q = 1; q < NT / 64; ++q) { MaxIdx o; o.v = redv[q]; o.i = redi[q]; r = better(r, o); }
+    __syncthreads();
+    return r;
+}
+template <int NT>
+__device__ __forceinline__ double block_max(double x, double* redv)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x = fmax(x, __shfl_xor(x, off));
+    if (NT == 64) return x;
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) redv[w] = x;
+    __syncthreads();
+    double r = redv[0];
+#pragma unroll
+    for (int q = 1; q < NT / 64; ++q) r = fmax(r, redv[q]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+    return x;
+}
+
+// ------------------------------------------------------------------------------------------------
+// value gather (duplicates summed in a fixed order => bitwise reproducible) and equilibration
+// ------------------------------------------------------------------------------------------------
+__global__ void k_gather_values(DevView V)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < V.nnz_a; q += gridDim.x * blockDim.x) {
+        double s = 0.0;
+        for (int p = V.dup_ptr[q]; p < V.dup_ptr[q + 1]; ++p) s += V.tvals[V.dup_src[p]];
+        V.aval[q] = s;
+    }
+}
+__global__ void k_fill(double* p, double v, long long n)
+{
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_zero_u64(unsigned long long* p, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
+}
+// one Ruiz sweep, part 1: rowmax_i = max_j |a_ij| s_i s_j  (max is order independent => deterministic)
+__global__ void k_ruiz_rowmax(DevView V)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < V.nnz_a; q += gridDim.x * blockDim.x) {
+        const int r = V.arow[q], c = V.acol[q];
+        const double v = fabs(V.aval[q]) * V.scale[r] * V.scale[c];
+        if (v > 0.0) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+            atomicMax(&V.rowmax[r], b);
+            if (r != c) atomicMax(&V.rowmax[c], b);
+        }
+    }
+}
+__global__ void k_ruiz_update(DevView V)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) {
+        const double m = __longlong_as_double((long long)V.rowmax[i]);
+        if (m > 0.0) V.scale[i] *= 1.0 / sqrt(m);
+    }
+}
+__global__ void k_apply_scale(DevView V)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < V.nnz_a; q += gridDim.x * blockDim.x)
+        V.aval[q] *= V.scale[V.arow[q]] * V.scale[V.acol[q]];
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-resident front kernel: assemble (A values + children contribution blocks), factor the k
+// fully-summed columns with Bunch-Kaufman pivoting restricted to the pivot block, write L, D,
+// the pivot order and the contribution block.   One workgroup (NT threads) per front.
+// ------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void swap_rc(double* F, int ld, int m, int p, int q, int* lp)
+{
+    // symmetric interchange of rows/columns p < q (both inside the pivot block) in LOWER storage;
+    // columns to the left of p hold finished L rows and are swapped as rows.
+    const int tid = threadIdx.x;
+    __syncthreads();
+    for (int c = tid; c < p; c += NT) { double t = F[p + c * ld]; F[p + c * ld] = F[q + c * ld]; F[q + c * ld] = t; }
+    for (int i = p + 1 + tid; i < q; i += NT) { double t = F[i + p * ld]; F[i + p * ld] = F[q + i * ld]; F[q + i * ld] = t; }
+    for (int i = q + 1 + tid; i < m; i += NT) { double t = F[i + p * ld]; F[i + p * ld] = F[i + q * ld]; F[i + q * ld] = t; }
+    if (tid == 0) { double t = F[p + p * ld]; F[p + p * ld] = F[q + q * ld]; F[q + q * ld] = t; int u = lp[p]; lp[p] = lp[q]; lp[q] = u; }
+    __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_front_lds(DevView V, int list_off, int top_mode)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const int ld = m | 1;
+    double* F    = reinterpret_cast<double*>(smem_raw);
+    double* lc0  = F + (size_t)ld * m;
+    double* lc1  = lc0 + m;
+    double* dinv_s = lc1 + m;
+    double* doff_s = dinv_s + k;
+    double* redv = doff_s + k;            // 4
+    int*    redi = reinterpret_cast<int*>(redv + 4);   // 4
+    int*    lp   = redi + 4;              // k
+    int*    pt_s = lp + k;                // k
+
+    // ---- (a) init: zero, or (multi-GPU replicated top) start from the all-reduced arena square ----
+    if (top_mode && V.arena) {
+        const double* Ar = V.arena + V.arena_off[s];
+        for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; F[i + c * ld] = Ar[idx]; }
+    } else {
+        for (int idx = tid; idx < ld * m; idx += NT) F[idx] = 0.0;
+    }
+    for (int j = tid; j < k; j += NT) lp[j] = j;
+    __syncthreads();
+    // ---- (b) scatter the A values of the pivot columns (distinct positions) ----
+    if (!(top_mode && V.arena)) {
+        const int q0 = V.acolptr[c0], q1 = V.acolptr[c0 + k];
+        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] = V.aval[q]; }
+    }
+    __syncthreads();
+    // ---- (c) extend-add the children's contribution blocks, one child at a time ----
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        if (top_mode && V.arena && V.sn_owner[ch] >= 0) continue;   // already inside the arena
+        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+        const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
+        const int* relc = V.rel + V.sn_rowptr[ch] + kc;
+        const double* C = V.cb + V.cb_off[ch];
+        for (int b = wave; b < mc; b += NW) {
+            const int rb = relc[b];
+            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * mc];
+        }
+        __syncthreads();
+    }
+
+    // ---- (d) LDL^T of the k pivot columns ----
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
+    const double u = V.pivtol, small = V.small;
+    int j = 0;
+    while (j < k) {
+        MaxIdx cand; cand.v = -1.0; cand.i = 0x7fffffff;
+        for (int i = j + 1 + tid; i < k; i += NT) { const double a = fabs(F[i + j * ld]); if (a > cand.v) { cand.v = a; cand.i = i; } }
+        cand = block_argmax<NT>(cand, redv, redi);
+        const double ajj = fabs(F[j + j * ld]);
+        const double lam = cand.v > 0.0 ? cand.v : 0.0;
+        int two = 0;
+        if (lam > 0.0 && ajj < BK_ALPHA * lam) {
+            const int r = cand.i;
+            double sig = 0.0;
+            for (int c = j + tid; c < k; c += NT) { if (c == r) continue; const double a = (c < r) ? fabs(F[r + c * ld]) : fabs(F[c + r * ld]); sig = fmax(sig, a); }
+            sig = block_max<NT>(sig, redv);
+            const double arr = fabs(F[r + r * ld]);
+            if (ajj * sig >= BK_ALPHA * lam * lam) { /* 1x1 at j, no interchange */ }
+            else if (arr >= BK_ALPHA * sig) { swap_rc<NT>(F, ld, m, j, r, lp); }
+            else { two = 1; if (r != j + 1) swap_rc<NT>(F, ld, m, j + 1, r, lp); }
+        }
+        if (two) {
+            const double a = F[j + j * ld], b = F[j + 1 + j * ld], c = F[j + 1 + (j + 1) * ld];
+            const double det = a * c - b * b;
+            if (fabs(det) <= small) two = 0;   // degenerate block: fall through to a (perturbed) 1x1
+            else {
+                const double idet = 1.0 / det;
+                double lmax = 0.0;
+                for (int i = j + 2 + tid; i < m; i += NT) {
+                    const double w0 = F[i + j * ld], w1 = F[i + (j + 1) * ld];
+                    const double l0 = (c * w0 - b * w1) * idet, l1 = (a * w1 - b * w0) * idet;
+                    lc0[i] = l0; lc1[i] = l1; lmax = fmax(lmax, fmax(fabs(l0), fabs(l1)));
+                }
+                lmax = block_max<NT>(lmax, redv);   // (contains the barrier that publishes lc0/lc1)
+                if (NT == 64) __syncthreads();
+                for (int cc = j + 2 + wave; cc < m; cc += NW) {
+                    const double w0 = F[cc + j * ld], w1 = F[cc + (j + 1) * ld];
+                    for (int i = cc + lane; i < m; i += 64) F[i + cc * ld] -= lc0[i] * w0 + lc1[i] * w1;
+                }
+                __syncthreads();
+                for (int i = j + 2 + tid; i < m; i += NT) { F[i + j * ld] = lc0[i]; F[i + (j + 1) * ld] = lc1[i]; }
+                if (tid == 0) {
+                    F[j + 1 + j * ld] = 0.0;
+                    dinv_s[j] = c * idet; dinv_s[j + 1] = a * idet; doff_s[j] = -b * idet; doff_s[j + 1] = 0.0;
+                    pt_s[j] = 2; pt_s[j + 1] = 3;
+                }
+                if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
+                if (lmax * u > 1.0) nsmall++;
+                ntwo++; j += 2;
+                __syncthreads();
+                continue;
+            }
+        }
+        {   // 1x1 pivot at j
+            double d = F[j + j * ld];
+            if (fabs(d) <= small) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
+            const double di = 1.0 / d;
+            double lmax = 0.0;
+            for (int i = j + 1 + tid; i < m; i += NT) { const double l = F[i + j * ld] * di; lc0[i] = l; lmax = fmax(lmax, fabs(l)); }
+            lmax = block_max<NT>(lmax, redv);
+            if (NT == 64) __syncthreads();
+            for (int cc = j + 1 + wave; cc < m; cc += NW) {
+                const double w = F[cc + j * ld];
+                if (w != 0.0) for (int i = cc + lane; i < m; i += 64) F[i + cc * ld] -= lc0[i] * w;
+            }
+            __syncthreads();
+            for (int i = j + 1 + tid; i < m; i += NT) F[i + j * ld] = lc0[i];
+            if (tid == 0) { dinv_s[j] = di; doff_s[j] = 0.0; pt_s[j] = 1; }
+            if (d < 0.0) nneg++;
+            if (lmax * u > 1.0) nsmall++;
+            j += 1;
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // ---- (e) write back: panel (ld = m), pivot data, contribution block (ld = m-k, lower) ----
+    double* Lg = V.L + V.panel_off[s];
+    for (int c = wave; c < k; c += NW)
+        for (int i = lane; i < m; i += 64) Lg[i + (size_t)c * m] = (i >= c) ? F[i + c * ld] : 0.0;
+    for (int jj = tid; jj < k; jj += NT) { V.dinv[c0 + jj] = dinv_s[jj]; V.doff[c0 + jj] = doff_s[jj]; V.ptype[c0 + jj] = pt_s[jj]; V.lperm[c0 + jj] = lp[jj]; }
+    const int mu = m - k;
+    double* Cg = V.cb + V.cb_off[s];
+    for (int c = wave; c < mu; c += NW)
+        for (int i = c + lane; i < mu; i += 64) Cg[i + (size_t)c * mu] = F[(k + i) + (k + c) * ld];
+    if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inertia / statistics reduction (fixed order => deterministic)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_reduce_stats(const int4* fstat, const int* owner, int nsn, int rank_filter, int* out)
+{
+    __shared__ int sh[4][256];
+    int a = 0, b = 0, c = 0, d = 0;
+    for (int s = threadIdx.x; s < nsn; s += 256) {
+        if (rank_filter >= -1 && owner[s] != rank_filter) continue;
+        const int4 v = fstat[s]; a += v.x; b += v.y; c += v.z; d += v.w;
+    }
+    sh[0][threadIdx.x] = a; sh[1][threadIdx.x] = b; sh[2][threadIdx.x] = c; sh[3][threadIdx.x] = d;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 4) out[threadIdx.x] = sh[threadIdx.x][0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// solves
+// ------------------------------------------------------------------------------------------------
+__global__ void k_load_rhs(DevView V, const double* b)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) V.xw[i] = V.scale[i] * b[V.perm[i]];
+}
+__global__ void k_store_sol(DevView V, double* b)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) b[V.perm[i]] = V.scale[i] * V.xw[i];
+}
+
+// forward: y = L^{-1} P b for the pivot rows of the front, contributions to the ancestors are left
+// in cvec (gathered by the parent: no atomics, deterministic), followed by z = D^{-1} y.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fwd_lds(DevView V, int list_off, int top_mode)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    double* xs = reinterpret_cast<double*>(smem_raw);   // m
+    double* ys = xs + m;                                // k
+    for (int i = tid; i < m; i += NT) xs[i] = (i < k) ? V.xw[c0 + i] : 0.0;
+    if (top_mode && V.top_rhs) { const double* tr = V.top_rhs + V.top_rhs_off[s]; __syncthreads(); for (int i = tid; i < m; i += NT) xs[i] += tr[i]; }
+    __syncthreads();
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        if (top_mode && V.top_rhs && V.sn_owner[ch] >= 0) continue;
+        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+        const int base = V.sn_rowptr[ch] + kc, mc = V.sn_rowptr[ch + 1] - base;
+        for (int t = tid; t < mc; t += NT) xs[V.rel[base + t]] += V.cvec[base + t];
+        __syncthreads();
+    }
+    for (int jj = tid; jj < k; jj += NT) ys[jj] = xs[V.lperm[c0 + jj]];
+    __syncthreads();
+    const double* Lg = V.L + V.panel_off[s];
+    for (int jj = 0; jj < k; ++jj) {
+        const double yj = ys[jj];
+        for (int i = jj + 1 + tid; i < k; i += NT) ys[i] -= Lg[i + (size_t)jj * m] * yj;
+        __syncthreads();
+    }
+    // update rows: t_i = sum_j L[i][j] y_j ; lanes walk rows (coalesced column reads)
+    for (int i = k + tid; i < m; i += NT) {
+        double t = 0.0;
+        for (int jj = 0; jj < k; ++jj) t += Lg[i + (size_t)jj * m] * ys[jj];
+        V.cvec[r0 + i] = xs[i] - t;
+    }
+    for (int jj = tid; jj < k; jj += NT) {
+        const int pt = V.ptype[c0 + jj];
+        double z;
+        if (pt == 1) z = ys[jj] * V.dinv[c0 + jj];
+        else if (pt == 2) z = V.dinv[c0 + jj] * ys[jj] + V.doff[c0 + jj] * ys[jj + 1];
+        else z = V.doff[c0 + jj - 1] * ys[jj - 1] + V.dinv[c0 + jj] * ys[jj];
+        V.xw[c0 + jj] = z;
+    }
+    (void)lane; (void)wave; (void)NW;
+}
+
+// backward: x_piv = L11^{-T} ( z - L21^T x_upd ), written un-permuted
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bwd_lds(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    double* xu = reinterpret_cast<double*>(smem_raw);   // m (only [k,m) used)
+    double* ws = xu + m;                                // k
+    for (int i = k + tid; i < m; i += NT) xu[i] = V.xw[V.sn_rows[r0 + i]];
+    for (int jj = tid; jj < k; jj += NT) ws[jj] = V.xw[c0 + jj];
+    __syncthreads();
+    const double* Lg = V.L + V.panel_off[s];
+    for (int jj = wave; jj < k; jj += NW) {
+        double t = 0.0;
+        for (int i = k + lane; i < m; i += 64) t += Lg[i + (size_t)jj * m] * xu[i];
+        t = wave_sum(t);
+        if (lane == 0) ws[jj] -= t;
+    }
+    __syncthreads();
+    for (int jj = k - 1; jj >= 1; --jj) {
+        const double wj = ws[jj];
+        for (int c = tid; c < jj; c += NT) ws[c] -= Lg[jj + (size_t)c * m] * wj;
+        __syncthreads();
+    }
+    for (int jj = tid; jj < k; jj += NT) V.xw[c0 + V.lperm[c0 + jj]] = ws[jj];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side orchestration
+// ------------------------------------------------------------------------------------------------
+class NumericImpl {
+public:
+    std::string err_;
+    const Symbolic* S = nullptr;
+    NumericOptions opt;
+    bool have_device = false, ready = false, have_values = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double factor_ms = 0, solve_ms = 0;
+    double* h_vals = nullptr;     // pinned
+    int* h_stats = nullptr;       // pinned, 4 ints
+    std::vector<void*> allocs;
+    DevView V{};
+    int* d_stats = nullptr;
+    double* d_rhs = nullptr; size_t d_rhs_cap = 0;
+    hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
+    bool scale_identity = true;
+
+    ~NumericImpl() { release(); }
+    void release() {
+        if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
+        if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
+        for (void* p : allocs) (void)hipFree(p);
+        allocs.clear();
+        if (d_rhs) { (void)hipFree(d_rhs); d_rhs = nullptr; d_rhs_cap = 0; }
+        if (h_vals) { (void)hipHostFree(h_vals); h_vals = nullptr; }
+        if (h_stats) { (void)hipHostFree(h_stats); h_stats = nullptr; }
+        if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
+        if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        ready = false;
+    }
+    template <class T> bool upload(const std::vector<T>& h, const T** d) {
+        T* p = nullptr; size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
+        HIPCHK(hipMalloc((void**)&p, bytes)); allocs.push_back(p);
+        if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+        *d = p; return true;
+    }
+    template <class T> bool dalloc(T** d, size_t count) {
+        T* p = nullptr; HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T))); allocs.push_back(p);
+        HIPCHK(hipMemset(p, 0, std::max<size_t>(count, 1) * sizeof(T)));
+        *d = p; return true;
+    }
+
+    bool setup(const Symbolic& Sy, const NumericOptions& o) {
+        release(); S = &Sy; opt = o;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+            err_ = "no HIP device available: the MI355X KKT backend has no CPU fallback"; have_device = false; return false; }
+        if (opt.device >= 0) HIPCHK(hipSetDevice(opt.device));
+        have_device = true;
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+        HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
+        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end());
+        if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
+            !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
+            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) ||
+            !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
+            !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.level_sn, &V.level_sn) ||
+            !upload(Sy.perm, &V.perm)) return false;
+        double* tv = nullptr;
+        if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
+        if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
+            !dalloc(&V.L, (size_t)Sy.l_doubles) || !dalloc(&V.cb, (size_t)Sy.cb_doubles) ||
+            !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
+            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
+            !dalloc(&d_stats, 4)) return false;
+        V.arena = nullptr; V.arena_off = nullptr; V.top_rhs = nullptr; V.top_rhs_off = nullptr;
+        V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
+        // allow the large dynamic LDS sizes
+        HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        if (Sy.num_big > 0) { err_ = "front larger than 128 rows: blocked path not built into this library yet"; return false; }
+        ready = true; return true;
+    }
+
+    static size_t front_lds_bytes(int mmax, int kmax) {
+        size_t ld = (size_t)mmax | 1;
+        return (ld * mmax + 2 * (size_t)mmax + 2 * (size_t)kmax + 4) * sizeof(double) + (4 + 2 * (size_t)kmax) * sizeof(int) + 16;
+    }
+    int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
+
+    bool enqueue_factor() {
+        const Symbolic& Sy = *S;
+        const int n = Sy.n;
+        hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
+        if (opt.scaling) {
+            for (int it = 0; it < 3; ++it) {
+                hipLaunchKernelGGL(k_zero_u64, dim3(grid1d(n)), dim3(256), 0, stream, V.rowmax, n);
+                hipLaunchKernelGGL(k_ruiz_rowmax, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+                hipLaunchKernelGGL(k_ruiz_update, dim3(grid1d(n)), dim3(256), 0, stream, V);
+            }
+            hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        }
+        for (int lv = 0; lv < Sy.num_levels; ++lv) {
+            for (int fc = 0; fc < FC_COUNT; ++fc) {
+                const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
+                if (b1 == b0) continue;
+                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(32, 32),   stream, V, b0, 0);
+                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(64, 64),   stream, V, b0, 0);
+                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(128, 128), stream, V, b0, 0);
+                else { err_ = "big front in schedule"; return false; }
+            }
+        }
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+
+    bool factor(const double* dvals, bool reuse, FactorStats& st) {
+        if (!ready) { if (err_.empty()) err_ = "factor: solver not set up (no device?)"; return false; }
+        const Symbolic& Sy = *S;
+        V.pivtol = opt.pivtol; V.small = opt.small;
+        if (!reuse) {
+            if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
+            have_values = true;
+        } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
+        HIPCHK(hipEventRecord(ev0, stream));
+        if (opt.use_graph) {
+            if (!g_factor || graph_pivtol != V.pivtol) {
+                if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                bool ok = enqueue_factor();
+                hipError_t e = hipStreamEndCapture(stream, &g);
+                if (!ok) return false;
+                if (e != hipSuccess) { err_ = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return false; }
+                HIPCHK(hipGraphInstantiate(&g_factor, g, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(g);
+                graph_pivtol = V.pivtol;
+                // the events recorded before capture are still valid; re-record for timing accuracy
+                HIPCHK(hipEventRecord(ev0, stream));
+            }
+            HIPCHK(hipGraphLaunch(g_factor, stream));
+        } else {
+            if (!enqueue_factor()) return false;
+        }
+        HIPCHK(hipEventRecord(ev1, stream));
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3];
+        return true;
+    }
+    double graph_pivtol = -1.0;
+
+    bool enqueue_solve(double* drhs) {
+        const Symbolic& Sy = *S;
+        const int n = Sy.n;
+        hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)drhs);
+        auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + kmax) * sizeof(double) + 16; };
+        for (int lv = 0; lv < Sy.num_levels; ++lv)
+            for (int fc = 0; fc < FC_COUNT; ++fc) {
+                const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
+                if (b1 == b0) continue;
+                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_fwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
+                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0, 0);
+                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
+                else { err_ = "big front in schedule"; return false; }
+            }
+        for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
+            for (int fc = 0; fc < FC_COUNT; ++fc) {
+                const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
+                if (b1 == b0) continue;
+                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_bwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0);
+                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
+                else { err_ = "big front in schedule"; return false; }
+            }
+        hipLaunchKernelGGL(k_store_sol, dim3(grid1d(n)), dim3(256), 0, stream, V, drhs);
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+    double* graph_rhs = nullptr;
+
+    bool solve_device(int nrhs, double* drhs, int ld, bool timed) {
+        if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
+        if (timed) HIPCHK(hipEventRecord(ev0, stream));
+        for (int r = 0; r < nrhs; ++r) {
+            double* col = drhs + (size_t)r * ld;
+            if (opt.use_graph) {
+                if (!g_solve || graph_rhs != col) {
+                    if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
+                    hipGraph_t g = nullptr;
+                    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                    bool ok = enqueue_solve(col);
+                    hipError_t e = hipStreamEndCapture(stream, &g);
+                    if (!ok) return false;
+                    if (e != hipSuccess) { err_ = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return false; }
+                    HIPCHK(hipGraphInstantiate(&g_solve, g, nullptr, nullptr, 0));
+                    (void)hipGraphDestroy(g);
+                    graph_rhs = col;
+                    if (timed && r == 0) HIPCHK(hipEventRecord(ev0, stream));
+                }
+                HIPCHK(hipGraphLaunch(g_solve, stream));
+            } else if (!enqueue_solve(col)) return false;
+        }
+        if (timed) { HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms; }
+        return true;
+    }
+    bool solve_host(int nrhs, double* rhs, int ld) {
+        if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
+        const size_t n = S->n;
+        if (d_rhs_cap < n) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(n, 1) * sizeof(double))); d_rhs_cap = n;
+                             if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
+        double total = 0;
+        for (int r = 0; r < nrhs; ++r) {
+            HIPCHK(hipMemcpyAsync(d_rhs, rhs + (size_t)r * ld, n * sizeof(double), hipMemcpyHostToDevice, stream));
+            if (!solve_device(1, d_rhs, (int)n, true)) return false;
+            total += solve_ms;
+            HIPCHK(hipMemcpyAsync(rhs + (size_t)r * ld, d_rhs, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+        }
+        solve_ms = total;
+        return true;
+    }
+};
+
+Numeric::Numeric() : p_(new NumericImpl) {}
+Numeric::~Numeric() { delete p_; }
+bool Numeric::setup(const Symbolic& S, const NumericOptions& opt) { return p_->setup(S, opt); }
+double* Numeric::values_buffer() { return p_->h_vals; }
+bool Numeric::factor(const double* dvals, bool reuse, FactorStats& st) { return p_->factor(dvals, reuse, st); }
+bool Numeric::solve_host(int nrhs, double* rhs, int ld) { return p_->solve_host(nrhs, rhs, ld); }
+bool Numeric::solve_device(int nrhs, double* drhs, int ld) { return p_->solve_device(nrhs, drhs, ld, true); }
+void Numeric::set_pivtol(double u) { p_->opt.pivtol = u; }
+double Numeric::last_factor_ms() const { return p_->factor_ms; }
+double Numeric::last_solve_ms() const { return p_->solve_ms; }
+const std::string& Numeric::error() const { return p_->err_; }
+bool Numeric::factor_local(const double*) { p_->err_ = "multi-GPU path not built yet"; return false; }
+bool Numeric::top_arena(double**, int64_t*) { p_->err_ = "multi-GPU path not built yet"; return false; }
+bool Numeric::factor_top(FactorStats&) { p_->err_ = "multi-GPU path not built yet"; return false; }
+bool Numeric::solve_fwd_local(double*) { p_->err_ = "multi-GPU path not built yet"; return false; }
+bool Numeric::top_rhs(double**, int64_t*) { p_->err_ = "multi-GPU path not built yet"; return false; }
+bool Numeric::solve_top_and_bwd(double*) { p_->err_ = "multi-GPU path not built yet"; return false; }
+
+} // namespace mi355x

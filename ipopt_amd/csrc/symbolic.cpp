@@ -1,0 +1,670 @@
+// symbolic.cpp -- host symbolic analysis (see symbolic.h).  Pure C++17, no GPU.
+//
+// Pipeline:  canonical lower pattern + duplicate maps  ->  zero-diagonal 2x2 pre-pairing
+// (bipartite matching)  ->  compressed graph  ->  nested dissection with minimum-degree
+// leaves  ->  elimination tree, postorder (pairs kept adjacent)  ->  column counts
+// (skeleton / least-common-ancestor method)  ->  fundamental + relaxed supernodes  ->
+// supernodal row structures, child->parent relative indices, A->front scatter map,
+// level schedule, storage offsets, multi-GPU subtree ownership.
+#include "symbolic.h"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <numeric>
+#include <set>
+#include <cstdio>
+
+namespace mi355x {
+namespace {
+
+using std::vector;
+
+// ---------------------------------------------------------------------------------------
+// 1. canonical lower pattern in the ORIGINAL numbering (col = min, row = max), dedup
+// ---------------------------------------------------------------------------------------
+struct Pattern {
+    vector<int> colptr, row;   // lower CSC, rows sorted, diagonal present
+    vector<int> t2slot;        // triplet -> slot
+};
+
+bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int format, Pattern& P,
+                   std::string& err)
+{
+    vector<int> lo(nnz), hi(nnz);
+    if (format == 0) {
+        for (int t = 0; t < nnz; ++t) {
+            int r = ri[t] - base, c = ci[t] - base;
+            if (r < 0 || r >= n || c < 0 || c >= n) { err = "analyse: index out of range"; return false; }
+            lo[t] = std::min(r, c); hi[t] = std::max(r, c);
+        }
+    } else {  // CSR upper: ri = ia[n+1], ci = ja[nnz]
+        if (ri[n] - base != nnz) { err = "analyse: ia[n] does not match nnz"; return false; }
+        for (int i = 0; i < n; ++i)
+            for (int p = ri[i] - base; p < ri[i + 1] - base; ++p) {
+                int c = ci[p] - base;
+                if (c < 0 || c >= n) { err = "analyse: index out of range"; return false; }
+                lo[p] = std::min(i, c); hi[p] = std::max(i, c);
+            }
+    }
+    // bucket by column (lo), then sort rows inside each column
+    vector<int> cnt(n + 1, 0);
+    for (int t = 0; t < nnz; ++t) cnt[lo[t] + 1]++;
+    for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
+    vector<int> order(nnz);
+    { vector<int> pos(cnt.begin(), cnt.end() - 1);
+      for (int t = 0; t < nnz; ++t) order[pos[lo[t]]++] = t; }
+    P.colptr.assign(n + 1, 0);
+    P.row.clear(); P.row.reserve((size_t)nnz + n);
+    P.t2slot.assign(nnz, -1);
+    vector<std::pair<int,int>> tmp;
+    for (int j = 0; j < n; ++j) {
+        tmp.clear();
+        for (int p = cnt[j]; p < cnt[j + 1]; ++p) tmp.emplace_back(hi[order[p]], order[p]);
+        std::sort(tmp.begin(), tmp.end());
+        P.colptr[j] = (int)P.row.size();
+        // diagonal first, always present
+        P.row.push_back(j);
+        int last = j;
+        for (auto& e : tmp) {
+            if (e.first != last) { P.row.push_back(e.first); last = e.first; }
+            P.t2slot[e.second] = (int)P.row.size() - 1;
+        }
+    }
+    P.colptr[n] = (int)P.row.size();
+    return true;
+}
+
+// symmetric adjacency (no diagonal) from a lower pattern
+void build_adjacency(int n, const vector<int>& colptr, const vector<int>& row, vector<int>& xadj, vector<int>& adj)
+{
+    xadj.assign(n + 1, 0);
+    for (int j = 0; j < n; ++j)
+        for (int p = colptr[j]; p < colptr[j + 1]; ++p) { int i = row[p]; if (i != j) { xadj[i + 1]++; xadj[j + 1]++; } }
+    for (int i = 0; i < n; ++i) xadj[i + 1] += xadj[i];
+    adj.resize(xadj[n]);
+    vector<int> pos(xadj.begin(), xadj.end() - 1);
+    for (int j = 0; j < n; ++j)
+        for (int p = colptr[j]; p < colptr[j + 1]; ++p) { int i = row[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
+}
+
+// ---------------------------------------------------------------------------------------
+// 2. zero-diagonal pre-pairing: maximum-cardinality bipartite matching (greedy by weight,
+//    then augmenting paths) between zero-diagonal rows and non-zero-diagonal neighbours.
+//    Cf. the "matching" orderings the reference can request from MA97/SPRAL
+//    (IpMa97SolverInterface.cpp:654-674, IpSpralSolverInterface.cpp:199-204).
+// ---------------------------------------------------------------------------------------
+void zero_diag_matching(int n, const Pattern& P, const vector<int>& xadj, const vector<int>& adj,
+                        const double* vals, int nnz, vector<int>& pair_of, int& num_pairs, vector<char>& zrow)
+{
+    pair_of.assign(n, -1); num_pairs = 0; zrow.assign(n, 0);
+    if (!vals) return;
+    // summed slot values
+    vector<double> sval(P.row.size(), 0.0);
+    for (int t = 0; t < nnz; ++t) sval[P.t2slot[t]] += vals[t];
+    vector<double> diag(n, 0.0), rowmax(n, 0.0);
+    for (int j = 0; j < n; ++j)
+        for (int p = P.colptr[j]; p < P.colptr[j + 1]; ++p) {
+            int i = P.row[p]; double a = std::fabs(sval[p]);
+            if (i == j) diag[j] = sval[p];
+            else { rowmax[i] = std::max(rowmax[i], a); rowmax[j] = std::max(rowmax[j], a); }
+        }
+    vector<char> isz(n, 0);
+    int nz = 0;
+    for (int i = 0; i < n; ++i)
+        if (rowmax[i] > 0 && std::fabs(diag[i]) <= 1e-10 * rowmax[i]) { isz[i] = 1; ++nz; }
+    if (nz == 0) return;
+    // weight lookup: |a_ij| for edge (i,j): build per-node weights aligned with adj
+    vector<double> w(adj.size(), 0.0);
+    { vector<int> pos(xadj.begin(), xadj.end() - 1);
+      for (int j = 0; j < n; ++j)
+          for (int p = P.colptr[j]; p < P.colptr[j + 1]; ++p) { int i = P.row[p]; if (i != j) { double a = std::fabs(sval[p]); w[pos[i]++] = a; w[pos[j]++] = a; } } }
+    vector<int> match_v(n, -1);   // for non-zero-diag node v: matched zero row
+    vector<int> match_z(n, -1);   // for zero row z: matched v
+    // greedy: zero rows in index order, best available neighbour by weight
+    for (int z = 0; z < n; ++z) if (isz[z]) {
+        int best = -1; double bw = 0;
+        for (int p = xadj[z]; p < xadj[z + 1]; ++p) {
+            int v = adj[p];
+            if (isz[v] || match_v[v] >= 0 || w[p] <= 0) continue;
+            if (w[p] > bw || (w[p] == bw && best >= 0 && v < best)) { bw = w[p]; best = v; }
+        }
+        if (best >= 0) { match_v[best] = z; match_z[z] = best; }
+    }
+    // augmenting paths (iterative DFS) for the rest
+    vector<int> visit(n, -1), stack_z, stack_p, via(n, -1);
+    for (int z0 = 0; z0 < n; ++z0) if (isz[z0] && match_z[z0] < 0) {
+        stack_z.assign(1, z0); stack_p.assign(1, xadj[z0]);
+        bool found = false; int vend = -1;
+        while (!stack_z.empty() && !found) {
+            int z = stack_z.back(); int& p = stack_p.back();
+            if (p >= xadj[z + 1]) { stack_z.pop_back(); stack_p.pop_back(); continue; }
+            int v = adj[p]; double wt = w[p]; ++p;
+            if (isz[v] || wt <= 0 || visit[v] == z0) continue;
+            visit[v] = z0; via[v] = z;
+            if (match_v[v] < 0) { found = true; vend = v; }
+            else { int z2 = match_v[v]; stack_z.push_back(z2); stack_p.push_back(xadj[z2]); }
+        }
+        if (found) {  // flip along the path
+            int v = vend;
+            while (v >= 0) { int z = via[v]; int vprev = match_z[z]; match_v[v] = z; match_z[z] = v; v = vprev; }
+        }
+    }
+    for (int z = 0; z < n; ++z) if (isz[z] && match_z[z] >= 0) { pair_of[z] = match_z[z]; pair_of[match_z[z]] = z; zrow[z] = 1; ++num_pairs; }
+}
+
+// ---------------------------------------------------------------------------------------
+// 3. ordering on a (compressed) graph: nested dissection by level structures with
+//    minimum-degree leaves
+// ---------------------------------------------------------------------------------------
+struct Graph { int n; vector<int> xadj, adj; };
+
+// exact minimum degree with a quotient graph on the subgraph induced by `nodes`
+// (neighbours outside the set are ignored).  Appends the elimination order to out.
+class MinDegree {
+public:
+    explicit MinDegree(const Graph& g) : G(g), loc(g.n, -1), mark(g.n, -1) {}
+    void order(const vector<int>& nodes, int* out) {
+        int m = (int)nodes.size();
+        if (m == 0) return;
+        if (m == 1) { out[0] = nodes[0]; return; }
+        for (int i = 0; i < m; ++i) loc[nodes[i]] = i;
+        adjv.assign(m, {}); adje.assign(m, {}); members.assign(m, {});
+        deg.assign(m, 0); alive.assign(m, 1); emark.assign(m, -1);
+        for (int i = 0; i < m; ++i) {
+            int g = nodes[i];
+            for (int p = G.xadj[g]; p < G.xadj[g + 1]; ++p) { int l = loc[G.adj[p]]; if (l >= 0) adjv[i].push_back(l); }
+            deg[i] = (int)adjv[i].size();
+        }
+        std::set<std::pair<int,int>> pq;
+        for (int i = 0; i < m; ++i) pq.insert({deg[i], i});
+        lmark.assign(m, -1); int stamp = 0;
+        vector<int> Lp;
+        for (int step = 0; step < m; ++step) {
+            int p = pq.begin()->second; pq.erase(pq.begin());
+            out[step] = nodes[p]; alive[p] = 0;
+            // reach set of p
+            Lp.clear(); ++stamp; lmark[p] = stamp;
+            for (int v : adjv[p]) if (alive[v] && lmark[v] != stamp) { lmark[v] = stamp; Lp.push_back(v); }
+            for (int e : adje[p]) for (int v : members[e]) if (alive[v] && lmark[v] != stamp) { lmark[v] = stamp; Lp.push_back(v); }
+            // absorbed elements
+            int estamp = ++stamp;
+            for (int e : adje[p]) { emark[e] = estamp; members[e].clear(); members[e].shrink_to_fit(); }
+            members[p] = Lp;
+            int lpstamp = ++stamp;
+            for (int v : Lp) lmark[v] = lpstamp;
+            for (int i : Lp) {
+                // prune adjv[i]: drop p, dead nodes and members of Lp (now reachable through element p)
+                auto& av = adjv[i]; size_t k = 0;
+                for (int v : av) if (alive[v] && lmark[v] != lpstamp) av[k++] = v;
+                av.resize(k);
+                auto& ae = adje[i]; k = 0;
+                for (int e : ae) if (emark[e] != estamp) ae[k++] = e;
+                ae.resize(k); ae.push_back(p);
+            }
+            // recompute exact degrees of the reach set
+            for (int i : Lp) {
+                int s = ++stamp; lmark[i] = s; int d = 0;
+                for (int v : adjv[i]) if (lmark[v] != s) { lmark[v] = s; ++d; }
+                for (int e : adje[i]) for (int v : members[e]) if (alive[v] && lmark[v] != s) { lmark[v] = s; ++d; }
+                if (d != deg[i]) { pq.erase({deg[i], i}); deg[i] = d; pq.insert({d, i}); }
+            }
+            // restore Lp marks are stale now (stamps moved on) -- fine, every use re-stamps
+        }
+        for (int i = 0; i < m; ++i) loc[nodes[i]] = -1;
+    }
+private:
+    const Graph& G;
+    vector<int> loc, mark;
+    vector<vector<int>> adjv, adje, members;
+    vector<int> deg, lmark, emark; vector<char> alive;
+};
+
+class NestedDissection {
+public:
+    NestedDissection(const Graph& g, int leaf) : G(g), leaf_(std::max(leaf, 8)), md(g), tag(g.n, -1), lev(g.n, -1) {}
+    void run(vector<int>& order, bool md_only) {
+        order.assign(G.n, -1);
+        vector<int> all(G.n); std::iota(all.begin(), all.end(), 0);
+        if (md_only) { md.order(all, order.data()); return; }
+        struct Task { vector<int> nodes; int start; };
+        vector<Task> st; st.push_back({std::move(all), 0});
+        int stamp = 0;
+        vector<int> queue, small;
+        while (!st.empty()) {
+            Task t = std::move(st.back()); st.pop_back();
+            int m = (int)t.nodes.size();
+            if (m == 0) continue;
+            if (m <= leaf_) { md.order(t.nodes, order.data() + t.start); continue; }
+            // connected components of the induced subgraph
+            ++stamp; for (int v : t.nodes) tag[v] = stamp;
+            int cstamp = ++stamp;   // visited marker
+            int pos = t.start; small.clear();
+            vector<vector<int>> comps;
+            for (int s : t.nodes) if (tag[s] == stamp - 1) {
+                vector<int> comp; comp.push_back(s); tag[s] = cstamp;
+                for (size_t q = 0; q < comp.size(); ++q) { int v = comp[q];
+                    for (int p = G.xadj[v]; p < G.xadj[v + 1]; ++p) { int u = G.adj[p]; if (tag[u] == stamp - 1) { tag[u] = cstamp; comp.push_back(u); } } }
+                comps.push_back(std::move(comp));
+            }
+            if (comps.size() > 1) {
+                // big components become tasks; small ones are batched into leaf-sized MD calls
+                for (auto& c : comps) {
+                    if ((int)c.size() > leaf_) { int sz = (int)c.size(); st.push_back({std::move(c), pos}); pos += sz; }
+                    else {
+                        if ((int)(small.size() + c.size()) > leaf_ && !small.empty()) { md.order(small, order.data() + pos); pos += (int)small.size(); small.clear(); }
+                        small.insert(small.end(), c.begin(), c.end());
+                    }
+                }
+                if (!small.empty()) { md.order(small, order.data() + pos); pos += (int)small.size(); small.clear(); }
+                continue;
+            }
+            // one connected component: level structure from a pseudo-peripheral node
+            vector<int>& comp = comps[0];
+            int root = comp[0]; int nlev = 0;
+            for (int it = 0; it < 4; ++it) {
+                int nl = bfs_levels(root, cstamp, ++stamp, queue); cstamp = stamp;
+                // candidate: min-degree node of last level
+                int best = -1, bd = 1 << 30;
+                for (int q = (int)queue.size() - 1; q >= 0 && lev[queue[q]] == nl - 1; --q) {
+                    int v = queue[q], d = G.xadj[v + 1] - G.xadj[v]; if (d < bd) { bd = d; best = v; } }
+                if (nl <= nlev) { break; }
+                nlev = nl; if (best == root) break; root = best;
+            }
+            nlev = bfs_levels(root, cstamp, ++stamp, queue); cstamp = stamp;
+            if (nlev < 3) { md.order(t.nodes, order.data() + t.start); continue; }
+            vector<int> lsize(nlev, 0);
+            for (int v : queue) lsize[lev[v]]++;
+            // choose the separator level: small and balanced
+            int bestl = -1; double bests = 1e300; int below = lsize[0];
+            for (int l = 1; l <= nlev - 2; ++l) {
+                int a = below, s = lsize[l], b = m - a - s; below += s;
+                if (a == 0 || b == 0) continue;
+                double imb = std::fabs((double)a - b) / (double)(a + b);
+                double score = (double)s * (1.0 + 4.0 * imb * imb) + 0.05 * m * imb;
+                if (score < bests) { bests = score; bestl = l; }
+            }
+            if (bestl < 0) { md.order(t.nodes, order.data() + t.start); continue; }
+            vector<int> A, B, S;
+            for (int v : queue) {
+                int l = lev[v];
+                if (l < bestl) A.push_back(v);
+                else if (l > bestl) B.push_back(v);
+                else {   // thin the separator: a node with no neighbour in level bestl+1 joins A
+                    bool touchesB = false;
+                    for (int p = G.xadj[v]; p < G.xadj[v + 1]; ++p) { int u = G.adj[p]; if (tag[u] == cstamp && lev[u] == bestl + 1) { touchesB = true; break; } }
+                    if (touchesB) S.push_back(v); else A.push_back(v);
+                }
+            }
+            if (A.empty() || B.empty() || (int)S.size() * 2 > m) { md.order(t.nodes, order.data() + t.start); continue; }
+            int sa = (int)A.size(), sb = (int)B.size();
+            // separator last; inside S keep BFS order (dense clique anyway)
+            for (size_t i = 0; i < S.size(); ++i) order[t.start + sa + sb + (int)i] = S[i];
+            st.push_back({std::move(A), t.start});
+            st.push_back({std::move(B), t.start + sa});
+        }
+    }
+private:
+    // BFS restricted to nodes with tag == in_stamp; re-tags visited with out_stamp; returns #levels
+    int bfs_levels(int root, int in_stamp, int out_stamp, vector<int>& queue) {
+        queue.clear(); queue.push_back(root); tag[root] = out_stamp; lev[root] = 0; int nl = 1;
+        for (size_t q = 0; q < queue.size(); ++q) { int v = queue[q];
+            for (int p = G.xadj[v]; p < G.xadj[v + 1]; ++p) { int u = G.adj[p];
+                if (tag[u] == in_stamp) { tag[u] = out_stamp; lev[u] = lev[v] + 1; nl = std::max(nl, lev[u] + 1); queue.push_back(u); } } }
+        return nl;
+    }
+    const Graph& G; int leaf_; MinDegree md; vector<int> tag, lev;
+};
+
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+} // namespace
+
+// =======================================================================================
+bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int* ri, const int* ci,
+             int format, const double* vals)
+{
+    double t0 = now_s();
+    S = Symbolic();
+    S.n = n; S.nnz_in = nnz;
+    if (n < 0 || nnz < 0) { S.error = "analyse: negative size"; return false; }
+    if (n == 0) { S.sn_colptr.assign(1, 0); S.sn_rowptr.assign(1, 0); S.acolptr.assign(1, 0); S.level_ptr.assign(1, 0); S.child_ptr.assign(1, 0); S.dup_ptr.assign(1, 0); return true; }
+
+    // ---- 1. pattern ----
+    Pattern P;
+    if (!build_pattern(n, nnz, ri, ci, opt.index_base, format, P, S.error)) return false;
+    vector<int> xadj, adj;
+    build_adjacency(n, P.colptr, P.row, xadj, adj);
+
+    // ---- 2. pairing ----
+    vector<char> zrow(n, 0);
+    if (opt.matching) zero_diag_matching(n, P, xadj, adj, vals, nnz, S.pair_of, S.num_pairs, zrow);
+    else S.pair_of.assign(n, -1);
+
+    // ---- 3. compressed graph ----
+    vector<int> cid(n, -1); int nc = 0;
+    vector<int> cfirst; cfirst.reserve(n);   // representative (first member) of each compressed node
+    for (int i = 0; i < n; ++i) if (cid[i] < 0) {
+        cid[i] = nc; int q = S.pair_of[i];
+        if (q >= 0) cid[q] = nc;
+        cfirst.push_back(i); ++nc;
+    }
+    Graph CG; CG.n = nc; CG.xadj.assign(nc + 1, 0);
+    {
+        vector<int> mark(nc, -1); vector<int> tmp; tmp.reserve(adj.size());
+        for (int c = 0; c < nc; ++c) {
+            int mem[2] = { cfirst[c], S.pair_of[cfirst[c]] };
+            mark[c] = c;
+            for (int k = 0; k < 2; ++k) { int i = mem[k]; if (i < 0) continue;
+                for (int p = xadj[i]; p < xadj[i + 1]; ++p) { int d = cid[adj[p]]; if (mark[d] != c) { mark[d] = c; tmp.push_back(d); } } }
+            CG.xadj[c + 1] = (int)tmp.size();
+        }
+        CG.adj = std::move(tmp);
+    }
+
+    // ---- 4. ordering ----
+    vector<int> corder(nc);
+    if (opt.ordering == 2) std::iota(corder.begin(), corder.end(), 0);
+    else { NestedDissection nd(CG, opt.nd_leaf); nd.run(corder, opt.ordering == 1); }
+    // expand: within a pair the non-zero-diagonal member (the "variable") comes first, the
+    // zero-diagonal row (the "constraint") second.
+    vector<int> perm; perm.reserve(n);
+    for (int k = 0; k < nc; ++k) {
+        int a = cfirst[corder[k]], b = S.pair_of[a];
+        if (b < 0) perm.push_back(a);
+        else { if (zrow[a]) std::swap(a, b); perm.push_back(a); perm.push_back(b); }
+    }
+    vector<int> iperm(n);
+    for (int k = 0; k < n; ++k) iperm[perm[k]] = k;
+
+    // ---- 5. elimination tree + postorder (pairs stay adjacent) ----
+    vector<int> parent(n, -1);
+    {
+        vector<int> anc(n, -1);
+        for (int k = 0; k < n; ++k) {
+            int i0 = perm[k];
+            for (int p = xadj[i0]; p < xadj[i0 + 1]; ++p) {
+                int r = iperm[adj[p]];
+                if (r >= k) continue;
+                while (anc[r] != -1 && anc[r] != k) { int nx = anc[r]; anc[r] = k; r = nx; }
+                if (anc[r] == -1) { anc[r] = k; parent[r] = k; }
+            }
+        }
+    }
+    vector<int> post(n);   // post[newnew] = new
+    {
+        vector<int> head(n, -1), next(n, -1);
+        // children in DEscending insertion so that lists come out ascending; the paired child is moved last
+        for (int k = n - 1; k >= 0; --k) if (parent[k] >= 0) { next[k] = head[parent[k]]; head[parent[k]] = k; }
+        // move paired child (k-1 of k when they form a pair) to the end of k's child list
+        for (int k = 1; k < n; ++k) {
+            if (S.pair_of[perm[k]] == perm[k - 1] && parent[k - 1] == k) {
+                // remove k-1 from list of k and append at the tail
+                int prev = -1, c = head[k];
+                while (c != -1 && c != k - 1) { prev = c; c = next[c]; }
+                if (c == k - 1 && next[c] != -1) {
+                    if (prev == -1) head[k] = next[c]; else next[prev] = next[c];
+                    int tail = head[k]; while (next[tail] != -1) tail = next[tail];
+                    next[tail] = c; next[c] = -1;
+                }
+            }
+        }
+        int cnt = 0; vector<int> stack; stack.reserve(64);
+        vector<int> roots; for (int k = 0; k < n; ++k) if (parent[k] < 0) roots.push_back(k);
+        for (int r : roots) {
+            stack.push_back(r);
+            while (!stack.empty()) {
+                int v = stack.back(); int c = head[v];
+                if (c == -1) { post[cnt++] = v; stack.pop_back(); }
+                else { head[v] = next[c]; stack.push_back(c); }
+            }
+        }
+    }
+    {   // compose permutations, relabel parent
+        vector<int> perm2(n), newlab(n);
+        for (int t = 0; t < n; ++t) { perm2[t] = perm[post[t]]; newlab[post[t]] = t; }
+        vector<int> parent2(n, -1);
+        for (int k = 0; k < n; ++k) if (parent[k] >= 0) parent2[newlab[k]] = newlab[parent[k]];
+        perm.swap(perm2); parent.swap(parent2);
+        for (int k = 0; k < n; ++k) iperm[perm[k]] = k;
+    }
+    S.perm = perm; S.iperm = iperm;
+
+    // ---- 6. permuted lower CSC + maps ----
+    {
+        const int nnzA = (int)P.row.size();
+        vector<int> pc(nnzA), pr(nnzA);
+        vector<int> cnt(n + 1, 0);
+        for (int j = 0; j < n; ++j)
+            for (int p = P.colptr[j]; p < P.colptr[j + 1]; ++p) {
+                int a = iperm[P.row[p]], b = iperm[j];
+                pc[p] = std::min(a, b); pr[p] = std::max(a, b); cnt[pc[p] + 1]++;
+            }
+        for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
+        S.acolptr = cnt;
+        // sort by row within column: bucket by row first (stable), then by column
+        vector<int> byrow(nnzA);
+        { vector<int> rc(n + 1, 0); for (int p = 0; p < nnzA; ++p) rc[pr[p] + 1]++; for (int i = 0; i < n; ++i) rc[i + 1] += rc[i];
+          for (int p = 0; p < nnzA; ++p) byrow[rc[pr[p]]++] = p; }
+        vector<int> old2new(nnzA); S.arow.resize(nnzA); S.acol.resize(nnzA);
+        { vector<int> pos(cnt.begin(), cnt.end() - 1);
+          for (int q = 0; q < nnzA; ++q) { int p = byrow[q]; int dst = pos[pc[p]]++; old2new[p] = dst; S.arow[dst] = pr[p]; S.acol[dst] = pc[p]; } }
+        S.nnz_a = nnzA;
+        S.trip2slot.resize(nnz);
+        for (int t = 0; t < nnz; ++t) S.trip2slot[t] = old2new[P.t2slot[t]];
+        S.dup_ptr.assign(nnzA + 1, 0);
+        for (int t = 0; t < nnz; ++t) S.dup_ptr[S.trip2slot[t] + 1]++;
+        for (int q = 0; q < nnzA; ++q) S.dup_ptr[q + 1] += S.dup_ptr[q];
+        S.dup_src.resize(nnz);
+        { vector<int> pos(S.dup_ptr.begin(), S.dup_ptr.end() - 1);
+          for (int t = 0; t < nnz; ++t) S.dup_src[pos[S.trip2slot[t]]++] = t; }
+    }
+
+    // ---- 7. column counts (skeleton matrix / least common ancestors; matrix is postordered) ----
+    vector<int> cc(n, 0);
+    {
+        vector<int> first(n, -1), maxfirst(n, -1), prevleaf(n, -1), anc(n), delta(n, 0);
+        for (int k = 0; k < n; ++k) { anc[k] = k; int j = k; delta[j] = (first[j] == -1) ? 1 : 0; for (; j != -1 && first[j] == -1; j = parent[j]) first[j] = k; }
+        for (int j = 0; j < n; ++j) {
+            if (parent[j] != -1) delta[parent[j]]--;
+            for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) {
+                int i = S.arow[p];
+                if (i <= j || first[j] <= maxfirst[i]) continue;
+                maxfirst[i] = first[j];
+                int jprev = prevleaf[i]; prevleaf[i] = j;
+                if (jprev == -1) { delta[j]++; continue; }
+                int q = jprev; while (q != anc[q]) q = anc[q];
+                for (int s = jprev; s != q;) { int sp = anc[s]; anc[s] = q; s = sp; }
+                delta[j]++; delta[q]--;
+            }
+            if (parent[j] != -1) anc[j] = parent[j];
+        }
+        for (int j = 0; j < n; ++j) cc[j] = delta[j];
+        for (int j = 0; j < n; ++j) if (parent[j] != -1) cc[parent[j]] += cc[j];
+    }
+
+    // ---- 8. supernodes: fundamental + forced pairs, then relaxed amalgamation of chains ----
+    const int maxcols = std::max(2, opt.max_sn_cols);
+    vector<int> fstart;   // first column of each fundamental supernode
+    {
+        int len = 0;
+        for (int j = 0; j < n; ++j) {
+            bool join = false;
+            if (j > 0 && parent[j - 1] == j) {
+                bool pair = (S.pair_of[perm[j]] == perm[j - 1]);
+                if (pair) join = true;
+                else if (cc[j - 1] == cc[j] + 1 && len < maxcols) join = true;
+            }
+            if (!join) { fstart.push_back(j); len = 1; } else ++len;
+        }
+    }
+    {
+        // relaxed amalgamation with a stack of merged supernodes (k cols, m front order, z explicit zeros)
+        struct M { int c0, k, m; double z; };
+        vector<M> st;
+        int nf = (int)fstart.size();
+        auto zfrac = [&](int k) { return k <= 16 ? 0.5 : (k <= 48 ? 0.15 : 0.05); };
+        for (int f = 0; f < nf; ++f) {
+            int c0 = fstart[f], c1 = (f + 1 < nf) ? fstart[f + 1] : n;
+            M cur{c0, c1 - c0, cc[c0], 0.0};
+            // try to absorb preceding merged supernodes that are children of cur
+            while (!st.empty()) {
+                M& ch = st.back();
+                int lastc = ch.c0 + ch.k - 1;
+                int pcol = parent[lastc];
+                if (pcol < cur.c0 || pcol >= cur.c0 + cur.k) break;          // not a child of cur
+                int knew = ch.k + cur.k;
+                if (knew > maxcols) break;
+                int mnew = ch.k + cur.m;
+                double znew = ch.z + cur.z + (double)ch.k * (double)(ch.k + cur.m - ch.m);
+                double total = (double)knew * mnew - 0.5 * knew * (knew - 1);
+                bool ok = (knew <= opt.nemin) || (znew <= zfrac(knew) * total);
+                if (!ok) break;
+                cur = M{ch.c0, knew, mnew, znew};
+                st.pop_back();
+            }
+            st.push_back(cur);
+        }
+        S.num_sn = (int)st.size();
+        S.sn_colptr.resize(S.num_sn + 1);
+        for (int s = 0; s < S.num_sn; ++s) S.sn_colptr[s] = st[s].c0;
+        S.sn_colptr[S.num_sn] = n;
+    }
+    const int nsn = S.num_sn;
+    S.sn_of.resize(n);
+    for (int s = 0; s < nsn; ++s) for (int j = S.sn_colptr[s]; j < S.sn_colptr[s + 1]; ++j) S.sn_of[j] = s;
+
+    // ---- 9. supernodal row structures ----
+    S.sn_rowptr.assign(nsn + 1, 0); S.sn_parent.assign(nsn, -1);
+    S.sn_rows.clear(); S.sn_rows.reserve((size_t)n * 4);
+    {
+        vector<int> mark(n, -1), upd;
+        vector<int> chead(nsn, -1), cnext(nsn, -1);
+        for (int s = 0; s < nsn; ++s) {
+            int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1];
+            upd.clear();
+            for (int j = c0; j < c1; ++j)
+                for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) { int i = S.arow[p]; if (i >= c1 && mark[i] != s) { mark[i] = s; upd.push_back(i); } }
+            for (int c = chead[s]; c != -1; c = cnext[c]) {
+                int kc = S.sn_colptr[c + 1] - S.sn_colptr[c];
+                for (int p = S.sn_rowptr[c] + kc; p < S.sn_rowptr[c + 1]; ++p) { int i = S.sn_rows[p]; if (i >= c1 && mark[i] != s) { mark[i] = s; upd.push_back(i); } }
+            }
+            std::sort(upd.begin(), upd.end());
+            S.sn_rowptr[s] = (int)S.sn_rows.size();
+            for (int j = c0; j < c1; ++j) S.sn_rows.push_back(j);
+            S.sn_rows.insert(S.sn_rows.end(), upd.begin(), upd.end());
+            S.sn_rowptr[s + 1] = (int)S.sn_rows.size();
+            if (!upd.empty()) { int p = S.sn_of[upd[0]]; S.sn_parent[s] = p; cnext[s] = chead[p]; chead[p] = s; }
+        }
+    }
+    S.sum_sn_rows = (int64_t)S.sn_rows.size();
+    // children lists (ascending)
+    S.child_ptr.assign(nsn + 1, 0);
+    for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_ptr[S.sn_parent[s] + 1]++;
+    for (int s = 0; s < nsn; ++s) S.child_ptr[s + 1] += S.child_ptr[s];
+    S.child_idx.resize(S.child_ptr[nsn]);
+    { vector<int> pos(S.child_ptr.begin(), S.child_ptr.end() - 1);
+      for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_idx[pos[S.sn_parent[s]]++] = s; }
+
+    // ---- 10. relative indices, A scatter positions, levels, offsets, stats ----
+    S.rel.assign(S.sn_rows.size(), -1);
+    for (int s = 0; s < nsn; ++s) {
+        int p = S.sn_parent[s]; if (p < 0) continue;
+        int k = S.sn_colptr[s + 1] - S.sn_colptr[s];
+        int p0 = S.sn_colptr[p], p1 = S.sn_colptr[p + 1], kp = p1 - p0;
+        int q = S.sn_rowptr[p] + kp, qe = S.sn_rowptr[p + 1];
+        for (int t = S.sn_rowptr[s] + k; t < S.sn_rowptr[s + 1]; ++t) {
+            int r = S.sn_rows[t];
+            if (r < p1) { S.rel[t] = r - p0; continue; }
+            while (q < qe && S.sn_rows[q] < r) ++q;
+            if (q >= qe || S.sn_rows[q] != r) { S.error = "analyse: internal error (child row missing in parent front)"; return false; }
+            S.rel[t] = kp + (q - (S.sn_rowptr[p] + kp));
+        }
+    }
+    S.apos.resize(S.nnz_a);
+    for (int s = 0; s < nsn; ++s) {
+        int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1], k = c1 - c0;
+        int m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+        for (int j = c0; j < c1; ++j) {
+            int q = S.sn_rowptr[s] + k, qe = S.sn_rowptr[s + 1];
+            for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) {
+                int i = S.arow[p], lr;
+                if (i < c1) lr = i - c0;
+                else { while (q < qe && S.sn_rows[q] < i) ++q;
+                       if (q >= qe || S.sn_rows[q] != i) { S.error = "analyse: internal error (A row missing in front)"; return false; }
+                       lr = k + (q - (S.sn_rowptr[s] + k)); }
+                S.apos[p] = lr + (j - c0) * m;
+            }
+        }
+    }
+    S.sn_level.assign(nsn, 0);
+    for (int s = 0; s < nsn; ++s) { int p = S.sn_parent[s]; if (p >= 0) S.sn_level[p] = std::max(S.sn_level[p], S.sn_level[s] + 1); }
+    S.num_levels = 0; for (int s = 0; s < nsn; ++s) S.num_levels = std::max(S.num_levels, S.sn_level[s] + 1);
+    S.sn_class.resize(nsn); S.panel_off.resize(nsn); S.cb_off.resize(nsn);
+    int64_t loff = 0, coff = 0;
+    for (int s = 0; s < nsn; ++s) {
+        int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+        S.sn_class[s] = m <= 32 ? FC_WAVE : (m <= 64 ? FC_LDS64 : (m <= 128 ? FC_LDS128 : FC_BIG));
+        if (S.sn_class[s] == FC_BIG) S.num_big++;
+        S.panel_off[s] = loff; loff += m * k;
+        S.cb_off[s] = coff; coff += (m - k) * (m - k);
+        S.nnz_l += k * m - k * (k - 1) / 2;
+        for (int64_t j = 0; j < k; ++j) { int64_t c = m - j; S.flops_factor += (c - 1) * (c + 2); }
+        S.maxfront = std::max<int>(S.maxfront, (int)m); S.maxsupernode = std::max<int>(S.maxsupernode, (int)k);
+    }
+    S.l_doubles = loff; S.cb_doubles = coff;
+    // level schedule buckets (level, class)
+    S.level_ptr.assign((size_t)S.num_levels * FC_COUNT + 1, 0);
+    for (int s = 0; s < nsn; ++s) S.level_ptr[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s] + 1]++;
+    for (size_t b = 0; b + 1 < S.level_ptr.size(); ++b) S.level_ptr[b + 1] += S.level_ptr[b];
+    S.level_sn.resize(nsn);
+    { vector<int> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
+      for (int s = 0; s < nsn; ++s) S.level_sn[pos[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s]]++] = s; }
+
+    // ---- 11. multi-GPU ownership: proportional subtree-to-rank mapping ----
+    S.sn_owner.assign(nsn, opt.nranks > 1 ? -1 : 0);
+    if (opt.nranks > 1) {
+        // subtree work estimates
+        vector<double> work(nsn, 0.0);
+        for (int s = 0; s < nsn; ++s) {
+            double k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+            work[s] += k * m * m + 64.0;   // flops-ish + launch overhead weight
+            if (S.sn_parent[s] >= 0) work[S.sn_parent[s]] += work[s];
+        }
+        // grow a frontier of subtree roots from the tree roots until there are enough, balanced pieces
+        std::set<std::pair<double,int>, std::greater<std::pair<double,int>>> front;
+        double total = 0;
+        for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] < 0) { front.insert({work[s], s}); total += work[s]; }
+        const double target = total / opt.nranks;
+        int guard = 0;
+        while (!front.empty() && guard++ < nsn) {
+            auto top = *front.begin();
+            bool enough = (int)front.size() >= 4 * opt.nranks && top.first <= 0.25 * target;
+            if (enough) break;
+            int s = top.second;
+            if (S.child_ptr[s + 1] == S.child_ptr[s]) {   // leaf: cannot split; stop if it is the biggest
+                break;
+            }
+            front.erase(front.begin());
+            // s moves to the replicated top; its children join the frontier
+            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) front.insert({work[S.child_idx[q]], S.child_idx[q]});
+        }
+        // greedy LPT assignment of frontier subtrees to ranks
+        vector<double> load(opt.nranks, 0.0);
+        vector<int> root_owner(nsn, -2);
+        for (auto& e : front) { int r = (int)(std::min_element(load.begin(), load.end()) - load.begin()); load[r] += e.first; root_owner[e.second] = r; }
+        // propagate ownership down (parents have larger indices than children)
+        for (int s = nsn - 1; s >= 0; --s) {
+            if (root_owner[s] >= 0) S.sn_owner[s] = root_owner[s];
+            else if (S.sn_parent[s] >= 0 && S.sn_owner[S.sn_parent[s]] >= 0) S.sn_owner[s] = S.sn_owner[S.sn_parent[s]];
+            else S.sn_owner[s] = -1;
+        }
+    }
+    S.time_analyse = now_s() - t0;
+    if (opt.verbose)
+        fprintf(stderr, "[mi355x_kkt] analyse: n=%d nnzA=%d pairs=%d nsn=%d levels=%d maxfront=%d maxsn=%d nnzL=%lld flops=%.3g big=%d  %.3fs\n",
+                n, S.nnz_a, S.num_pairs, nsn, S.num_levels, S.maxfront, S.maxsupernode, (long long)S.nnz_l, (double)S.flops_factor, S.num_big, S.time_analyse);
+    return true;
+}
+
+} // namespace mi355x

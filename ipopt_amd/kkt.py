@@ -1,0 +1,233 @@
+"""ctypes binding of include/mi355x_kkt.h.
+
+Mirrors, method for method, the contract of the reference's SparseSymLinearSolverInterface
+(reference src/Algorithm/LinearSolvers/IpSparseSymLinearSolverInterface.hpp:98-256):
+``initialize_structure`` / ``values`` / ``multi_solve`` / ``number_of_neg_evals`` /
+``increase_quality`` / ``provides_inertia`` -- same argument meaning, same status codes
+(IpSymLinearSolver.hpp:19-33) -- so the parity tests read like the reference's adapters' callers
+(IpTSymLinearSolver.cpp:159-312).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+STATUS = {0: "SUCCESS", 1: "SINGULAR", 2: "WRONG_INERTIA", 3: "CALL_AGAIN", 4: "FATAL_ERROR"}
+SUCCESS, SINGULAR, WRONG_INERTIA, CALL_AGAIN, FATAL = 0, 1, 2, 3, 4
+FMT_TRIPLET, FMT_CSR_UPPER = 0, 1
+
+
+class KKTError(RuntimeError):
+    pass
+
+
+class _Options(C.Structure):
+    _fields_ = [("device", C.c_int), ("index_base", C.c_int), ("ordering", C.c_int), ("matching", C.c_int),
+                ("scaling", C.c_int), ("nd_leaf", C.c_int), ("nemin", C.c_int), ("max_sn_cols", C.c_int),
+                ("pivtol", C.c_double), ("pivtolmax", C.c_double), ("small", C.c_double),
+                ("refine_steps", C.c_int), ("use_graph", C.c_int), ("nranks", C.c_int), ("rank", C.c_int),
+                ("verbose", C.c_int), ("reserved", C.c_int * 8)]
+
+
+class _Info(C.Structure):
+    _fields_ = [("n", C.c_int), ("nnz_in", C.c_int), ("nnz_a", C.c_int), ("nnz_l", C.c_int64),
+                ("flops_factor", C.c_int64), ("flops_solve", C.c_int64), ("bytes_factor", C.c_int64),
+                ("bytes_solve", C.c_int64), ("sum_sn_rows", C.c_int64), ("cb_doubles", C.c_int64),
+                ("num_sn", C.c_int), ("num_levels", C.c_int), ("maxfront", C.c_int), ("maxsupernode", C.c_int),
+                ("num_pairs", C.c_int), ("num_neg", C.c_int), ("num_zero", C.c_int), ("num_two", C.c_int),
+                ("num_small", C.c_int), ("num_big_fronts", C.c_int), ("time_analyse", C.c_double),
+                ("time_factor_ms", C.c_double), ("time_solve_ms", C.c_double), ("reserved", C.c_double * 8)]
+
+
+@dataclass
+class KKTInfo:
+    n: int; nnz_in: int; nnz_a: int; nnz_l: int; flops_factor: int; flops_solve: int; bytes_factor: int
+    bytes_solve: int; sum_sn_rows: int; cb_doubles: int; num_sn: int; num_levels: int; maxfront: int
+    maxsupernode: int; num_pairs: int; num_neg: int; num_zero: int; num_two: int; num_small: int
+    num_big_fronts: int; time_analyse: float; time_factor_ms: float; time_solve_ms: float
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355x_kkt.so")
+
+
+_LIB = None
+
+# every symbol include/mi355x_kkt.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "mi355x_kkt_default_options", "mi355x_kkt_create", "mi355x_kkt_destroy", "mi355x_kkt_analyse",
+    "mi355x_kkt_values_buffer", "mi355x_kkt_factor", "mi355x_kkt_refactor", "mi355x_kkt_solve",
+    "mi355x_kkt_solve_device", "mi355x_kkt_set_pivtol", "mi355x_kkt_get_info", "mi355x_kkt_last_error",
+    "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
+    "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd",
+]
+
+
+def load_library():
+    """dlopen the in-tree HIP library.  Fails loudly if it has not been built: there is no
+    Python/numpy stand-in for the product path."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise KKTError(f"{path} is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+    lib = C.CDLL(path)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    lib.mi355x_kkt_default_options.argtypes = [C.POINTER(_Options)]
+    lib.mi355x_kkt_default_options.restype = None
+    lib.mi355x_kkt_create.argtypes = [C.POINTER(vp), C.POINTER(_Options)]
+    lib.mi355x_kkt_destroy.argtypes = [vp]
+    lib.mi355x_kkt_destroy.restype = None
+    lib.mi355x_kkt_analyse.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]
+    lib.mi355x_kkt_values_buffer.argtypes = [vp]
+    lib.mi355x_kkt_values_buffer.restype = dp
+    lib.mi355x_kkt_factor.argtypes = [vp, vp, ip, ip]
+    lib.mi355x_kkt_refactor.argtypes = [vp, ip, ip]
+    lib.mi355x_kkt_solve.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.mi355x_kkt_solve_device.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.mi355x_kkt_set_pivtol.argtypes = [vp, C.c_double]
+    lib.mi355x_kkt_get_info.argtypes = [vp, C.POINTER(_Info)]
+    lib.mi355x_kkt_last_error.argtypes = [vp]
+    lib.mi355x_kkt_last_error.restype = C.c_char_p
+    lib.mi355x_kkt_get_symbolic.argtypes = [vp, C.c_int, vp, C.c_int64]
+    lib.mi355x_kkt_factor_local.argtypes = [vp, vp]
+    lib.mi355x_kkt_top_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.mi355x_kkt_factor_top.argtypes = [vp, ip, ip]
+    lib.mi355x_kkt_solve_fwd_local.argtypes = [vp, vp]
+    lib.mi355x_kkt_top_rhs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
+    lib.mi355x_kkt_solve_top_and_bwd.argtypes = [vp, vp]
+    _LIB = lib
+    return lib
+
+
+class KKTSolver:
+    """One solver instance == one ``mi355x_kkt_handle``."""
+
+    def __init__(self, **opts):
+        self.lib = load_library()
+        o = _Options()
+        self.lib.mi355x_kkt_default_options(C.byref(o))
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise KKTError(f"unknown option {k}")
+            setattr(o, k, v)
+        self._opts = o
+        self._h = C.c_void_p()
+        if self.lib.mi355x_kkt_create(C.byref(self._h), C.byref(o)) != 0:
+            raise KKTError("mi355x_kkt_create failed")
+        self._nnz = 0
+        self._n = 0
+        self._neg = 0
+        self.pivtol = o.pivtol
+        self.pivtolmax = o.pivtolmax
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self.lib.mi355x_kkt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self) -> str:
+        return self.lib.mi355x_kkt_last_error(self._h).decode()
+
+    # --- InitializeStructure (IpSparseSymLinearSolverInterface.hpp:139) ---
+    def initialize_structure(self, n, row, col, fmt=FMT_TRIPLET, vals=None) -> int:
+        row = np.ascontiguousarray(row, dtype=np.int32)
+        col = np.ascontiguousarray(col, dtype=np.int32)
+        nnz = int(col.shape[0])
+        v = None
+        if vals is not None:
+            v = np.ascontiguousarray(vals, dtype=np.float64)
+            assert v.shape[0] == nnz
+        st = self.lib.mi355x_kkt_analyse(self._h, int(n), nnz, row.ctypes.data, col.ctypes.data, int(fmt),
+                                         v.ctypes.data if v is not None else None)
+        if st != 0:
+            raise KKTError("analyse: " + self.last_error())
+        self._nnz, self._n = nnz, int(n)
+        return st
+
+    # --- GetValuesArrayPtr (hpp:155) ---
+    def values(self) -> np.ndarray:
+        p = self.lib.mi355x_kkt_values_buffer(self._h)
+        if not p:
+            raise KKTError("values_buffer: " + self.last_error())
+        return np.ctypeslib.as_array(p, shape=(max(self._nnz, 1),))[: self._nnz]
+
+    # --- MultiSolve (hpp:190) ---
+    def multi_solve(self, new_matrix: bool, rhs: np.ndarray | None, check_neg_evals=False, number_of_neg_evals=0) -> int:
+        if new_matrix or self._pending_refactor():
+            neg, zero = C.c_int(0), C.c_int(0)
+            if new_matrix:
+                st = self.lib.mi355x_kkt_factor(self._h, None, C.byref(neg), C.byref(zero))
+            else:
+                st = self.lib.mi355x_kkt_refactor(self._h, C.byref(neg), C.byref(zero))
+            self._refactor = False
+            if st == FATAL:
+                raise KKTError("factor: " + self.last_error())
+            self._neg = neg.value
+            if st == SINGULAR:
+                return SINGULAR
+            if check_neg_evals and self._neg != number_of_neg_evals:
+                return WRONG_INERTIA
+        if rhs is not None and rhs.size:
+            assert rhs.dtype == np.float64 and rhs.flags.c_contiguous
+            nrhs = 1 if rhs.ndim == 1 else rhs.shape[0]
+            st = self.lib.mi355x_kkt_solve(self._h, nrhs, rhs.ctypes.data, self._n)
+            if st != 0:
+                raise KKTError("solve: " + self.last_error())
+        return SUCCESS
+
+    def factor_device(self, dvals_ptr: int):
+        neg, zero = C.c_int(0), C.c_int(0)
+        st = self.lib.mi355x_kkt_factor(self._h, C.c_void_p(dvals_ptr), C.byref(neg), C.byref(zero))
+        if st == FATAL:
+            raise KKTError("factor: " + self.last_error())
+        self._neg = neg.value
+        return st, neg.value, zero.value
+
+    def solve_device(self, drhs_ptr: int, nrhs=1):
+        st = self.lib.mi355x_kkt_solve_device(self._h, nrhs, C.c_void_p(drhs_ptr), self._n)
+        if st != 0:
+            raise KKTError("solve_device: " + self.last_error())
+
+    _refactor = False
+
+    def _pending_refactor(self):
+        return self._refactor
+
+    def number_of_neg_evals(self) -> int:
+        return self._neg
+
+    # --- IncreaseQuality (hpp:220): u <- min(umax, u^0.75), as MA97/SPRAL/MA27 adapters do ---
+    def increase_quality(self) -> bool:
+        if self.pivtol >= self.pivtolmax:
+            return False
+        self.pivtol = min(self.pivtolmax, self.pivtol ** 0.75)
+        self.lib.mi355x_kkt_set_pivtol(self._h, self.pivtol)
+        self._refactor = True
+        return True
+
+    @staticmethod
+    def provides_inertia() -> bool:
+        return True
+
+    def info(self) -> KKTInfo:
+        i = _Info()
+        self.lib.mi355x_kkt_get_info(self._h, C.byref(i))
+        return KKTInfo(**{f: getattr(i, f) for f in KKTInfo.__dataclass_fields__})
+
+    def symbolic(self, what: int, size: int) -> np.ndarray:
+        out = np.empty(max(size, 1), dtype=np.int32)
+        if self.lib.mi355x_kkt_get_symbolic(self._h, what, out.ctypes.data, out.shape[0]) != 0:
+            raise KKTError("get_symbolic: " + self.last_error())
+        return out[:size]

@@ -1,0 +1,81 @@
+# Recipe that compiles the UNMODIFIED reference (coin-or/Ipopt 3.14.15) from the
+# sources where they lie under $(REF)/src into oracle/_ref/ -- without running the
+# reference's autotools build.  TEST / ORACLE INFRASTRUCTURE ONLY.
+#
+#   make -f oracle/ref_build.mk -j8        (from the repo root)
+#
+# Products (all git-ignored, but they travel to the GPU box with the snapshot):
+#   oracle/_ref/libipopt_ref.so   the reference host library, LAPACK+PARDISO from oneMKL
+#   oracle/_ref/solve_problem     reference examples/ScalableProblems driver (LukVlE1, MBndryCntrl1, ...)
+#                                 linked with tests' own main that can select our backend
+#   oracle/_ref/hs071_cpp         reference test/hs071_cpp
+# Source list = libipopt_la_SOURCES of $(REF)/src/Makefile.am:85-196 (+ PardisoMKL, :198-200;
+# + the !IPOPT_INT64 group, :202-211).  No reference file is copied.
+REF     ?= /root/reference
+OUT     ?= oracle/_ref
+CFG     := oracle/ipopt_cfg
+MKLDIR  ?= /opt/conda/lib
+CXX     ?= g++
+CXXFLAGS_REF := -O2 -DNDEBUG -fPIC -DHAVE_CONFIG_H -DIPOPTLIB_BUILD -std=c++11 -w
+INCS := -I$(CFG) -I$(REF)/src/Common -I$(REF)/src/LinAlg -I$(REF)/src/LinAlg/TMatrices \
+        -I$(REF)/src/Algorithm -I$(REF)/src/Algorithm/LinearSolvers -I$(REF)/src/Algorithm/Inexact \
+        -I$(REF)/src/Interfaces -I$(REF)/src/contrib/CGPenalty
+
+SRCS_CPP := $(wildcard $(REF)/src/Common/*.cpp) $(wildcard $(REF)/src/LinAlg/*.cpp) \
+            $(wildcard $(REF)/src/LinAlg/TMatrices/*.cpp) $(wildcard $(REF)/src/Algorithm/*.cpp) \
+            $(wildcard $(REF)/src/contrib/CGPenalty/*.cpp) \
+            $(addprefix $(REF)/src/Interfaces/, IpInterfacesRegOp.cpp IpIpoptApplication.cpp IpSolveStatistics.cpp \
+               IpStdCInterface.cpp IpStdInterfaceTNLP.cpp IpTNLP.cpp IpTNLPAdapter.cpp IpTNLPReducer.cpp) \
+            $(addprefix $(REF)/src/Algorithm/LinearSolvers/, IpLinearSolversRegOp.cpp IpSlackBasedTSymScalingMethod.cpp \
+               IpTripletToCSRConverter.cpp IpTSymDependencyDetector.cpp IpTSymLinearSolver.cpp \
+               IpPardisoMKLSolverInterface.cpp IpMc19TSymScalingMethod.cpp IpMa27TSolverInterface.cpp \
+               IpMa57TSolverInterface.cpp IpMa77SolverInterface.cpp IpMa86SolverInterface.cpp \
+               IpMa97SolverInterface.cpp IpPardisoSolverInterface.cpp)
+SRCS_C   := $(REF)/src/Algorithm/LinearSolvers/IpLinearSolvers.c $(REF)/src/Interfaces/IpStdFInterface.c
+OBJS := $(patsubst $(REF)/src/%.cpp,$(OUT)/obj/%.o,$(SRCS_CPP)) $(patsubst $(REF)/src/%.c,$(OUT)/obj/%.o,$(SRCS_C))
+
+# MKL is isolated behind symlinks so that conda's older libstdc++ is never on the link path
+MKLLINK := -L$(OUT)/mkl -lmkl_rt -Wl,-rpath,'$$ORIGIN/mkl' -ldl -lm -lpthread
+
+all: $(OUT)/libipopt_ref.so $(OUT)/hs071_cpp $(OUT)/scalable.a
+
+$(OUT)/mkl/.stamp:
+	mkdir -p $(OUT)/mkl
+	for f in $(MKLDIR)/libmkl_* $(MKLDIR)/libiomp5.so; do ln -sf $$f $(OUT)/mkl/; done
+	touch $@
+
+$(OUT)/obj/%.o: $(REF)/src/%.cpp
+	@mkdir -p $(dir $@)
+	@$(CXX) $(CXXFLAGS_REF) $(INCS) -c $< -o $@
+$(OUT)/obj/%.o: $(REF)/src/%.c
+	@mkdir -p $(dir $@)
+	@gcc -O2 -fPIC -DHAVE_CONFIG_H -DIPOPTLIB_BUILD -w $(INCS) -c $< -o $@
+
+$(OUT)/libipopt_ref.so: $(OBJS) $(OUT)/mkl/.stamp
+	@$(CXX) -shared -o $@ $(OBJS) $(MKLLINK)
+
+# public-side include path for code compiled against the reference headers
+PUBINC := -I$(CFG)/public $(INCS)
+$(CFG)/public/.stamp:
+	mkdir -p $(CFG)/public
+	touch $@
+
+# reference test/hs071_cpp (3 files, compiled in place)
+$(OUT)/hs071_cpp: $(OUT)/libipopt_ref.so
+	$(CXX) -O2 -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -I$(REF)/examples/hs071_cpp \
+	  $(REF)/examples/hs071_cpp/hs071_main.cpp $(REF)/examples/hs071_cpp/hs071_nlp.cpp \
+	  -o $@ -L$(OUT) -lipopt_ref -Wl,-rpath,'$$ORIGIN' $(MKLLINK)
+
+# reference examples/ScalableProblems: every problem class, archived (their own main is NOT used;
+# tests/support/ipopt_driver.cpp provides a main that can select the MI355X backend)
+SCAL_SRCS := $(filter-out %/solve_problem.cpp,$(wildcard $(REF)/examples/ScalableProblems/*.cpp))
+SCAL_OBJS := $(patsubst $(REF)/examples/ScalableProblems/%.cpp,$(OUT)/obj/scal/%.o,$(SCAL_SRCS))
+$(OUT)/obj/scal/%.o: $(REF)/examples/ScalableProblems/%.cpp
+	@mkdir -p $(dir $@)
+	@$(CXX) -O2 -fPIC -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -c $< -o $@
+$(OUT)/scalable.a: $(SCAL_OBJS)
+	@ar rcs $@ $(SCAL_OBJS)
+
+clean:
+	rm -rf $(OUT)
+.PHONY: all clean

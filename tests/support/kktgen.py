@@ -1,0 +1,102 @@
+"""Synthetic symmetric-indefinite KKT systems with inertia known BY CONSTRUCTION (SURVEY 8(c) pin 2,
+8(d) item 4).  Pure numpy; used by the tests and by bench.py (no reference code involved).
+
+All generators return (n, row, col, val, expected_neg) with 1-based triplets of ONE triangle,
+possibly with duplicates and with entries in either triangle, exactly like the arrays Ipopt's
+TripletHelper hands to a Triplet_Format backend (reference IpTripletHelper.cpp:805-842)."""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _finish(n, rows, cols, vals):
+    return n, np.concatenate(rows).astype(np.int32) + 1, np.concatenate(cols).astype(np.int32) + 1, np.concatenate(vals).astype(np.float64)
+
+
+def kkt_from_blocks(H_trip, Sigma, J_trip, dc, nx, m, h_upper=True):
+    """K = [[H + diag(Sigma), J^T], [J, -diag(dc)]] as Ipopt lays it out: H entries (given upper when
+    h_upper), a SEPARATE duplicate diagonal for Sigma, J strictly lower (row offset nx), explicit
+    (2,2) diagonal."""
+    hi, hj, hv = H_trip
+    ji, jj, jv = J_trip
+    rows = [np.minimum(hi, hj) if h_upper else np.maximum(hi, hj), np.arange(nx), ji + nx, np.arange(m) + nx]
+    cols = [np.maximum(hi, hj) if h_upper else np.minimum(hi, hj), np.arange(nx), jj, np.arange(m) + nx]
+    vals = [hv, Sigma, jv, -dc]
+    return _finish(nx + m, rows, cols, vals)
+
+
+def lukvl_like(n, seed=0, delta_c=0.0, sigma_scale=1.0):
+    """Banded KKT with the sparsity of ScalableProblems LukVlE1 (reference
+    examples/ScalableProblems/LuksanVlcek1.cpp:45-51,245-256): tridiagonal Hessian (upper), constraint
+    i couples x_i, x_{i+1}, x_{i+2}; n variables, n-2 equality constraints.  H is made diagonally
+    dominant so that the inertia is exactly (n, n-2, 0)."""
+    rng = np.random.default_rng(seed)
+    m = n - 2
+    off = rng.uniform(-1, 1, n - 1)
+    diag = np.zeros(n)
+    diag[:-1] += np.abs(off); diag[1:] += np.abs(off)
+    diag += rng.uniform(0.1, 1.0, n)
+    hi = np.concatenate([np.arange(n), np.arange(n - 1)]); hj = np.concatenate([np.arange(n), np.arange(1, n)])
+    hv = np.concatenate([diag, off])
+    Sigma = sigma_scale * 10.0 ** rng.uniform(-3, 3, n)
+    ji = np.repeat(np.arange(m), 3); jj = (np.arange(m)[:, None] + np.arange(3)[None, :]).ravel()
+    jv = rng.uniform(-1, 1, (m, 3)); jv[:, 1] = 1.5 + rng.uniform(0, 1, m)   # anchor => full row rank
+    return kkt_from_blocks((hi, hj, hv), Sigma, (ji, jj, jv.ravel()), np.full(m, delta_c), n, m) + (m,)
+
+
+def grid_kkt(nx_grid, ny_grid, dof=1, ncon=1, seed=0, delta_c=0.0, sigma_exp=3.0):
+    """PDE-constrained-like KKT on an nx x ny grid (scaled down): `dof` primal
+    unknowns and `ncon` (<= dof) constraints per node, 9-point coupling.  H SPD by diagonal
+    dominance, J full row rank through a dominant anchor entry => inertia (n_x, m, 0) exactly."""
+    assert ncon <= dof
+    rng = np.random.default_rng(seed)
+    N = nx_grid * ny_grid
+    ii, jj_ = np.meshgrid(np.arange(nx_grid), np.arange(ny_grid), indexing="ij")
+    pid = (ii + nx_grid * jj_).ravel()
+    nbrs = []
+    for di in (-1, 0, 1):
+        for dj in (-1, 0, 1):
+            a, b = ii + di, jj_ + dj
+            ok = ((a >= 0) & (a < nx_grid) & (b >= 0) & (b < ny_grid)).ravel()
+            nbrs.append((pid[ok], (a + nx_grid * b).ravel()[ok]))
+    P = np.concatenate([p for p, _ in nbrs]); Q = np.concatenate([q for _, q in nbrs])
+    keep = Q <= P
+    P, Q = P[keep], Q[keep]
+    # H blocks: dense dof x dof between neighbouring nodes (lower node pairs), symmetrised on the diagonal
+    npair = P.shape[0]
+    blk = rng.uniform(-1, 1, (npair, dof, dof))
+    same = P == Q
+    blk[same] = 0.5 * (blk[same] + np.transpose(blk[same], (0, 2, 1)))
+    r = (P[:, None, None] * dof + np.arange(dof)[None, :, None]) + np.zeros((1, 1, dof), dtype=np.int64)
+    c = (Q[:, None, None] * dof + np.arange(dof)[None, None, :]) + np.zeros((1, dof, 1), dtype=np.int64)
+    r, c, v = r.ravel(), c.ravel(), blk.ravel()
+    low = r >= c
+    # for diagonal blocks keep only the lower triangle; for off-diagonal node pairs keep everything
+    keep2 = low | np.repeat(~same, dof * dof)
+    r, c, v = r[keep2], c[keep2], v[keep2]
+    nxv = N * dof
+    offd = r != c
+    rowsum = np.zeros(nxv)
+    np.add.at(rowsum, r[offd], np.abs(v[offd])); np.add.at(rowsum, c[offd], np.abs(v[offd]))
+    dmask = ~offd
+    v[dmask] = rowsum[r[dmask]] + rng.uniform(0.1, 1.0, dmask.sum())
+    Sigma = 10.0 ** rng.uniform(-sigma_exp, sigma_exp, nxv)
+    # J: row (p, cidx) touches all dofs of all 9 neighbours with small entries, anchor at (p, cidx)
+    Pj = np.concatenate([p for p, _ in nbrs]); Qj = np.concatenate([q for _, q in nbrs])
+    m = N * ncon
+    jr = (Pj[:, None, None] * ncon + np.arange(ncon)[None, :, None]) + np.zeros((1, 1, dof), dtype=np.int64)
+    jc = (Qj[:, None, None] * dof + np.arange(dof)[None, None, :]) + np.zeros((1, ncon, 1), dtype=np.int64)
+    jv = 0.05 * rng.uniform(-1, 1, jr.shape)
+    anchor = (Pj == Qj)[:, None, None] & (np.arange(ncon)[None, :, None] == np.arange(dof)[None, None, :])
+    jv = np.where(anchor, 1.0 + rng.uniform(0, 1, jr.shape), jv)
+    return kkt_from_blocks((r, c, v), Sigma, (jr.ravel(), jc.ravel(), jv.ravel()), np.full(m, delta_c), nxv, m) + (m,)
+
+
+def to_scipy(n, row, col, val):
+    """full symmetric scipy CSR matrix of a one-triangle triplet list (duplicates summed)."""
+    import scipy.sparse as sp
+    r, c = row - 1, col - 1
+    lo, hi = np.minimum(r, c), np.maximum(r, c)
+    L = sp.coo_matrix((val, (hi, lo)), shape=(n, n)).tocsr()
+    D = sp.diags(L.diagonal())
+    return (L + L.T - D).tocsr()
