@@ -1,0 +1,294 @@
+// IpMi355xSolverInterface.cpp -- see the header.  Status protocol as in IpSymLinearSolver.hpp:19-33.
+#include "IpMi355xSolverInterface.hpp"
+#include "IpTSymLinearSolver.hpp"
+#include "IpIpoptData.hpp"
+#include "IpTimingStatistics.hpp"
+#include <cmath>
+#include <cstring>
+#include <cstdlib>
+
+namespace Ipopt
+{
+
+Mi355xSolverInterface::Mi355xSolverInterface()
+   : handle_(NULL), dim_(0), nonzeros_(0), ia_(NULL), ja_(NULL), analysed_(false), pivtol_changed_(false),
+     warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1)
+{
+   mi355x_kkt_default_options(&kopts_);
+}
+
+Mi355xSolverInterface::~Mi355xSolverInterface()
+{
+   if( handle_ )
+   {
+      mi355x_kkt_destroy(handle_);
+   }
+}
+
+void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions)
+{
+   roptions->SetRegisteringCategory("MI355X Linear Solver");
+   roptions->AddBoundedNumberOption("mi355x_pivtol", "Pivot tolerance for the MI355X LDL^T solver.", 0., true, 0.5,
+                                    false, 1e-8, "Relative threshold u used inside the fully-summed block of a front.");
+   roptions->AddBoundedNumberOption("mi355x_pivtolmax", "Maximum pivot tolerance for the MI355X LDL^T solver.", 0.,
+                                    true, 0.5, false, 1e-4, "IncreaseQuality raises the tolerance u <- u^0.75 up to this value.");
+   roptions->AddStringOption2("mi355x_scaling", "Symmetric equilibration of the KKT matrix on the device.", "ruiz", "none",
+                              "no scaling", "ruiz", "3 sweeps of inf-norm Ruiz equilibration");
+   roptions->AddStringOption3("mi355x_ordering", "Fill-reducing ordering.", "nd", "nd",
+                              "nested dissection with minimum-degree leaves", "md", "minimum degree", "natural", "identity");
+   roptions->AddStringOption2("mi355x_matching", "Pre-pair zero-diagonal rows into 2x2-capable supernodes.", "yes", "no", "",
+                              "yes", "");
+   roptions->AddLowerBoundedIntegerOption("mi355x_nemin", "Supernode amalgamation parameter.", 1, 8, "");
+   roptions->AddLowerBoundedIntegerOption("mi355x_nd_leaf", "Nested dissection leaf size.", 8, 96, "");
+   roptions->AddLowerBoundedIntegerOption("mi355x_max_sn_cols", "Maximum columns per supernode.", 2, 64, "");
+   roptions->AddLowerBoundedIntegerOption("mi355x_device", "HIP device ordinal (-1: current).", -1, -1, "");
+   roptions->AddLowerBoundedIntegerOption("mi355x_verbose", "Verbosity of the MI355X backend.", 0, 0, "");
+}
+
+bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std::string& prefix)
+{
+   // options are optional: a host that has not called RegisterOptions simply gets the defaults
+   try
+   {
+      Number v;
+      Index iv;
+      std::string sv;
+      if( options.GetNumericValue("mi355x_pivtol", v, prefix) )
+      {
+         pivtol_ = v;
+      }
+      if( options.GetNumericValue("mi355x_pivtolmax", v, prefix) )
+      {
+         pivtolmax_ = v;
+      }
+      if( options.GetStringValue("mi355x_scaling", sv, prefix) )
+      {
+         kopts_.scaling = (sv == "none") ? 0 : 1;
+      }
+      if( options.GetStringValue("mi355x_ordering", sv, prefix) )
+      {
+         kopts_.ordering = (sv == "md") ? 1 : (sv == "natural" ? 2 : 0);
+      }
+      if( options.GetStringValue("mi355x_matching", sv, prefix) )
+      {
+         kopts_.matching = (sv == "no") ? 0 : 1;
+      }
+      if( options.GetIntegerValue("mi355x_nemin", iv, prefix) )
+      {
+         kopts_.nemin = iv;
+      }
+      if( options.GetIntegerValue("mi355x_nd_leaf", iv, prefix) )
+      {
+         kopts_.nd_leaf = iv;
+      }
+      if( options.GetIntegerValue("mi355x_max_sn_cols", iv, prefix) )
+      {
+         kopts_.max_sn_cols = iv;
+      }
+      if( options.GetIntegerValue("mi355x_device", iv, prefix) )
+      {
+         kopts_.device = iv;
+      }
+      if( options.GetIntegerValue("mi355x_verbose", iv, prefix) )
+      {
+         kopts_.verbose = iv;
+      }
+   }
+   catch( ... )
+   {
+      // unregistered options: keep defaults
+   }
+   if( pivtolmax_ < pivtol_ )
+   {
+      pivtolmax_ = pivtol_;
+   }
+   kopts_.pivtol = pivtol_;
+   kopts_.pivtolmax = pivtolmax_;
+   kopts_.index_base = 1;
+
+   bool ws = false;
+   try
+   {
+      options.GetBoolValue("warm_start_same_structure", ws, prefix);
+   }
+   catch( ... )
+   { }
+   warm_start_same_structure_ = ws;
+   if( !warm_start_same_structure_ || !handle_ )
+   {
+      // new structure: throw away symbolic data (cf. IpMumpsSolverInterface.cpp:227-236)
+      if( handle_ )
+      {
+         mi355x_kkt_destroy(handle_);
+         handle_ = NULL;
+      }
+      if( mi355x_kkt_create(&handle_, &kopts_) != MI355X_KKT_SUCCESS )
+      {
+         return false;
+      }
+      analysed_ = false;
+      dim_ = 0;
+      nonzeros_ = 0;
+   }
+   else
+   {
+      mi355x_kkt_set_pivtol(handle_, pivtol_);
+   }
+   pivtol_changed_ = false;
+   negevals_ = -1;
+   return true;
+}
+
+ESymSolverStatus Mi355xSolverInterface::InitializeStructure(Index dim, Index nonzeros, const Index* ia, const Index* ja)
+{
+   if( warm_start_same_structure_ && analysed_ )
+   {
+      ASSERT_EXCEPTION(dim_ == dim && nonzeros_ == nonzeros, INVALID_WARMSTART,
+                       "Mi355xSolverInterface called with warm_start_same_structure, but the problem size has changed.");
+      return SYMSOLVER_SUCCESS;
+   }
+   dim_ = dim;
+   nonzeros_ = nonzeros;
+   ia_ = ia;   // owned by TSymLinearSolver, valid for the whole run (IpTSymLinearSolver.cpp:371)
+   ja_ = ja;
+   analysed_ = false;   // symbolic phase is lazy: it wants the first values for the 2x2 pre-pairing
+   staging_.assign(nonzeros > 0 ? nonzeros : 1, 0.);
+   return SYMSOLVER_SUCCESS;
+}
+
+Number* Mi355xSolverInterface::GetValuesArrayPtr()
+{
+   if( analysed_ )
+   {
+      return mi355x_kkt_values_buffer(handle_);
+   }
+   return &staging_[0];
+}
+
+ESymSolverStatus Mi355xSolverInterface::MultiSolve(bool new_matrix, const Index* ia, const Index* ja, Index nrhs,
+      Number* rhs_vals, bool check_NegEVals, Index numberOfNegEVals)
+{
+   (void) ia;
+   (void) ja;
+   if( !analysed_ )
+   {
+      if( HaveIpData() )
+      {
+         IpData().TimingStats().LinearSystemSymbolicFactorization().Start();
+      }
+      int st = mi355x_kkt_analyse(handle_, dim_, nonzeros_, ia_, ja_, MI355X_KKT_FMT_TRIPLET, &staging_[0]);
+      if( HaveIpData() )
+      {
+         IpData().TimingStats().LinearSystemSymbolicFactorization().End();
+      }
+      if( st != MI355X_KKT_SUCCESS )
+      {
+         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_analyse failed: %s\n", mi355x_kkt_last_error(handle_));
+         return SYMSOLVER_FATAL_ERROR;
+      }
+      Number* buf = mi355x_kkt_values_buffer(handle_);
+      if( !buf )
+      {
+         return SYMSOLVER_FATAL_ERROR;
+      }
+      std::memcpy(buf, &staging_[0], sizeof(Number) * (size_t) nonzeros_);
+      std::vector<Number>().swap(staging_);
+      analysed_ = true;
+      new_matrix = true;
+      mi355x_kkt_info info;
+      mi355x_kkt_get_info(handle_, &info);
+      Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA,
+                     "MI355X analyse: n=%d nnz(A)=%d nnz(L)=%lld flops=%lld supernodes=%d levels=%d maxfront=%d pairs=%d\n",
+                     info.n, info.nnz_a, (long long) info.nnz_l, (long long) info.flops_factor, info.num_sn, info.num_levels,
+                     info.maxfront, info.num_pairs);
+   }
+
+   if( new_matrix || pivtol_changed_ )
+   {
+      if( HaveIpData() )
+      {
+         IpData().TimingStats().LinearSystemFactorization().Start();
+      }
+      int nneg = 0, nzero = 0;
+      int st;
+      if( new_matrix )
+      {
+         st = mi355x_kkt_factor(handle_, NULL, &nneg, &nzero);
+      }
+      else
+      {
+         st = mi355x_kkt_refactor(handle_, &nneg, &nzero);
+      }
+      if( HaveIpData() )
+      {
+         IpData().TimingStats().LinearSystemFactorization().End();
+      }
+      pivtol_changed_ = false;
+      if( st == MI355X_KKT_FATAL )
+      {
+         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_factor failed: %s\n", mi355x_kkt_last_error(handle_));
+         return SYMSOLVER_FATAL_ERROR;
+      }
+      negevals_ = nneg;
+      Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X factor: %d negative eigenvalues, %d zero pivots (status %d)\n",
+                     nneg, nzero, st);
+      if( st == MI355X_KKT_SINGULAR )
+      {
+         return SYMSOLVER_SINGULAR;
+      }
+      if( check_NegEVals && negevals_ != numberOfNegEVals )
+      {
+         Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA,
+                        "In Mi355xSolverInterface::MultiSolve: wrong inertia: negevals_ = %d, but numberOfNegEVals = %d\n",
+                        negevals_, numberOfNegEVals);
+         return SYMSOLVER_WRONG_INERTIA;
+      }
+   }
+
+   if( HaveIpData() )
+   {
+      IpData().TimingStats().LinearSystemBackSolve().Start();
+   }
+   int st = mi355x_kkt_solve(handle_, nrhs, rhs_vals, dim_);
+   if( HaveIpData() )
+   {
+      IpData().TimingStats().LinearSystemBackSolve().End();
+   }
+   if( st != MI355X_KKT_SUCCESS )
+   {
+      Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_solve failed: %s\n", mi355x_kkt_last_error(handle_));
+      return SYMSOLVER_FATAL_ERROR;
+   }
+   return SYMSOLVER_SUCCESS;
+}
+
+Index Mi355xSolverInterface::NumberOfNegEVals() const
+{
+   return negevals_;
+}
+
+bool Mi355xSolverInterface::IncreaseQuality()
+{
+   // same escalation rule as the MA27 / MA97 / SPRAL adapters: u <- min(umax, u^0.75)
+   // (IpMa97SolverInterface.cpp:822-854, IpMa27TSolverInterface.cpp:724-740)
+   if( pivtol_ >= pivtolmax_ )
+   {
+      return false;
+   }
+   pivtol_changed_ = true;
+   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Increasing pivot tolerance for MI355X solver from %7.2e ", pivtol_);
+   pivtol_ = Min(pivtolmax_, std::pow(pivtol_, Number(0.75)));
+   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "to %7.2e.\n", pivtol_);
+   mi355x_kkt_set_pivtol(handle_, pivtol_);
+   return true;
+}
+
+SmartPtr<SymLinearSolver> Mi355xAlgorithmBuilder::SymLinearSolverFactory(const Journalist& /*jnlst*/,
+      const OptionsList& /*options*/, const std::string& /*prefix*/)
+{
+   SmartPtr<SparseSymLinearSolverInterface> iface = new Mi355xSolverInterface();
+   SmartPtr<TSymScalingMethod> noscaling;
+   return new TSymLinearSolver(iface, noscaling);
+}
+
+} // namespace Ipopt

@@ -1,0 +1,78 @@
+// IpMi355xSolverInterface.hpp -- Ipopt plug-in (route B1 of SURVEY 8(b)): an implementation of the
+// reference's abstract SparseSymLinearSolverInterface
+// (reference src/Algorithm/LinearSolvers/IpSparseSymLinearSolverInterface.hpp:98-256) that forwards to
+// the C ABI of include/mi355x_kkt.h.  Compiled against the reference's installed headers only; the
+// rest of src/Algorithm runs unmodified on top of it.
+//
+// Behavioural template: the reference's MA97 / SPRAL adapters (IpMa97SolverInterface.cpp:611-820,
+// IpSpralSolverInterface.cpp:510-708) -- keep a private copy of the values so that a pivot-tolerance
+// change can re-factor without SYMSOLVER_CALL_AGAIN (SURVEY 8(b) pitfall 7) -- and the MUMPS adapter's
+// lazy symbolic phase (IpMumpsSolverInterface.cpp:349-383).
+#ifndef IPMI355XSOLVERINTERFACE_HPP
+#define IPMI355XSOLVERINTERFACE_HPP
+
+#include "IpSparseSymLinearSolverInterface.hpp"
+#include "IpAlgBuilder.hpp"
+#include "IpRegOptions.hpp"
+#include "mi355x_kkt.h"
+#include <vector>
+
+namespace Ipopt
+{
+
+class Mi355xSolverInterface: public SparseSymLinearSolverInterface
+{
+public:
+   Mi355xSolverInterface();
+   virtual ~Mi355xSolverInterface();
+
+   bool InitializeImpl(const OptionsList& options, const std::string& prefix);
+
+   ESymSolverStatus InitializeStructure(Index dim, Index nonzeros, const Index* ia, const Index* ja);
+   Number* GetValuesArrayPtr();
+   ESymSolverStatus MultiSolve(bool new_matrix, const Index* ia, const Index* ja, Index nrhs, Number* rhs_vals,
+                               bool check_NegEVals, Index numberOfNegEVals);
+   Index NumberOfNegEVals() const;
+   bool IncreaseQuality();
+   bool ProvidesInertia() const
+   {
+      return true;
+   }
+   EMatrixFormat MatrixFormat() const
+   {
+      return Triplet_Format;   // duplicates / mixed triangles are canonicalised by our own analysis
+   }
+
+   static void RegisterOptions(SmartPtr<RegisteredOptions> roptions);
+
+private:
+   Mi355xSolverInterface(const Mi355xSolverInterface&);
+   void operator=(const Mi355xSolverInterface&);
+
+   mi355x_kkt_handle handle_;
+   mi355x_kkt_options kopts_;
+   Index dim_, nonzeros_;
+   const Index* ia_;
+   const Index* ja_;
+   bool analysed_;
+   bool pivtol_changed_;
+   bool warm_start_same_structure_;
+   Number pivtol_, pivtolmax_;
+   Index negevals_;
+   std::vector<Number> staging_;   // values before the (lazy) analysis has produced the pinned buffer
+};
+
+/** AlgorithmBuilder that injects the MI355X backend through the reference's own virtual factory
+ *  (IpAlgBuilder.hpp:88; selection route (i) of SURVEY 8(b)). */
+class Mi355xAlgorithmBuilder: public AlgorithmBuilder
+{
+public:
+   Mi355xAlgorithmBuilder()
+      : AlgorithmBuilder()
+   { }
+   virtual SmartPtr<SymLinearSolver> SymLinearSolverFactory(const Journalist& jnlst, const OptionsList& options,
+         const std::string& prefix);
+};
+
+} // namespace Ipopt
+#endif

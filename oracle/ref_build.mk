@@ -37,7 +37,7 @@ OBJS := $(patsubst $(REF)/src/%.cpp,$(OUT)/obj/%.o,$(SRCS_CPP)) $(patsubst $(REF
 # MKL is isolated behind symlinks so that conda's older libstdc++ is never on the link path
 MKLLINK := -L$(OUT)/mkl -lmkl_rt -Wl,-rpath,'$$ORIGIN/mkl' -ldl -lm -lpthread
 
-all: $(OUT)/libipopt_ref.so $(OUT)/hs071_cpp $(OUT)/scalable.a
+all: $(OUT)/libipopt_ref.so $(OUT)/hs071_cpp $(OUT)/scalable.a $(OUT)/ref_driver $(OUT)/libmi355x_ipopt.so $(OUT)/ipopt_mi355x_driver
 
 $(OUT)/mkl/.stamp:
 	mkdir -p $(OUT)/mkl
@@ -75,6 +75,23 @@ $(OUT)/obj/scal/%.o: $(REF)/examples/ScalableProblems/%.cpp
 	@$(CXX) -O2 -fPIC -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -c $< -o $@
 $(OUT)/scalable.a: $(SCAL_OBJS)
 	@ar rcs $@ $(SCAL_OBJS)
+
+# --- the product's Ipopt adapter (B1), compiled against the reference headers where they lie.  The
+#     adapter SOURCE is product code (ipopt_amd/csrc/ipopt_adapter); only its build needs the reference. ---
+KKTLIB := ipopt_amd/lib
+$(OUT)/libmi355x_ipopt.so: ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.hpp $(OUT)/libipopt_ref.so
+	$(CXX) -O2 -fPIC -shared -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter $< -o $@ \
+	  -L$(OUT) -lipopt_ref -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib'
+
+DRV_INCS := $(INCS) -I$(REF)/examples/hs071_cpp -I$(REF)/examples/ScalableProblems -Iinclude -Iipopt_amd/csrc/ipopt_adapter
+# CPU-only driver (reference + MKL PARDISO): the oracle / golden-fixture generator / CPU baseline
+$(OUT)/ref_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/scalable.a
+	$(CXX) -O2 -DHAVE_CONFIG_H -std=c++11 -w $(DRV_INCS) $< $(REF)/examples/hs071_cpp/hs071_nlp.cpp $(OUT)/scalable.a -o $@ \
+	  -L$(OUT) -lipopt_ref -Wl,-rpath,'$$ORIGIN' $(MKLLINK)
+# same driver with the MI355X backend linked in (end-to-end Ipopt runs on the GPU box)
+$(OUT)/ipopt_mi355x_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/scalable.a $(OUT)/libmi355x_ipopt.so
+	$(CXX) -O2 -DHAVE_CONFIG_H -DWITH_MI355X -std=c++11 -w $(DRV_INCS) $< $(REF)/examples/hs071_cpp/hs071_nlp.cpp $(OUT)/scalable.a -o $@ \
+	  -L$(OUT) -lipopt_ref -lmi355x_ipopt -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib' $(MKLLINK)
 
 clean:
 	rm -rf $(OUT)

@@ -1,0 +1,212 @@
+// ref_driver.cpp -- TEST / ORACLE INFRASTRUCTURE (never shipped, never on the product path).
+//
+// One executable that hosts the UNMODIFIED reference (oracle/_ref/libipopt_ref.so, built from
+// /root/reference by oracle/ref_build.mk) and runs one of its own example NLPs
+//   hs071                       reference examples/hs071_cpp/hs071_nlp.cpp
+//   LukVlE1 / MBndryCntrl1 ...  reference examples/ScalableProblems/*.cpp (archive scalable.a)
+// with either the reference's CPU linear solver (MKL PARDISO through the reference's own
+// PardisoMKLSolverInterface -- the only CPU backend available offline) or the MI355X
+// backend injected through the reference's virtual SymLinearSolverFactory (IpAlgBuilder.hpp:88).
+//
+// --record FILE wraps the chosen SparseSymLinearSolverInterface in a decorator that stores every
+// call crossing the boundary (structure, values, rhs, returned status / inertia / solution).  That
+// is how tests/golden/*.kktrec are produced from the reference itself (tests/golden/make_golden.sh).
+//
+// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x] [--record file] [--max-records K]
+//                   [--set name value]... [--quiet]
+#include "IpIpoptApplication.hpp"
+#include "IpTNLPAdapter.hpp"
+#include "IpAlgBuilder.hpp"
+#include "IpTSymLinearSolver.hpp"
+#include "IpSparseSymLinearSolverInterface.hpp"
+#include "IpPardisoMKLSolverInterface.hpp"
+#include "IpIpoptData.hpp"
+#include "IpTimingStatistics.hpp"
+#include "IpSolveStatistics.hpp"
+#include "hs071_nlp.hpp"
+#include "LuksanVlcek1.hpp"
+#include "LuksanVlcek5.hpp"
+#include "MittelmannBndryCntrlDiri.hpp"
+#include "MittelmannBndryCntrlDiri3D.hpp"
+#include "MittelmannDistCntrlDiri.hpp"
+#ifdef WITH_MI355X
+#include "IpMi355xSolverInterface.hpp"
+#endif
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <chrono>
+
+using namespace Ipopt;
+
+// ------------------------------------------------------------------------------------------
+// recording decorator
+// ------------------------------------------------------------------------------------------
+class RecordingSolverInterface: public SparseSymLinearSolverInterface
+{
+public:
+   RecordingSolverInterface(SmartPtr<SparseSymLinearSolverInterface> inner, const std::string& file, int max_records)
+      : inner_(inner), f_(NULL), dim_(0), nnz_(0), nrec_(0), max_records_(max_records), vals_(NULL)
+   {
+      f_ = fopen(file.c_str(), "wb");
+      if( f_ ) fwrite("KKTREC1\n", 1, 8, f_);
+   }
+   ~RecordingSolverInterface() { if( f_ ) fclose(f_); }
+   bool InitializeImpl(const OptionsList& options, const std::string& prefix)
+   {
+      return inner_->Initialize(Jnlst(), IpNLP(), IpData(), IpCq(), options, prefix);
+   }
+   ESymSolverStatus InitializeStructure(Index dim, Index nonzeros, const Index* ia, const Index* ja)
+   {
+      dim_ = dim; nnz_ = nonzeros;
+      int fmt = (int) inner_->MatrixFormat();
+      Index nia = (fmt == (int) Triplet_Format) ? nonzeros : dim + 1;
+      if( f_ )
+      {
+         int hdr[8] = {0, dim, nonzeros, fmt, (int) nia, 0, 0, 0};
+         fwrite(hdr, sizeof(int), 8, f_);
+         fwrite(ia, sizeof(Index), nia, f_);
+         fwrite(ja, sizeof(Index), nonzeros, f_);
+      }
+      return inner_->InitializeStructure(dim, nonzeros, ia, ja);
+   }
+   Number* GetValuesArrayPtr() { vals_ = inner_->GetValuesArrayPtr(); return vals_; }
+   ESymSolverStatus MultiSolve(bool new_matrix, const Index* ia, const Index* ja, Index nrhs, Number* rhs_vals,
+                               bool check_NegEVals, Index numberOfNegEVals)
+   {
+      std::vector<Number> a, rhs(rhs_vals, rhs_vals + (size_t) dim_ * nrhs);
+      // NB: some backends (MKL adapter) may overwrite their value array; copy before the call
+      if( new_matrix && vals_ ) a.assign(vals_, vals_ + nnz_);
+      ESymSolverStatus st = inner_->MultiSolve(new_matrix, ia, ja, nrhs, rhs_vals, check_NegEVals, numberOfNegEVals);
+      if( f_ && (max_records_ < 0 || nrec_ < max_records_) )
+      {
+         int hdr[8] = {1, dim_, nnz_, nrhs, new_matrix ? 1 : 0, check_NegEVals ? 1 : 0, numberOfNegEVals, (int) st};
+         fwrite(hdr, sizeof(int), 8, f_);
+         int neg = inner_->ProvidesInertia() ? inner_->NumberOfNegEVals() : -1;
+         fwrite(&neg, sizeof(int), 1, f_);
+         if( new_matrix ) fwrite(a.data(), sizeof(Number), nnz_, f_);
+         fwrite(rhs.data(), sizeof(Number), (size_t) dim_ * nrhs, f_);
+         fwrite(rhs_vals, sizeof(Number), (size_t) dim_ * nrhs, f_);
+         ++nrec_;
+      }
+      return st;
+   }
+   Index NumberOfNegEVals() const { return inner_->NumberOfNegEVals(); }
+   bool IncreaseQuality() { return inner_->IncreaseQuality(); }
+   bool ProvidesInertia() const { return inner_->ProvidesInertia(); }
+   EMatrixFormat MatrixFormat() const { return inner_->MatrixFormat(); }
+private:
+   SmartPtr<SparseSymLinearSolverInterface> inner_;
+   FILE* f_;
+   Index dim_, nnz_;
+   int nrec_, max_records_;
+   Number* vals_;
+};
+
+class DriverAlgBuilder: public AlgorithmBuilder
+{
+public:
+   DriverAlgBuilder(const std::string& solver, const std::string& record, int max_records)
+      : solver_(solver), record_(record), max_records_(max_records) { }
+   virtual SmartPtr<SymLinearSolver> SymLinearSolverFactory(const Journalist&, const OptionsList&, const std::string&)
+   {
+      SmartPtr<SparseSymLinearSolverInterface> iface;
+      if( solver_ == "pardisomkl" ) iface = new PardisoMKLSolverInterface();
+#ifdef WITH_MI355X
+      else if( solver_ == "mi355x" ) iface = new Mi355xSolverInterface();
+#endif
+      else { fprintf(stderr, "unknown --solver %s\n", solver_.c_str()); exit(2); }
+      if( !record_.empty() ) iface = new RecordingSolverInterface(iface, record_, max_records_);
+      SmartPtr<TSymScalingMethod> none;
+      return new TSymLinearSolver(iface, none);
+   }
+private:
+   std::string solver_, record_;
+   int max_records_;
+};
+
+static double wall(const TimedTask& t) { return t.TotalWallclockTime(); }
+
+int main(int argc, char** argv)
+{
+   if( argc < 3 ) { fprintf(stderr, "usage: %s <problem> <N> [--solver s] [--record f] [--max-records k] [--set k v]... [--quiet]\n", argv[0]); return 2; }
+   std::string problem = argv[1];
+   int N = atoi(argv[2]);
+   std::string solver = "pardisomkl", record;
+   int max_records = -1;
+   bool quiet = false;
+   std::vector<std::pair<std::string, std::string> > sets;
+   for( int i = 3; i < argc; ++i )
+   {
+      std::string a = argv[i];
+      if( a == "--solver" && i + 1 < argc ) solver = argv[++i];
+      else if( a == "--record" && i + 1 < argc ) record = argv[++i];
+      else if( a == "--max-records" && i + 1 < argc ) max_records = atoi(argv[++i]);
+      else if( a == "--set" && i + 2 < argc ) { sets.push_back(std::make_pair(std::string(argv[i + 1]), std::string(argv[i + 2]))); i += 2; }
+      else if( a == "--quiet" ) quiet = true;
+      else { fprintf(stderr, "bad argument %s\n", a.c_str()); return 2; }
+   }
+
+   SmartPtr<TNLP> tnlp;
+   if( problem == "hs071" ) tnlp = new HS071_NLP();
+   else
+   {
+      SmartPtr<RegisteredTNLP> r;
+      if( problem == "LukVlE1" ) r = new LuksanVlcek1(0, 0);
+      else if( problem == "LukVlI1" ) r = new LuksanVlcek1(-1., 0.);
+      else if( problem == "LukVlE5" ) r = new LuksanVlcek5(0, 0);
+      else if( problem == "MBndryCntrl1" ) r = new MittelmannBndryCntrlDiri1();
+      else if( problem == "MBndryCntrl2" ) r = new MittelmannBndryCntrlDiri2();
+      else if( problem == "MBndryCntrl_3D" ) r = new MittelmannBndryCntrlDiri3D();
+      else if( problem == "MDistCntrl1" ) r = new MittelmannDistCntrlDiri1();
+      else { fprintf(stderr, "unknown problem %s\n", problem.c_str()); return 2; }
+      if( !r->InitializeProblem(N) ) { fprintf(stderr, "InitializeProblem(%d) failed\n", N); return 2; }
+      tnlp = GetRawPtr(r);
+   }
+
+   SmartPtr<IpoptApplication> app = IpoptApplicationFactory();
+#ifdef WITH_MI355X
+   Mi355xSolverInterface::RegisterOptions(app->RegOptions());
+#endif
+   app->Options()->SetStringValue("print_timing_statistics", "yes");
+   if( problem == "hs071" )
+   {  // the settings of the reference's own test driver, examples/hs071_cpp/hs071_main.cpp:33-35
+      app->Options()->SetNumericValue("tol", 3.82e-6);
+      app->Options()->SetStringValue("mu_strategy", "adaptive");
+   }
+   if( quiet ) app->Options()->SetIntegerValue("print_level", 0);
+   for( size_t i = 0; i < sets.size(); ++i )
+   {
+      const std::string& k = sets[i].first; const std::string& v = sets[i].second;
+      char* end = NULL; double d = strtod(v.c_str(), &end);
+      bool isnum = end && *end == 0 && !v.empty();
+      bool ok = false;
+      if( isnum && v.find_first_of(".eE") == std::string::npos ) ok = app->Options()->SetIntegerValue(k, atoi(v.c_str()), true, true);
+      if( !ok && isnum ) ok = app->Options()->SetNumericValue(k, d, true, true);
+      if( !ok ) ok = app->Options()->SetStringValue(k, v, true, true);
+      if( !ok ) { fprintf(stderr, "could not set option %s=%s\n", k.c_str(), v.c_str()); return 2; }
+   }
+   if( app->Initialize("") != Solve_Succeeded ) { fprintf(stderr, "Initialize failed\n"); return 3; }
+
+   SmartPtr<NLP> nlp = new TNLPAdapter(tnlp, app->Jnlst());
+   SmartPtr<AlgorithmBuilder> builder = new DriverAlgBuilder(solver, record, max_records);
+   auto t0 = std::chrono::steady_clock::now();
+   ApplicationReturnStatus status = app->OptimizeNLP(nlp, builder);
+   double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+   SmartPtr<SolveStatistics> stats = app->Statistics();
+   int iters = IsValid(stats) ? stats->IterationCount() : -1;
+   double obj = IsValid(stats) ? stats->FinalObjective() : 0.;
+   TimingStatistics& ts = app->IpoptDataObject()->TimingStats();
+   printf("DRIVER_SUMMARY {\"problem\": \"%s\", \"N\": %d, \"solver\": \"%s\", \"status\": %d, \"iterations\": %d, \"objective\": %.16e, "
+          "\"wall_total\": %.6f, \"PDSystemSolverTotal\": %.6f, \"PDSystemSolverSolveOnce\": %.6f, \"LinearSystemFactorization\": %.6f, "
+          "\"LinearSystemBackSolve\": %.6f, \"LinearSystemSymbolicFactorization\": %.6f, \"LinearSystemStructureConverter\": %.6f, "
+          "\"StdAugSystemSolverMultiSolve\": %.6f, \"OverallAlgorithm\": %.6f, \"TotalFunctionEvaluations\": %.6f}\n",
+          problem.c_str(), N, solver.c_str(), (int) status, iters, obj, total,
+          wall(ts.PDSystemSolverTotal()), wall(ts.PDSystemSolverSolveOnce()), wall(ts.LinearSystemFactorization()),
+          wall(ts.LinearSystemBackSolve()), wall(ts.LinearSystemSymbolicFactorization()), wall(ts.LinearSystemStructureConverter()),
+          wall(ts.StdAugSystemSolverMultiSolve()), wall(ts.OverallAlgorithm()), (double) ts.TotalFunctionEvaluationWallclockTime());
+   return (status == Solve_Succeeded || status == Solved_To_Acceptable_Level) ? 0 : 1;
+}
