@@ -112,7 +112,7 @@ void zero_diag_matching(int n, const Pattern& P, const vector<int>& xadj, const 
     vector<char> isz(n, 0);
     int nz = 0;
     for (int i = 0; i < n; ++i)
-        if (rowmax[i] > 0 && std::fabs(diag[i]) <= 1e-10 * rowmax[i]) { isz[i] = 1; ++nz; }
+        if (rowmax[i] > 0 && std::fabs(diag[i]) <= 1e-6 * rowmax[i]) { isz[i] = 1; ++nz; }
     if (nz == 0) return;
     // weight lookup: |a_ij| for edge (i,j): build per-node weights aligned with adj
     vector<double> w(adj.size(), 0.0);
@@ -151,6 +151,17 @@ void zero_diag_matching(int n, const Pattern& P, const vector<int>& xadj, const 
         }
     }
     for (int z = 0; z < n; ++z) if (isz[z] && match_z[z] >= 0) { pair_of[z] = match_z[z]; pair_of[match_z[z]] = z; zrow[z] = 1; ++num_pairs; }
+    // second pass: small-diagonal rows that found no well-conditioned partner pair up among themselves
+    // ([[0,a],[a,0]] is a perfectly good 2x2 pivot)
+    for (int z = 0; z < n; ++z) if (isz[z] && pair_of[z] < 0) {
+        int best = -1; double bw = 0;
+        for (int p = xadj[z]; p < xadj[z + 1]; ++p) {
+            int v = adj[p];
+            if (!isz[v] || pair_of[v] >= 0 || w[p] <= 0) continue;
+            if (w[p] > bw || (w[p] == bw && best >= 0 && v < best)) { bw = w[p]; best = v; }
+        }
+        if (best >= 0) { pair_of[z] = best; pair_of[best] = z; zrow[std::max(z, best)] = 1; ++num_pairs; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------

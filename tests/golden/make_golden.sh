@@ -1,0 +1,28 @@
+#!/bin/bash
+# Regenerates tests/golden/ from the REFERENCE ITSELF (unmodified coin-or/Ipopt 3.14.15 built by
+# oracle/ref_build.mk, linear solver = the reference's PardisoMKLSolverInterface on oneMKL -- the only
+# CPU backend available offline).  Needs /root/reference; run in the build container:
+#     make -f oracle/ref_build.mk -j8 && bash tests/golden/make_golden.sh
+# Products:
+#   *.kktrec   every call that crossed the SparseSymLinearSolverInterface boundary during the run
+#              (structure, values, rhs, returned status / inertia / solution); reader: oracle/kkt_oracle.py
+#   *.iters    the iteration table of the reference run (iter objective inf_pr inf_du lg(mu) lg(rg) ls)
+#   *.summary  DRIVER_SUMMARY json (iteration count, objective, reference timers on the build container)
+set -e
+cd "$(dirname "$0")"
+D=../../oracle/_ref
+export MKL_NUM_THREADS=1 OMP_NUM_THREADS=1
+run() {  # name problem N record?
+  name=$1; p=$2; n=$3; rec=$4
+  if [ "$rec" = rec ]; then $D/ref_driver $p $n --record $name.kktrec > /tmp/$name.log; else $D/ref_driver $p $n > /tmp/$name.log; fi
+  grep -E "^ +[0-9]+r? " /tmp/$name.log | awk '{print $1, $2, $3, $4, $5, $7, $10}' > $name.iters
+  grep DRIVER_SUMMARY /tmp/$name.log | sed 's/^DRIVER_SUMMARY //' > $name.summary
+  echo "$name: $(wc -l < $name.iters) iteration lines"
+}
+run hs071 hs071 0 rec
+run lukvle1_100 LukVlE1 100 rec
+run mbndry1_8 MBndryCntrl1 8 rec
+run lukvle1_10000 LukVlE1 10000 norec
+run mbndry1_100 MBndryCntrl1 100 norec
+run lukvle1_1000000 LukVlE1 1000000 norec
+ls -la

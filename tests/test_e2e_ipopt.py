@@ -1,0 +1,37 @@
+"""-m gpu: end-to-end -- the UNMODIFIED reference (oracle/_ref/libipopt_ref.so) drives the MI355X backend
+through its own plug-in point and must reproduce the iteration sequence of its CPU run (golden
+*.iters from tests/golden/make_golden.sh): same iteration count, same per-iteration
+objective / inf_pr / inf_du / lg(mu) / lg(rg) / #line-search columns (SURVEY 8(c) pin 4)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "ipopt_mi355x_driver")
+
+
+def run_driver(problem, n, solver="mi355x"):
+    out = subprocess.run([DRIVER, problem, str(n), "--solver", solver], capture_output=True, text=True, timeout=900, cwd="/tmp").stdout
+    iters = []
+    for ln in out.splitlines():
+        f = ln.split()
+        if len(f) >= 10 and f[0].rstrip("r").isdigit() and ln.startswith(" "):
+            iters.append(" ".join([f[0], f[1], f[2], f[3], f[4], f[6], f[9]]))
+    summ = json.loads(next(ln for ln in out.splitlines() if ln.startswith("DRIVER_SUMMARY"))[len("DRIVER_SUMMARY "):])
+    return iters, summ, out
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("name,problem,n", [("hs071", "hs071", 0), ("lukvle1_100", "LukVlE1", 100), ("mbndry1_8", "MBndryCntrl1", 8),
+                                            ("lukvle1_10000", "LukVlE1", 10000), ("mbndry1_100", "MBndryCntrl1", 100)])
+def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_dir):
+    gold = open(os.path.join(golden_dir, name + ".iters")).read().splitlines()
+    gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
+    iters, summ, out = run_driver(problem, n)
+    assert "EXIT: Optimal Solution Found." in out
+    assert summ["iterations"] == gsum["iterations"]
+    assert abs(summ["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
+    assert iters == gold, "\n".join(f"{a}   |   {b}" for a, b in zip(iters, gold))

@@ -1,0 +1,168 @@
+"""-m gpu: parity of the HIP path (through the C ABI) with the oracle and with the reference's own
+recorded boundary traffic.
+
+Stated fp64 tolerances:
+  * inertia (number of negative eigenvalues): EXACT;
+  * scaled residual  ||K x - b||_inf / (||K||_inf ||x||_inf + ||b||_inf)  <= 1e-12 after our solve
+    (no internal refinement; Ipopt applies its own, IpPDFullSpaceSolver.cpp:256-346);
+  * solution agreement with the oracle / the reference's recorded solution:
+    ||x - x_ref||_inf <= 1e-7 max(1, ||x_ref||_inf) on the (well-conditioned) fixtures;
+  * repeated factor+solve of the same values: bitwise identical (no atomics on fp data).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import ipopt_amd
+from ipopt_amd import kkt
+from oracle import kkt_oracle as ko
+from tests.support import kktgen
+
+pytestmark = pytest.mark.gpu
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.kktrec")))
+RES_TOL = 1e-12
+
+
+def sres(K, x, b):
+    return np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max() + 1e-300)
+
+
+def gpu_factor_solve(n, r, c, v, b, check=False, required=0, **opts):
+    s = ipopt_amd.KKTSolver(**opts)
+    s.initialize_structure(n, r, c, vals=v)
+    s.values()[:] = v
+    x = np.array(b, dtype=np.float64, copy=True)
+    st = s.multi_solve(True, x, check, required)
+    return s, st, x
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_replay_reference_boundary_recordings(path):
+    """Replays, call for call, what the reference sent through SparseSymLinearSolverInterface::MultiSolve
+    and checks status / inertia / solution against what the reference's own backend returned."""
+    rec = ko.read_kktrec(path)
+    r, c = ko.rec_triplets(rec)
+    n = rec["dim"]
+    s = ipopt_amd.KKTSolver()
+    first = next(call for call in rec["calls"] if call["new_matrix"])
+    s.initialize_structure(n, r, c, vals=first["a"])      # lazy analysis with the first values, as the adapter does
+    nsolved = 0
+    for call in rec["calls"]:
+        if call["new_matrix"]:
+            s.values()[:] = call["a"]
+        x = call["rhs"].copy()
+        st = s.multi_solve(bool(call["new_matrix"]), x, bool(call["check"]), call["required_neg"])
+        K = kktgen.to_scipy(n, r, c, call["a"])
+        if call["new_matrix"]:
+            _, oneg, ozero, _ = ko.factor_solve(n, r, c, call["a"], u=0.01)
+            assert s.number_of_neg_evals() == oneg, "inertia differs from the oracle"
+        # reference status: MKL hides 'too few negatives' (IpPardisoMKLSolverInterface.cpp:555); otherwise identical
+        if not (call["check"] and s.number_of_neg_evals() < call["required_neg"]):
+            assert st == call["status"], (st, call["status"])
+            if call["new_matrix"] and call["status"] in (0, 2):
+                assert s.number_of_neg_evals() == call["neg"]
+        if st == kkt.SUCCESS:
+            for k in range(x.shape[0]):
+                assert sres(K, x[k], call["rhs"][k]) <= RES_TOL
+                if call["status"] == 0:
+                    ref = call["sol"][k]
+                    assert np.abs(x[k] - ref).max() <= 1e-7 * max(1.0, np.abs(ref).max())
+            nsolved += 1
+    assert nsolved > 0
+
+
+SEEDED = {
+    "lukvl_1e3": lambda: kktgen.lukvl_like(1000, seed=11),
+    "lukvl_1e4_config2_shape": lambda: kktgen.lukvl_like(10000, seed=12),          # BASELINE configs[1] sizes
+    "lukvl_dc1e-8": lambda: kktgen.lukvl_like(2000, seed=13, delta_c=1e-8),
+    "grid10x9_d2c1": lambda: kktgen.grid_kkt(10, 9, dof=2, ncon=1, seed=14),
+    "grid24x24_d3c2": lambda: kktgen.grid_kkt(24, 24, dof=3, ncon=2, seed=15),       # fronts > 128: blocked path
+    "grid64x64_d1c1": lambda: kktgen.grid_kkt(64, 64, dof=1, ncon=1, seed=16),
+    "grid40x40_wide_sigma": lambda: kktgen.grid_kkt(40, 40, dof=2, ncon=2, seed=17, sigma_exp=8.0),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SEEDED))
+def test_seeded_systems_against_oracle(case):
+    n, r, c, v, neg = SEEDED[case]()
+    K = kktgen.to_scipy(n, r, c, v)
+    rng = np.random.default_rng(1)
+    b = np.stack([K @ np.ones(n), rng.standard_normal(n)])
+    s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+    xo, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=0.01)
+    assert st == kkt.SUCCESS and s.number_of_neg_evals() == neg == oneg and ozero == 0
+    for k in range(2):
+        assert sres(K, x[k], b[k]) <= RES_TOL
+        assert sres(K, xo[k], b[k]) <= 1e-11
+        assert np.abs(x[k] - xo[k]).max() <= 1e-6 * max(1.0, np.abs(xo[k]).max())
+    # bitwise reproducibility
+    x2 = b.copy(); s.multi_solve(True, x2)
+    assert np.array_equal(x, x2)
+
+
+def test_wrong_inertia_and_singular_statuses():
+    n, r, c, v, neg = kktgen.lukvl_like(400, seed=21)
+    v2 = v.copy(); v2[np.where((r == 7) & (c == 7))[0][0]] -= 1e7       # one extra negative eigenvalue
+    s, st, _ = gpu_factor_solve(n, r, c, v2, np.ones(n), check=True, required=neg)
+    assert st == kkt.WRONG_INERTIA and s.number_of_neg_evals() == neg + 1   # readable after WRONG_INERTIA (pitfall 3)
+    _, oneg, _, _ = ko.factor_solve(n, r, c, v2)
+    assert oneg == neg + 1
+    # rank-deficient Jacobian (two identical constraint rows) with delta_c = 0  =>  SINGULAR, like MA27/MA97/MUMPS
+    nx, m = 6, 3
+    H = (np.arange(nx), np.arange(nx), np.full(nx, 2.0))
+    ji = np.array([0, 0, 1, 1, 2, 2]); jj = np.array([0, 1, 0, 1, 3, 4]); jv = np.array([1.0, 2.0, 1.0, 2.0, 1.0, 1.0])
+    n2, r2, c2, v2 = kktgen.kkt_from_blocks(H, np.zeros(nx), (ji, jj, jv), np.zeros(m), nx, m)
+    s, st, _ = gpu_factor_solve(n2, r2, c2, v2, np.ones(n2))
+    _, _, ozero, _ = ko.factor_solve(n2, r2, c2, v2)
+    assert st == kkt.SINGULAR and ozero >= 1
+    # ... and Ipopt's cure (delta_c > 0, IpPDPerturbationHandler.cpp:467-470) makes it regular with inertia (nx, m, 0)
+    n2, r2, c2, v2 = kktgen.kkt_from_blocks(H, np.zeros(nx), (ji, jj, jv), np.full(m, 1e-8), nx, m)
+    s, st, x = gpu_factor_solve(n2, r2, c2, v2, np.ones(n2), check=True, required=m)
+    assert st == kkt.SUCCESS
+
+
+def test_edge_cases_tiny_empty_diagonal_multirhs():
+    s, st, x = gpu_factor_solve(1, np.array([1], np.int32), np.array([1], np.int32), np.array([-4.0]), np.array([8.0]))
+    assert st == 0 and s.number_of_neg_evals() == 1 and x[0] == -2.0
+    s = ipopt_amd.KKTSolver(); s.initialize_structure(0, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert s.multi_solve(True, np.zeros(0)) == 0
+    d = np.array([2.0, -3.0, 5.0, -7.0, 11.0])
+    s, st, x = gpu_factor_solve(5, np.arange(1, 6), np.arange(1, 6), d, np.stack([d, 2 * d, -d]))
+    assert st == 0 and s.number_of_neg_evals() == 2 and np.allclose(x, [[1] * 5, [2] * 5, [-1] * 5], rtol=1e-15)
+
+
+def test_new_matrix_false_reuses_factor_and_increase_quality_refactors():
+    n, r, c, v, neg = kktgen.grid_kkt(12, 12, dof=2, ncon=1, seed=31)
+    K = kktgen.to_scipy(n, r, c, v)
+    s, st, x = gpu_factor_solve(n, r, c, v, K @ np.ones(n))
+    b2 = K @ np.arange(n, dtype=np.float64)
+    x2 = b2.copy(); assert s.multi_solve(False, x2) == 0
+    assert np.abs(x2 - np.arange(n)).max() <= 1e-8 * n
+    # IncreaseQuality then MultiSolve(new_matrix=false) must re-factor from the device copy (pitfall 7)
+    u0 = s.pivtol
+    assert s.increase_quality() and s.pivtol == pytest.approx(u0 ** 0.75)
+    s.values()[:] = 0.0       # the host staging buffer is NOT consulted on a refactor
+    x3 = b2.copy(); assert s.multi_solve(False, x3, True, neg) == 0
+    assert np.abs(x3 - np.arange(n)).max() <= 1e-8 * n
+    while s.increase_quality():
+        pass
+    assert s.pivtol == s.pivtolmax and not s.increase_quality()
+
+
+def test_full_size_properties_config_sized():
+    """BASELINE.json sizes without the oracle: LukVlE1-shaped KKT with n = 10^6 variables (dim 1 999 998):
+    by-construction inertia, residual, linearity of the solve, idempotence."""
+    n, r, c, v, neg = kktgen.lukvl_like(1_000_000, seed=41)
+    K = kktgen.to_scipy(n, r, c, v)
+    rng = np.random.default_rng(2)
+    b1, b2 = K @ np.ones(n), rng.standard_normal(n)
+    s, st, x1 = gpu_factor_solve(n, r, c, v, b1, check=True, required=neg)
+    assert st == 0 and s.number_of_neg_evals() == neg
+    assert sres(K, x1, b1) <= RES_TOL and np.abs(x1 - 1).max() <= 1e-6
+    x2 = b2.copy(); s.multi_solve(False, x2)
+    x12 = b1 + 2.0 * b2; s.multi_solve(False, x12)
+    assert np.abs(x12 - (x1 + 2.0 * x2)).max() <= 1e-9 * np.abs(x12).max()
+    x1b = b1.copy(); s.multi_solve(True, x1b)
+    assert np.array_equal(x1, x1b)

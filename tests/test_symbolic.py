@@ -1,0 +1,121 @@
+"""-m 'not gpu': host logic.  The symbolic analysis (canonicalisation of duplicate / mixed-triangle
+triplets, 2x2 pre-pairing, ordering, supernodes, relative indices, scatter map, level schedule,
+multi-GPU ownership) is validated by walking its exported structures with a numpy block-multifrontal
+(tests/support/mirror.py) and comparing with scipy / by-construction inertia."""
+import numpy as np
+import pytest
+
+import ipopt_amd
+from tests.support import kktgen, mirror
+
+CASES = {
+    "lukvl300": lambda dc=0.0: kktgen.lukvl_like(300, seed=1, delta_c=dc),
+    "lukvl300_dc": lambda dc=1e-8: kktgen.lukvl_like(300, seed=2, delta_c=dc),
+    "grid9x7": lambda dc=0.0: kktgen.grid_kkt(9, 7, dof=2, ncon=1, seed=3, delta_c=dc),
+    "grid16x16_d3c2": lambda dc=0.0: kktgen.grid_kkt(16, 16, dof=3, ncon=2, seed=4, delta_c=dc),
+}
+OPTS = [dict(), dict(ordering=1), dict(ordering=2, nemin=1), dict(matching=0), dict(nemin=32, max_sn_cols=128), dict(nd_leaf=16, nemin=2)]
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("opts", OPTS, ids=[str(o) for o in OPTS])
+def test_symbolic_structures_solve_the_system(case, opts):
+    # without the 2x2 pre-pairing a zero (2,2) diagonal is a zero pivot by construction: exercise that
+    # option on the quasi-definite variant (delta_c = 1) -- this test is about structures, not pivoting
+    n, r, c, v, neg = CASES[case](1.0) if not opts.get("matching", 1) else CASES[case]()
+    s = ipopt_amd.KKTSolver(**opts)
+    s.initialize_structure(n, r, c, vals=v)
+    sym = mirror.fetch(s)
+    I = sym["info"]
+    assert sorted(sym["perm"].tolist()) == list(range(n))
+    assert I.nnz_l >= I.nnz_a and I.num_levels >= 1 and I.maxfront <= n
+    # level schedule: every child strictly below its parent; buckets cover every supernode once
+    par, lev = sym["parent"], sym["level"]
+    for sn in range(I.num_sn):
+        if par[sn] >= 0:
+            assert lev[sn] < lev[par[sn]]
+    lsn = s.symbolic(14, I.num_sn)
+    assert sorted(lsn.tolist()) == list(range(I.num_sn))
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.linspace(1.0, 2.0, n)
+    x, nneg = mirror.factor_solve(sym, v, b)
+    assert nneg == neg
+    assert np.abs(K @ x - b).max() <= 1e-9 * np.abs(b).max()
+    # pre-pairing: pairs are mutual, adjacent in the elimination order and inside one supernode
+    pair = sym["pair"]
+    iperm = np.empty(n, dtype=np.int64); iperm[sym["perm"]] = np.arange(n)
+    snof = np.repeat(np.arange(I.num_sn), np.diff(sym["colptr"]))
+    for i in np.where(pair >= 0)[0]:
+        j = pair[i]
+        assert pair[j] == i and abs(iperm[i] - iperm[j]) == 1 and snof[iperm[i]] == snof[iperm[j]]
+    if opts.get("matching", 1):
+        assert I.num_pairs == neg    # every zero-diagonal constraint row found a partner
+
+
+def test_duplicates_and_mixed_triangles_are_summed():
+    """SURVEY 8(b) pitfall 1: Ipopt's triplets always contain duplicates (diag(W) and D_x) and may list an
+    entry in either triangle; both must be canonicalised (reference IpTripletToCSRConverter.cpp:352-359)."""
+    n, r, c, v, _ = kktgen.lukvl_like(50, seed=5)
+    rng = np.random.default_rng(0)
+    # split every value into two duplicates, flip triangles at random, shuffle
+    r2 = np.concatenate([r, r]); c2 = np.concatenate([c, c]); v2 = np.concatenate([0.25 * v, 0.75 * v])
+    flip = rng.random(r2.shape[0]) < 0.5
+    r2[flip], c2[flip] = c2[flip].copy(), r2[flip].copy()
+    p = rng.permutation(r2.shape[0]); r2, c2, v2 = r2[p], c2[p], v2[p]
+    s1 = ipopt_amd.KKTSolver(); s1.initialize_structure(n, r, c, vals=v)
+    s2 = ipopt_amd.KKTSolver(); s2.initialize_structure(n, r2, c2, vals=v2)
+    assert s1.info().nnz_a == s2.info().nnz_a
+    K = kktgen.to_scipy(n, r, c, v); b = K @ np.ones(n)
+    x2, _ = mirror.factor_solve(mirror.fetch(s2), v2, b)
+    assert np.abs(x2 - 1).max() < 1e-8
+
+
+def test_csr_upper_format_equals_triplet():
+    n, r, c, v, _ = kktgen.grid_kkt(6, 5, dof=1, ncon=1, seed=6)
+    K = kktgen.to_scipy(n, r, c, v)
+    import scipy.sparse as sp
+    U = sp.triu(K).tocsr(); U.sort_indices()
+    s = ipopt_amd.KKTSolver()
+    s.initialize_structure(n, (U.indptr + 1).astype(np.int32), (U.indices + 1).astype(np.int32), fmt=1, vals=U.data)
+    b = K @ np.ones(n)
+    x, _ = mirror.factor_solve(mirror.fetch(s), U.data, b)
+    assert np.abs(x - 1).max() < 1e-8
+
+
+def test_edge_cases_empty_diagonal_and_ragged():
+    s = ipopt_amd.KKTSolver()
+    s.initialize_structure(0, np.zeros(0, np.int32), np.zeros(0, np.int32))
+    assert s.info().n == 0 and s.info().num_sn == 0
+    # purely diagonal matrix given with a missing diagonal entry (structurally singular row is allowed)
+    s = ipopt_amd.KKTSolver()
+    s.initialize_structure(4, np.array([1, 2, 4], np.int32), np.array([1, 2, 4], np.int32), vals=np.array([1.0, -2.0, 3.0]))
+    I = s.info()
+    assert I.n == 4 and I.nnz_a == 4 and I.nnz_l == 4
+    # one dense row (arrow matrix): everything ends up in few fronts, still valid
+    n = 40
+    r = np.concatenate([np.arange(1, n + 1), np.full(n - 1, n)]).astype(np.int32)
+    c = np.concatenate([np.arange(1, n + 1), np.arange(1, n)]).astype(np.int32)
+    v = np.concatenate([np.full(n, 4.0), np.full(n - 1, 0.1)])
+    s = ipopt_amd.KKTSolver(); s.initialize_structure(n, r, c, vals=v)
+    K = kktgen.to_scipy(n, r, c, v); b = K @ np.ones(n)
+    x, neg = mirror.factor_solve(mirror.fetch(s), v, b)
+    assert neg == 0 and np.abs(x - 1).max() < 1e-10
+    with pytest.raises(ipopt_amd.KKTError):
+        ipopt_amd.KKTSolver().initialize_structure(3, np.array([1, 5], np.int32), np.array([1, 1], np.int32))
+
+
+@pytest.mark.parametrize("nranks", [2, 4, 8])
+def test_multigpu_ownership_is_a_subtree_partition(nranks):
+    n, r, c, v, _ = kktgen.grid_kkt(24, 24, dof=2, ncon=1, seed=7)
+    s = ipopt_amd.KKTSolver(nranks=nranks)
+    s.initialize_structure(n, r, c, vals=v)
+    sym = mirror.fetch(s)
+    own, par = sym["owner"], sym["parent"]
+    assert set(np.unique(own)) <= set(range(-1, nranks)) and (own >= 0).any()
+    for sn in range(sym["info"].num_sn):
+        p = par[sn]
+        if own[sn] == -1:
+            assert p < 0 or own[p] == -1            # the replicated top is closed upwards
+        elif p >= 0:
+            assert own[p] in (own[sn], -1)          # a subtree never crosses ranks
+    assert len(set(own[own >= 0].tolist())) == nranks
