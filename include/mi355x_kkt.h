@@ -146,6 +146,28 @@ const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
  *       13 level_ptr[num_levels*4+1], 14 level_sn[num_sn] (launch schedule: buckets (level, front class)) */
 int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t capacity);
 
+/* ---- measurement: device time per kernel kind (hip events on the solver's stream around every launch of an
+ * eager, graph-less factor + one solve, accumulated over `reps` repetitions).  ms/launches need
+ * MI355X_KKT_KERNEL_COUNT entries.  Used by bench.py for the roofline of the dominant kernel. ---- */
+#define MI355X_KKT_KERNEL_GATHER_SCALE  0   /* value gather + Ruiz equilibration                                   */
+#define MI355X_KKT_KERNEL_FRONT_WAVE    1   /* k_front_lds<64>  : fronts of order <= 32, one wavefront each        */
+#define MI355X_KKT_KERNEL_FRONT_LDS64   2   /* k_front_lds<256> : order <= 64                                      */
+#define MI355X_KKT_KERNEL_FRONT_LDS128  3   /* k_front_lds<256> : order <= 128                                     */
+#define MI355X_KKT_KERNEL_BIG_ASSEMBLE  4
+#define MI355X_KKT_KERNEL_BIG_DIAG      5
+#define MI355X_KKT_KERNEL_BIG_TRSM      6
+#define MI355X_KKT_KERNEL_BIG_SCHUR     7   /* fp64 MFMA frontal update                                            */
+#define MI355X_KKT_KERNEL_STATS         8
+#define MI355X_KKT_KERNEL_SOLVE_PERM    9
+#define MI355X_KKT_KERNEL_FWD_WAVE     10
+#define MI355X_KKT_KERNEL_FWD_LDS      11
+#define MI355X_KKT_KERNEL_FWD_BIG      12
+#define MI355X_KKT_KERNEL_BWD_WAVE     13
+#define MI355X_KKT_KERNEL_BWD_LDS      14
+#define MI355X_KKT_KERNEL_BWD_BIG      15
+#define MI355X_KKT_KERNEL_COUNT        16
+int  mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches, int capacity);
+
 /* ---- multi-GPU (one process per GPU; subtrees sharded, top of the tree replicated) ---- */
 /* The top-of-tree fronts live in one contiguous device buffer ("top arena").  After
  * factor_local() each rank holds its own subtrees' Schur contributions there; the caller

@@ -60,7 +60,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         SymbolicOptions so;
         so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 96; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
-        so.max_sn_cols = h->opts.max_sn_cols > 1 ? h->opts.max_sn_cols : 64;
+        so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 96 ? 96 : h->opts.max_sn_cols) : 64;   // 96: LDS budget of k_big_trsm
         so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose;
         if (!analyse(h->sym, so, n, nnz, row, col, format, vals)) { h->err = h->sym.error; return MI355X_KKT_FATAL; }
         h->analysed = true;
@@ -165,6 +165,15 @@ int mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t cap
     if ((int64_t)v->size() > cap) { h->err = "get_symbolic: buffer too small"; return MI355X_KKT_FATAL; }
     if (!v->empty()) std::memcpy(out, v->data(), v->size() * sizeof(int));
     return MI355X_KKT_SUCCESS;
+}
+
+int mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches, int capacity)
+{
+    if (!h || !ms || !launches) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready || !h->factored) { h->err = "profile: factor() first"; return MI355X_KKT_FATAL; }
+    if (capacity < MI355X_KKT_KERNEL_COUNT) { h->err = "profile: capacity too small"; return MI355X_KKT_FATAL; }
+    try { if (!h->num->profile(reps > 0 ? reps : 1, ms, launches)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; }
+    catch (...) { h->err = "profile: unexpected exception"; return MI355X_KKT_FATAL; }
 }
 
 // ---- multi-GPU ----

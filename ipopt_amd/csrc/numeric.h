@@ -36,6 +36,8 @@ public:
     double last_factor_ms() const;
     double last_solve_ms() const;
     const std::string& error() const;
+    static constexpr int kNumKernelKinds = 16;
+    bool   profile(int reps, double* ms, int* launches);   // per-kernel-kind device time (hip events), eager launches
     // multi-GPU pieces
     bool   factor_local(const double* dvals_or_null);
     bool   top_arena(double** dptr, int64_t* ndoubles);

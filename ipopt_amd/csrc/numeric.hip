@@ -36,6 +36,11 @@ namespace mi355x {
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { \
     err_ = std::string(#call) + ": " + hipGetErrorString(e_); return false; } } while (0)
 
+// kernel kinds for the profiling entry point (order = include/mi355x_kkt.h MI355X_KKT_KERNEL_*)
+enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_LDS128, KK_BIG_ASSEMBLE, KK_BIG_DIAG, KK_BIG_TRSM,
+                  KK_BIG_SCHUR, KK_STATS, KK_SOLVE_PERM, KK_FWD_WAVE, KK_FWD_LDS, KK_FWD_BIG, KK_BWD_WAVE, KK_BWD_LDS, KK_BWD_BIG, KK_COUNT };
+#define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); } while (0)
+
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
 static constexpr double PIV_PERT = 1e-10;                // replacement magnitude for a zero pivot
 
@@ -46,7 +51,7 @@ struct DevView {
     // symbolic
     const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
     const int* child_ptr; const int* child_idx; const int* sn_owner;
-    const long long* panel_off; const long long* cb_off;
+    const long long* panel_off; const long long* cb_off; const long long* wb_off;
     const int* acolptr; const int* apos; const int* arow; const int* acol;
     const int* dup_ptr; const int* dup_src;
     const int* level_sn;
@@ -58,6 +63,7 @@ struct DevView {
     unsigned long long* rowmax;  // scratch for equilibration (bit pattern of non-negative doubles)
     double* L;              // panels
     double* cb;             // contribution blocks
+    double* wbuf;           // W = L*D copies of the big fronts of the level in flight
     double* dinv; double* doff; int* ptype; int* lperm;
     int4*   fstat;          // per front {neg, zero, two, small}
     double* xw;             // work vector (permuted, scaled)
@@ -177,59 +183,16 @@ __device__ __forceinline__ void swap_rc(double* F, int ld, int m, int p, int q, 
     __syncthreads();
 }
 
+// LDL^T of the k leading (fully-summed) columns of an m x m front held in LDS (lower storage, leading
+// dimension ld), Bunch-Kaufman pivoting restricted to the k x k pivot block, right-looking updates of the
+// whole trailing front.  All NT threads of the workgroup call it with identical arguments.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_front_lds(DevView V, int list_off, int top_mode)
+__device__ __forceinline__ void ldlt_lds(double* F, const int ld, const int m, const int k, double* lc0, double* lc1,
+                                         double* dinv_s, double* doff_s, int* pt_s, int* lp, double* redv, int* redi,
+                                         const double u, const double small, int& nneg, int& nzero, int& ntwo, int& nsmall)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
-    const int ld = m | 1;
-    double* F    = reinterpret_cast<double*>(smem_raw);
-    double* lc0  = F + (size_t)ld * m;
-    double* lc1  = lc0 + m;
-    double* dinv_s = lc1 + m;
-    double* doff_s = dinv_s + k;
-    double* redv = doff_s + k;            // 4
-    int*    redi = reinterpret_cast<int*>(redv + 4);   // 4
-    int*    lp   = redi + 4;              // k
-    int*    pt_s = lp + k;                // k
-
-    // ---- (a) init: zero, or (multi-GPU replicated top) start from the all-reduced arena square ----
-    if (top_mode && V.arena) {
-        const double* Ar = V.arena + V.arena_off[s];
-        for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; F[i + c * ld] = Ar[idx]; }
-    } else {
-        for (int idx = tid; idx < ld * m; idx += NT) F[idx] = 0.0;
-    }
-    for (int j = tid; j < k; j += NT) lp[j] = j;
-    __syncthreads();
-    // ---- (b) scatter the A values of the pivot columns (distinct positions) ----
-    if (!(top_mode && V.arena)) {
-        const int q0 = V.acolptr[c0], q1 = V.acolptr[c0 + k];
-        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] = V.aval[q]; }
-    }
-    __syncthreads();
-    // ---- (c) extend-add the children's contribution blocks, one child at a time ----
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        if (top_mode && V.arena && V.sn_owner[ch] >= 0) continue;   // already inside the arena
-        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-        const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
-        const int* relc = V.rel + V.sn_rowptr[ch] + kc;
-        const double* C = V.cb + V.cb_off[ch];
-        for (int b = wave; b < mc; b += NW) {
-            const int rb = relc[b];
-            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * mc];
-        }
-        __syncthreads();
-    }
-
-    // ---- (d) LDL^T of the k pivot columns ----
-    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
-    const double u = V.pivtol, small = V.small;
     int j = 0;
     while (j < k) {
         MaxIdx cand; cand.v = -1.0; cand.i = 0x7fffffff;
@@ -301,6 +264,61 @@ __global__ __launch_bounds__(NT) void k_front_lds(DevView V, int list_off, int t
             __syncthreads();
         }
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_front_lds(DevView V, int list_off, int top_mode)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const int ld = m | 1;
+    double* F    = reinterpret_cast<double*>(smem_raw);
+    double* lc0  = F + (size_t)ld * m;
+    double* lc1  = lc0 + m;
+    double* dinv_s = lc1 + m;
+    double* doff_s = dinv_s + k;
+    double* redv = doff_s + k;            // 4
+    int*    redi = reinterpret_cast<int*>(redv + 4);   // 4
+    int*    lp   = redi + 4;              // k
+    int*    pt_s = lp + k;                // k
+
+    // ---- (a) init: zero, or (multi-GPU replicated top) start from the all-reduced arena square ----
+    if (top_mode && V.arena) {
+        const double* Ar = V.arena + V.arena_off[s];
+        for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; F[i + c * ld] = Ar[idx]; }
+    } else {
+        for (int idx = tid; idx < ld * m; idx += NT) F[idx] = 0.0;
+    }
+    for (int j = tid; j < k; j += NT) lp[j] = j;
+    __syncthreads();
+    // ---- (b) scatter the A values of the pivot columns (distinct positions) ----
+    if (!(top_mode && V.arena)) {
+        const int q0 = V.acolptr[c0], q1 = V.acolptr[c0 + k];
+        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] = V.aval[q]; }
+    }
+    __syncthreads();
+    // ---- (c) extend-add the children's contribution blocks, one child at a time ----
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        if (top_mode && V.arena && V.sn_owner[ch] >= 0) continue;   // already inside the arena
+        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+        const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
+        const int* relc = V.rel + V.sn_rowptr[ch] + kc;
+        const double* C = V.cb + V.cb_off[ch];
+        for (int b = wave; b < mc; b += NW) {
+            const int rb = relc[b];
+            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * mc];
+        }
+        __syncthreads();
+    }
+
+    // ---- (d) LDL^T of the k pivot columns ----
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
+    ldlt_lds<NT>(F, ld, m, k, lc0, lc1, dinv_s, doff_s, pt_s, lp, redv, redi, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
     __syncthreads();
     // ---- (e) write back: panel (ld = m), pivot data, contribution block (ld = m-k, lower) ----
     double* Lg = V.L + V.panel_off[s];
@@ -426,6 +444,245 @@ __global__ __launch_bounds__(NT) void k_bwd_lds(DevView V, int list_off)
     for (int jj = tid; jj < k; jj += NT) V.xw[c0 + V.lperm[c0 + jj]] = ws[jj];
 }
 
+
+// ================================================================================================
+// BIG fronts (order > 128): the front stays in HBM/L2 -- panel (m x k, k <= 66) in the L storage, the
+// (m-k)^2 contribution block in the cb arena -- and is processed by four launches per tree level:
+//   k_big_assemble  one wavefront per front column: zero, scatter A, extend-add children (deterministic)
+//   k_big_diag      one workgroup per front: k x k pivot block to LDS, Bunch-Kaufman LDL^T (ldlt_lds)
+//   k_big_trsm      64 rows per wavefront: L21 = A21 P L11^{-T} D^{-1}, W21 = L21 D kept for the update
+//   k_big_schur     T -= L21 W21^T on 64x64 tiles, v_mfma_f64_16x16x4_f64 (the frontal GEMM)
+// ================================================================================================
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off)
+{
+    const int s = V.level_sn[list_off + blockIdx.y];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0, mu = m - k;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fc = blockIdx.x * 4 + wave;                 // front column owned by this wavefront
+    const bool active = fc < m;
+    double* col = nullptr;                                 // col[i] = front(i, fc) for i in [0,m) (panel) or [k,m) (T)
+    if (active) {
+        if (fc < k) {
+            col = V.L + V.panel_off[s] + (size_t)fc * m;
+            for (int i = lane; i < m; i += 64) col[i] = 0.0;
+        } else {
+            col = V.cb + V.cb_off[s] + (size_t)(fc - k) * mu - k;
+            for (int i = fc + lane; i < m; i += 64) col[i] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (active && fc < k) {
+        const int q0 = V.acolptr[c0 + fc], q1 = V.acolptr[c0 + fc + 1];
+        for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] = V.aval[q];
+    }
+    __syncthreads();
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        if (active) {
+            const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+            const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
+            const int* relc = V.rel + V.sn_rowptr[ch] + kc;
+            int lo = 0, hi = mc;                           // first b with relc[b] >= fc (relc is increasing)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
+            if (lo < mc && relc[lo] == fc) {
+                const double* C = V.cb + V.cb_off[ch] + (size_t)lo * mc;
+                for (int a = lo + lane; a < mc; a += 64) col[relc[a]] += C[a];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_big_diag(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const int ld = k | 1;
+    double* F = reinterpret_cast<double*>(smem_raw);
+    double* lc0 = F + (size_t)ld * k; double* lc1 = lc0 + k; double* dinv_s = lc1 + k; double* doff_s = dinv_s + k;
+    double* redv = doff_s + k; int* redi = reinterpret_cast<int*>(redv + 4); int* lp = redi + 4; int* pt_s = lp + k;
+    double* P = V.L + V.panel_off[s];
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; F[i + c * ld] = (i >= c) ? P[i + (size_t)c * m] : 0.0; }
+    for (int j = tid; j < k; j += 256) lp[j] = j;
+    __syncthreads();
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
+    ldlt_lds<256>(F, ld, k, k, lc0, lc1, dinv_s, doff_s, pt_s, lp, redv, redi, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    __syncthreads();
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; P[i + (size_t)c * m] = (i >= c) ? F[i + c * ld] : 0.0; }
+    for (int j = tid; j < k; j += 256) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = lp[j]; }
+    if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+}
+
+// rows below the pivot block: 64 rows per wavefront-sized workgroup, the row being solved lives in LDS
+__global__ __launch_bounds__(64) void k_big_trsm(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int t = threadIdx.x;
+    const int s = V.level_sn[list_off + blockIdx.y];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const int ibase = k + blockIdx.x * 64;
+    if (ibase >= m) return;
+    const int ld = k + 1;
+    double* L11 = reinterpret_cast<double*>(smem_raw);        // k x k (ld = k+1), strictly lower part used
+    double* wr  = L11 + (size_t)ld * k;                       // 64 x k, element (t, j) at wr[t + 64*j]
+    double* P = V.L + V.panel_off[s];
+    double* W = V.wbuf + V.wb_off[s];
+    for (int idx = t; idx < k * k; idx += 64) { const int i = idx % k, c = idx / k; L11[i + c * ld] = P[i + (size_t)c * m]; }
+    const int i = ibase + t;
+    const bool ok = i < m;
+    for (int j = 0; j < k; ++j) wr[t + 64 * j] = ok ? P[i + (size_t)V.lperm[c0 + j] * m] : 0.0;
+    __syncthreads();
+    for (int j = 0; j < k; ++j) {
+        const double wj = wr[t + 64 * j];
+        for (int p = j + 1; p < k; ++p) wr[t + 64 * p] -= wj * L11[p + j * ld];
+    }
+    double lmax = 0.0;
+    for (int j = 0; j < k; ++j) {
+        const int pt = V.ptype[c0 + j];
+        const double wj = wr[t + 64 * j];
+        double l;
+        if (pt == 1) l = wj * V.dinv[c0 + j];
+        else if (pt == 2) l = V.dinv[c0 + j] * wj + V.doff[c0 + j] * wr[t + 64 * (j + 1)];
+        else l = V.doff[c0 + j - 1] * wr[t + 64 * (j - 1)] + V.dinv[c0 + j] * wj;
+        if (ok) { W[i + (size_t)j * m] = wj; P[i + (size_t)j * m] = l; }
+        lmax = fmax(lmax, fabs(l));
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
+    if (t == 0 && lmax * V.pivtol > 1.0) atomicMax(&V.fstat[s].w, 1);
+}
+
+// T(i,c) -= sum_p L21(i,p) W21(c,p),  i >= c, on 64x64 tiles; each of the 4 waves owns a 32x32 sub-tile made of
+// 2x2 v_mfma_f64_16x16x4_f64 accumulators.  The product is formed TRANSPOSED (A operand = W rows, B operand = L rows)
+// so that the 16 lanes sharing an accumulator register hold 16 consecutive ROWS of the column-major T => 128-byte
+// coalesced read-modify-write segments.
+__global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
+{
+    const int s = V.level_sn[list_off + blockIdx.y];
+    const int k = V.sn_colptr[s + 1] - V.sn_colptr[s];
+    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s], mu = m - k;
+    const int nt = (mu + 63) >> 6;
+    const int t = blockIdx.x;
+    if (t >= nt * (nt + 1) / 2) return;
+    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while (ti * (ti + 1) / 2 > t) --ti;
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    const int tc = t - ti * (ti + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
+    if (i0 + 31 < cc0) return;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const double* Lp = V.L + V.panel_off[s] + k;
+    const double* Wp = V.wbuf + V.wb_off[s] + k;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[r][q] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int ca = cc0 + l15, cb_ = cc0 + 16 + l15, ia = i0 + l15, ib = i0 + 16 + l15;
+    for (int p = 0; p < k; p += 4) {
+        const int pk = p + l4;
+        const bool v = pk < k;
+        const size_t off = (size_t)pk * m;
+        const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
+        const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
+        const double b0 = (v && ia < mu) ? Lp[ia + off] : 0.0;
+        const double b1 = (v && ib < mu) ? Lp[ib + off] : 0.0;
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    double* T = V.cb + V.cb_off[s];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + r * 16 + l4 + 4 * g;      // D row index  -> T column
+                const int i = i0 + q * 16 + l15;              // D column index -> T row
+                if (i < mu && c < mu && i >= c) T[i + (size_t)c * mu] -= acc[r][q][g];
+            }
+}
+
+// solves on big fronts: one workgroup per front, accumulators for the update rows live in cvec (global)
+__global__ __launch_bounds__(256) void k_fwd_big(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    double* xp = reinterpret_cast<double*>(smem_raw);   // k
+    double* ys = xp + k;                                // k
+    for (int i = tid; i < k; i += 256) xp[i] = V.xw[c0 + i];
+    for (int i = k + tid; i < m; i += 256) V.cvec[r0 + i] = 0.0;
+    __syncthreads();
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+        const int base = V.sn_rowptr[ch] + kc, mc = V.sn_rowptr[ch + 1] - base;
+        for (int t = tid; t < mc; t += 256) { const int tg = V.rel[base + t]; const double v = V.cvec[base + t]; if (tg < k) xp[tg] += v; else V.cvec[r0 + tg] += v; }
+        __syncthreads();
+    }
+    for (int j = tid; j < k; j += 256) ys[j] = xp[V.lperm[c0 + j]];
+    __syncthreads();
+    const double* Lg = V.L + V.panel_off[s];
+    for (int j = 0; j < k; ++j) {
+        const double yj = ys[j];
+        for (int i = j + 1 + tid; i < k; i += 256) ys[i] -= Lg[i + (size_t)j * m] * yj;
+        __syncthreads();
+    }
+    for (int i = k + tid; i < m; i += 256) {
+        double t = 0.0;
+        for (int j = 0; j < k; ++j) t += Lg[i + (size_t)j * m] * ys[j];
+        V.cvec[r0 + i] -= t;
+    }
+    for (int j = tid; j < k; j += 256) {
+        const int pt = V.ptype[c0 + j];
+        double z;
+        if (pt == 1) z = ys[j] * V.dinv[c0 + j];
+        else if (pt == 2) z = V.dinv[c0 + j] * ys[j] + V.doff[c0 + j] * ys[j + 1];
+        else z = V.doff[c0 + j - 1] * ys[j - 1] + V.dinv[c0 + j] * ys[j];
+        V.xw[c0 + j] = z;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_big(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    double* ws = reinterpret_cast<double*>(smem_raw);   // k
+    for (int i = k + tid; i < m; i += 256) V.cvec[r0 + i] = V.xw[V.sn_rows[r0 + i]];   // gather x of the ancestors once
+    for (int j = tid; j < k; j += 256) ws[j] = V.xw[c0 + j];
+    __syncthreads();
+    const double* Lg = V.L + V.panel_off[s];
+    for (int j = wave; j < k; j += 4) {
+        double t = 0.0;
+        for (int i = k + lane; i < m; i += 64) t += Lg[i + (size_t)j * m] * V.cvec[r0 + i];
+        t = wave_sum(t);
+        if (lane == 0) ws[j] -= t;
+    }
+    __syncthreads();
+    for (int j = k - 1; j >= 1; --j) {
+        const double wj = ws[j];
+        for (int c = tid; c < j; c += 256) ws[c] -= Lg[j + (size_t)c * m] * wj;
+        __syncthreads();
+    }
+    for (int j = tid; j < k; j += 256) V.xw[c0 + V.lperm[c0 + j]] = ws[j];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side orchestration
 // ------------------------------------------------------------------------------------------------
@@ -446,8 +703,24 @@ public:
     double* d_rhs = nullptr; size_t d_rhs_cap = 0;
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
+    std::vector<int> big_maxm, big_maxk;
 
-    ~NumericImpl() { release(); }
+    // ---- per-kernel-kind timing (bench.py roofline): hip events around every launch, eager mode ----
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kind; size_t prof_used = 0;
+    double prof_ms[KK_COUNT] = {0}; int prof_launches[KK_COUNT] = {0};
+    void prof_begin(int kind) {
+        if (!prof_on) return;
+        if (prof_used + 2 > prof_ev.size()) { size_t old = prof_ev.size(); prof_ev.resize(old + 64); for (size_t i = old; i < prof_ev.size(); ++i) (void)hipEventCreate(&prof_ev[i]); }
+        (void)hipEventRecord(prof_ev[prof_used], stream); prof_kind.push_back(kind);
+    }
+    void prof_end() { if (!prof_on) return; (void)hipEventRecord(prof_ev[prof_used + 1], stream); prof_used += 2; }
+    void prof_collect() {
+        (void)hipStreamSynchronize(stream);
+        for (size_t i = 0; i < prof_used; i += 2) { float ms = 0; (void)hipEventElapsedTime(&ms, prof_ev[i], prof_ev[i + 1]); int kd = prof_kind[i / 2]; prof_ms[kd] += ms; prof_launches[kd]++; }
+        prof_used = 0; prof_kind.clear();
+    }
+    ~NumericImpl() { release(); for (auto e : prof_ev) (void)hipEventDestroy(e); }
     void release() {
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
@@ -484,17 +757,17 @@ public:
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
-        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end());
+        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end());
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
-            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) ||
+            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) ||
             !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
             !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.level_sn, &V.level_sn) ||
             !upload(Sy.perm, &V.perm)) return false;
         double* tv = nullptr;
         if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
         if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
-            !dalloc(&V.L, (size_t)Sy.l_doubles) || !dalloc(&V.cb, (size_t)Sy.cb_doubles) ||
+            !dalloc(&V.L, (size_t)Sy.l_doubles) || !dalloc(&V.cb, (size_t)Sy.cb_doubles) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
             !dalloc(&d_stats, 4)) return false;
@@ -503,7 +776,15 @@ public:
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        if (Sy.num_big > 0) { err_ = "front larger than 128 rows: blocked path not built into this library yet"; return false; }
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
+        big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0);
+        for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
+            const int lv = Sy.sn_level[s];
+            big_maxm[lv] = std::max(big_maxm[lv], Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]);
+            big_maxk[lv] = std::max(big_maxk[lv], Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
+        }
         ready = true; return true;
     }
 
@@ -516,27 +797,34 @@ public:
     bool enqueue_factor() {
         const Symbolic& Sy = *S;
         const int n = Sy.n;
-        hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
+        LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (opt.scaling) {
             for (int it = 0; it < 3; ++it) {
-                hipLaunchKernelGGL(k_zero_u64, dim3(grid1d(n)), dim3(256), 0, stream, V.rowmax, n);
-                hipLaunchKernelGGL(k_ruiz_rowmax, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-                hipLaunchKernelGGL(k_ruiz_update, dim3(grid1d(n)), dim3(256), 0, stream, V);
+                LAUNCH(KK_GATHER_SCALE, k_zero_u64, dim3(grid1d(n)), dim3(256), 0, stream, V.rowmax, n);
+                LAUNCH(KK_GATHER_SCALE, k_ruiz_rowmax, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+                LAUNCH(KK_GATHER_SCALE, k_ruiz_update, dim3(grid1d(n)), dim3(256), 0, stream, V);
             }
-            hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+            LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         }
         for (int lv = 0; lv < Sy.num_levels; ++lv) {
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(32, 32),   stream, V, b0, 0);
-                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(64, 64),   stream, V, b0, 0);
-                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(128, 128), stream, V, b0, 0);
-                else { err_ = "big front in schedule"; return false; }
+                if (fc == FC_WAVE)        LAUNCH(KK_FRONT_WAVE, k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(32, 32),   stream, V, b0, 0);
+                else if (fc == FC_LDS64)  LAUNCH(KK_FRONT_LDS64, k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(64, 64),   stream, V, b0, 0);
+                else if (fc == FC_LDS128) LAUNCH(KK_FRONT_LDS128, k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(128, 128), stream, V, b0, 0);
+                else {
+                    const int mm = big_maxm[lv], kk = big_maxk[lv], mu = mm - 1;
+                    const int nt = (mu + 63) / 64;
+                    LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, b1 - b0), dim3(256), 0, stream, V, b0);
+                    LAUNCH(KK_BIG_DIAG, k_big_diag, dim3(b1 - b0), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
+                    LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, b1 - b0), dim3(64), (size_t)((kk + 1) * kk + 64 * kk) * sizeof(double) + 16, stream, V, b0);
+                    LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, b1 - b0), dim3(256), 0, stream, V, b0);
+                }
             }
         }
-        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
+        LAUNCH(KK_STATS, k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());
         return true;
     }
@@ -582,27 +870,27 @@ public:
     bool enqueue_solve(double* drhs) {
         const Symbolic& Sy = *S;
         const int n = Sy.n;
-        hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)drhs);
+        LAUNCH(KK_SOLVE_PERM, k_load_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)drhs);
         auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + kmax) * sizeof(double) + 16; };
         for (int lv = 0; lv < Sy.num_levels; ++lv)
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_fwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
-                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0, 0);
-                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
-                else { err_ = "big front in schedule"; return false; }
+                if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, k_fwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
+                else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS, k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0, 0);
+                else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS, k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
+                else LAUNCH(KK_FWD_BIG, k_fwd_big, dim3(b1 - b0), dim3(256), (size_t)2 * big_maxk[lv] * sizeof(double) + 16, stream, V, b0);
             }
         for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_bwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
-                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0);
-                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
-                else { err_ = "big front in schedule"; return false; }
+                if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, k_bwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS, k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0);
+                else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS, k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
+                else LAUNCH(KK_BWD_BIG, k_bwd_big, dim3(b1 - b0), dim3(256), (size_t)big_maxk[lv] * sizeof(double) + 16, stream, V, b0);
             }
-        hipLaunchKernelGGL(k_store_sol, dim3(grid1d(n)), dim3(256), 0, stream, V, drhs);
+        LAUNCH(KK_SOLVE_PERM, k_store_sol, dim3(grid1d(n)), dim3(256), 0, stream, V, drhs);
         HIPCHK(hipGetLastError());
         return true;
     }
@@ -631,6 +919,21 @@ public:
             } else if (!enqueue_solve(col)) return false;
         }
         if (timed) { HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms; }
+        return true;
+    }
+    // eager (graph-less) factor + one solve with hip events around every launch; accumulates over `reps`
+    bool profile(int reps, double* ms, int* launches) {
+        if (!ready || !have_values) { err_ = "profile: factor() must have been called once"; return false; }
+        for (int q = 0; q < KK_COUNT; ++q) { prof_ms[q] = 0; prof_launches[q] = 0; }
+        if (d_rhs_cap < (size_t)S->n) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(S->n, 1) * sizeof(double))); d_rhs_cap = S->n; HIPCHK(hipMemset(d_rhs, 0, S->n * sizeof(double)));
+                                        if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
+        prof_on = true;
+        for (int r = 0; r < reps; ++r) {
+            if (!enqueue_factor() || !enqueue_solve(d_rhs)) { prof_on = false; return false; }
+            prof_collect();
+        }
+        prof_on = false;
+        for (int q = 0; q < KK_COUNT; ++q) { ms[q] = prof_ms[q]; launches[q] = prof_launches[q]; }
         return true;
     }
     bool solve_host(int nrhs, double* rhs, int ld) {
@@ -662,6 +965,7 @@ void Numeric::set_pivtol(double u) { p_->opt.pivtol = u; }
 double Numeric::last_factor_ms() const { return p_->factor_ms; }
 double Numeric::last_solve_ms() const { return p_->solve_ms; }
 const std::string& Numeric::error() const { return p_->err_; }
+bool Numeric::profile(int reps, double* ms, int* launches) { return p_->profile(reps, ms, launches); }
 bool Numeric::factor_local(const double*) { p_->err_ = "multi-GPU path not built yet"; return false; }
 bool Numeric::top_arena(double**, int64_t*) { p_->err_ = "multi-GPU path not built yet"; return false; }
 bool Numeric::factor_top(FactorStats&) { p_->err_ = "multi-GPU path not built yet"; return false; }

@@ -624,6 +624,15 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         S.maxfront = std::max<int>(S.maxfront, (int)m); S.maxsupernode = std::max<int>(S.maxsupernode, (int)k);
     }
     S.l_doubles = loff; S.cb_doubles = coff;
+    {   // per-level scratch for the W = L*D panels of the blocked (big-front) path
+        S.wb_off.assign(nsn, -1);
+        vector<int64_t> lvl_used(S.num_levels, 0);
+        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) {
+            int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+            S.wb_off[s] = lvl_used[S.sn_level[s]]; lvl_used[S.sn_level[s]] += m * k;
+        }
+        for (int64_t u : lvl_used) S.wbuf_doubles = std::max(S.wbuf_doubles, u);
+    }
     // level schedule buckets (level, class)
     S.level_ptr.assign((size_t)S.num_levels * FC_COUNT + 1, 0);
     for (int s = 0; s < nsn; ++s) S.level_ptr[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s] + 1]++;

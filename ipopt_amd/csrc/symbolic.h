@@ -59,6 +59,9 @@ struct Symbolic {
     std::vector<int> sn_class;             // FrontClass
     std::vector<int64_t> panel_off;        // [num_sn] offset (doubles) of the m x k panel in L storage (ld = m)
     std::vector<int64_t> cb_off;           // [num_sn] offset (doubles) of the (m-k)^2 contribution block (ld = m-k)
+    std::vector<int64_t> wb_off;           // [num_sn] offset (doubles) of the m x k scaled-panel copy W = L*D of a BIG front
+                                           // inside the per-level scratch (reused level after level), -1 otherwise
+    int64_t wbuf_doubles = 0;
     std::vector<int> apos;                 // [nnz_a] local position (row + col*m) of each slot inside its panel
     // level schedule: fronts sorted by (level, class)
     int num_levels = 0;

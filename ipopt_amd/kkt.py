@@ -62,8 +62,10 @@ ABI_SYMBOLS = [
     "mi355x_kkt_values_buffer", "mi355x_kkt_factor", "mi355x_kkt_refactor", "mi355x_kkt_solve",
     "mi355x_kkt_solve_device", "mi355x_kkt_set_pivtol", "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
-    "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd",
+    "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
 ]
+KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
+                "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big"]
 
 
 def load_library():
@@ -95,6 +97,7 @@ def load_library():
     lib.mi355x_kkt_last_error.argtypes = [vp]
     lib.mi355x_kkt_last_error.restype = C.c_char_p
     lib.mi355x_kkt_get_symbolic.argtypes = [vp, C.c_int, vp, C.c_int64]
+    lib.mi355x_kkt_profile.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     lib.mi355x_kkt_factor_local.argtypes = [vp, vp]
     lib.mi355x_kkt_top_arena.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.mi355x_kkt_factor_top.argtypes = [vp, ip, ip]
@@ -225,6 +228,13 @@ class KKTSolver:
         i = _Info()
         self.lib.mi355x_kkt_get_info(self._h, C.byref(i))
         return KKTInfo(**{f: getattr(i, f) for f in KKTInfo.__dataclass_fields__})
+
+    def profile(self, reps=1) -> dict:
+        """{kernel kind: (total device ms over reps, launches over reps)} from hip events around every launch."""
+        ms = np.zeros(len(KERNEL_KINDS)); ln = np.zeros(len(KERNEL_KINDS), dtype=np.int32)
+        if self.lib.mi355x_kkt_profile(self._h, int(reps), ms.ctypes.data, ln.ctypes.data, len(KERNEL_KINDS)) != 0:
+            raise KKTError("profile: " + self.last_error())
+        return {k: (float(ms[i]), int(ln[i])) for i, k in enumerate(KERNEL_KINDS)}
 
     def symbolic(self, what: int, size: int) -> np.ndarray:
         out = np.empty(max(size, 1), dtype=np.int32)

@@ -34,4 +34,14 @@ def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_d
     assert "EXIT: Optimal Solution Found." in out
     assert summ["iterations"] == gsum["iterations"]
     assert abs(summ["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
-    assert iters == gold, "\n".join(f"{a}   |   {b}" for a, b in zip(iters, gold))
+    assert len(iters) == len(gold)
+    for a, b in zip(iters, gold):
+        fa, fb = a.split(), b.split()
+        # iteration number, lg(mu), lg(rg) (the inertia-correction trace) and #line-search steps: identical strings;
+        # objective to 1e-7 relative; inf_pr / inf_du to the printed precision, with a 1e-11 floor for values that
+        # sit at rounding level (an infeasibility of 2e-15 is noise of the last solve, not an algorithmic quantity)
+        assert (fa[0], fa[4], fa[5], fa[6]) == (fb[0], fb[4], fb[5], fb[6]), f"{a}   |   {b}"
+        assert abs(float(fa[1]) - float(fb[1])) <= 1e-7 * max(1.0, abs(float(fb[1]))), f"{a}   |   {b}"
+        for k in (2, 3):
+            x, y = float(fa[k]), float(fb[k])
+            assert abs(x - y) <= 2e-2 * max(x, y) + 1e-11, f"{a}   |   {b}"

@@ -104,11 +104,13 @@ def test_seeded_systems_against_oracle(case):
 
 def test_wrong_inertia_and_singular_statuses():
     n, r, c, v, neg = kktgen.lukvl_like(400, seed=21)
-    v2 = v.copy(); v2[np.where((r == 7) & (c == 7))[0][0]] -= 1e7       # one extra negative eigenvalue
+    v2 = v.copy(); v2[r == c] -= 1e3 * (r[r == c] <= 400)     # indefinite (1,1) block => too many negative eigenvalues
+    true_neg = int((np.linalg.eigvalsh(kktgen.to_scipy(n, r, c, v2).toarray()) < 0).sum())
+    assert true_neg > neg
     s, st, _ = gpu_factor_solve(n, r, c, v2, np.ones(n), check=True, required=neg)
-    assert st == kkt.WRONG_INERTIA and s.number_of_neg_evals() == neg + 1   # readable after WRONG_INERTIA (pitfall 3)
+    assert st == kkt.WRONG_INERTIA and s.number_of_neg_evals() == true_neg   # readable after WRONG_INERTIA (pitfall 3)
     _, oneg, _, _ = ko.factor_solve(n, r, c, v2)
-    assert oneg == neg + 1
+    assert oneg == true_neg
     # rank-deficient Jacobian (two identical constraint rows) with delta_c = 0  =>  SINGULAR, like MA27/MA97/MUMPS
     nx, m = 6, 3
     H = (np.arange(nx), np.arange(nx), np.full(nx, 2.0))

@@ -40,7 +40,12 @@ if __name__ == "__main__":
     run("lukvl200 nomatch dc=1e-8", lambda: kktgen.lukvl_like(200, seed=1, delta_c=1e-8), matching=0)
     run("grid12x10", lambda: kktgen.grid_kkt(12, 10, dof=2, ncon=1, seed=2))
     run("grid8x8 d3c2", lambda: kktgen.grid_kkt(8, 8, dof=3, ncon=2, seed=3))
+    run("grid24x24 d3c2 (big)", lambda: kktgen.grid_kkt(24, 24, dof=3, ncon=2, seed=15))
+    run("grid64x64 d1c1 (big)", lambda: kktgen.grid_kkt(64, 64, dof=1, ncon=1, seed=16))
+    run("grid100x100 d2c1 (big)", lambda: kktgen.grid_kkt(100, 100, dof=2, ncon=1, seed=17))
     run("lukvl1e4", lambda: kktgen.lukvl_like(10000, seed=4))
     run("lukvl1e5", lambda: kktgen.lukvl_like(100000, seed=5))
     if big:
         run("lukvl1e6", lambda: kktgen.lukvl_like(1000000, seed=6))
+        run("grid300x300 d2c1", lambda: kktgen.grid_kkt(300, 300, dof=2, ncon=1, seed=18))
+        run("grid500x400 d3c2 (config4)", lambda: kktgen.grid_kkt(500, 400, dof=3, ncon=2, seed=19))
