@@ -58,9 +58,9 @@ typedef struct mi355x_kkt_options {
     int    matching;        /* 1 (default) = pre-pair zero-diagonal rows with a partner column so that  */
                             /* the pair is one 2x2-capable supernode; 0 = off                           */
     int    scaling;         /* 0 none, 1 (default) = symmetric Ruiz inf-norm equilibration on device    */
-    int    nd_leaf;         /* ND stops splitting below this many (compressed) nodes; default 96        */
+    int    nd_leaf;         /* ND stops splitting below this many (compressed) nodes; default 32        */
     int    nemin;           /* relaxed-supernode amalgamation: always merge below this #cols; default 8 */
-    int    max_sn_cols;     /* cap on columns of an amalgamated supernode; default 64                   */
+    int    max_sn_cols;     /* cap on columns of an amalgamated supernode; default (and max) 64                */
     double pivtol;          /* relative pivot threshold u (default 1e-8, cf. ma97_u)                    */
     double pivtolmax;       /* upper bound for set_pivtol escalation (default 1e-4)                     */
     double small;           /* |pivot| below this (after scaling) counts as zero (default 1e-20)        */
@@ -131,6 +131,10 @@ int  mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero);
 int  mi355x_kkt_solve(mi355x_kkt_handle h, int nrhs, double* rhs_inout, int ld);
 /* Same with rhs/solution resident in device memory (nrhs columns, leading dimension ld). */
 int  mi355x_kkt_solve_device(mi355x_kkt_handle h, int nrhs, double* d_rhs_inout, int ld);
+/* Out-of-place variant: X = A^{-1} B, B untouched.  All device buffers handed to the library must be
+ * complete when the call is made (the library works on its own stream; the caller synchronises the
+ * stream that produced them). */
+int  mi355x_kkt_solve_device2(mi355x_kkt_handle h, int nrhs, const double* d_b, int ldb, double* d_x, int ldx);
 
 int  mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u);
 int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);

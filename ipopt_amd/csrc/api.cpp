@@ -28,7 +28,7 @@ void mi355x_kkt_default_options(mi355x_kkt_options* o)
     if (!o) return;
     std::memset(o, 0, sizeof(*o));
     o->device = -1; o->index_base = 1; o->ordering = 0; o->matching = 1; o->scaling = 1;
-    o->nd_leaf = 96; o->nemin = 8; o->max_sn_cols = 64;
+    o->nd_leaf = 32; o->nemin = 8; o->max_sn_cols = 64;
     o->pivtol = 1e-8; o->pivtolmax = 1e-4; o->small = 1e-20;
     o->refine_steps = 0; o->use_graph = 1; o->nranks = 1; o->rank = 0; o->verbose = 0;
 }
@@ -59,8 +59,8 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         delete h->num; h->num = nullptr;
         SymbolicOptions so;
         so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
-        so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 96; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
-        so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 96 ? 96 : h->opts.max_sn_cols) : 64;   // 96: LDS budget of k_big_trsm
+        so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
+        so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 64 ? 64 : h->opts.max_sn_cols) : 64;   // 64: LDS budget of k_big_trsm (104 KiB at k = 65)
         so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose;
         if (!analyse(h->sym, so, n, nnz, row, col, format, vals)) { h->err = h->sym.error; return MI355X_KKT_FATAL; }
         h->analysed = true;
@@ -119,6 +119,15 @@ int mi355x_kkt_solve_device(mi355x_kkt_handle h, int nrhs, double* drhs, int ld)
     if (!h->factored || !h->numeric_ready) { h->err = "solve: no factorisation available"; return MI355X_KKT_FATAL; }
     if (h->sym.n == 0 || nrhs == 0) return MI355X_KKT_SUCCESS;
     try { if (!h->num->solve_device(nrhs, drhs, ld)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; }
+    catch (...) { h->err = "solve: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
+int mi355x_kkt_solve_device2(mi355x_kkt_handle h, int nrhs, const double* db, int ldb, double* dx, int ldx)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->factored || !h->numeric_ready) { h->err = "solve: no factorisation available"; return MI355X_KKT_FATAL; }
+    if (h->sym.n == 0 || nrhs == 0) return MI355X_KKT_SUCCESS;
+    try { if (!h->num->solve_device2(nrhs, db, ldb, dx, ldx)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; }
     catch (...) { h->err = "solve: unexpected exception"; return MI355X_KKT_FATAL; }
 }
 

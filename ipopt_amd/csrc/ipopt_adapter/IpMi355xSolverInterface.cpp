@@ -39,7 +39,7 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
    roptions->AddStringOption2("mi355x_matching", "Pre-pair zero-diagonal rows into 2x2-capable supernodes.", "yes", "no", "",
                               "yes", "");
    roptions->AddLowerBoundedIntegerOption("mi355x_nemin", "Supernode amalgamation parameter.", 1, 8, "");
-   roptions->AddLowerBoundedIntegerOption("mi355x_nd_leaf", "Nested dissection leaf size.", 8, 96, "");
+   roptions->AddLowerBoundedIntegerOption("mi355x_nd_leaf", "Nested dissection leaf size.", 8, 32, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_max_sn_cols", "Maximum columns per supernode.", 2, 64, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_device", "HIP device ordinal (-1: current).", -1, -1, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_verbose", "Verbosity of the MI355X backend.", 0, 0, "");

@@ -32,6 +32,7 @@ public:
     bool   factor(const double* dvals_or_null, bool reuse_device_values, FactorStats& st);
     bool   solve_host(int nrhs, double* rhs, int ld);
     bool   solve_device(int nrhs, double* drhs, int ld);
+    bool   solve_device2(int nrhs, const double* db, int ldb, double* dx, int ldx);   // out of place
     void   set_pivtol(double u);
     double last_factor_ms() const;
     double last_solve_ms() const;

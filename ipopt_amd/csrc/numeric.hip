@@ -51,7 +51,7 @@ struct DevView {
     // symbolic
     const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
     const int* child_ptr; const int* child_idx; const int* sn_owner;
-    const long long* panel_off; const long long* cb_off; const long long* wb_off;
+    const long long* panel_off; const long long* cb_off; const long long* wb_off; const long long* minv_off;
     const int* acolptr; const int* apos; const int* arow; const int* acol;
     const int* dup_ptr; const int* dup_src;
     const int* level_sn;
@@ -64,6 +64,7 @@ struct DevView {
     double* L;              // panels
     double* cb;             // contribution blocks
     double* wbuf;           // W = L*D copies of the big fronts of the level in flight
+    double* minv;           // k x k inverses of the unit-lower pivot blocks (column-major, ld = k)
     double* dinv; double* doff; int* ptype; int* lperm;
     int4*   fstat;          // per front {neg, zero, two, small}
     double* xw;             // work vector (permuted, scaled)
@@ -183,6 +184,65 @@ __device__ __forceinline__ void swap_rc(double* F, int ld, int m, int p, int q, 
     __syncthreads();
 }
 
+// Trailing update  F(i,c) -= l0(i) w0(c) [+ l1(i) w1(c)],  c in [cbeg, m), rows i >= (first column of the batch).
+// Columns are handled CB at a time with every LDS load issued before the first store, so the LDS round trip
+// is paid once per CB columns instead of once per column; entries above the diagonal that get touched are
+// never read (lower storage).  One wave with short columns splits into two half-waves on different batches.
+template <int NT, bool TWO>
+__device__ __forceinline__ void trailing_update(double* F, const int ld, const int m, const int cbeg, const int j,
+                                                const double* lc0, const double* lc1)
+{
+    constexpr int CB = 4;
+    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int rlane, cgrp, ngrp, rstride;
+    if (NT == 64 && (m - cbeg) <= 32) { rlane = lane & 31; cgrp = lane >> 5; ngrp = 2; rstride = 32; }
+    else { rlane = lane; cgrp = wave; ngrp = NW; rstride = 64; }
+    for (int cc = cbeg + cgrp * CB; cc < m; cc += ngrp * CB) {
+        double w0[CB], w1[CB];
+#pragma unroll
+        for (int q = 0; q < CB; ++q) {
+            const bool v = cc + q < m;
+            w0[q] = v ? F[cc + q + j * ld] : 0.0;
+            w1[q] = (TWO && v) ? F[cc + q + (j + 1) * ld] : 0.0;
+        }
+        for (int i = cc + rlane; i < m; i += rstride) {
+            const double a0 = lc0[i];
+            const double a1 = TWO ? lc1[i] : 0.0;
+            double f[CB];
+#pragma unroll
+            for (int q = 0; q < CB; ++q) f[q] = (cc + q < m) ? F[i + (cc + q) * ld] : 0.0;
+#pragma unroll
+            for (int q = 0; q < CB; ++q) if (cc + q < m) F[i + (cc + q) * ld] = f[q] - a0 * w0[q] - a1 * w1[q];
+        }
+    }
+}
+
+// In-place inverse of the unit lower triangular k x k block at the top of F (LAPACK trti2 order: last column
+// first).  Every solve then multiplies by L11^{-1} instead of running a k-step substitution chain.
+template <int NT>
+__device__ __forceinline__ void invert_unit_lower(double* F, const int ld, const int k)
+{
+    const int tid = threadIdx.x;
+    for (int j = k - 2; j >= 0; --j) {
+        // x(i) = - sum_{p=j+1..i} Minv(i,p) L(p,j),   Minv(i,i) = 1
+        double x[ (NT >= 64) ? 2 : 1 ];
+        int cnt = 0;
+        for (int i = j + 1 + tid; i < k; i += NT) {
+            double acc0 = F[i + j * ld], acc1 = 0.0;      // p = i term: Minv(i,i) L(i,j)
+            int p = j + 1;
+            for (; p + 1 < i; p += 2) { acc0 += F[i + p * ld] * F[p + j * ld]; acc1 += F[i + (p + 1) * ld] * F[p + 1 + j * ld]; }
+            if (p < i) acc0 += F[i + p * ld] * F[p + j * ld];
+            if (cnt < 2) x[cnt] = -(acc0 + acc1);
+            ++cnt;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int i = j + 1 + tid; i < k; i += NT) { if (cnt < 2) F[i + j * ld] = x[cnt]; ++cnt; }
+        __syncthreads();
+    }
+}
+
 // LDL^T of the k leading (fully-summed) columns of an m x m front held in LDS (lower storage, leading
 // dimension ld), Bunch-Kaufman pivoting restricted to the k x k pivot block, right-looking updates of the
 // whole trailing front.  All NT threads of the workgroup call it with identical arguments.
@@ -191,8 +251,7 @@ __device__ __forceinline__ void ldlt_lds(double* F, const int ld, const int m, c
                                          double* dinv_s, double* doff_s, int* pt_s, int* lp, double* redv, int* redi,
                                          const double u, const double small, int& nneg, int& nzero, int& ntwo, int& nsmall)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x;
     int j = 0;
     while (j < k) {
         MaxIdx cand; cand.v = -1.0; cand.i = 0x7fffffff;
@@ -225,10 +284,7 @@ __device__ __forceinline__ void ldlt_lds(double* F, const int ld, const int m, c
                 }
                 lmax = block_max<NT>(lmax, redv);   // (contains the barrier that publishes lc0/lc1)
                 if (NT == 64) __syncthreads();
-                for (int cc = j + 2 + wave; cc < m; cc += NW) {
-                    const double w0 = F[cc + j * ld], w1 = F[cc + (j + 1) * ld];
-                    for (int i = cc + lane; i < m; i += 64) F[i + cc * ld] -= lc0[i] * w0 + lc1[i] * w1;
-                }
+                trailing_update<NT, true>(F, ld, m, j + 2, j, lc0, lc1);
                 __syncthreads();
                 for (int i = j + 2 + tid; i < m; i += NT) { F[i + j * ld] = lc0[i]; F[i + (j + 1) * ld] = lc1[i]; }
                 if (tid == 0) {
@@ -251,10 +307,7 @@ __device__ __forceinline__ void ldlt_lds(double* F, const int ld, const int m, c
             for (int i = j + 1 + tid; i < m; i += NT) { const double l = F[i + j * ld] * di; lc0[i] = l; lmax = fmax(lmax, fabs(l)); }
             lmax = block_max<NT>(lmax, redv);
             if (NT == 64) __syncthreads();
-            for (int cc = j + 1 + wave; cc < m; cc += NW) {
-                const double w = F[cc + j * ld];
-                if (w != 0.0) for (int i = cc + lane; i < m; i += 64) F[i + cc * ld] -= lc0[i] * w;
-            }
+            trailing_update<NT, false>(F, ld, m, j + 1, j, lc0, lc1);
             __syncthreads();
             for (int i = j + 1 + tid; i < m; i += NT) F[i + j * ld] = lc0[i];
             if (tid == 0) { dinv_s[j] = di; doff_s[j] = 0.0; pt_s[j] = 1; }
@@ -330,6 +383,11 @@ __global__ __launch_bounds__(NT) void k_front_lds(DevView V, int list_off, int t
     for (int c = wave; c < mu; c += NW)
         for (int i = c + lane; i < mu; i += 64) Cg[i + (size_t)c * mu] = F[(k + i) + (k + c) * ld];
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+    // ---- (f) L11^{-1} for the solves (in place in LDS, the front has been written back) ----
+    __syncthreads();
+    invert_unit_lower<NT>(F, ld, k);
+    double* Mg = V.minv + V.minv_off[s];
+    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? F[i + c * ld] : (i == c ? 1.0 : 0.0); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -364,58 +422,75 @@ __global__ void k_store_sol(DevView V, double* b)
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) b[V.perm[i]] = V.scale[i] * V.xw[i];
 }
 
-// forward: y = L^{-1} P b for the pivot rows of the front, contributions to the ancestors are left
-// in cvec (gathered by the parent: no atomics, deterministic), followed by z = D^{-1} y.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_fwd_lds(DevView V, int list_off, int top_mode)
+// forward: y = L11^{-1} P b for the pivot rows (a k x k mat-vec with the stored inverse: no substitution chain),
+// z = D^{-1} y, and the contribution  c = (children) - L21 y  for the ancestors is left in cvec (the parent
+// gathers it: no atomics, deterministic).  One workgroup per front; works for every front size (accumulators
+// of the update rows live in cvec / global when the front is too large for LDS).
+template <int NT, bool BIG>
+__global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = NT / 64;
+    const int tid = threadIdx.x;
     const int s = V.level_sn[list_off + blockIdx.x];
     const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
     const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
-    double* xs = reinterpret_cast<double*>(smem_raw);   // m
-    double* ys = xs + m;                                // k
-    for (int i = tid; i < m; i += NT) xs[i] = (i < k) ? V.xw[c0 + i] : 0.0;
-    if (top_mode && V.top_rhs) { const double* tr = V.top_rhs + V.top_rhs_off[s]; __syncthreads(); for (int i = tid; i < m; i += NT) xs[i] += tr[i]; }
+    double* xp = reinterpret_cast<double*>(smem_raw);   // k   pivot rows (original local order)
+    double* ys = xp + k;                                // k
+    double* bp = ys + k;                                // k   pivot rows in pivot order
+    double* xu = bp + k;                                // m-k update-row accumulators (LDS classes only)
+    for (int i = tid; i < k; i += NT) xp[i] = V.xw[c0 + i];
+    if (BIG) { for (int i = k + tid; i < m; i += NT) V.cvec[r0 + i] = 0.0; }
+    else     { for (int i = k + tid; i < m; i += NT) xu[i - k] = 0.0; }
+    if (top_mode && V.top_rhs) {
+        const double* tr = V.top_rhs + V.top_rhs_off[s];
+        __syncthreads();
+        for (int i = tid; i < m; i += NT) { if (i < k) xp[i] += tr[i]; else if (BIG) V.cvec[r0 + i] += tr[i]; else xu[i - k] += tr[i]; }
+    }
     __syncthreads();
     for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
         const int ch = V.child_idx[cp];
         if (top_mode && V.top_rhs && V.sn_owner[ch] >= 0) continue;
         const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
         const int base = V.sn_rowptr[ch] + kc, mc = V.sn_rowptr[ch + 1] - base;
-        for (int t = tid; t < mc; t += NT) xs[V.rel[base + t]] += V.cvec[base + t];
+        for (int t = tid; t < mc; t += NT) {
+            const int tg = V.rel[base + t]; const double v = V.cvec[base + t];
+            if (tg < k) xp[tg] += v; else if (BIG) V.cvec[r0 + tg] += v; else xu[tg - k] += v;
+        }
         __syncthreads();
     }
-    for (int jj = tid; jj < k; jj += NT) ys[jj] = xs[V.lperm[c0 + jj]];
+    // y = Minv * (P b): thread j, independent (pipelined) loads down row j of the column-major inverse
+    const double* Mg = V.minv + V.minv_off[s];
+    for (int j = tid; j < k; j += NT) bp[j] = xp[V.lperm[c0 + j]];
+    __syncthreads();
+    for (int j = tid; j < k; j += NT) {
+        double a0 = 0.0, a1 = 0.0;
+        int p = 0;
+        for (; p + 1 <= j; p += 2) { a0 += Mg[j + (size_t)p * k] * bp[p]; a1 += Mg[j + (size_t)(p + 1) * k] * bp[p + 1]; }
+        if (p <= j) a0 += Mg[j + (size_t)p * k] * bp[p];
+        ys[j] = a0 + a1;
+    }
     __syncthreads();
     const double* Lg = V.L + V.panel_off[s];
-    for (int jj = 0; jj < k; ++jj) {
-        const double yj = ys[jj];
-        for (int i = jj + 1 + tid; i < k; i += NT) ys[i] -= Lg[i + (size_t)jj * m] * yj;
-        __syncthreads();
-    }
-    // update rows: t_i = sum_j L[i][j] y_j ; lanes walk rows (coalesced column reads)
     for (int i = k + tid; i < m; i += NT) {
-        double t = 0.0;
-        for (int jj = 0; jj < k; ++jj) t += Lg[i + (size_t)jj * m] * ys[jj];
-        V.cvec[r0 + i] = xs[i] - t;
+        double t0 = 0.0, t1 = 0.0;
+        int j = 0;
+        for (; j + 1 < k; j += 2) { t0 += Lg[i + (size_t)j * m] * ys[j]; t1 += Lg[i + (size_t)(j + 1) * m] * ys[j + 1]; }
+        if (j < k) t0 += Lg[i + (size_t)j * m] * ys[j];
+        if (BIG) V.cvec[r0 + i] -= t0 + t1; else V.cvec[r0 + i] = xu[i - k] - (t0 + t1);
     }
-    for (int jj = tid; jj < k; jj += NT) {
-        const int pt = V.ptype[c0 + jj];
+    for (int j = tid; j < k; j += NT) {
+        const int pt = V.ptype[c0 + j];
         double z;
-        if (pt == 1) z = ys[jj] * V.dinv[c0 + jj];
-        else if (pt == 2) z = V.dinv[c0 + jj] * ys[jj] + V.doff[c0 + jj] * ys[jj + 1];
-        else z = V.doff[c0 + jj - 1] * ys[jj - 1] + V.dinv[c0 + jj] * ys[jj];
-        V.xw[c0 + jj] = z;
+        if (pt == 1) z = ys[j] * V.dinv[c0 + j];
+        else if (pt == 2) z = V.dinv[c0 + j] * ys[j] + V.doff[c0 + j] * ys[j + 1];
+        else z = V.doff[c0 + j - 1] * ys[j - 1] + V.dinv[c0 + j] * ys[j];
+        V.xw[c0 + j] = z;
     }
-    (void)lane; (void)wave; (void)NW;
 }
 
-// backward: x_piv = L11^{-T} ( z - L21^T x_upd ), written un-permuted
-template <int NT>
-__global__ __launch_bounds__(NT) void k_bwd_lds(DevView V, int list_off)
+// backward: x_piv = P^T L11^{-T} ( z - L21^T x_upd ), written un-permuted
+template <int NT, bool BIG>
+__global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -423,27 +498,31 @@ __global__ __launch_bounds__(NT) void k_bwd_lds(DevView V, int list_off)
     const int s = V.level_sn[list_off + blockIdx.x];
     const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
     const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
-    double* xu = reinterpret_cast<double*>(smem_raw);   // m (only [k,m) used)
-    double* ws = xu + m;                                // k
-    for (int i = k + tid; i < m; i += NT) xu[i] = V.xw[V.sn_rows[r0 + i]];
-    for (int jj = tid; jj < k; jj += NT) ws[jj] = V.xw[c0 + jj];
+    double* ws = reinterpret_cast<double*>(smem_raw);   // k
+    double* xu = ws + k;                                // m-k gathered ancestor values (LDS classes)
+    if (BIG) { for (int i = k + tid; i < m; i += NT) V.cvec[r0 + i] = V.xw[V.sn_rows[r0 + i]]; }
+    else     { for (int i = k + tid; i < m; i += NT) xu[i - k] = V.xw[V.sn_rows[r0 + i]]; }
+    for (int j = tid; j < k; j += NT) ws[j] = V.xw[c0 + j];
     __syncthreads();
     const double* Lg = V.L + V.panel_off[s];
-    for (int jj = wave; jj < k; jj += NW) {
+    const double* xg = BIG ? (V.cvec + r0 + k) : xu;
+    for (int j = wave; j < k; j += NW) {
         double t = 0.0;
-        for (int i = k + lane; i < m; i += 64) t += Lg[i + (size_t)jj * m] * xu[i];
+        for (int i = lane; i < m - k; i += 64) t += Lg[k + i + (size_t)j * m] * xg[i];
         t = wave_sum(t);
-        if (lane == 0) ws[jj] -= t;
+        if (lane == 0) ws[j] -= t;
     }
     __syncthreads();
-    for (int jj = k - 1; jj >= 1; --jj) {
-        const double wj = ws[jj];
-        for (int c = tid; c < jj; c += NT) ws[c] -= Lg[jj + (size_t)c * m] * wj;
-        __syncthreads();
+    // x_p = sum_{j >= p} Minv(j,p) w_j : thread p walks its own (contiguous) column of the inverse
+    const double* Mg = V.minv + V.minv_off[s];
+    for (int p = tid; p < k; p += NT) {
+        double a0 = 0.0, a1 = 0.0;
+        int j = p;
+        for (; j + 1 < k; j += 2) { a0 += Mg[j + (size_t)p * k] * ws[j]; a1 += Mg[j + 1 + (size_t)p * k] * ws[j + 1]; }
+        if (j < k) a0 += Mg[j + (size_t)p * k] * ws[j];
+        V.xw[c0 + V.lperm[c0 + p]] = a0 + a1;
     }
-    for (int jj = tid; jj < k; jj += NT) V.xw[c0 + V.lperm[c0 + jj]] = ws[jj];
 }
-
 
 // ================================================================================================
 // BIG fronts (order > 128): the front stays in HBM/L2 -- panel (m x k, k <= 66) in the L storage, the
@@ -517,46 +596,68 @@ __global__ __launch_bounds__(256) void k_big_diag(DevView V, int list_off)
     for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; P[i + (size_t)c * m] = (i >= c) ? F[i + c * ld] : 0.0; }
     for (int j = tid; j < k; j += 256) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = lp[j]; }
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+    __syncthreads();
+    invert_unit_lower<256>(F, ld, k);
+    double* Mg = V.minv + V.minv_off[s];
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? F[i + c * ld] : (i == c ? 1.0 : 0.0); }
 }
 
-// rows below the pivot block: 64 rows per wavefront-sized workgroup, the row being solved lives in LDS
-__global__ __launch_bounds__(64) void k_big_trsm(DevView V, int list_off)
+// rows below the pivot block:  W21 = (A21 P) L11^{-T}  as a GEMM with the stored inverse (fp64 MFMA, no
+// substitution chain), then L21 = W21 D^{-1}.  64 rows per workgroup, 16 rows per wavefront; the product is formed
+// transposed (A operand = rows of L11^{-1}, B operand = rows of A21 P) so that lanes hold consecutive rows.
+__global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int t = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = V.level_sn[list_off + blockIdx.y];
     const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
     const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
     const int ibase = k + blockIdx.x * 64;
     if (ibase >= m) return;
-    const int ld = k + 1;
-    double* L11 = reinterpret_cast<double*>(smem_raw);        // k x k (ld = k+1), strictly lower part used
-    double* wr  = L11 + (size_t)ld * k;                       // 64 x k, element (t, j) at wr[t + 64*j]
+    const int kp = (k + 3) & ~3;                              // K padded to the MFMA depth
+    const int ldm = k | 1;
+    double* Ms = reinterpret_cast<double*>(smem_raw);         // k x kp : Ms[j + p*ldm] = Minv(j,p)
+    double* As = Ms + (size_t)ldm * kp;                       // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
+    double* Ws = As + (size_t)65 * kp;                        // 64 x k : Ws[r + j*65]
     double* P = V.L + V.panel_off[s];
     double* W = V.wbuf + V.wb_off[s];
-    for (int idx = t; idx < k * k; idx += 64) { const int i = idx % k, c = idx / k; L11[i + c * ld] = P[i + (size_t)c * m]; }
-    const int i = ibase + t;
-    const bool ok = i < m;
-    for (int j = 0; j < k; ++j) wr[t + 64 * j] = ok ? P[i + (size_t)V.lperm[c0 + j] * m] : 0.0;
-    __syncthreads();
-    for (int j = 0; j < k; ++j) {
-        const double wj = wr[t + 64 * j];
-        for (int p = j + 1; p < k; ++p) wr[t + 64 * p] -= wj * L11[p + j * ld];
+    const double* Mg = V.minv + V.minv_off[s];
+    for (int idx = tid; idx < k * kp; idx += 256) { const int j = idx % k, p = idx / k; Ms[j + p * ldm] = (p < k) ? Mg[j + (size_t)p * k] : 0.0; }
+    for (int idx = tid; idx < 64 * kp; idx += 256) {
+        const int r = idx & 63, p = idx >> 6;
+        As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)V.lperm[c0 + p] * m] : 0.0;
     }
+    __syncthreads();
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int r16 = wave * 16;
+    for (int c16 = 0; c16 < k; c16 += 16) {
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+        const int col = c16 + l15;
+        const int pend = min(kp, (c16 + 16 + 3) & ~3);        // Minv(col,p) = 0 for p > col
+        for (int p = 0; p < pend; p += 4) {
+            const double a = (col < k) ? Ms[col + (p + l4) * ldm] : 0.0;
+            const double b = As[r16 + l15 + (p + l4) * 65];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const int cc = c16 + l4 + 4 * g; if (cc < k) Ws[r16 + l15 + cc * 65] = acc[g]; }
+    }
+    __syncthreads();
     double lmax = 0.0;
-    for (int j = 0; j < k; ++j) {
+    for (int idx = tid; idx < 64 * k; idx += 256) {
+        const int r = idx & 63, j = idx >> 6;
+        const int i = ibase + r;
         const int pt = V.ptype[c0 + j];
-        const double wj = wr[t + 64 * j];
+        const double wj = Ws[r + j * 65];
         double l;
         if (pt == 1) l = wj * V.dinv[c0 + j];
-        else if (pt == 2) l = V.dinv[c0 + j] * wj + V.doff[c0 + j] * wr[t + 64 * (j + 1)];
-        else l = V.doff[c0 + j - 1] * wr[t + 64 * (j - 1)] + V.dinv[c0 + j] * wj;
-        if (ok) { W[i + (size_t)j * m] = wj; P[i + (size_t)j * m] = l; }
-        lmax = fmax(lmax, fabs(l));
+        else if (pt == 2) l = V.dinv[c0 + j] * wj + V.doff[c0 + j] * Ws[r + (j + 1) * 65];
+        else l = V.doff[c0 + j - 1] * Ws[r + (j - 1) * 65] + V.dinv[c0 + j] * wj;
+        if (i < m) { W[i + (size_t)j * m] = wj; P[i + (size_t)j * m] = l; lmax = fmax(lmax, fabs(l)); }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
-    if (t == 0 && lmax * V.pivtol > 1.0) atomicMax(&V.fstat[s].w, 1);
+    if (lane == 0 && lmax * V.pivtol > 1.0) atomicMax(&V.fstat[s].w, 1);
 }
 
 // T(i,c) -= sum_p L21(i,p) W21(c,p),  i >= c, on 64x64 tiles; each of the 4 waves owns a 32x32 sub-tile made of
@@ -611,76 +712,6 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
                 const int i = i0 + q * 16 + l15;              // D column index -> T row
                 if (i < mu && c < mu && i >= c) T[i + (size_t)c * mu] -= acc[r][q][g];
             }
-}
-
-// solves on big fronts: one workgroup per front, accumulators for the update rows live in cvec (global)
-__global__ __launch_bounds__(256) void k_fwd_big(DevView V, int list_off)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
-    double* xp = reinterpret_cast<double*>(smem_raw);   // k
-    double* ys = xp + k;                                // k
-    for (int i = tid; i < k; i += 256) xp[i] = V.xw[c0 + i];
-    for (int i = k + tid; i < m; i += 256) V.cvec[r0 + i] = 0.0;
-    __syncthreads();
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-        const int base = V.sn_rowptr[ch] + kc, mc = V.sn_rowptr[ch + 1] - base;
-        for (int t = tid; t < mc; t += 256) { const int tg = V.rel[base + t]; const double v = V.cvec[base + t]; if (tg < k) xp[tg] += v; else V.cvec[r0 + tg] += v; }
-        __syncthreads();
-    }
-    for (int j = tid; j < k; j += 256) ys[j] = xp[V.lperm[c0 + j]];
-    __syncthreads();
-    const double* Lg = V.L + V.panel_off[s];
-    for (int j = 0; j < k; ++j) {
-        const double yj = ys[j];
-        for (int i = j + 1 + tid; i < k; i += 256) ys[i] -= Lg[i + (size_t)j * m] * yj;
-        __syncthreads();
-    }
-    for (int i = k + tid; i < m; i += 256) {
-        double t = 0.0;
-        for (int j = 0; j < k; ++j) t += Lg[i + (size_t)j * m] * ys[j];
-        V.cvec[r0 + i] -= t;
-    }
-    for (int j = tid; j < k; j += 256) {
-        const int pt = V.ptype[c0 + j];
-        double z;
-        if (pt == 1) z = ys[j] * V.dinv[c0 + j];
-        else if (pt == 2) z = V.dinv[c0 + j] * ys[j] + V.doff[c0 + j] * ys[j + 1];
-        else z = V.doff[c0 + j - 1] * ys[j - 1] + V.dinv[c0 + j] * ys[j];
-        V.xw[c0 + j] = z;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_bwd_big(DevView V, int list_off)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
-    double* ws = reinterpret_cast<double*>(smem_raw);   // k
-    for (int i = k + tid; i < m; i += 256) V.cvec[r0 + i] = V.xw[V.sn_rows[r0 + i]];   // gather x of the ancestors once
-    for (int j = tid; j < k; j += 256) ws[j] = V.xw[c0 + j];
-    __syncthreads();
-    const double* Lg = V.L + V.panel_off[s];
-    for (int j = wave; j < k; j += 4) {
-        double t = 0.0;
-        for (int i = k + lane; i < m; i += 64) t += Lg[i + (size_t)j * m] * V.cvec[r0 + i];
-        t = wave_sum(t);
-        if (lane == 0) ws[j] -= t;
-    }
-    __syncthreads();
-    for (int j = k - 1; j >= 1; --j) {
-        const double wj = ws[j];
-        for (int c = tid; c < j; c += 256) ws[c] -= Lg[j + (size_t)c * m] * wj;
-        __syncthreads();
-    }
-    for (int j = tid; j < k; j += 256) V.xw[c0 + V.lperm[c0 + j]] = ws[j];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -757,17 +788,17 @@ public:
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
-        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end());
+        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
-            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) ||
+            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) || !upload(moff, &V.minv_off) ||
             !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
             !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.level_sn, &V.level_sn) ||
             !upload(Sy.perm, &V.perm)) return false;
         double* tv = nullptr;
         if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
         if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
-            !dalloc(&V.L, (size_t)Sy.l_doubles) || !dalloc(&V.cb, (size_t)Sy.cb_doubles) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) ||
+            !dalloc(&V.L, (size_t)Sy.l_doubles) || !dalloc(&V.cb, (size_t)Sy.cb_doubles) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
             !dalloc(&d_stats, 4)) return false;
@@ -812,14 +843,14 @@ public:
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
                 if (fc == FC_WAVE)        LAUNCH(KK_FRONT_WAVE, k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(32, 32),   stream, V, b0, 0);
-                else if (fc == FC_LDS64)  LAUNCH(KK_FRONT_LDS64, k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(64, 64),   stream, V, b0, 0);
+                else if (fc == FC_LDS64)  LAUNCH(KK_FRONT_LDS64, k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(64, 64),   stream, V, b0, 0);
                 else if (fc == FC_LDS128) LAUNCH(KK_FRONT_LDS128, k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(128, 128), stream, V, b0, 0);
                 else {
                     const int mm = big_maxm[lv], kk = big_maxk[lv], mu = mm - 1;
                     const int nt = (mu + 63) / 64;
                     LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, b1 - b0), dim3(256), 0, stream, V, b0);
                     LAUNCH(KK_BIG_DIAG, k_big_diag, dim3(b1 - b0), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
-                    LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, b1 - b0), dim3(64), (size_t)((kk + 1) * kk + 64 * kk) * sizeof(double) + 16, stream, V, b0);
+                    LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, b1 - b0), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
                     LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, b1 - b0), dim3(256), 0, stream, V, b0);
                 }
             }
@@ -867,56 +898,57 @@ public:
     }
     double graph_pivtol = -1.0;
 
-    bool enqueue_solve(double* drhs) {
+    bool enqueue_solve(const double* dsrc, double* drhs) {
         const Symbolic& Sy = *S;
         const int n = Sy.n;
-        LAUNCH(KK_SOLVE_PERM, k_load_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)drhs);
-        auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + kmax) * sizeof(double) + 16; };
+        LAUNCH(KK_SOLVE_PERM, k_load_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V, dsrc);
+        auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
         for (int lv = 0; lv < Sy.num_levels; ++lv)
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, k_fwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
-                else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS, k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0, 0);
-                else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS, k_fwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
-                else LAUNCH(KK_FWD_BIG, k_fwd_big, dim3(b1 - b0), dim3(256), (size_t)2 * big_maxk[lv] * sizeof(double) + 16, stream, V, b0);
+                if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
+                else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
+                else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
+                else                      LAUNCH(KK_FWD_BIG,  (k_fwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0, 0);
             }
         for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, k_bwd_lds<64>,  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
-                else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS, k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(64, 64),   stream, V, b0);
-                else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS, k_bwd_lds<256>, dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
-                else LAUNCH(KK_BWD_BIG, k_bwd_big, dim3(b1 - b0), dim3(256), (size_t)big_maxk[lv] * sizeof(double) + 16, stream, V, b0);
+                if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
+                else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
+                else                      LAUNCH(KK_BWD_BIG,  (k_bwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0);
             }
         LAUNCH(KK_SOLVE_PERM, k_store_sol, dim3(grid1d(n)), dim3(256), 0, stream, V, drhs);
         HIPCHK(hipGetLastError());
         return true;
     }
-    double* graph_rhs = nullptr;
+    double* graph_rhs = nullptr; const double* graph_src = nullptr;
 
-    bool solve_device(int nrhs, double* drhs, int ld, bool timed) {
+    bool solve_device(int nrhs, const double* dsrc, int lds_, double* drhs, int ld, bool timed) {
         if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
         if (timed) HIPCHK(hipEventRecord(ev0, stream));
         for (int r = 0; r < nrhs; ++r) {
             double* col = drhs + (size_t)r * ld;
+            const double* src = dsrc + (size_t)r * lds_;
             if (opt.use_graph) {
-                if (!g_solve || graph_rhs != col) {
+                if (!g_solve || graph_rhs != col || graph_src != src) {
                     if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
                     hipGraph_t g = nullptr;
                     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                    bool ok = enqueue_solve(col);
+                    bool ok = enqueue_solve(src, col);
                     hipError_t e = hipStreamEndCapture(stream, &g);
                     if (!ok) return false;
                     if (e != hipSuccess) { err_ = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return false; }
                     HIPCHK(hipGraphInstantiate(&g_solve, g, nullptr, nullptr, 0));
                     (void)hipGraphDestroy(g);
-                    graph_rhs = col;
+                    graph_rhs = col; graph_src = src;
                     if (timed && r == 0) HIPCHK(hipEventRecord(ev0, stream));
                 }
                 HIPCHK(hipGraphLaunch(g_solve, stream));
-            } else if (!enqueue_solve(col)) return false;
+            } else if (!enqueue_solve(src, col)) return false;
         }
         if (timed) { HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms; }
         return true;
@@ -929,7 +961,7 @@ public:
                                         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
         prof_on = true;
         for (int r = 0; r < reps; ++r) {
-            if (!enqueue_factor() || !enqueue_solve(d_rhs)) { prof_on = false; return false; }
+            if (!enqueue_factor() || !enqueue_solve(d_rhs, d_rhs)) { prof_on = false; return false; }
             prof_collect();
         }
         prof_on = false;
@@ -944,7 +976,7 @@ public:
         double total = 0;
         for (int r = 0; r < nrhs; ++r) {
             HIPCHK(hipMemcpyAsync(d_rhs, rhs + (size_t)r * ld, n * sizeof(double), hipMemcpyHostToDevice, stream));
-            if (!solve_device(1, d_rhs, (int)n, true)) return false;
+            if (!solve_device(1, d_rhs, (int)n, d_rhs, (int)n, true)) return false;
             total += solve_ms;
             HIPCHK(hipMemcpyAsync(rhs + (size_t)r * ld, d_rhs, n * sizeof(double), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
@@ -960,7 +992,8 @@ bool Numeric::setup(const Symbolic& S, const NumericOptions& opt) { return p_->s
 double* Numeric::values_buffer() { return p_->h_vals; }
 bool Numeric::factor(const double* dvals, bool reuse, FactorStats& st) { return p_->factor(dvals, reuse, st); }
 bool Numeric::solve_host(int nrhs, double* rhs, int ld) { return p_->solve_host(nrhs, rhs, ld); }
-bool Numeric::solve_device(int nrhs, double* drhs, int ld) { return p_->solve_device(nrhs, drhs, ld, true); }
+bool Numeric::solve_device(int nrhs, double* drhs, int ld) { return p_->solve_device(nrhs, drhs, ld, drhs, ld, true); }
+bool Numeric::solve_device2(int nrhs, const double* db, int ldb, double* dx, int ldx) { return p_->solve_device(nrhs, db, ldb, dx, ldx, true); }
 void Numeric::set_pivtol(double u) { p_->opt.pivtol = u; }
 double Numeric::last_factor_ms() const { return p_->factor_ms; }
 double Numeric::last_solve_ms() const { return p_->solve_ms; }

@@ -624,6 +624,8 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         S.maxfront = std::max<int>(S.maxfront, (int)m); S.maxsupernode = std::max<int>(S.maxsupernode, (int)k);
     }
     S.l_doubles = loff; S.cb_doubles = coff;
+    S.minv_off.resize(nsn);
+    { int64_t mo = 0; for (int s = 0; s < nsn; ++s) { int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s]; S.minv_off[s] = mo; mo += k * k; } S.minv_doubles = mo; }
     {   // per-level scratch for the W = L*D panels of the blocked (big-front) path
         S.wb_off.assign(nsn, -1);
         vector<int64_t> lvl_used(S.num_levels, 0);

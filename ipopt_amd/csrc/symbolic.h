@@ -19,7 +19,7 @@ struct SymbolicOptions {
     int    index_base  = 1;
     int    ordering    = 0;    // 0 ND+MD, 1 MD, 2 natural
     int    matching    = 1;
-    int    nd_leaf     = 96;
+    int    nd_leaf     = 32;
     int    nemin       = 8;
     int    max_sn_cols = 64;
     int    nranks      = 1;
@@ -62,6 +62,8 @@ struct Symbolic {
     std::vector<int64_t> wb_off;           // [num_sn] offset (doubles) of the m x k scaled-panel copy W = L*D of a BIG front
                                            // inside the per-level scratch (reused level after level), -1 otherwise
     int64_t wbuf_doubles = 0;
+    std::vector<int64_t> minv_off;         // [num_sn] offset (doubles) of the k x k inverse of the unit-lower pivot block
+    int64_t minv_doubles = 0;
     std::vector<int> apos;                 // [nnz_a] local position (row + col*m) of each slot inside its panel
     // level schedule: fronts sorted by (level, class)
     int num_levels = 0;

@@ -60,7 +60,7 @@ _LIB = None
 ABI_SYMBOLS = [
     "mi355x_kkt_default_options", "mi355x_kkt_create", "mi355x_kkt_destroy", "mi355x_kkt_analyse",
     "mi355x_kkt_values_buffer", "mi355x_kkt_factor", "mi355x_kkt_refactor", "mi355x_kkt_solve",
-    "mi355x_kkt_solve_device", "mi355x_kkt_set_pivtol", "mi355x_kkt_get_info", "mi355x_kkt_last_error",
+    "mi355x_kkt_solve_device", "mi355x_kkt_solve_device2", "mi355x_kkt_set_pivtol", "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
 ]
@@ -92,6 +92,7 @@ def load_library():
     lib.mi355x_kkt_refactor.argtypes = [vp, ip, ip]
     lib.mi355x_kkt_solve.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.mi355x_kkt_solve_device.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.mi355x_kkt_solve_device2.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
     lib.mi355x_kkt_set_pivtol.argtypes = [vp, C.c_double]
     lib.mi355x_kkt_get_info.argtypes = [vp, C.POINTER(_Info)]
     lib.mi355x_kkt_last_error.argtypes = [vp]
@@ -202,6 +203,11 @@ class KKTSolver:
         st = self.lib.mi355x_kkt_solve_device(self._h, nrhs, C.c_void_p(drhs_ptr), self._n)
         if st != 0:
             raise KKTError("solve_device: " + self.last_error())
+
+    def solve_device2(self, db_ptr: int, dx_ptr: int, nrhs=1):
+        st = self.lib.mi355x_kkt_solve_device2(self._h, nrhs, C.c_void_p(db_ptr), self._n, C.c_void_p(dx_ptr), self._n)
+        if st != 0:
+            raise KKTError("solve_device2: " + self.last_error())
 
     _refactor = False
 

@@ -37,7 +37,7 @@ OBJS := $(patsubst $(REF)/src/%.cpp,$(OUT)/obj/%.o,$(SRCS_CPP)) $(patsubst $(REF
 # MKL is isolated behind symlinks so that conda's older libstdc++ is never on the link path
 MKLLINK := -L$(OUT)/mkl -lmkl_rt -Wl,-rpath,'$$ORIGIN/mkl' -ldl -lm -lpthread
 
-all: $(OUT)/libipopt_ref.so $(OUT)/hs071_cpp $(OUT)/scalable.a $(OUT)/ref_driver $(OUT)/libmi355x_ipopt.so $(OUT)/ipopt_mi355x_driver
+all: $(OUT)/libipopt_ref.so $(OUT)/hs071_cpp $(OUT)/scalable.a $(OUT)/ref_driver $(OUT)/ref_kkt_solve $(OUT)/libmi355x_ipopt.so $(OUT)/ipopt_mi355x_driver
 
 $(OUT)/mkl/.stamp:
 	mkdir -p $(OUT)/mkl
@@ -88,6 +88,9 @@ DRV_INCS := $(INCS) -I$(REF)/examples/hs071_cpp -I$(REF)/examples/ScalableProble
 $(OUT)/ref_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/scalable.a
 	$(CXX) -O2 -DHAVE_CONFIG_H -std=c++11 -w $(DRV_INCS) $< $(REF)/examples/hs071_cpp/hs071_nlp.cpp $(OUT)/scalable.a -o $@ \
 	  -L$(OUT) -lipopt_ref -Wl,-rpath,'$$ORIGIN' $(MKLLINK)
+# stand-alone timing of the reference's CPU linear-solver path on one KKT system (bench.py cpu_baseline)
+$(OUT)/ref_kkt_solve: oracle/ref_kkt_solve.cpp $(OUT)/libipopt_ref.so
+	$(CXX) -O2 -DHAVE_CONFIG_H -std=c++11 -w $(INCS) $< -o $@ -L$(OUT) -lipopt_ref -Wl,-rpath,'$$ORIGIN' $(MKLLINK)
 # same driver with the MI355X backend linked in (end-to-end Ipopt runs on the GPU box)
 $(OUT)/ipopt_mi355x_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/scalable.a $(OUT)/libmi355x_ipopt.so
 	$(CXX) -O2 -DHAVE_CONFIG_H -DWITH_MI355X -std=c++11 -w $(DRV_INCS) $< $(REF)/examples/hs071_cpp/hs071_nlp.cpp $(OUT)/scalable.a -o $@ \

@@ -41,7 +41,7 @@ def test_option_struct_layout_matches_header():
     o = kkt._Options()
     kkt.load_library().mi355x_kkt_default_options(ctypes.byref(o))
     assert (o.device, o.index_base, o.ordering, o.matching, o.scaling) == (-1, 1, 0, 1, 1)
-    assert (o.nd_leaf, o.nemin, o.max_sn_cols) == (96, 8, 64)
+    assert (o.nd_leaf, o.nemin, o.max_sn_cols) == (32, 8, 64)
     assert (o.pivtol, o.pivtolmax, o.small) == (1e-8, 1e-4, 1e-20)
     assert (o.use_graph, o.nranks, o.rank) == (1, 1, 0)
 
