@@ -70,7 +70,9 @@ typedef struct mi355x_kkt_options {
     int    nranks;          /* multi-GPU: number of ranks sharing one matrix (default 1)                */
     int    rank;            /* multi-GPU: this rank                                                     */
     int    verbose;         /* 0 silent                                                                 */
-    int    reserved[8];
+    int    leaf_cols;       /* whole elimination subtrees of <= this many columns become one supernode  */
+                            /* (default 0 = off; measured: not a win)                                               */
+    int    reserved[7];
 } mi355x_kkt_options;
 
 typedef struct mi355x_kkt_info {

@@ -113,6 +113,39 @@ __device__ __forceinline__ double block_max(double x, double* redv)
     __syncthreads();
     return r;
 }
+// ---- wavefront reductions on the DPP path (row-local butterflies, then 4 readlanes): ~10x lower latency than the
+// ds_bpermute shuffles on the serial pivot chain.  Results are wave-uniform. ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), l), __builtin_amdgcn_readlane(__double2loint(x), l));
+}
+__device__ __forceinline__ double wave_max_all(double x)
+{
+    x = fmax(x, dpp_f64<0xB1>(x));    // quad_perm [1,0,3,2]
+    x = fmax(x, dpp_f64<0x4E>(x));    // quad_perm [2,3,0,1]
+    x = fmax(x, dpp_f64<0x141>(x));   // row_half_mirror
+    x = fmax(x, dpp_f64<0x140>(x));   // row_mirror  -> every lane of a 16-lane row holds the row maximum
+    return fmax(fmax(readlane_f64(x, 0), readlane_f64(x, 16)), fmax(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+__device__ __forceinline__ unsigned long long wave_or_all(unsigned long long v)
+{
+    int lo = (int)(v & 0xffffffffull), hi = (int)(v >> 32);
+    lo |= __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);  hi |= __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    lo |= __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);  hi |= __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+    lo |= __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false); hi |= __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false);
+    lo |= __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false); hi |= __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false);
+    const unsigned int l = (unsigned)(__builtin_amdgcn_readlane(lo, 0) | __builtin_amdgcn_readlane(lo, 16) | __builtin_amdgcn_readlane(lo, 32) | __builtin_amdgcn_readlane(lo, 48));
+    const unsigned int h = (unsigned)(__builtin_amdgcn_readlane(hi, 0) | __builtin_amdgcn_readlane(hi, 16) | __builtin_amdgcn_readlane(hi, 32) | __builtin_amdgcn_readlane(hi, 48));
+    return ((unsigned long long)h << 32) | l;
+}
 __device__ __forceinline__ double wave_sum(double x)
 {
 #pragma unroll
@@ -218,27 +251,38 @@ __device__ __forceinline__ void trailing_update(double* F, const int ld, const i
     }
 }
 
-// In-place inverse of the unit lower triangular k x k block at the top of F (LAPACK trti2 order: last column
-// first).  Every solve then multiplies by L11^{-1} instead of running a k-step substitution chain.
+// In-place inverse of the unit lower triangular k x k block at the top of F by recursive doubling:
+//   [A 0; B C]^{-1} = [A^{-1} 0; -C^{-1} B A^{-1}  C^{-1}],  block size h = 1, 2, 4, ...
+// Each stage is two fully parallel small products (T = B A^{-1} parked in the unused mirror position above the
+// diagonal, then B <- -C^{-1} T): log2(k) stages of 2 barriers instead of a k-step substitution chain.  Every solve
+// then multiplies by L11^{-1}.
 template <int NT>
 __device__ __forceinline__ void invert_unit_lower(double* F, const int ld, const int k)
 {
     const int tid = threadIdx.x;
-    for (int j = k - 2; j >= 0; --j) {
-        // x(i) = - sum_{p=j+1..i} Minv(i,p) L(p,j),   Minv(i,i) = 1
-        double x[ (NT >= 64) ? 2 : 1 ];
-        int cnt = 0;
-        for (int i = j + 1 + tid; i < k; i += NT) {
-            double acc0 = F[i + j * ld], acc1 = 0.0;      // p = i term: Minv(i,i) L(i,j)
-            int p = j + 1;
-            for (; p + 1 < i; p += 2) { acc0 += F[i + p * ld] * F[p + j * ld]; acc1 += F[i + (p + 1) * ld] * F[p + 1 + j * ld]; }
-            if (p < i) acc0 += F[i + p * ld] * F[p + j * ld];
-            if (cnt < 2) x[cnt] = -(acc0 + acc1);
-            ++cnt;
+    for (int sh = 0; (1 << sh) < k; ++sh) {
+        const int h = 1 << sh;
+        const int npair = (k + 2 * h - 1) >> (sh + 1);
+        const int total = npair << (2 * sh);
+        for (int e = tid; e < total; e += NT) {
+            const int pr = e >> (2 * sh), rem = e & ((1 << (2 * sh)) - 1);
+            const int i = rem & (h - 1), c = rem >> sh, o = pr << (sh + 1);
+            const int gi = o + h + i, gc = o + c;
+            if (gi >= k) continue;
+            double acc = F[gi + gc * ld];                                   // p = c term (A^{-1}(c,c) = 1)
+            for (int p = c + 1; p < h; ++p) acc += F[gi + (o + p) * ld] * F[o + p + gc * ld];
+            F[gc + gi * ld] = acc;                                          // T(i,c) -> mirror position (upper part)
         }
         __syncthreads();
-        cnt = 0;
-        for (int i = j + 1 + tid; i < k; i += NT) { if (cnt < 2) F[i + j * ld] = x[cnt]; ++cnt; }
+        for (int e = tid; e < total; e += NT) {
+            const int pr = e >> (2 * sh), rem = e & ((1 << (2 * sh)) - 1);
+            const int i = rem & (h - 1), c = rem >> sh, o = pr << (sh + 1);
+            const int gi = o + h + i, gc = o + c;
+            if (gi >= k) continue;
+            double acc = F[gc + gi * ld];                                   // p = i term (C^{-1}(i,i) = 1)
+            for (int p = 0; p < i; ++p) acc += F[gi + (o + h + p) * ld] * F[gc + (o + h + p) * ld];
+            F[gi + gc * ld] = -acc;
+        }
         __syncthreads();
     }
 }
@@ -251,51 +295,55 @@ __device__ __forceinline__ void ldlt_lds(double* F, const int ld, const int m, c
                                          double* dinv_s, double* doff_s, int* pt_s, int* lp, double* redv, int* redi,
                                          const double u, const double small, int& nneg, int& nzero, int& ntwo, int& nsmall)
 {
-    const int tid = threadIdx.x;
+    // Per pivot: the search is done REDUNDANTLY by every wavefront (identical LDS data, deterministic DPP reduction =>
+    // identical decisions, no barrier, no LDS exchange); then  scale -> barrier -> update -> barrier.
+    // Row i of the work columns lc0/lc1 is owned by thread i % NT for the whole factorisation.
+    const int tid = threadIdx.x, lane = tid & 63;
+    unsigned long long bigmask = 0ull;          // bit min(j,63): some multiplier of pivot j exceeded 1/u
     int j = 0;
     while (j < k) {
-        MaxIdx cand; cand.v = -1.0; cand.i = 0x7fffffff;
-        for (int i = j + 1 + tid; i < k; i += NT) { const double a = fabs(F[i + j * ld]); if (a > cand.v) { cand.v = a; cand.i = i; } }
-        cand = block_argmax<NT>(cand, redv, redi);
+        double best = -1.0; int bi = 0x7fffffff;
+        for (int i = j + 1 + lane; i < k; i += 64) { const double a = fabs(F[i + j * ld]); if (a > best) { best = a; bi = i; } }
+        const double lam = wave_max_all(best);
         const double ajj = fabs(F[j + j * ld]);
-        const double lam = cand.v > 0.0 ? cand.v : 0.0;
         int two = 0;
         if (lam > 0.0 && ajj < BK_ALPHA * lam) {
-            const int r = cand.i;
-            double sig = 0.0;
-            for (int c = j + tid; c < k; c += NT) { if (c == r) continue; const double a = (c < r) ? fabs(F[r + c * ld]) : fabs(F[c + r * ld]); sig = fmax(sig, a); }
-            sig = block_max<NT>(sig, redv);
+            const unsigned long long hit = __ballot(best == lam);
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            const int r = __builtin_amdgcn_readlane(bi, src);
+            double sg = 0.0;
+            for (int c = j + lane; c < k; c += 64) { if (c == r) continue; const double a = (c < r) ? fabs(F[r + c * ld]) : fabs(F[c + r * ld]); sg = fmax(sg, a); }
+            const double sig = wave_max_all(sg);
             const double arr = fabs(F[r + r * ld]);
             if (ajj * sig >= BK_ALPHA * lam * lam) { /* 1x1 at j, no interchange */ }
             else if (arr >= BK_ALPHA * sig) { swap_rc<NT>(F, ld, m, j, r, lp); }
             else { two = 1; if (r != j + 1) swap_rc<NT>(F, ld, m, j + 1, r, lp); }
         }
+        const unsigned long long jbit = 1ull << (j < 63 ? j : 63);
+        const int ifirst = tid + ((j + 1 - tid + NT - 1) / NT) * NT;     // first owned row > j (tid + NT*q)
         if (two) {
             const double a = F[j + j * ld], b = F[j + 1 + j * ld], c = F[j + 1 + (j + 1) * ld];
             const double det = a * c - b * b;
             if (fabs(det) <= small) two = 0;   // degenerate block: fall through to a (perturbed) 1x1
             else {
                 const double idet = 1.0 / det;
-                double lmax = 0.0;
-                for (int i = j + 2 + tid; i < m; i += NT) {
+                for (int i = ifirst; i < m; i += NT) if (i > j + 1) {
                     const double w0 = F[i + j * ld], w1 = F[i + (j + 1) * ld];
                     const double l0 = (c * w0 - b * w1) * idet, l1 = (a * w1 - b * w0) * idet;
-                    lc0[i] = l0; lc1[i] = l1; lmax = fmax(lmax, fmax(fabs(l0), fabs(l1)));
+                    lc0[i] = l0; lc1[i] = l1;
+                    if (fmax(fabs(l0), fabs(l1)) * u > 1.0) bigmask |= jbit;
                 }
-                lmax = block_max<NT>(lmax, redv);   // (contains the barrier that publishes lc0/lc1)
-                if (NT == 64) __syncthreads();
+                __syncthreads();
                 trailing_update<NT, true>(F, ld, m, j + 2, j, lc0, lc1);
                 __syncthreads();
-                for (int i = j + 2 + tid; i < m; i += NT) { F[i + j * ld] = lc0[i]; F[i + (j + 1) * ld] = lc1[i]; }
+                for (int i = ifirst; i < m; i += NT) if (i > j + 1) { F[i + j * ld] = lc0[i]; F[i + (j + 1) * ld] = lc1[i]; }
                 if (tid == 0) {
                     F[j + 1 + j * ld] = 0.0;
                     dinv_s[j] = c * idet; dinv_s[j + 1] = a * idet; doff_s[j] = -b * idet; doff_s[j + 1] = 0.0;
                     pt_s[j] = 2; pt_s[j + 1] = 3;
                 }
                 if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
-                if (lmax * u > 1.0) nsmall++;
                 ntwo++; j += 2;
-                __syncthreads();
                 continue;
             }
         }
@@ -303,20 +351,30 @@ __device__ __forceinline__ void ldlt_lds(double* F, const int ld, const int m, c
             double d = F[j + j * ld];
             if (fabs(d) <= small) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
             const double di = 1.0 / d;
-            double lmax = 0.0;
-            for (int i = j + 1 + tid; i < m; i += NT) { const double l = F[i + j * ld] * di; lc0[i] = l; lmax = fmax(lmax, fabs(l)); }
-            lmax = block_max<NT>(lmax, redv);
-            if (NT == 64) __syncthreads();
+            for (int i = ifirst; i < m; i += NT) { const double l = F[i + j * ld] * di; lc0[i] = l; if (fabs(l) * u > 1.0) bigmask |= jbit; }
+            __syncthreads();
             trailing_update<NT, false>(F, ld, m, j + 1, j, lc0, lc1);
             __syncthreads();
-            for (int i = j + 1 + tid; i < m; i += NT) F[i + j * ld] = lc0[i];
+            for (int i = ifirst; i < m; i += NT) F[i + j * ld] = lc0[i];
             if (tid == 0) { dinv_s[j] = di; doff_s[j] = 0.0; pt_s[j] = 1; }
             if (d < 0.0) nneg++;
-            if (lmax * u > 1.0) nsmall++;
             j += 1;
-            __syncthreads();
         }
     }
+    // number of pivots with an oversized multiplier (the analogue of a delayed pivot): OR the per-thread masks
+    bigmask = wave_or_all(bigmask);
+    if (NT > 64) {
+        unsigned long long* red = reinterpret_cast<unsigned long long*>(redv);
+        __syncthreads();
+        if (lane == 0) red[tid >> 6] = bigmask;
+        __syncthreads();
+        bigmask = 0ull;
+#pragma unroll
+        for (int q = 0; q < NT / 64; ++q) bigmask |= red[q];
+        __syncthreads();
+    }
+    nsmall = __popcll(bigmask);
+    (void)redi;
 }
 
 template <int NT>

@@ -496,12 +496,30 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
 
     // ---- 8. supernodes: fundamental + forced pairs, then relaxed amalgamation of chains ----
     const int maxcols = std::max(2, opt.max_sn_cols);
+    // (a) whole small subtrees become one dense supernode: in the latency-bound regime (fronts of a few rows) dense
+    //     arithmetic on <= leaf_cols columns is free, while every tree level costs a kernel launch and a dependent
+    //     HBM round trip.  A subtree is a contiguous column range in the postorder.
+    vector<char> forced_join(n, 0), forced_start(n, 0);
+    if (opt.leaf_cols > 1) {
+        const int cap_m = 64;     // the merged front must still fit the one-wavefront LDS kernel
+        vector<int> desc(n, 1);
+        for (int j = 0; j < n; ++j) if (parent[j] >= 0) desc[parent[j]] += desc[j];
+        auto mergeable = [&](int j) { return desc[j] <= opt.leaf_cols && desc[j] + cc[j] - 1 <= cap_m; };
+        for (int j = 0; j < n; ++j) {
+            if (desc[j] < 2 || !mergeable(j)) continue;
+            if (parent[j] >= 0 && mergeable(parent[j])) continue;      // not maximal
+            const int first = j - desc[j] + 1;
+            forced_start[first] = 1;
+            for (int c = first + 1; c <= j; ++c) forced_join[c] = 1;
+        }
+    }
     vector<int> fstart;   // first column of each fundamental supernode
     {
         int len = 0;
         for (int j = 0; j < n; ++j) {
             bool join = false;
-            if (j > 0 && parent[j - 1] == j) {
+            if (forced_join[j]) join = true;
+            else if (!forced_start[j] && j > 0 && parent[j - 1] == j) {
                 bool pair = (S.pair_of[perm[j]] == perm[j - 1]);
                 if (pair) join = true;
                 else if (cc[j - 1] == cc[j] + 1 && len < maxcols) join = true;
@@ -517,7 +535,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         auto zfrac = [&](int k) { return k <= 16 ? 0.5 : (k <= 48 ? 0.15 : 0.05); };
         for (int f = 0; f < nf; ++f) {
             int c0 = fstart[f], c1 = (f + 1 < nf) ? fstart[f + 1] : n;
-            M cur{c0, c1 - c0, cc[c0], 0.0};
+            M cur{c0, c1 - c0, (c1 - c0) + cc[c1 - 1] - 1, 0.0};   // front order = columns + update rows of the last column
             // try to absorb preceding merged supernodes that are children of cur
             while (!st.empty()) {
                 M& ch = st.back();

@@ -22,6 +22,7 @@ struct SymbolicOptions {
     int    nd_leaf     = 32;
     int    nemin       = 8;
     int    max_sn_cols = 64;
+    int    leaf_cols   = 0;    // whole elimination subtrees with at most this many columns become ONE supernode
     int    nranks      = 1;
     int    verbose     = 0;
 };

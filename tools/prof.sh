@@ -5,13 +5,13 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 WL=${1:-lukvle1_1e4}
 OUT=$R/gpurun_out/prof_$WL
 rm -rf $OUT; mkdir -p $OUT
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $R/bench.py --workload $WL --steps 20 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python $R/bench.py --workload $WL --steps 20 --no-cpu-baseline > $OUT/bench_under_trace.json 2> $OUT/trace.log
 find $OUT/trace -name "*kernel_stats*" | head -3
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -25 $f
 # separate PMC passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: one pass each)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o pmc -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.log
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o pmc -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.log
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_fetch.log
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $OUT/pmc_write.log
 python3 - <<PY
 import csv, glob, collections, json
 def agg(d, name):
