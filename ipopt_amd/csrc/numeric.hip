@@ -50,7 +50,7 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 struct DevView {
     // symbolic
     const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
-    const int* child_ptr; const int* child_idx; const int* sn_owner;
+    const int* child_ptr; const int* child_idx; const int* sn_owner; const int* sn_parent; const int* col_owner;
     const long long* panel_off; const long long* cb_off; const long long* wb_off; const long long* minv_off;
     const int* acolptr; const int* apos; const int* arow; const int* acol;
     const int* dup_ptr; const int* dup_src;
@@ -74,7 +74,7 @@ struct DevView {
     double* top_rhs; const long long* top_rhs_off;
     // parameters
     double pivtol, small;
-    int n, nnz_a, nsn;
+    int n, nnz_a, nsn, rank;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -592,7 +592,7 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
 // ================================================================================================
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off)
+__global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, int top_mode)
 {
     const int s = V.level_sn[list_off + blockIdx.y];
     const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
@@ -601,24 +601,26 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off)
     const int fc = blockIdx.x * 4 + wave;                 // front column owned by this wavefront
     const bool active = fc < m;
     double* col = nullptr;                                 // col[i] = front(i, fc) for i in [0,m) (panel) or [k,m) (T)
+    const bool from_arena = top_mode && V.arena;
     if (active) {
+        const double* Ar = from_arena ? V.arena + V.arena_off[s] + (size_t)fc * m : nullptr;   // all-reduced square, lower part
         if (fc < k) {
             col = V.L + V.panel_off[s] + (size_t)fc * m;
-            for (int i = lane; i < m; i += 64) col[i] = 0.0;
+            for (int i = lane; i < m; i += 64) col[i] = (from_arena && i >= fc) ? Ar[i] : 0.0;
         } else {
             col = V.cb + V.cb_off[s] + (size_t)(fc - k) * mu - k;
-            for (int i = fc + lane; i < m; i += 64) col[i] = 0.0;
+            for (int i = fc + lane; i < m; i += 64) col[i] = from_arena ? Ar[i] : 0.0;
         }
     }
     __syncthreads();
-    if (active && fc < k) {
+    if (active && fc < k && !from_arena) {
         const int q0 = V.acolptr[c0 + fc], q1 = V.acolptr[c0 + fc + 1];
         for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] = V.aval[q];
     }
     __syncthreads();
     for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
         const int ch = V.child_idx[cp];
-        if (active) {
+        if (active && !(from_arena && V.sn_owner[ch] >= 0)) {
             const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
             const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
             const int* relc = V.rel + V.sn_rowptr[ch] + kc;
@@ -772,6 +774,71 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
             }
 }
 
+
+// ================================================================================================
+// multi-GPU pieces (one process per GPU, subtrees sharded, top of the tree replicated)
+// ================================================================================================
+// Every rank adds what IT knows about each replicated (top) front into that front's m x m arena square: rank 0 the
+// A entries, every rank the contribution blocks of its own subtree roots.  One wavefront per front column, children
+// in fixed order => deterministic.  The arena is then summed over ranks (RCCL all-reduce) by the caller.
+__global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off)
+{
+    const int s = V.level_sn[list_off + blockIdx.y];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fc = blockIdx.x * 4 + wave;
+    const bool active = fc < m;
+    double* col = active ? V.arena + V.arena_off[s] + (size_t)fc * m : nullptr;
+    if (active && fc < k && V.rank == 0) {
+        const int q0 = V.acolptr[c0 + fc], q1 = V.acolptr[c0 + fc + 1];
+        for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] = V.aval[q];
+    }
+    __syncthreads();
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        if (active && V.sn_owner[ch] == V.rank) {
+            const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+            const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
+            const int* relc = V.rel + V.sn_rowptr[ch] + kc;
+            int lo = 0, hi = mc;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
+            if (lo < mc && relc[lo] == fc) {
+                const double* C = V.cb + V.cb_off[ch] + (size_t)lo * mc;
+                for (int a = lo + lane; a < mc; a += 64) col[relc[a]] += C[a];
+            }
+        }
+        __syncthreads();
+    }
+}
+// forward-solve contributions of this rank's subtree roots to the replicated fronts (summed over ranks by the caller)
+__global__ __launch_bounds__(256) void k_top_rhs_assemble(DevView V, int list_off)
+{
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    double* tr = V.top_rhs + V.top_rhs_off[s];
+    for (int i = threadIdx.x; i < m; i += 256) tr[i] = 0.0;
+    __syncthreads();
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        if (V.sn_owner[ch] == V.rank) {
+            const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+            const int base = V.sn_rowptr[ch] + kc, mc = V.sn_rowptr[ch + 1] - base;
+            for (int t = threadIdx.x; t < mc; t += 256) tr[V.rel[base + t]] += V.cvec[base + t];
+        }
+        __syncthreads();
+    }
+}
+// this rank's part of the solution (own subtrees; rank 0 also the replicated columns), zero elsewhere => the
+// caller's all-reduce(sum) assembles the full vector on every rank
+__global__ void k_store_sol_mg(DevView V, double* b)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) {
+        const int o = V.col_owner[i];
+        b[V.perm[i]] = (o == V.rank || (o < 0 && V.rank == 0)) ? V.scale[i] * V.xw[i] : 0.0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host-side orchestration
 // ------------------------------------------------------------------------------------------------
@@ -793,6 +860,13 @@ public:
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
     std::vector<int> big_maxm, big_maxk;
+    // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
+    // the single-GPU list in the same device array
+    struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk; };
+    Sched sch_local, sch_top;
+    int top_list_base = 0, top_count = 0, top_maxm = 0;      // all top fronts (for arena / top-rhs assembly)
+    long long arena_doubles = 0, toprhs_doubles = 0;
+    bool multi = false;
 
     // ---- per-kernel-kind timing (bench.py roofline): hip events around every launch, eager mode ----
     bool prof_on = false;
@@ -847,11 +921,40 @@ public:
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
+        multi = opt.nranks > 1;
+        std::vector<int> lvl_list(Sy.level_sn);
+        std::vector<long long> aoff(Sy.num_sn, -1), troff(Sy.num_sn, -1);
+        std::vector<int> colown(Sy.n, 0);
+        if (multi) {
+            auto build = [&](Sched& sc, bool top) {
+                sc.ptr.assign((size_t)Sy.num_levels * FC_COUNT + 1, 0); sc.base = (int)lvl_list.size();
+                sc.maxm.assign(Sy.num_levels, 0); sc.maxk.assign(Sy.num_levels, 0);
+                std::vector<std::vector<int>> bucket((size_t)Sy.num_levels * FC_COUNT);
+                for (int s = 0; s < Sy.num_sn; ++s) {
+                    const bool mine = top ? (Sy.sn_owner[s] < 0) : (Sy.sn_owner[s] == opt.rank);
+                    if (!mine) continue;
+                    bucket[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]].push_back(s);
+                    if (Sy.sn_class[s] == FC_BIG) { sc.maxm[Sy.sn_level[s]] = std::max(sc.maxm[Sy.sn_level[s]], Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]);
+                                                    sc.maxk[Sy.sn_level[s]] = std::max(sc.maxk[Sy.sn_level[s]], Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]); }
+                }
+                for (size_t b = 0; b < bucket.size(); ++b) { sc.ptr[b + 1] = sc.ptr[b] + (int)bucket[b].size(); lvl_list.insert(lvl_list.end(), bucket[b].begin(), bucket[b].end()); }
+            };
+            build(sch_local, false); build(sch_top, true);
+            top_list_base = (int)lvl_list.size();
+            for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0) {
+                const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
+                lvl_list.push_back(s); ++top_count; top_maxm = std::max<int>(top_maxm, (int)m);
+                aoff[s] = arena_doubles; arena_doubles += m * m;
+                troff[s] = toprhs_doubles; toprhs_doubles += m;
+            }
+            for (int s = 0; s < Sy.num_sn; ++s) for (int j = Sy.sn_colptr[s]; j < Sy.sn_colptr[s + 1]; ++j) colown[j] = Sy.sn_owner[s];
+        }
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
             !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) || !upload(moff, &V.minv_off) ||
             !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
-            !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.level_sn, &V.level_sn) ||
+            !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(lvl_list, &V.level_sn) ||
+            !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
             !upload(Sy.perm, &V.perm)) return false;
         double* tv = nullptr;
         if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
@@ -860,7 +963,8 @@ public:
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
             !dalloc(&d_stats, 4)) return false;
-        V.arena = nullptr; V.arena_off = nullptr; V.top_rhs = nullptr; V.top_rhs_off = nullptr;
+        V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank;
+        if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
         V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -906,7 +1010,7 @@ public:
                 else {
                     const int mm = big_maxm[lv], kk = big_maxk[lv], mu = mm - 1;
                     const int nt = (mu + 63) / 64;
-                    LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, b1 - b0), dim3(256), 0, stream, V, b0);
+                    LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, b1 - b0), dim3(256), 0, stream, V, b0, 0);
                     LAUNCH(KK_BIG_DIAG, k_big_diag, dim3(b1 - b0), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
                     LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, b1 - b0), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
                     LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, b1 - b0), dim3(256), 0, stream, V, b0);
@@ -1011,6 +1115,122 @@ public:
         if (timed) { HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms; }
         return true;
     }
+
+    // ---------------- multi-GPU orchestration (eager launches) ----------------
+    bool launch_fronts(const Sched& sc, int top_mode) {
+        const Symbolic& Sy = *S;
+        for (int lv = 0; lv < Sy.num_levels; ++lv)
+            for (int fc = 0; fc < FC_COUNT; ++fc) {
+                const int b0 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc], b1 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc + 1];
+                if (b1 == b0) continue;
+                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(32, 32),   stream, V, b0, top_mode);
+                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(64, 64),   stream, V, b0, top_mode);
+                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(128, 128), stream, V, b0, top_mode);
+                else {
+                    const int mm = sc.maxm[lv], kk = sc.maxk[lv], nt = (mm - 1 + 63) / 64;
+                    hipLaunchKernelGGL(k_big_assemble, dim3((mm + 3) / 4, b1 - b0), dim3(256), 0, stream, V, b0, top_mode);
+                    hipLaunchKernelGGL(k_big_diag, dim3(b1 - b0), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
+                    hipLaunchKernelGGL(k_big_trsm, dim3((mm + 63) / 64, b1 - b0), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
+                    hipLaunchKernelGGL(k_big_schur, dim3(nt * (nt + 1) / 2, b1 - b0), dim3(256), 0, stream, V, b0);
+                }
+            }
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+    bool launch_solve_sweep(const Sched& sc, bool forward, int top_mode) {
+        const Symbolic& Sy = *S;
+        auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
+        for (int q = 0; q < Sy.num_levels; ++q) {
+            const int lv = forward ? q : Sy.num_levels - 1 - q;
+            for (int fc = 0; fc < FC_COUNT; ++fc) {
+                const int b0 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc], b1 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc + 1];
+                if (b1 == b0) continue;
+                if (forward) {
+                    if (fc == FC_WAVE)        hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, top_mode);
+                    else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, top_mode);
+                    else if (fc == FC_LDS128) hipLaunchKernelGGL((k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, top_mode);
+                    else                      hipLaunchKernelGGL((k_fwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0, top_mode);
+                } else {
+                    if (fc == FC_WAVE)        hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                    else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
+                    else if (fc == FC_LDS128) hipLaunchKernelGGL((k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
+                    else                      hipLaunchKernelGGL((k_bwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0);
+                }
+            }
+        }
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+    bool factor_local(const double* dvals) {
+        if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
+        const Symbolic& Sy = *S; const int n = Sy.n;
+        V.pivtol = opt.pivtol; V.small = opt.small;
+        if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
+        have_values = true;
+        HIPCHK(hipEventRecord(ev0, stream));
+        hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
+        if (opt.scaling) {
+            for (int it = 0; it < 3; ++it) {
+                hipLaunchKernelGGL(k_zero_u64, dim3(grid1d(n)), dim3(256), 0, stream, V.rowmax, n);
+                hipLaunchKernelGGL(k_ruiz_rowmax, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+                hipLaunchKernelGGL(k_ruiz_update, dim3(grid1d(n)), dim3(256), 0, stream, V);
+            }
+            hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        }
+        if (!launch_fronts(sch_local, 0)) return false;
+        HIPCHK(hipMemsetAsync(V.arena, 0, (size_t)arena_doubles * sizeof(double), stream));
+        if (top_count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((top_maxm + 3) / 4, top_count), dim3(256), 0, stream, V, top_list_base);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev1, stream));
+        HIPCHK(hipStreamSynchronize(stream));       // the caller's collective runs on another stream
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
+        return true;
+    }
+    bool factor_top(FactorStats& st) {
+        if (!ready || !multi) { err_ = "factor_top: not a multi-GPU handle"; return false; }
+        HIPCHK(hipEventRecord(ev0, stream));
+        if (!launch_fronts(sch_top, 1)) return false;
+        // this rank reports its own subtrees; rank 0 also the replicated top => the sum over ranks is the inertia
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3];
+        if (opt.rank == 0) {
+            hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
+            HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            st.num_neg += h_stats[0]; st.num_zero += h_stats[1]; st.num_two += h_stats[2]; st.num_small += h_stats[3];
+        }
+        HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms += ms;
+        return true;
+    }
+    bool solve_fwd_local(double* drhs) {
+        if (!ready || !multi) { err_ = "solve_fwd_local: not a multi-GPU handle"; return false; }
+        HIPCHK(hipEventRecord(ev0, stream));
+        hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, (const double*)drhs);
+        if (!launch_solve_sweep(sch_local, true, 0)) return false;
+        if (top_count > 0) hipLaunchKernelGGL(k_top_rhs_assemble, dim3(top_count), dim3(256), 0, stream, V, top_list_base);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms;
+        return true;
+    }
+    bool solve_top_and_bwd(double* drhs) {
+        if (!ready || !multi) { err_ = "solve_top_and_bwd: not a multi-GPU handle"; return false; }
+        HIPCHK(hipEventRecord(ev0, stream));
+        if (!launch_solve_sweep(sch_top, true, 1)) return false;
+        if (!launch_solve_sweep(sch_top, false, 1)) return false;
+        if (!launch_solve_sweep(sch_local, false, 0)) return false;
+        hipLaunchKernelGGL(k_store_sol_mg, dim3(grid1d(S->n)), dim3(256), 0, stream, V, drhs);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms += ms;
+        return true;
+    }
+
     // eager (graph-less) factor + one solve with hip events around every launch; accumulates over `reps`
     bool profile(int reps, double* ms, int* launches) {
         if (!ready || !have_values) { err_ = "profile: factor() must have been called once"; return false; }
@@ -1057,11 +1277,11 @@ double Numeric::last_factor_ms() const { return p_->factor_ms; }
 double Numeric::last_solve_ms() const { return p_->solve_ms; }
 const std::string& Numeric::error() const { return p_->err_; }
 bool Numeric::profile(int reps, double* ms, int* launches) { return p_->profile(reps, ms, launches); }
-bool Numeric::factor_local(const double*) { p_->err_ = "multi-GPU path not built yet"; return false; }
-bool Numeric::top_arena(double**, int64_t*) { p_->err_ = "multi-GPU path not built yet"; return false; }
-bool Numeric::factor_top(FactorStats&) { p_->err_ = "multi-GPU path not built yet"; return false; }
-bool Numeric::solve_fwd_local(double*) { p_->err_ = "multi-GPU path not built yet"; return false; }
-bool Numeric::top_rhs(double**, int64_t*) { p_->err_ = "multi-GPU path not built yet"; return false; }
-bool Numeric::solve_top_and_bwd(double*) { p_->err_ = "multi-GPU path not built yet"; return false; }
+bool Numeric::factor_local(const double* dvals) { return p_->factor_local(dvals); }
+bool Numeric::top_arena(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_arena: not a multi-GPU handle"; return false; } *d = p_->V.arena; *nd = p_->arena_doubles; return true; }
+bool Numeric::factor_top(FactorStats& st) { return p_->factor_top(st); }
+bool Numeric::solve_fwd_local(double* drhs) { return p_->solve_fwd_local(drhs); }
+bool Numeric::top_rhs(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_rhs: not a multi-GPU handle"; return false; } *d = p_->V.top_rhs; *nd = p_->toprhs_doubles; return true; }
+bool Numeric::solve_top_and_bwd(double* drhs) { return p_->solve_top_and_bwd(drhs); }
 
 } // namespace mi355x
