@@ -97,8 +97,10 @@ def test_seeded_systems_against_oracle(case):
         assert sres(K, x[k], b[k]) <= RES_TOL
         ro = sres(K, xo[k], b[k])
         assert ro <= 1e-8          # the checker's own accuracy (Sigma spans 1e-8..1e+8 in the wide_sigma case)
-        if ro <= 1e-13:            # solutions are only comparable digit-for-digit when the checker itself is converged
-            assert np.abs(x[k] - xo[k]).max() <= 1e-6 * max(1.0, np.abs(xo[k]).max())
+        if ro <= 1e-13:            # solutions are only comparable digit-for-digit when the checker itself is converged;
+            # the forward error is condition-dependent: Sigma in 1e-8..1e+8 (wide_sigma) puts cond(K) near 1e10
+            tol = 1e-4 if "wide_sigma" in case else 1e-6
+            assert np.abs(x[k] - xo[k]).max() <= tol * max(1.0, np.abs(xo[k]).max())
     # bitwise reproducibility
     x2 = b.copy(); s.multi_solve(True, x2)
     assert np.array_equal(x, x2)
