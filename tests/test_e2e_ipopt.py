@@ -45,3 +45,23 @@ def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_d
         for k in (2, 3):
             x, y = float(fa[k]), float(fb[k])
             assert abs(x - y) <= 2e-2 * max(x, y) + 1e-11, f"{a}   |   {b}"
+
+
+HS071 = os.path.join(ROOT, "oracle", "_ref", "hs071_cpp")
+
+
+@pytest.mark.skipif(not os.path.exists(HS071), reason="oracle/_ref not built")
+def test_hsllib_route_stock_ipopt_loads_our_ma97_symbols(tmp_path, golden_dir):
+    """Route B2: the reference's UNMODIFIED test binary + `linear_solver ma97` + `hsllib libmi355x_kkt.so`
+    (reference IpMa97SolverInterface.cpp:303-315 dlsym()s our seven ma97_*_d exports)."""
+    import ipopt_amd
+    (tmp_path / "ipopt.opt").write_text(f"linear_solver ma97\nhsllib {ipopt_amd.library_path()}\nma97_scaling none\n")
+    out = subprocess.run([HS071], capture_output=True, text=True, timeout=300, cwd=str(tmp_path)).stdout
+    assert "EXIT: Optimal Solution Found." in out, out[-2000:]
+    iters = [ln.split() for ln in out.splitlines() if ln.startswith(" ") and len(ln.split()) >= 10 and ln.split()[0].isdigit()]
+    gold = open(os.path.join(golden_dir, "hs071.iters")).read().splitlines()
+    assert len(iters) == len(gold)
+    for f, g in zip(iters, gold):
+        g = g.split()
+        assert f[0] == g[0] and f[4] == g[4] and f[6] == g[5] and f[9] == g[6]      # iter, lg(mu), lg(rg), ls
+        assert abs(float(f[1]) - float(g[1])) <= 1e-7 * max(1.0, abs(float(g[1])))
