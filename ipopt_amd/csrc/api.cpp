@@ -185,6 +185,13 @@ int mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches,
     catch (...) { h->err = "profile: unexpected exception"; return MI355X_KKT_FATAL; }
 }
 
+/* development aid, not part of the public header: phase time stamps of one workgroup */
+int mi355x_kkt_debug_clocks(mi355x_kkt_handle h, unsigned long long* out16)
+{
+    if (!h || !h->numeric_ready) return MI355X_KKT_FATAL;
+    try { return h->num->debug_clocks(out16) ? 0 : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
+}
+
 // ---- multi-GPU ----
 #define MG_GUARD if (!h) return MI355X_KKT_FATAL; if (!h->numeric_ready) { h->err = "multi-GPU call without a device"; return MI355X_KKT_FATAL; }
 int mi355x_kkt_factor_local(mi355x_kkt_handle h, const double* dvals) { MG_GUARD try { if (!h->num->factor_local(dvals)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }

@@ -39,6 +39,7 @@ namespace mi355x {
 // kernel kinds for the profiling entry point (order = include/mi355x_kkt.h MI355X_KKT_KERNEL_*)
 enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_LDS128, KK_BIG_ASSEMBLE, KK_BIG_DIAG, KK_BIG_TRSM,
                   KK_BIG_SCHUR, KK_STATS, KK_SOLVE_PERM, KK_FWD_WAVE, KK_FWD_LDS, KK_FWD_BIG, KK_BWD_WAVE, KK_BWD_LDS, KK_BWD_BIG, KK_COUNT };
+#define DBGSTAMP(slot) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { V.dbg[2 * (slot)] = clock64(); V.dbg[2 * (slot) + 1] = wall_clock64(); } } while (0)
 #define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); } while (0)
 
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
@@ -69,12 +70,14 @@ struct DevView {
     int4*   fstat;          // per front {neg, zero, two, small}
     double* xw;             // work vector (permuted, scaled)
     double* cvec;           // forward-solve contributions, aligned with sn_rows
+    double* ybuf;           // y of the pivot rows (big fronts: the update rows are handled by a second, multi-workgroup launch)
     // multi-GPU top arena (full m x m squares per replicated front), null on 1 GPU
     double* arena; const long long* arena_off;
     double* top_rhs; const long long* top_rhs_off;
     // parameters
     double pivtol, small;
     int n, nnz_a, nsn, rank;
+    unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -448,6 +451,311 @@ __global__ __launch_bounds__(NT) void k_front_lds(DevView V, int list_off, int t
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? F[i + c * ld] : (i == c ? 1.0 : 0.0); }
 }
 
+
+// ================================================================================================
+// Register-tiled LDL^T core (the production path).  The assembled front is pulled from LDS into VGPRs as a
+// G x G grid of TS x TS tiles (full symmetric storage, thread (ti,tj) owns rows ti*TS.., columns tj*TS..);
+// LDS only carries the pivot column(s) of the current step (published by the G owner threads, read by everybody:
+// by symmetry the same vector serves as row and column multipliers) and the finished L columns.
+//   * no interchanges: Bunch-Kaufman picks the pivot among the still-alive fully-summed rows and the chosen
+//     PHYSICAL row is eliminated in place; the pivot order `ord` is applied once at write-back;
+//   * one barrier per 1x1 pivot (two when the BK test needs the partner column), none of them inside a wavefront's
+//     own dependency chain when the workgroup is a single wave (fronts of order <= 64);
+//   * pivot search: DPP wave reduction, done redundantly by every wave on the published column.
+// (NT,TS) = (64,4): order <= 32, (64,8): <= 64, (256,8): <= 128, (256,4): the 64-column pivot block of a big front.
+// ================================================================================================
+template <int TS>
+__device__ __forceinline__ void publish_col(double* buf, const double (&t)[TS][TS], const int row0, const int jl)
+{
+    // jl is wave-uniform: a scalar branch selects the STATICALLY indexed register column.  The empty asm keeps the
+    // cases apart -- merged, they become a dynamically indexed t[a][jl] and the whole tile array moves to scratch.
+#pragma unroll
+    for (int b = 0; b < TS; ++b)
+        if (jl == b) {
+#pragma unroll
+            for (int a = 0; a < TS; ++a) { double v = t[a][b]; asm volatile("" : "+v"(v)); buf[row0 + a] = v; }
+        }
+}
+
+__device__ __forceinline__ double fast_rcp(double d)
+{
+    double r = __builtin_amdgcn_rcp(d);          // v_rcp_f64 + two Newton steps: full fp64 accuracy without the division macro
+    double e = fma(-d, r, 1.0); r = fma(r, e, r);
+    e = fma(-d, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+
+template <int NT, int TS>
+__device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const int k, double* Lbuf, const int ldL, double* colbuf,
+                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double small,
+                                         int& nneg, int& nzero, int& ntwo, int& nsmall)
+{
+    // The per-pivot instruction stream IS the critical path (measured: ~5 cycles per wave instruction), so the common
+    // case -- 1x1 pivot on the first alive row -- is kept to ~100 instructions: unconditional wide LDS reads + bit-mask
+    // selects, one ballot instead of a max-reduction for the Bunch-Kaufman acceptance test, reciprocal by v_rcp_f64 +
+    // Newton, L column written by the 16 (8) threads that already hold it.
+    constexpr int G = (NT == 64) ? 8 : 16;
+    constexpr int MAXM = G * TS;
+    constexpr unsigned TMASK = (1u << TS) - 1u;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ti = tid % G, tj = tid / G;
+    const int row0 = ti * TS, col0 = tj * TS;
+    unsigned rowvalid = 0, rowupd = 0, colvalid = 0, colupd = 0;
+#pragma unroll
+    for (int x = 0; x < TS; ++x) {
+        if (row0 + x < m) { rowvalid |= 1u << x; if (row0 + x >= k) rowupd |= 1u << x; }
+        if (col0 + x < m) { colvalid |= 1u << x; if (col0 + x >= k) colupd |= 1u << x; }
+    }
+    const unsigned long long lanebit = 1ull << lane;
+    unsigned long long alive = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);     // fully-summed rows not yet eliminated (k <= 64)
+    unsigned long long bigmask = 0ull;
+    int step = 0, bufsel = 0;
+    while (alive != 0ull) {
+        double* colA = colbuf + bufsel * 2 * MAXM; bufsel ^= 1;
+        double* colB = colA + MAXM;
+        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);
+        if (tj == j / TS) publish_col<TS>(colA, t, row0, j % TS);
+        __syncthreads();
+        const double djj = colA[j];
+        const double ajj = fabs(djj);
+        const bool cand = (alive & lanebit) != 0ull && lane != j;
+        const double av = cand ? fabs(colA[lane]) : -1.0;
+        int p = j, q = -1;                 // 1x1 pivot p, or 2x2 pivot (p, q)
+        const double* W0 = colA;
+        if (__ballot(av * BK_ALPHA > ajj) != 0ull) {          // some |a_ij| > |a_jj| / alpha: run the full Bunch-Kaufman test
+            const double lam = wave_max_all(av);
+            const unsigned long long hit = __ballot(av == lam);
+            const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            if (tj == r / TS) publish_col<TS>(colB, t, row0, r % TS);
+            __syncthreads();
+            const bool cs = (alive & lanebit) != 0ull && lane != r;
+            const double sig = wave_max_all(cs ? fabs(colB[lane]) : 0.0);
+            const double arr = fabs(colB[r]);
+            if (ajj * sig >= BK_ALPHA * lam * lam) { /* 1x1 at j */ }
+            else if (arr >= BK_ALPHA * sig) { p = r; W0 = colB; }
+            else { q = r; }
+        }
+        if (q >= 0) {
+            const double a = colA[p], b = colA[q], c = colB[q];
+            const double det = a * c - b * b;
+            if (fabs(det) <= small) q = -1;            // degenerate block: (perturbed) 1x1 at j instead
+            else {
+                const double idet = fast_rcp(det);
+                const unsigned long long keep = alive & ~(1ull << p) & ~(1ull << q);
+                const unsigned rm = (((row0 < 64) ? (unsigned)(keep >> row0) : 0u) | rowupd) & rowvalid & TMASK;
+                const unsigned cm = (((col0 < 64) ? (unsigned)(keep >> col0) : 0u) | colupd) & colvalid & TMASK;
+                double l0[TS], l1[TS], w0[TS], w1[TS];
+#pragma unroll
+                for (int x = 0; x < TS; ++x) {
+                    const double r0 = colA[row0 + x], r1 = colB[row0 + x], c0_ = colA[col0 + x], c1_ = colB[col0 + x];
+                    const bool ra = (rm >> x) & 1u, ca = (cm >> x) & 1u;
+                    l0[x] = ra ? (c * r0 - b * r1) * idet : 0.0; l1[x] = ra ? (a * r1 - b * r0) * idet : 0.0;
+                    w0[x] = ca ? c0_ : 0.0; w1[x] = ca ? c1_ : 0.0;
+                }
+#pragma unroll
+                for (int x = 0; x < TS; ++x)
+#pragma unroll
+                    for (int y = 0; y < TS; ++y) t[x][y] -= l0[x] * w0[y] + l1[x] * w1[y];
+                if (tj == 0) {
+#pragma unroll
+                    for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) {
+                        Lbuf[row0 + x + step * ldL] = l0[x]; Lbuf[row0 + x + (step + 1) * ldL] = l1[x];
+                        if (fmax(fabs(l0[x]), fabs(l1[x])) * u > 1.0) bigmask |= 1ull << (step < 63 ? step : 63);
+                    }
+                }
+                if (tid == 0) {
+                    ord[step] = p; ord[step + 1] = q; pt_s[step] = 2; pt_s[step + 1] = 3;
+                    dinv_s[step] = c * idet; dinv_s[step + 1] = a * idet; doff_s[step] = -b * idet; doff_s[step + 1] = 0.0;
+                }
+                if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
+                ntwo++; alive = keep; step += 2;
+                continue;
+            }
+        }
+        {   // 1x1 pivot on physical row p, pivot column W0
+            double d = W0[p];
+            if (fabs(d) <= small) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
+            const double di = fast_rcp(d);
+            const unsigned long long keep = alive & ~(1ull << p);
+            const unsigned rm = (((row0 < 64) ? (unsigned)(keep >> row0) : 0u) | rowupd) & rowvalid & TMASK;
+            const unsigned cm = (((col0 < 64) ? (unsigned)(keep >> col0) : 0u) | colupd) & colvalid & TMASK;
+            double l0[TS], w0[TS];
+#pragma unroll
+            for (int x = 0; x < TS; ++x) {
+                const double rv = W0[row0 + x], cv = W0[col0 + x];
+                l0[x] = ((rm >> x) & 1u) ? rv * di : 0.0;
+                w0[x] = ((cm >> x) & 1u) ? cv : 0.0;
+            }
+#pragma unroll
+            for (int x = 0; x < TS; ++x)
+#pragma unroll
+                for (int y = 0; y < TS; ++y) t[x][y] -= l0[x] * w0[y];
+            if (tj == 0) {
+#pragma unroll
+                for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) {
+                    Lbuf[row0 + x + step * ldL] = l0[x];
+                    if (fabs(l0[x]) * u > 1.0) bigmask |= 1ull << (step < 63 ? step : 63);
+                }
+            }
+            if (tid == 0) { ord[step] = p; pt_s[step] = 1; dinv_s[step] = di; doff_s[step] = 0.0; }
+            if (d < 0.0) nneg++;
+            alive = keep; step += 1;
+        }
+    }
+    bigmask = wave_or_all(bigmask);
+    __syncthreads();
+    if (NT > 64) {
+        unsigned long long* red = reinterpret_cast<unsigned long long*>(colbuf);
+        if (lane == 0) red[tid >> 6] = bigmask;
+        __syncthreads();
+        bigmask = 0ull;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) bigmask |= red[w];
+        __syncthreads();
+    }
+    nsmall = __popcll(bigmask);
+}
+
+// front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
+// write-back of the pivot-ordered panel, the contribution block (straight from registers), pivot data and L11^{-1}.
+template <int NT, int TS>
+__global__ __launch_bounds__(NT) void k_front_reg(DevView V, int list_off, int top_mode)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int G = (NT == 64) ? 8 : 16;
+    constexpr int MAXM = G * TS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NW = NT / 64;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const int ld = m | 1, ldi = k | 1;
+    DBGSTAMP(4);
+    const int fdoubles = max(ld * m, k * ld + k * ldi);          // F, later overlaid by Lbuf (k columns) + the k x k inverse
+    double* F      = reinterpret_cast<double*>(smem_raw);
+    double* colbuf = F + fdoubles;               // 4 * MAXM
+    double* dinv_s = colbuf + 4 * MAXM;          // k
+    double* doff_s = dinv_s + k;                 // k
+    int*    ord    = reinterpret_cast<int*>(doff_s + k);   // k
+    int*    pt_s   = ord + k;                    // k
+
+    // ---- (a)-(c) assembly in LDS (lower storage) ----
+    if (top_mode && V.arena) {
+        const double* Ar = V.arena + V.arena_off[s];
+        for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; F[i + c * ld] = Ar[idx]; }
+    } else {
+        for (int idx = tid; idx < ld * m; idx += NT) F[idx] = 0.0;
+    }
+    __syncthreads();
+    if (!(top_mode && V.arena)) {
+        const int q0 = V.acolptr[c0], q1 = V.acolptr[c0 + k];
+        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] = V.aval[q]; }
+    }
+    __syncthreads();
+    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
+        const int ch = V.child_idx[cp];
+        if (top_mode && V.arena && V.sn_owner[ch] >= 0) continue;
+        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
+        const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
+        const int* relc = V.rel + V.sn_rowptr[ch] + kc;
+        const double* C = V.cb + V.cb_off[ch];
+        for (int b = wave; b < mc; b += NW) {
+            const int rb = relc[b];
+            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * mc];
+        }
+        __syncthreads();
+    }
+    // ---- tiles -> registers (full symmetric) ----
+    const int ti = tid % G, tj = tid / G, row0 = ti * TS, col0 = tj * TS;
+    double t[TS][TS];
+#pragma unroll
+    for (int x = 0; x < TS; ++x)
+#pragma unroll
+        for (int y = 0; y < TS; ++y) {
+            const int i = row0 + x, c = col0 + y;
+            t[x][y] = (i < m && c < m) ? ((i >= c) ? F[i + c * ld] : F[c + i * ld]) : 0.0;
+        }
+    __syncthreads();                                   // F is dead from here on: its storage becomes Lbuf
+    // ---- (d) LDL^T ----
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
+    DBGSTAMP(5);
+    ldlt_reg<NT, TS>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    __syncthreads();
+    DBGSTAMP(6);
+    if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[14] = (unsigned long long)k * 1000 + m;
+    // ---- (e) write back: pivot-ordered panel, pivot data, contribution block from the registers ----
+    double* Lg = V.L + V.panel_off[s];
+    for (int c = wave; c < k; c += NW)
+        for (int i = lane; i < m; i += 64) {
+            const int src = (i < k) ? ord[i] : i;
+            Lg[i + (size_t)c * m] = (i > c) ? F[src + c * ld] : 0.0;
+        }
+    for (int jj = tid; jj < k; jj += NT) { V.dinv[c0 + jj] = dinv_s[jj]; V.doff[c0 + jj] = doff_s[jj]; V.ptype[c0 + jj] = pt_s[jj]; V.lperm[c0 + jj] = ord[jj]; }
+    const int mu = m - k;
+    double* Cg = V.cb + V.cb_off[s];
+#pragma unroll
+    for (int y = 0; y < TS; ++y)
+#pragma unroll
+        for (int x = 0; x < TS; ++x) {
+            const int i = row0 + x, c = col0 + y;
+            if (c >= k && i >= c && i < m) Cg[(i - k) + (size_t)(c - k) * mu] = t[x][y];
+        }
+    if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+    // ---- (f) L11^{-1}: pivot-ordered unit-lower block built behind Lbuf, inverted in place ----
+    double* Li = F + k * ld;
+    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Li[i + c * ldi] = (i > c) ? F[ord[i] + c * ld] : 0.0; }
+    __syncthreads();
+    invert_unit_lower<NT>(Li, ldi, k);
+    double* Mg = V.minv + V.minv_off[s];
+    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ldi] : (i == c ? 1.0 : 0.0); }
+}
+
+// pivot block (k <= 64 columns) of a BIG front on the register-tiled core
+__global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TS = 4, G = 16, MAXM = 64;
+    const int tid = threadIdx.x;
+    const int s = V.level_sn[list_off + blockIdx.x];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const int ld = k | 1;
+    double* Lb     = reinterpret_cast<double*>(smem_raw);   // k x k L columns (physical rows)
+    double* Li     = Lb + (size_t)ld * k;                    // k x k pivot-ordered copy / inverse
+    double* colbuf = Li + (size_t)ld * k;
+    double* dinv_s = colbuf + 4 * MAXM; double* doff_s = dinv_s + k;
+    int* ord = reinterpret_cast<int*>(doff_s + k); int* pt_s = ord + k;
+    double* P = V.L + V.panel_off[s];
+    const int ti = tid % G, tj = tid / G, row0 = ti * TS, col0 = tj * TS;
+    double t[TS][TS];
+#pragma unroll
+    for (int x = 0; x < TS; ++x)
+#pragma unroll
+        for (int y = 0; y < TS; ++y) {
+            const int i = row0 + x, c = col0 + y;
+            t[x][y] = (i < k && c < k) ? ((i >= c) ? P[i + (size_t)c * m] : P[c + (size_t)i * m]) : 0.0;
+        }
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
+    DBGSTAMP(0);
+    ldlt_reg<256, TS>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    __syncthreads();
+    DBGSTAMP(1);
+    for (int idx = tid; idx < k * k; idx += 256) {
+        const int i = idx % k, c = idx / k;
+        const double v = (i > c) ? Lb[ord[i] + c * ld] : 0.0;
+        P[i + (size_t)c * m] = v; Li[i + c * ld] = v;
+    }
+    for (int j = tid; j < k; j += 256) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
+    if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+    __syncthreads();
+    DBGSTAMP(2);
+    invert_unit_lower<256>(Li, ld, k);
+    DBGSTAMP(3);
+    double* Mg = V.minv + V.minv_off[s];
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ld] : (i == c ? 1.0 : 0.0); }
+    if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[15] = (unsigned long long)k;
+}
+
 // ------------------------------------------------------------------------------------------------
 // inertia / statistics reduction (fixed order => deterministic)
 // ------------------------------------------------------------------------------------------------
@@ -528,13 +836,17 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         ys[j] = a0 + a1;
     }
     __syncthreads();
-    const double* Lg = V.L + V.panel_off[s];
-    for (int i = k + tid; i < m; i += NT) {
-        double t0 = 0.0, t1 = 0.0;
-        int j = 0;
-        for (; j + 1 < k; j += 2) { t0 += Lg[i + (size_t)j * m] * ys[j]; t1 += Lg[i + (size_t)(j + 1) * m] * ys[j + 1]; }
-        if (j < k) t0 += Lg[i + (size_t)j * m] * ys[j];
-        if (BIG) V.cvec[r0 + i] -= t0 + t1; else V.cvec[r0 + i] = xu[i - k] - (t0 + t1);
+    if (BIG) {
+        for (int j = tid; j < k; j += NT) V.ybuf[c0 + j] = ys[j];      // update rows: k_fwd_big_upd, many workgroups per front
+    } else {
+        const double* Lg = V.L + V.panel_off[s];
+        for (int i = k + tid; i < m; i += NT) {
+            double t0 = 0.0, t1 = 0.0;
+            int j = 0;
+            for (; j + 1 < k; j += 2) { t0 += Lg[i + (size_t)j * m] * ys[j]; t1 += Lg[i + (size_t)(j + 1) * m] * ys[j + 1]; }
+            if (j < k) t0 += Lg[i + (size_t)j * m] * ys[j];
+            V.cvec[r0 + i] = xu[i - k] - (t0 + t1);
+        }
     }
     for (int j = tid; j < k; j += NT) {
         const int pt = V.ptype[c0 + j];
@@ -558,17 +870,22 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
     const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
     double* ws = reinterpret_cast<double*>(smem_raw);   // k
     double* xu = ws + k;                                // m-k gathered ancestor values (LDS classes)
-    if (BIG) { for (int i = k + tid; i < m; i += NT) V.cvec[r0 + i] = V.xw[V.sn_rows[r0 + i]]; }
-    else     { for (int i = k + tid; i < m; i += NT) xu[i - k] = V.xw[V.sn_rows[r0 + i]]; }
+    if (!BIG) { for (int i = k + tid; i < m; i += NT) xu[i - k] = V.xw[V.sn_rows[r0 + i]]; }
     for (int j = tid; j < k; j += NT) ws[j] = V.xw[c0 + j];
     __syncthreads();
-    const double* Lg = V.L + V.panel_off[s];
-    const double* xg = BIG ? (V.cvec + r0 + k) : xu;
-    for (int j = wave; j < k; j += NW) {
-        double t = 0.0;
-        for (int i = lane; i < m - k; i += 64) t += Lg[k + i + (size_t)j * m] * xg[i];
-        t = wave_sum(t);
-        if (lane == 0) ws[j] -= t;
+    if (BIG) {
+        // L21^T x_upd was formed by k_bwd_big_dot in row chunks of 256: add the partial sums in fixed order
+        const int nch = (m - k + 255) / 256;
+        const double* part = V.wbuf + V.wb_off[s];
+        for (int j = tid; j < k; j += NT) { double t = 0.0; for (int c = 0; c < nch; ++c) t += part[(size_t)c * k + j]; ws[j] -= t; }
+    } else {
+        const double* Lg = V.L + V.panel_off[s];
+        for (int j = wave; j < k; j += NW) {
+            double t = 0.0;
+            for (int i = lane; i < m - k; i += 64) t += Lg[k + i + (size_t)j * m] * xu[i];
+            t = wave_sum(t);
+            if (lane == 0) ws[j] -= t;
+        }
     }
     __syncthreads();
     // x_p = sum_{j >= p} Minv(j,p) w_j : thread p walks its own (contiguous) column of the inverse
@@ -579,6 +896,53 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
         for (; j + 1 < k; j += 2) { a0 += Mg[j + (size_t)p * k] * ws[j]; a1 += Mg[j + 1 + (size_t)p * k] * ws[j + 1]; }
         if (j < k) a0 += Mg[j + (size_t)p * k] * ws[j];
         V.xw[c0 + V.lperm[c0 + p]] = a0 + a1;
+    }
+}
+
+
+// big fronts, forward part 2: c(i) -= sum_j L21(i,j) y_j, one thread per update row, 256 rows per workgroup
+__global__ __launch_bounds__(256) void k_fwd_big_upd(DevView V, int list_off)
+{
+    __shared__ double ys[72];
+    const int tid = threadIdx.x;
+    const int s = V.level_sn[list_off + blockIdx.y];
+    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    if (k + blockIdx.x * 256 >= m) return;
+    if (tid < k) ys[tid] = V.ybuf[c0 + tid];
+    __syncthreads();
+    const int i = k + blockIdx.x * 256 + tid;
+    if (i >= m) return;
+    const double* Lg = V.L + V.panel_off[s] + i;
+    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+    int j = 0;
+    for (; j + 3 < k; j += 4) {
+        t0 += Lg[(size_t)j * m] * ys[j]; t1 += Lg[(size_t)(j + 1) * m] * ys[j + 1];
+        t2 += Lg[(size_t)(j + 2) * m] * ys[j + 2]; t3 += Lg[(size_t)(j + 3) * m] * ys[j + 3];
+    }
+    for (; j < k; ++j) t0 += Lg[(size_t)j * m] * ys[j];
+    V.cvec[r0 + i] -= (t0 + t1) + (t2 + t3);
+}
+// big fronts, backward part 1: partial(chunk, j) = sum_{i in chunk} L21(i,j) x(rows(i)), 256 rows per workgroup
+__global__ __launch_bounds__(256) void k_bwd_big_dot(DevView V, int list_off)
+{
+    __shared__ double xs[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = V.level_sn[list_off + blockIdx.y];
+    const int k = V.sn_colptr[s + 1] - V.sn_colptr[s];
+    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const int ibase = k + blockIdx.x * 256;
+    if (ibase >= m) return;
+    const int nrow = min(256, m - ibase);
+    xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[r0 + ibase + tid]] : 0.0;
+    __syncthreads();
+    const double* Lg = V.L + V.panel_off[s] + ibase;
+    double* part = V.wbuf + V.wb_off[s] + (size_t)blockIdx.x * k;
+    for (int j = wave; j < k; j += 4) {
+        double t = 0.0;
+        for (int i = lane; i < nrow; i += 64) t += Lg[i + (size_t)j * m] * xs[i];
+        t = wave_sum(t);
+        if (lane == 0) part[j] = t;
     }
 }
 
@@ -860,6 +1224,7 @@ public:
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
     std::vector<int> big_maxm, big_maxk;
+    std::vector<size_t> reg_lds;
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
     struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk; };
@@ -867,6 +1232,7 @@ public:
     int top_list_base = 0, top_count = 0, top_maxm = 0;      // all top fronts (for arena / top-rhs assembly)
     long long arena_doubles = 0, toprhs_doubles = 0;
     bool multi = false;
+    bool legacy = false;          // MI355X_KKT_LEGACY=1: the LDS-resident LDL^T kernels (A/B comparisons)
 
     // ---- per-kernel-kind timing (bench.py roofline): hip events around every launch, eager mode ----
     bool prof_on = false;
@@ -922,6 +1288,7 @@ public:
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1;
+        { const char* e = getenv("MI355X_KKT_LEGACY"); legacy = e && e[0] == '1'; }
         std::vector<int> lvl_list(Sy.level_sn);
         std::vector<long long> aoff(Sy.num_sn, -1), troff(Sy.num_sn, -1);
         std::vector<int> colown(Sy.n, 0);
@@ -961,15 +1328,30 @@ public:
         if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
             !dalloc(&V.L, (size_t)Sy.l_doubles) || !dalloc(&V.cb, (size_t)Sy.cb_doubles) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
-            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
+            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
             !dalloc(&d_stats, 4)) return false;
-        V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank;
+        V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
+        if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 16)) return false; }
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
         V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        // exact LDS need of the register-tiled front kernel per (level, class) bucket
+        reg_lds.assign((size_t)Sy.num_levels * FC_COUNT, 0);
+        for (int s = 0; s < Sy.num_sn; ++s) {
+            const size_t m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s], k = Sy.sn_colptr[s + 1] - Sy.sn_colptr[s];
+            const size_t ld = m | 1, ldi = k | 1;
+            const size_t maxm = Sy.sn_class[s] == FC_WAVE ? 32 : (Sy.sn_class[s] == FC_LDS64 ? 64 : 128);
+            const size_t need = (std::max(ld * m, k * ld + k * ldi) + 4 * maxm + 2 * k) * sizeof(double) + 2 * k * sizeof(int) + 64;
+            size_t& r = reg_lds[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]];
+            r = std::max(r, need);
+        }
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0);
@@ -986,6 +1368,31 @@ public:
         return (ld * mmax + 2 * (size_t)mmax + 2 * (size_t)kmax + 4) * sizeof(double) + (4 + 2 * (size_t)kmax) * sizeof(int) + 16;
     }
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
+
+
+    // one (level, class) bucket of fronts: register-tiled kernels by default, LDS-resident ones with MI355X_KKT_LEGACY=1
+    bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk) {
+        const int nb = b1 - b0;
+        const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
+        if (fc == FC_WAVE) {
+            if (legacy) LAUNCH(KK_FRONT_WAVE, k_front_lds<64>, dim3(nb), dim3(64), front_lds_bytes(32, 32), stream, V, b0, top_mode);
+            else        LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
+        } else if (fc == FC_LDS64) {
+            if (legacy) LAUNCH(KK_FRONT_LDS64, k_front_lds<64>, dim3(nb), dim3(64), front_lds_bytes(64, 64), stream, V, b0, top_mode);
+            else        LAUNCH(KK_FRONT_LDS64, (k_front_reg<64, 8>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
+        } else if (fc == FC_LDS128) {
+            if (legacy) LAUNCH(KK_FRONT_LDS128, k_front_lds<256>, dim3(nb), dim3(256), front_lds_bytes(128, 128), stream, V, b0, top_mode);
+            else        LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb), dim3(256), rl, stream, V, b0, top_mode);
+        } else {
+            const int nt = (mm - 1 + 63) / 64;
+            LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
+            if (legacy) LAUNCH(KK_BIG_DIAG, k_big_diag, dim3(nb), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
+            else        LAUNCH(KK_BIG_DIAG, k_big_diag_reg, dim3(nb), dim3(256), (size_t)(2 * (kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+            LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
+            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, nb), dim3(256), 0, stream, V, b0);
+        }
+        return true;
+    }
 
     bool enqueue_factor() {
         const Symbolic& Sy = *S;
@@ -1004,17 +1411,7 @@ public:
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                if (fc == FC_WAVE)        LAUNCH(KK_FRONT_WAVE, k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(32, 32),   stream, V, b0, 0);
-                else if (fc == FC_LDS64)  LAUNCH(KK_FRONT_LDS64, k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(64, 64),   stream, V, b0, 0);
-                else if (fc == FC_LDS128) LAUNCH(KK_FRONT_LDS128, k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(128, 128), stream, V, b0, 0);
-                else {
-                    const int mm = big_maxm[lv], kk = big_maxk[lv], mu = mm - 1;
-                    const int nt = (mu + 63) / 64;
-                    LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, b1 - b0), dim3(256), 0, stream, V, b0, 0);
-                    LAUNCH(KK_BIG_DIAG, k_big_diag, dim3(b1 - b0), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
-                    LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, b1 - b0), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
-                    LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, b1 - b0), dim3(256), 0, stream, V, b0);
-                }
+                launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv]);
             }
         }
         LAUNCH(KK_STATS, k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
@@ -1072,7 +1469,8 @@ public:
                 if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
                 else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
                 else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
-                else                      LAUNCH(KK_FWD_BIG,  (k_fwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0, 0);
+                else { LAUNCH(KK_FWD_BIG, (k_fwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0, 0);
+                       LAUNCH(KK_FWD_BIG, k_fwd_big_upd, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0); }
             }
         for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
             for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -1081,7 +1479,8 @@ public:
                 if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
                 else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
                 else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
-                else                      LAUNCH(KK_BWD_BIG,  (k_bwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0);
+                else { LAUNCH(KK_BWD_BIG, k_bwd_big_dot, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0);
+                       LAUNCH(KK_BWD_BIG, (k_bwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0); }
             }
         LAUNCH(KK_SOLVE_PERM, k_store_sol, dim3(grid1d(n)), dim3(256), 0, stream, V, drhs);
         HIPCHK(hipGetLastError());
@@ -1123,16 +1522,7 @@ public:
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc], b1 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                if (fc == FC_WAVE)        hipLaunchKernelGGL(k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(32, 32),   stream, V, b0, top_mode);
-                else if (fc == FC_LDS64)  hipLaunchKernelGGL(k_front_lds<64>,  dim3(b1 - b0), dim3(64),  front_lds_bytes(64, 64),   stream, V, b0, top_mode);
-                else if (fc == FC_LDS128) hipLaunchKernelGGL(k_front_lds<256>, dim3(b1 - b0), dim3(256), front_lds_bytes(128, 128), stream, V, b0, top_mode);
-                else {
-                    const int mm = sc.maxm[lv], kk = sc.maxk[lv], nt = (mm - 1 + 63) / 64;
-                    hipLaunchKernelGGL(k_big_assemble, dim3((mm + 3) / 4, b1 - b0), dim3(256), 0, stream, V, b0, top_mode);
-                    hipLaunchKernelGGL(k_big_diag, dim3(b1 - b0), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
-                    hipLaunchKernelGGL(k_big_trsm, dim3((mm + 63) / 64, b1 - b0), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
-                    hipLaunchKernelGGL(k_big_schur, dim3(nt * (nt + 1) / 2, b1 - b0), dim3(256), 0, stream, V, b0);
-                }
+                launch_bucket(lv, fc, b0, b1, top_mode, sc.maxm[lv], sc.maxk[lv]);
             }
         HIPCHK(hipGetLastError());
         return true;
@@ -1149,12 +1539,14 @@ public:
                     if (fc == FC_WAVE)        hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, top_mode);
                     else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, top_mode);
                     else if (fc == FC_LDS128) hipLaunchKernelGGL((k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, top_mode);
-                    else                      hipLaunchKernelGGL((k_fwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0, top_mode);
+                    else { hipLaunchKernelGGL((k_fwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0, top_mode);
+                           hipLaunchKernelGGL(k_fwd_big_upd, dim3((sc.maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0); }
                 } else {
                     if (fc == FC_WAVE)        hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
                     else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
                     else if (fc == FC_LDS128) hipLaunchKernelGGL((k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
-                    else                      hipLaunchKernelGGL((k_bwd<256, true>),  dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0);
+                    else { hipLaunchKernelGGL(k_bwd_big_dot, dim3((sc.maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0);
+                           hipLaunchKernelGGL((k_bwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0); }
                 }
             }
         }
@@ -1231,6 +1623,10 @@ public:
         return true;
     }
 
+    bool debug_clocks(unsigned long long* out) {
+        if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
+        HIPCHK(hipMemcpy(out, V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost)); return true;
+    }
     // eager (graph-less) factor + one solve with hip events around every launch; accumulates over `reps`
     bool profile(int reps, double* ms, int* launches) {
         if (!ready || !have_values) { err_ = "profile: factor() must have been called once"; return false; }
@@ -1277,6 +1673,7 @@ double Numeric::last_factor_ms() const { return p_->factor_ms; }
 double Numeric::last_solve_ms() const { return p_->solve_ms; }
 const std::string& Numeric::error() const { return p_->err_; }
 bool Numeric::profile(int reps, double* ms, int* launches) { return p_->profile(reps, ms, launches); }
+bool Numeric::debug_clocks(unsigned long long* out) { return p_->debug_clocks(out); }
 bool Numeric::factor_local(const double* dvals) { return p_->factor_local(dvals); }
 bool Numeric::top_arena(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_arena: not a multi-GPU handle"; return false; } *d = p_->V.arena; *nd = p_->arena_doubles; return true; }
 bool Numeric::factor_top(FactorStats& st) { return p_->factor_top(st); }

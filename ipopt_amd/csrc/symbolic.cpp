@@ -522,7 +522,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             else if (!forced_start[j] && j > 0 && parent[j - 1] == j) {
                 bool pair = (S.pair_of[perm[j]] == perm[j - 1]);
                 if (pair) join = true;
-                else if (cc[j - 1] == cc[j] + 1 && len < maxcols) join = true;
+                else if (cc[j - 1] == cc[j] + 1 && len < maxcols - 1) join = true;   // -1: a forced pair may still add one column
             }
             if (!join) { fstart.push_back(j); len = 1; } else ++len;
         }
