@@ -48,6 +48,11 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // ------------------------------------------------------------------------------------------------
 // device-side view of the symbolic structure + numeric storage (passed by value to kernels)
 // ------------------------------------------------------------------------------------------------
+// per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
+// head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
+struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, pad; long long panel_off, cb_off, minv_off; };
+struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; };
+
 struct DevView {
     // symbolic
     const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
@@ -56,6 +61,8 @@ struct DevView {
     const int* acolptr; const int* apos; const int* arow; const int* acol;
     const int* dup_ptr; const int* dup_src;
     const int* level_sn;
+    const FrontMeta* fmeta;   // parallel to level_sn
+    const ChildMeta* cmeta;   // parallel to child_idx
     const int* perm;
     // numeric
     const double* tvals;    // triplet values (device copy)
@@ -496,16 +503,12 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
     // Newton, L column written by the 16 (8) threads that already hold it.
     constexpr int G = (NT == 64) ? 8 : 16;
     constexpr int MAXM = G * TS;
-    constexpr unsigned TMASK = (1u << TS) - 1u;
     const int tid = threadIdx.x, lane = tid & 63;
     const int ti = tid % G, tj = tid / G;
     const int row0 = ti * TS, col0 = tj * TS;
-    unsigned rowvalid = 0, rowupd = 0, colvalid = 0, colupd = 0;
+    unsigned rowvalid = 0;
 #pragma unroll
-    for (int x = 0; x < TS; ++x) {
-        if (row0 + x < m) { rowvalid |= 1u << x; if (row0 + x >= k) rowupd |= 1u << x; }
-        if (col0 + x < m) { colvalid |= 1u << x; if (col0 + x >= k) colupd |= 1u << x; }
-    }
+    for (int x = 0; x < TS; ++x) if (row0 + x < m) rowvalid |= 1u << x;
     const unsigned long long lanebit = 1ull << lane;
     unsigned long long alive = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);     // fully-summed rows not yet eliminated (k <= 64)
     unsigned long long bigmask = 0ull;
@@ -516,12 +519,17 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
         const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);
         if (tj == j / TS) publish_col<TS>(colA, t, row0, j % TS);
         __syncthreads();
+        // every LDS read of the common case (1x1 pivot on row j) is issued here, in ONE round trip
         const double djj = colA[j];
+        const double avr = colA[lane];
+        double rv[TS], cv[TS];
+#pragma unroll
+        for (int x = 0; x < TS; ++x) { rv[x] = colA[row0 + x]; cv[x] = colA[col0 + x]; }
         const double ajj = fabs(djj);
         const bool cand = (alive & lanebit) != 0ull && lane != j;
-        const double av = cand ? fabs(colA[lane]) : -1.0;
+        const double av = cand ? fabs(avr) : -1.0;
         int p = j, q = -1;                 // 1x1 pivot p, or 2x2 pivot (p, q)
-        const double* W0 = colA;
+        double dpiv = djj;
         if (__ballot(av * BK_ALPHA > ajj) != 0ull) {          // some |a_ij| > |a_jj| / alpha: run the full Bunch-Kaufman test
             const double lam = wave_max_all(av);
             const unsigned long long hit = __ballot(av == lam);
@@ -532,7 +540,11 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             const double sig = wave_max_all(cs ? fabs(colB[lane]) : 0.0);
             const double arr = fabs(colB[r]);
             if (ajj * sig >= BK_ALPHA * lam * lam) { /* 1x1 at j */ }
-            else if (arr >= BK_ALPHA * sig) { p = r; W0 = colB; }
+            else if (arr >= BK_ALPHA * sig) {
+                p = r; dpiv = colB[r];
+#pragma unroll
+                for (int x = 0; x < TS; ++x) { rv[x] = colB[row0 + x]; cv[x] = colB[col0 + x]; }
+            }
             else { q = r; }
         }
         if (q >= 0) {
@@ -542,15 +554,12 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             else {
                 const double idet = fast_rcp(det);
                 const unsigned long long keep = alive & ~(1ull << p) & ~(1ull << q);
-                const unsigned rm = (((row0 < 64) ? (unsigned)(keep >> row0) : 0u) | rowupd) & rowvalid & TMASK;
-                const unsigned cm = (((col0 < 64) ? (unsigned)(keep >> col0) : 0u) | colupd) & colvalid & TMASK;
                 double l0[TS], l1[TS], w0[TS], w1[TS];
 #pragma unroll
                 for (int x = 0; x < TS; ++x) {
-                    const double r0 = colA[row0 + x], r1 = colB[row0 + x], c0_ = colA[col0 + x], c1_ = colB[col0 + x];
-                    const bool ra = (rm >> x) & 1u, ca = (cm >> x) & 1u;
-                    l0[x] = ra ? (c * r0 - b * r1) * idet : 0.0; l1[x] = ra ? (a * r1 - b * r0) * idet : 0.0;
-                    w0[x] = ca ? c0_ : 0.0; w1[x] = ca ? c1_ : 0.0;
+                    const double r0 = colA[row0 + x], r1 = colB[row0 + x];
+                    l0[x] = (c * r0 - b * r1) * idet; l1[x] = (a * r1 - b * r0) * idet;
+                    w0[x] = colA[col0 + x]; w1[x] = colB[col0 + x];
                 }
 #pragma unroll
                 for (int x = 0; x < TS; ++x)
@@ -572,20 +581,18 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                 continue;
             }
         }
-        {   // 1x1 pivot on physical row p, pivot column W0
-            double d = W0[p];
+        {   // 1x1 pivot on physical row p (pivot column already in rv / cv)
+            double d = dpiv;
             if (fabs(d) <= small) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
             const double di = fast_rcp(d);
             const unsigned long long keep = alive & ~(1ull << p);
-            const unsigned rm = (((row0 < 64) ? (unsigned)(keep >> row0) : 0u) | rowupd) & rowvalid & TMASK;
-            const unsigned cm = (((col0 < 64) ? (unsigned)(keep >> col0) : 0u) | colupd) & colvalid & TMASK;
-            double l0[TS], w0[TS];
+            // No masking of dead rows / columns: the rank-1 update itself annihilates row and column p (l_p = 1 up to
+            // rounding), padding rows are exact zeros, and whatever residue is left in dead positions is never read
+            // (alive mask in the search, (i > c) filter at write-back).  That removes ~50 instructions per pivot.
+            double l0[TS];
 #pragma unroll
-            for (int x = 0; x < TS; ++x) {
-                const double rv = W0[row0 + x], cv = W0[col0 + x];
-                l0[x] = ((rm >> x) & 1u) ? rv * di : 0.0;
-                w0[x] = ((cm >> x) & 1u) ? cv : 0.0;
-            }
+            for (int x = 0; x < TS; ++x) l0[x] = rv[x] * di;
+            const double (&w0)[TS] = cv;
 #pragma unroll
             for (int x = 0; x < TS; ++x)
 #pragma unroll
@@ -619,16 +626,15 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
 // write-back of the pivot-ordered panel, the contribution block (straight from registers), pivot data and L11^{-1}.
 template <int NT, int TS>
-__global__ __launch_bounds__(NT) void k_front_reg(DevView V, int list_off, int top_mode)
+__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : 1) void k_front_reg(DevView V, int list_off, int top_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = (NT == 64) ? 8 : 16;
     constexpr int MAXM = G * TS;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     const int ld = m | 1, ldi = k | 1;
     DBGSTAMP(4);
     const int fdoubles = max(ld * m, k * ld + k * ldi);          // F, later overlaid by Lbuf (k columns) + the k x k inverse
@@ -640,25 +646,26 @@ __global__ __launch_bounds__(NT) void k_front_reg(DevView V, int list_off, int t
     int*    pt_s   = ord + k;                    // k
 
     // ---- (a)-(c) assembly in LDS (lower storage) ----
-    if (top_mode && V.arena) {
+    const bool from_arena = top_mode && V.arena && V.arena_off[s] >= 0;   // replicated front at a subtree join
+    const bool skip_owned = top_mode && V.arena;
+    if (from_arena) {
         const double* Ar = V.arena + V.arena_off[s];
         for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; F[i + c * ld] = Ar[idx]; }
     } else {
         for (int idx = tid; idx < ld * m; idx += NT) F[idx] = 0.0;
     }
     __syncthreads();
-    if (!(top_mode && V.arena)) {
-        const int q0 = V.acolptr[c0], q1 = V.acolptr[c0 + k];
-        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] = V.aval[q]; }
+    {
+        const int q0 = M.aq0, q1 = M.aq1;
+        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] += V.aval[q]; }
     }
     __syncthreads();
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        if (top_mode && V.arena && V.sn_owner[ch] >= 0) continue;
-        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-        const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
-        const int* relc = V.rel + V.sn_rowptr[ch] + kc;
-        const double* C = V.cb + V.cb_off[ch];
+    for (int cp = M.ch0; cp < M.ch1; ++cp) {
+        const ChildMeta Cm = V.cmeta[cp];
+        if (skip_owned && Cm.owner >= 0) continue;
+        const int mc = Cm.mc;
+        const int* relc = V.rel + Cm.relbase;
+        const double* C = V.cb + Cm.cb_off;
         for (int b = wave; b < mc; b += NW) {
             const int rb = relc[b];
             for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * mc];
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(NT) void k_front_reg(DevView V, int list_off, int t
     DBGSTAMP(6);
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[14] = (unsigned long long)k * 1000 + m;
     // ---- (e) write back: pivot-ordered panel, pivot data, contribution block from the registers ----
-    double* Lg = V.L + V.panel_off[s];
+    double* Lg = V.L + M.panel_off;
     for (int c = wave; c < k; c += NW)
         for (int i = lane; i < m; i += 64) {
             const int src = (i < k) ? ord[i] : i;
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(NT) void k_front_reg(DevView V, int list_off, int t
         }
     for (int jj = tid; jj < k; jj += NT) { V.dinv[c0 + jj] = dinv_s[jj]; V.doff[c0 + jj] = doff_s[jj]; V.ptype[c0 + jj] = pt_s[jj]; V.lperm[c0 + jj] = ord[jj]; }
     const int mu = m - k;
-    double* Cg = V.cb + V.cb_off[s];
+    double* Cg = V.cb + M.cb_off;
 #pragma unroll
     for (int y = 0; y < TS; ++y)
 #pragma unroll
@@ -706,7 +713,7 @@ __global__ __launch_bounds__(NT) void k_front_reg(DevView V, int list_off, int t
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Li[i + c * ldi] = (i > c) ? F[ord[i] + c * ld] : 0.0; }
     __syncthreads();
     invert_unit_lower<NT>(Li, ldi, k);
-    double* Mg = V.minv + V.minv_off[s];
+    double* Mg = V.minv + M.minv_off;
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ldi] : (i == c ? 1.0 : 0.0); }
 }
 
@@ -716,16 +723,15 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TS = 4, G = 16, MAXM = 64;
     const int tid = threadIdx.x;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     const int ld = k | 1;
     double* Lb     = reinterpret_cast<double*>(smem_raw);   // k x k L columns (physical rows)
     double* Li     = Lb + (size_t)ld * k;                    // k x k pivot-ordered copy / inverse
     double* colbuf = Li + (size_t)ld * k;
     double* dinv_s = colbuf + 4 * MAXM; double* doff_s = dinv_s + k;
     int* ord = reinterpret_cast<int*>(doff_s + k); int* pt_s = ord + k;
-    double* P = V.L + V.panel_off[s];
+    double* P = V.L + M.panel_off;
     const int ti = tid % G, tj = tid / G, row0 = ti * TS, col0 = tj * TS;
     double t[TS][TS];
 #pragma unroll
@@ -751,7 +757,7 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
     DBGSTAMP(2);
     invert_unit_lower<256>(Li, ld, k);
     DBGSTAMP(3);
-    double* Mg = V.minv + V.minv_off[s];
+    double* Mg = V.minv + M.minv_off;
     for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ld] : (i == c ? 1.0 : 0.0); }
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[15] = (unsigned long long)k;
 }
@@ -797,9 +803,8 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     double* xp = reinterpret_cast<double*>(smem_raw);   // k   pivot rows (original local order)
     double* ys = xp + k;                                // k
     double* bp = ys + k;                                // k   pivot rows in pivot order
@@ -813,11 +818,11 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         for (int i = tid; i < m; i += NT) { if (i < k) xp[i] += tr[i]; else if (BIG) V.cvec[r0 + i] += tr[i]; else xu[i - k] += tr[i]; }
     }
     __syncthreads();
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        if (top_mode && V.top_rhs && V.sn_owner[ch] >= 0) continue;
-        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-        const int base = V.sn_rowptr[ch] + kc, mc = V.sn_rowptr[ch + 1] - base;
+    for (int cp = M.ch0; cp < M.ch1; ++cp) {
+        const ChildMeta Cm = V.cmeta[cp];
+        const int ch = Cm.ch; (void)ch;
+        if (top_mode && V.top_rhs && Cm.owner >= 0) continue;
+        const int base = Cm.relbase, mc = Cm.mc;
         for (int t = tid; t < mc; t += NT) {
             const int tg = V.rel[base + t]; const double v = V.cvec[base + t];
             if (tg < k) xp[tg] += v; else if (BIG) V.cvec[r0 + tg] += v; else xu[tg - k] += v;
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         __syncthreads();
     }
     // y = Minv * (P b): thread j, independent (pipelined) loads down row j of the column-major inverse
-    const double* Mg = V.minv + V.minv_off[s];
+    const double* Mg = V.minv + M.minv_off;
     for (int j = tid; j < k; j += NT) bp[j] = xp[V.lperm[c0 + j]];
     __syncthreads();
     for (int j = tid; j < k; j += NT) {
@@ -839,7 +844,7 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
     if (BIG) {
         for (int j = tid; j < k; j += NT) V.ybuf[c0 + j] = ys[j];      // update rows: k_fwd_big_upd, many workgroups per front
     } else {
-        const double* Lg = V.L + V.panel_off[s];
+        const double* Lg = V.L + M.panel_off;
         for (int i = k + tid; i < m; i += NT) {
             double t0 = 0.0, t1 = 0.0;
             int j = 0;
@@ -865,9 +870,8 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int NW = NT / 64;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     double* ws = reinterpret_cast<double*>(smem_raw);   // k
     double* xu = ws + k;                                // m-k gathered ancestor values (LDS classes)
     if (!BIG) { for (int i = k + tid; i < m; i += NT) xu[i - k] = V.xw[V.sn_rows[r0 + i]]; }
@@ -879,7 +883,7 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
         const double* part = V.wbuf + V.wb_off[s];
         for (int j = tid; j < k; j += NT) { double t = 0.0; for (int c = 0; c < nch; ++c) t += part[(size_t)c * k + j]; ws[j] -= t; }
     } else {
-        const double* Lg = V.L + V.panel_off[s];
+        const double* Lg = V.L + M.panel_off;
         for (int j = wave; j < k; j += NW) {
             double t = 0.0;
             for (int i = lane; i < m - k; i += 64) t += Lg[k + i + (size_t)j * m] * xu[i];
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
     }
     __syncthreads();
     // x_p = sum_{j >= p} Minv(j,p) w_j : thread p walks its own (contiguous) column of the inverse
-    const double* Mg = V.minv + V.minv_off[s];
+    const double* Mg = V.minv + M.minv_off;
     for (int p = tid; p < k; p += NT) {
         double a0 = 0.0, a1 = 0.0;
         int j = p;
@@ -905,15 +909,14 @@ __global__ __launch_bounds__(256) void k_fwd_big_upd(DevView V, int list_off)
 {
     __shared__ double ys[72];
     const int tid = threadIdx.x;
-    const int s = V.level_sn[list_off + blockIdx.y];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     if (k + blockIdx.x * 256 >= m) return;
     if (tid < k) ys[tid] = V.ybuf[c0 + tid];
     __syncthreads();
     const int i = k + blockIdx.x * 256 + tid;
     if (i >= m) return;
-    const double* Lg = V.L + V.panel_off[s] + i;
+    const double* Lg = V.L + M.panel_off + i;
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     int j = 0;
     for (; j + 3 < k; j += 4) {
@@ -928,15 +931,14 @@ __global__ __launch_bounds__(256) void k_bwd_big_dot(DevView V, int list_off)
 {
     __shared__ double xs[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = V.level_sn[list_off + blockIdx.y];
-    const int k = V.sn_colptr[s + 1] - V.sn_colptr[s];
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     const int ibase = k + blockIdx.x * 256;
     if (ibase >= m) return;
     const int nrow = min(256, m - ibase);
     xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[r0 + ibase + tid]] : 0.0;
     __syncthreads();
-    const double* Lg = V.L + V.panel_off[s] + ibase;
+    const double* Lg = V.L + M.panel_off + ibase;
     double* part = V.wbuf + V.wb_off[s] + (size_t)blockIdx.x * k;
     for (int j = wave; j < k; j += 4) {
         double t = 0.0;
@@ -958,40 +960,41 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, int top_mode)
 {
-    const int s = V.level_sn[list_off + blockIdx.y];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0, mu = m - k;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
+    const int mu = m - k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fc = blockIdx.x * 4 + wave;                 // front column owned by this wavefront
     const bool active = fc < m;
     double* col = nullptr;                                 // col[i] = front(i, fc) for i in [0,m) (panel) or [k,m) (T)
-    const bool from_arena = top_mode && V.arena;
+    const bool from_arena = top_mode && V.arena && V.arena_off[s] >= 0;   // replicated front at a subtree join
+    const bool skip_owned = top_mode && V.arena;                           // rank-owned children are inside the arena
     if (active) {
         const double* Ar = from_arena ? V.arena + V.arena_off[s] + (size_t)fc * m : nullptr;   // all-reduced square, lower part
         if (fc < k) {
-            col = V.L + V.panel_off[s] + (size_t)fc * m;
+            col = V.L + M.panel_off + (size_t)fc * m;
             for (int i = lane; i < m; i += 64) col[i] = (from_arena && i >= fc) ? Ar[i] : 0.0;
         } else {
-            col = V.cb + V.cb_off[s] + (size_t)(fc - k) * mu - k;
+            col = V.cb + M.cb_off + (size_t)(fc - k) * mu - k;
             for (int i = fc + lane; i < m; i += 64) col[i] = from_arena ? Ar[i] : 0.0;
         }
     }
     __syncthreads();
-    if (active && fc < k && !from_arena) {
+    if (active && fc < k) {
         const int q0 = V.acolptr[c0 + fc], q1 = V.acolptr[c0 + fc + 1];
-        for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] = V.aval[q];
+        for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] += V.aval[q];
     }
     __syncthreads();
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        if (active && !(from_arena && V.sn_owner[ch] >= 0)) {
-            const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-            const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
-            const int* relc = V.rel + V.sn_rowptr[ch] + kc;
+    for (int cp = M.ch0; cp < M.ch1; ++cp) {
+        const ChildMeta Cm = V.cmeta[cp];
+        const int ch = Cm.ch; (void)ch;
+        if (active && !(skip_owned && Cm.owner >= 0)) {
+            const int mc = Cm.mc;
+            const int* relc = V.rel + Cm.relbase;
             int lo = 0, hi = mc;                           // first b with relc[b] >= fc (relc is increasing)
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
             if (lo < mc && relc[lo] == fc) {
-                const double* C = V.cb + V.cb_off[ch] + (size_t)lo * mc;
+                const double* C = V.cb + Cm.cb_off + (size_t)lo * mc;
                 for (int a = lo + lane; a < mc; a += 64) col[relc[a]] += C[a];
             }
         }
@@ -1033,9 +1036,8 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = V.level_sn[list_off + blockIdx.y];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     const int ibase = k + blockIdx.x * 64;
     if (ibase >= m) return;
     const int kp = (k + 3) & ~3;                              // K padded to the MFMA depth
@@ -1043,9 +1045,9 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     double* Ms = reinterpret_cast<double*>(smem_raw);         // k x kp : Ms[j + p*ldm] = Minv(j,p)
     double* As = Ms + (size_t)ldm * kp;                       // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
     double* Ws = As + (size_t)65 * kp;                        // 64 x k : Ws[r + j*65]
-    double* P = V.L + V.panel_off[s];
+    double* P = V.L + M.panel_off;
     double* W = V.wbuf + V.wb_off[s];
-    const double* Mg = V.minv + V.minv_off[s];
+    const double* Mg = V.minv + M.minv_off;
     for (int idx = tid; idx < k * kp; idx += 256) { const int j = idx % k, p = idx / k; Ms[j + p * ldm] = (p < k) ? Mg[j + (size_t)p * k] : 0.0; }
     for (int idx = tid; idx < 64 * kp; idx += 256) {
         const int r = idx & 63, p = idx >> 6;
@@ -1090,9 +1092,9 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 // coalesced read-modify-write segments.
 __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
 {
-    const int s = V.level_sn[list_off + blockIdx.y];
-    const int k = V.sn_colptr[s + 1] - V.sn_colptr[s];
-    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s], mu = m - k;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
+    const int mu = m - k;
     const int nt = (mu + 63) >> 6;
     const int t = blockIdx.x;
     if (t >= nt * (nt + 1) / 2) return;
@@ -1104,7 +1106,7 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
     const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
     if (i0 + 31 < cc0) return;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const double* Lp = V.L + V.panel_off[s] + k;
+    const double* Lp = V.L + M.panel_off + k;
     const double* Wp = V.wbuf + V.wb_off[s] + k;
     v4f64 acc[2][2];
 #pragma unroll
@@ -1125,7 +1127,7 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
     }
-    double* T = V.cb + V.cb_off[s];
+    double* T = V.cb + M.cb_off;
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
@@ -1147,28 +1149,22 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
 // in fixed order => deterministic.  The arena is then summed over ranks (RCCL all-reduce) by the caller.
 __global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off)
 {
-    const int s = V.level_sn[list_off + blockIdx.y];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fc = blockIdx.x * 4 + wave;
     const bool active = fc < m;
     double* col = active ? V.arena + V.arena_off[s] + (size_t)fc * m : nullptr;
-    if (active && fc < k && V.rank == 0) {
-        const int q0 = V.acolptr[c0 + fc], q1 = V.acolptr[c0 + fc + 1];
-        for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] = V.aval[q];
-    }
-    __syncthreads();
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        if (active && V.sn_owner[ch] == V.rank) {
-            const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-            const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
-            const int* relc = V.rel + V.sn_rowptr[ch] + kc;
+    for (int cp = M.ch0; cp < M.ch1; ++cp) {
+        const ChildMeta Cm = V.cmeta[cp];
+        const int ch = Cm.ch; (void)ch;
+        if (active && Cm.owner == V.rank) {
+            const int mc = Cm.mc;
+            const int* relc = V.rel + Cm.relbase;
             int lo = 0, hi = mc;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
             if (lo < mc && relc[lo] == fc) {
-                const double* C = V.cb + V.cb_off[ch] + (size_t)lo * mc;
+                const double* C = V.cb + Cm.cb_off + (size_t)lo * mc;
                 for (int a = lo + lane; a < mc; a += 64) col[relc[a]] += C[a];
             }
         }
@@ -1178,16 +1174,16 @@ __global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off)
 // forward-solve contributions of this rank's subtree roots to the replicated fronts (summed over ranks by the caller)
 __global__ __launch_bounds__(256) void k_top_rhs_assemble(DevView V, int list_off)
 {
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     double* tr = V.top_rhs + V.top_rhs_off[s];
     for (int i = threadIdx.x; i < m; i += 256) tr[i] = 0.0;
     __syncthreads();
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        if (V.sn_owner[ch] == V.rank) {
-            const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-            const int base = V.sn_rowptr[ch] + kc, mc = V.sn_rowptr[ch + 1] - base;
+    for (int cp = M.ch0; cp < M.ch1; ++cp) {
+        const ChildMeta Cm = V.cmeta[cp];
+        const int ch = Cm.ch; (void)ch;
+        if (Cm.owner == V.rank) {
+            const int base = Cm.relbase, mc = Cm.mc;
             for (int t = threadIdx.x; t < mc; t += 256) tr[V.rel[base + t]] += V.cvec[base + t];
         }
         __syncthreads();
@@ -1229,7 +1225,8 @@ public:
     // the single-GPU list in the same device array
     struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk; };
     Sched sch_local, sch_top;
-    int top_list_base = 0, top_count = 0, top_maxm = 0;      // all top fronts (for arena / top-rhs assembly)
+    int top_list_base = 0, top_count = 0, top_maxm = 0;      // all replicated fronts (top-rhs assembly)
+    int join_list_base = 0, join_count = 0, join_maxm = 0;   // replicated fronts with a rank-owned child (arena squares)
     long long arena_doubles = 0, toprhs_doubles = 0;
     bool multi = false;
     bool legacy = false;          // MI355X_KKT_LEGACY=1: the LDS-resident LDL^T kernels (A/B comparisons)
@@ -1307,15 +1304,39 @@ public:
                 for (size_t b = 0; b < bucket.size(); ++b) { sc.ptr[b + 1] = sc.ptr[b] + (int)bucket[b].size(); lvl_list.insert(lvl_list.end(), bucket[b].begin(), bucket[b].end()); }
             };
             build(sch_local, false); build(sch_top, true);
+            // top-rhs accumulators for every replicated front; arena squares only for those that have a child owned by some
+            // rank (the subtree joins): that is all the all-reduce has to carry (A is replicated input, not reduced)
+            std::vector<char> has_local_child(Sy.num_sn, 0);
+            for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] >= 0 && Sy.sn_parent[s] >= 0 && Sy.sn_owner[Sy.sn_parent[s]] < 0) has_local_child[Sy.sn_parent[s]] = 1;
             top_list_base = (int)lvl_list.size();
             for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0) {
                 const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
                 lvl_list.push_back(s); ++top_count; top_maxm = std::max<int>(top_maxm, (int)m);
-                aoff[s] = arena_doubles; arena_doubles += m * m;
                 troff[s] = toprhs_doubles; toprhs_doubles += m;
+            }
+            join_list_base = (int)lvl_list.size();
+            for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && has_local_child[s]) {
+                const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
+                lvl_list.push_back(s); ++join_count; join_maxm = std::max<int>(join_maxm, (int)m);
+                aoff[s] = arena_doubles; arena_doubles += m * m;
             }
             for (int s = 0; s < Sy.num_sn; ++s) for (int j = Sy.sn_colptr[s]; j < Sy.sn_colptr[s + 1]; ++j) colown[j] = Sy.sn_owner[s];
         }
+        std::vector<FrontMeta> fm(lvl_list.size());
+        for (size_t q = 0; q < lvl_list.size(); ++q) {
+            const int sn = lvl_list[q];
+            FrontMeta& M = fm[q];
+            M.s = sn; M.c0 = Sy.sn_colptr[sn]; M.k = Sy.sn_colptr[sn + 1] - M.c0; M.r0 = Sy.sn_rowptr[sn]; M.m = Sy.sn_rowptr[sn + 1] - M.r0;
+            M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.pad = 0;
+            M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
+        }
+        std::vector<ChildMeta> cm(Sy.child_idx.size());
+        for (size_t q = 0; q < cm.size(); ++q) {
+            const int ch = Sy.child_idx[q]; const int kc = Sy.sn_colptr[ch + 1] - Sy.sn_colptr[ch];
+            cm[q].ch = ch; cm[q].relbase = Sy.sn_rowptr[ch] + kc; cm[q].mc = Sy.sn_rowptr[ch + 1] - cm[q].relbase;
+            cm[q].owner = Sy.sn_owner[ch]; cm[q].cb_off = Sy.cb_off[ch];
+        }
+        if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta)) return false;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
             !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) || !upload(moff, &V.minv_off) ||
@@ -1555,6 +1576,7 @@ public:
     }
     bool factor_local(const double* dvals) {
         if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
+        if (legacy) { err_ = "MI355X_KKT_LEGACY kernels do not implement the multi-GPU top mode"; return false; }
         const Symbolic& Sy = *S; const int n = Sy.n;
         V.pivtol = opt.pivtol; V.small = opt.small;
         if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
@@ -1573,7 +1595,7 @@ public:
         }
         if (!launch_fronts(sch_local, 0)) return false;
         HIPCHK(hipMemsetAsync(V.arena, 0, (size_t)arena_doubles * sizeof(double), stream));
-        if (top_count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((top_maxm + 3) / 4, top_count), dim3(256), 0, stream, V, top_list_base);
+        if (join_count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((join_maxm + 3) / 4, join_count), dim3(256), 0, stream, V, join_list_base);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipStreamSynchronize(stream));       // the caller's collective runs on another stream

@@ -679,7 +679,9 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         int guard = 0;
         while (!front.empty() && guard++ < nsn) {
             auto top = *front.begin();
-            bool enough = (int)front.size() >= 4 * opt.nranks && top.first <= 0.25 * target;
+            // split the heaviest frontier subtree until there are >= 2 pieces per rank and none is heavier than 60% of a
+            // rank's share: deeper cuts only move work into the REPLICATED top, which every rank repeats (Amdahl)
+            bool enough = (int)front.size() >= 2 * opt.nranks && top.first <= 0.6 * target;
             if (enough) break;
             int s = top.second;
             if (S.child_ptr[s + 1] == S.child_ptr[s]) {   // leaf: cannot split; stop if it is the biggest

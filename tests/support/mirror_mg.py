@@ -26,11 +26,14 @@ class MirrorEngine:
             if sy["parent"][s] >= 0:
                 self.children[sy["parent"][s]].append(s)
         self.top = [s for s in range(self.nsn) if sy["owner"][s] < 0]
+        # arena squares only for replicated fronts with a rank-owned child (the subtree joins), as in numeric.hip
+        self.join = [s for s in self.top if any(sy["owner"][ch] >= 0 for ch in self.children[s])]
         self.aoff, self.toff, a, t = {}, {}, 0, 0
         for s in self.top:
+            self.toff[s] = t; t += sy["rowptr"][s + 1] - sy["rowptr"][s]
+        for s in self.join:
             m = sy["rowptr"][s + 1] - sy["rowptr"][s]
-            self.aoff[s], self.toff[s] = a, t
-            a += m * m; t += m
+            self.aoff[s] = a; a += m * m
         self._arena = np.zeros(a); self._toprhs = np.zeros(t)
 
     def _front_dims(self, s):
@@ -76,11 +79,9 @@ class MirrorEngine:
                 rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
             self._eliminate(s, F)
         self._arena[:] = 0.0
-        for s in self.top:
+        for s in self.join:
             c0, k, r, m = self._front_dims(s)
             F = np.zeros((m, m))
-            if self.rank == 0:
-                self._a_entries(s, F)
             for ch in self.children[s]:
                 if sy["owner"][ch] == self.rank:
                     rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
@@ -93,7 +94,8 @@ class MirrorEngine:
         sy = self.sym
         for s in self.top:
             c0, k, r, m = self._front_dims(s)
-            F = self._arena[self.aoff[s]:self.aoff[s] + m * m].reshape(m, m).copy()
+            F = self._arena[self.aoff[s]:self.aoff[s] + m * m].reshape(m, m).copy() if s in self.aoff else np.zeros((m, m))
+            self._a_entries(s, F)                      # A is replicated input: every rank adds it itself
             for ch in self.children[s]:
                 if sy["owner"][ch] < 0:
                     rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]

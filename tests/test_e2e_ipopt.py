@@ -14,7 +14,8 @@ DRIVER = os.path.join(ROOT, "oracle", "_ref", "ipopt_mi355x_driver")
 
 
 def run_driver(problem, n, solver="mi355x"):
-    out = subprocess.run([DRIVER, problem, str(n), "--solver", solver], capture_output=True, text=True, timeout=900, cwd="/tmp").stdout
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")   # Ipopt's own BLAS-1: one host thread
+    out = subprocess.run([DRIVER, problem, str(n), "--solver", solver], capture_output=True, text=True, timeout=900, cwd="/tmp", env=env).stdout
     iters = []
     for ln in out.splitlines():
         f = ln.split()
