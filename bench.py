@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("MI355X_KKT_FORCE_MULTI"):
         from ipopt_amd import multigpu
         return multigpu.bench_main(args, rank, world, local)
 
@@ -179,7 +179,9 @@ def main():
         roof = dict(bound="mfma", kernel="k_big_schur", achieved=ach, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F64_PEAK_TFLOPS)
     else:
         ach = w["bytes"] / (dms * 1e-3) / 1e9
-        kn = {"front_wave": "k_front_lds<64>", "front_lds64": "k_front_lds<256>", "front_lds128": "k_front_lds<256>"}.get(dom, "k_" + dom)
+        kn = {"front_wave": "k_front_reg<64,4>", "front_lds64": "k_front_reg<64,8>", "front_lds128": "k_front_reg<256,8>", "big_diag": "k_big_diag_reg",
+              "fwd_wave": "k_fwd<64,false>", "bwd_wave": "k_bwd<64,false>", "fwd_lds": "k_fwd<*,false>", "bwd_lds": "k_bwd<*,false>",
+              "fwd_big": "k_fwd<256,true>+k_fwd_big_upd", "bwd_big": "k_bwd_big_dot+k_bwd<256,true>"}.get(dom, "k_" + dom)
         roof = dict(bound="hbm", kernel=kn, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
     roof.update(launches_per_factor_solve=dlaunch, avg_launch_us=1e3 * dms / max(dlaunch, 1),
                 algorithmic_bytes_per_launch=w["bytes"] / max(dlaunch, 1), algorithmic_flops_per_launch=w["flops"] / max(dlaunch, 1), traffic=None)

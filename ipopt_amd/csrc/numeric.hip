@@ -1284,7 +1284,7 @@ public:
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
-        multi = opt.nranks > 1;
+        multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
         { const char* e = getenv("MI355X_KKT_LEGACY"); legacy = e && e[0] == '1'; }
         std::vector<int> lvl_list(Sy.level_sn);
         std::vector<long long> aoff(Sy.num_sn, -1), troff(Sy.num_sn, -1);

@@ -190,7 +190,7 @@ def bench_main(args, rank, world, local):
             roof = dict(bound="mfma", kernel="k_big_schur", achieved=ach, peak=B.MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / B.MFMA_F64_PEAK_TFLOPS, traffic=None)
         else:
             ach = w["bytes"] / (per_rep[dom] * 1e-3) / 1e9
-            roof = dict(bound="hbm", kernel="k_" + dom, achieved=ach, peak=B.HBM_PEAK_GBS, unit="GB/s", frac=ach / B.HBM_PEAK_GBS, traffic=None)
+            roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=B.HBM_PEAK_GBS, unit="GB/s", frac=ach / B.HBM_PEAK_GBS, traffic=None)
         roof["measured_on"] = "rank 0, single-GPU pass over the same workload (same kernels)"
         line = {
             "metric": "KKT factor+solve GFLOP/s (1 numeric LDL^T factorisation + 2 solves per Ipopt iteration)",
