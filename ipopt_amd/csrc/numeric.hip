@@ -50,8 +50,8 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // ------------------------------------------------------------------------------------------------
 // per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
-struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, pad; long long panel_off, cb_off, minv_off; };
-struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; };
+struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt; };
+struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; };
 
 struct DevView {
     // symbolic
@@ -208,59 +208,6 @@ __global__ void k_apply_scale(DevView V)
         V.aval[q] *= V.scale[V.arow[q]] * V.scale[V.acol[q]];
 }
 
-// ------------------------------------------------------------------------------------------------
-// LDS-resident front kernel: assemble (A values + children contribution blocks), factor the k
-// fully-summed columns with Bunch-Kaufman pivoting restricted to the pivot block, write L, D,
-// the pivot order and the contribution block.   One workgroup (NT threads) per front.
-// ------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void swap_rc(double* F, int ld, int m, int p, int q, int* lp)
-{
-    // symmetric interchange of rows/columns p < q (both inside the pivot block) in LOWER storage;
-    // columns to the left of p hold finished L rows and are swapped as rows.
-    const int tid = threadIdx.x;
-    __syncthreads();
-    for (int c = tid; c < p; c += NT) { double t = F[p + c * ld]; F[p + c * ld] = F[q + c * ld]; F[q + c * ld] = t; }
-    for (int i = p + 1 + tid; i < q; i += NT) { double t = F[i + p * ld]; F[i + p * ld] = F[q + i * ld]; F[q + i * ld] = t; }
-    for (int i = q + 1 + tid; i < m; i += NT) { double t = F[i + p * ld]; F[i + p * ld] = F[i + q * ld]; F[i + q * ld] = t; }
-    if (tid == 0) { double t = F[p + p * ld]; F[p + p * ld] = F[q + q * ld]; F[q + q * ld] = t; int u = lp[p]; lp[p] = lp[q]; lp[q] = u; }
-    __syncthreads();
-}
-
-// Trailing update  F(i,c) -= l0(i) w0(c) [+ l1(i) w1(c)],  c in [cbeg, m), rows i >= (first column of the batch).
-// Columns are handled CB at a time with every LDS load issued before the first store, so the LDS round trip
-// is paid once per CB columns instead of once per column; entries above the diagonal that get touched are
-// never read (lower storage).  One wave with short columns splits into two half-waves on different batches.
-template <int NT, bool TWO>
-__device__ __forceinline__ void trailing_update(double* F, const int ld, const int m, const int cbeg, const int j,
-                                                const double* lc0, const double* lc1)
-{
-    constexpr int CB = 4;
-    constexpr int NW = NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int rlane, cgrp, ngrp, rstride;
-    if (NT == 64 && (m - cbeg) <= 32) { rlane = lane & 31; cgrp = lane >> 5; ngrp = 2; rstride = 32; }
-    else { rlane = lane; cgrp = wave; ngrp = NW; rstride = 64; }
-    for (int cc = cbeg + cgrp * CB; cc < m; cc += ngrp * CB) {
-        double w0[CB], w1[CB];
-#pragma unroll
-        for (int q = 0; q < CB; ++q) {
-            const bool v = cc + q < m;
-            w0[q] = v ? F[cc + q + j * ld] : 0.0;
-            w1[q] = (TWO && v) ? F[cc + q + (j + 1) * ld] : 0.0;
-        }
-        for (int i = cc + rlane; i < m; i += rstride) {
-            const double a0 = lc0[i];
-            const double a1 = TWO ? lc1[i] : 0.0;
-            double f[CB];
-#pragma unroll
-            for (int q = 0; q < CB; ++q) f[q] = (cc + q < m) ? F[i + (cc + q) * ld] : 0.0;
-#pragma unroll
-            for (int q = 0; q < CB; ++q) if (cc + q < m) F[i + (cc + q) * ld] = f[q] - a0 * w0[q] - a1 * w1[q];
-        }
-    }
-}
-
 // In-place inverse of the unit lower triangular k x k block at the top of F by recursive doubling:
 //   [A 0; B C]^{-1} = [A^{-1} 0; -C^{-1} B A^{-1}  C^{-1}],  block size h = 1, 2, 4, ...
 // Each stage is two fully parallel small products (T = B A^{-1} parked in the unused mirror position above the
@@ -296,168 +243,6 @@ __device__ __forceinline__ void invert_unit_lower(double* F, const int ld, const
         __syncthreads();
     }
 }
-
-// LDL^T of the k leading (fully-summed) columns of an m x m front held in LDS (lower storage, leading
-// dimension ld), Bunch-Kaufman pivoting restricted to the k x k pivot block, right-looking updates of the
-// whole trailing front.  All NT threads of the workgroup call it with identical arguments.
-template <int NT>
-__device__ __forceinline__ void ldlt_lds(double* F, const int ld, const int m, const int k, double* lc0, double* lc1,
-                                         double* dinv_s, double* doff_s, int* pt_s, int* lp, double* redv, int* redi,
-                                         const double u, const double small, int& nneg, int& nzero, int& ntwo, int& nsmall)
-{
-    // Per pivot: the search is done REDUNDANTLY by every wavefront (identical LDS data, deterministic DPP reduction =>
-    // identical decisions, no barrier, no LDS exchange); then  scale -> barrier -> update -> barrier.
-    // Row i of the work columns lc0/lc1 is owned by thread i % NT for the whole factorisation.
-    const int tid = threadIdx.x, lane = tid & 63;
-    unsigned long long bigmask = 0ull;          // bit min(j,63): some multiplier of pivot j exceeded 1/u
-    int j = 0;
-    while (j < k) {
-        double best = -1.0; int bi = 0x7fffffff;
-        for (int i = j + 1 + lane; i < k; i += 64) { const double a = fabs(F[i + j * ld]); if (a > best) { best = a; bi = i; } }
-        const double lam = wave_max_all(best);
-        const double ajj = fabs(F[j + j * ld]);
-        int two = 0;
-        if (lam > 0.0 && ajj < BK_ALPHA * lam) {
-            const unsigned long long hit = __ballot(best == lam);
-            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
-            const int r = __builtin_amdgcn_readlane(bi, src);
-            double sg = 0.0;
-            for (int c = j + lane; c < k; c += 64) { if (c == r) continue; const double a = (c < r) ? fabs(F[r + c * ld]) : fabs(F[c + r * ld]); sg = fmax(sg, a); }
-            const double sig = wave_max_all(sg);
-            const double arr = fabs(F[r + r * ld]);
-            if (ajj * sig >= BK_ALPHA * lam * lam) { /* 1x1 at j, no interchange */ }
-            else if (arr >= BK_ALPHA * sig) { swap_rc<NT>(F, ld, m, j, r, lp); }
-            else { two = 1; if (r != j + 1) swap_rc<NT>(F, ld, m, j + 1, r, lp); }
-        }
-        const unsigned long long jbit = 1ull << (j < 63 ? j : 63);
-        const int ifirst = tid + ((j + 1 - tid + NT - 1) / NT) * NT;     // first owned row > j (tid + NT*q)
-        if (two) {
-            const double a = F[j + j * ld], b = F[j + 1 + j * ld], c = F[j + 1 + (j + 1) * ld];
-            const double det = a * c - b * b;
-            if (fabs(det) <= small) two = 0;   // degenerate block: fall through to a (perturbed) 1x1
-            else {
-                const double idet = 1.0 / det;
-                for (int i = ifirst; i < m; i += NT) if (i > j + 1) {
-                    const double w0 = F[i + j * ld], w1 = F[i + (j + 1) * ld];
-                    const double l0 = (c * w0 - b * w1) * idet, l1 = (a * w1 - b * w0) * idet;
-                    lc0[i] = l0; lc1[i] = l1;
-                    if (fmax(fabs(l0), fabs(l1)) * u > 1.0) bigmask |= jbit;
-                }
-                __syncthreads();
-                trailing_update<NT, true>(F, ld, m, j + 2, j, lc0, lc1);
-                __syncthreads();
-                for (int i = ifirst; i < m; i += NT) if (i > j + 1) { F[i + j * ld] = lc0[i]; F[i + (j + 1) * ld] = lc1[i]; }
-                if (tid == 0) {
-                    F[j + 1 + j * ld] = 0.0;
-                    dinv_s[j] = c * idet; dinv_s[j + 1] = a * idet; doff_s[j] = -b * idet; doff_s[j + 1] = 0.0;
-                    pt_s[j] = 2; pt_s[j + 1] = 3;
-                }
-                if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
-                ntwo++; j += 2;
-                continue;
-            }
-        }
-        {   // 1x1 pivot at j
-            double d = F[j + j * ld];
-            if (fabs(d) <= small) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
-            const double di = 1.0 / d;
-            for (int i = ifirst; i < m; i += NT) { const double l = F[i + j * ld] * di; lc0[i] = l; if (fabs(l) * u > 1.0) bigmask |= jbit; }
-            __syncthreads();
-            trailing_update<NT, false>(F, ld, m, j + 1, j, lc0, lc1);
-            __syncthreads();
-            for (int i = ifirst; i < m; i += NT) F[i + j * ld] = lc0[i];
-            if (tid == 0) { dinv_s[j] = di; doff_s[j] = 0.0; pt_s[j] = 1; }
-            if (d < 0.0) nneg++;
-            j += 1;
-        }
-    }
-    // number of pivots with an oversized multiplier (the analogue of a delayed pivot): OR the per-thread masks
-    bigmask = wave_or_all(bigmask);
-    if (NT > 64) {
-        unsigned long long* red = reinterpret_cast<unsigned long long*>(redv);
-        __syncthreads();
-        if (lane == 0) red[tid >> 6] = bigmask;
-        __syncthreads();
-        bigmask = 0ull;
-#pragma unroll
-        for (int q = 0; q < NT / 64; ++q) bigmask |= red[q];
-        __syncthreads();
-    }
-    nsmall = __popcll(bigmask);
-    (void)redi;
-}
-
-template <int NT>
-__global__ __launch_bounds__(NT) void k_front_lds(DevView V, int list_off, int top_mode)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int NW = NT / 64;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int r0 = V.sn_rowptr[s], m = V.sn_rowptr[s + 1] - r0;
-    const int ld = m | 1;
-    double* F    = reinterpret_cast<double*>(smem_raw);
-    double* lc0  = F + (size_t)ld * m;
-    double* lc1  = lc0 + m;
-    double* dinv_s = lc1 + m;
-    double* doff_s = dinv_s + k;
-    double* redv = doff_s + k;            // 4
-    int*    redi = reinterpret_cast<int*>(redv + 4);   // 4
-    int*    lp   = redi + 4;              // k
-    int*    pt_s = lp + k;                // k
-
-    // ---- (a) init: zero, or (multi-GPU replicated top) start from the all-reduced arena square ----
-    if (top_mode && V.arena) {
-        const double* Ar = V.arena + V.arena_off[s];
-        for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; F[i + c * ld] = Ar[idx]; }
-    } else {
-        for (int idx = tid; idx < ld * m; idx += NT) F[idx] = 0.0;
-    }
-    for (int j = tid; j < k; j += NT) lp[j] = j;
-    __syncthreads();
-    // ---- (b) scatter the A values of the pivot columns (distinct positions) ----
-    if (!(top_mode && V.arena)) {
-        const int q0 = V.acolptr[c0], q1 = V.acolptr[c0 + k];
-        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] = V.aval[q]; }
-    }
-    __syncthreads();
-    // ---- (c) extend-add the children's contribution blocks, one child at a time ----
-    for (int cp = V.child_ptr[s]; cp < V.child_ptr[s + 1]; ++cp) {
-        const int ch = V.child_idx[cp];
-        if (top_mode && V.arena && V.sn_owner[ch] >= 0) continue;   // already inside the arena
-        const int kc = V.sn_colptr[ch + 1] - V.sn_colptr[ch];
-        const int mc = V.sn_rowptr[ch + 1] - V.sn_rowptr[ch] - kc;
-        const int* relc = V.rel + V.sn_rowptr[ch] + kc;
-        const double* C = V.cb + V.cb_off[ch];
-        for (int b = wave; b < mc; b += NW) {
-            const int rb = relc[b];
-            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * mc];
-        }
-        __syncthreads();
-    }
-
-    // ---- (d) LDL^T of the k pivot columns ----
-    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
-    ldlt_lds<NT>(F, ld, m, k, lc0, lc1, dinv_s, doff_s, pt_s, lp, redv, redi, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
-    __syncthreads();
-    // ---- (e) write back: panel (ld = m), pivot data, contribution block (ld = m-k, lower) ----
-    double* Lg = V.L + V.panel_off[s];
-    for (int c = wave; c < k; c += NW)
-        for (int i = lane; i < m; i += 64) Lg[i + (size_t)c * m] = (i >= c) ? F[i + c * ld] : 0.0;
-    for (int jj = tid; jj < k; jj += NT) { V.dinv[c0 + jj] = dinv_s[jj]; V.doff[c0 + jj] = doff_s[jj]; V.ptype[c0 + jj] = pt_s[jj]; V.lperm[c0 + jj] = lp[jj]; }
-    const int mu = m - k;
-    double* Cg = V.cb + V.cb_off[s];
-    for (int c = wave; c < mu; c += NW)
-        for (int i = c + lane; i < mu; i += 64) Cg[i + (size_t)c * mu] = F[(k + i) + (k + c) * ld];
-    if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
-    // ---- (f) L11^{-1} for the solves (in place in LDS, the front has been written back) ----
-    __syncthreads();
-    invert_unit_lower<NT>(F, ld, k);
-    double* Mg = V.minv + V.minv_off[s];
-    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? F[i + c * ld] : (i == c ? 1.0 : 0.0); }
-}
-
 
 // ================================================================================================
 // Register-tiled LDL^T core (the production path).  The assembled front is pulled from LDS into VGPRs as a
@@ -668,7 +453,7 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : 1) void k_front_reg
         const double* C = V.cb + Cm.cb_off;
         for (int b = wave; b < mc; b += NW) {
             const int rb = relc[b];
-            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * mc];
+            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * Cm.ldt];
         }
         __syncthreads();
     }
@@ -724,7 +509,7 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
     constexpr int TS = 4, G = 16, MAXM = 64;
     const int tid = threadIdx.x;
     const FrontMeta M = V.fmeta[list_off + blockIdx.x];
-    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k; (void)m;
     const int ld = k | 1;
     double* Lb     = reinterpret_cast<double*>(smem_raw);   // k x k L columns (physical rows)
     double* Li     = Lb + (size_t)ld * k;                    // k x k pivot-ordered copy / inverse
@@ -732,6 +517,7 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
     double* dinv_s = colbuf + 4 * MAXM; double* doff_s = dinv_s + k;
     int* ord = reinterpret_cast<int*>(doff_s + k); int* pt_s = ord + k;
     double* P = V.L + M.panel_off;
+    const size_t ldp = (size_t)M.ldp;
     const int ti = tid % G, tj = tid / G, row0 = ti * TS, col0 = tj * TS;
     double t[TS][TS];
 #pragma unroll
@@ -739,7 +525,7 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
 #pragma unroll
         for (int y = 0; y < TS; ++y) {
             const int i = row0 + x, c = col0 + y;
-            t[x][y] = (i < k && c < k) ? ((i >= c) ? P[i + (size_t)c * m] : P[c + (size_t)i * m]) : 0.0;
+            t[x][y] = (i < k && c < k) ? ((i >= c) ? P[i + (size_t)c * ldp] : P[c + (size_t)i * ldp]) : 0.0;
         }
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
     DBGSTAMP(0);
@@ -749,7 +535,7 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
     for (int idx = tid; idx < k * k; idx += 256) {
         const int i = idx % k, c = idx / k;
         const double v = (i > c) ? Lb[ord[i] + c * ld] : 0.0;
-        P[i + (size_t)c * m] = v; Li[i + c * ld] = v;
+        P[i + (size_t)c * ldp] = v; Li[i + c * ld] = v;
     }
     for (int j = tid; j < k; j += 256) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
@@ -848,8 +634,8 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         for (int i = k + tid; i < m; i += NT) {
             double t0 = 0.0, t1 = 0.0;
             int j = 0;
-            for (; j + 1 < k; j += 2) { t0 += Lg[i + (size_t)j * m] * ys[j]; t1 += Lg[i + (size_t)(j + 1) * m] * ys[j + 1]; }
-            if (j < k) t0 += Lg[i + (size_t)j * m] * ys[j];
+            for (; j + 1 < k; j += 2) { t0 += Lg[i + (size_t)j * M.ldp] * ys[j]; t1 += Lg[i + (size_t)(j + 1) * M.ldp] * ys[j + 1]; }
+            if (j < k) t0 += Lg[i + (size_t)j * M.ldp] * ys[j];
             V.cvec[r0 + i] = xu[i - k] - (t0 + t1);
         }
     }
@@ -886,7 +672,7 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
         const double* Lg = V.L + M.panel_off;
         for (int j = wave; j < k; j += NW) {
             double t = 0.0;
-            for (int i = lane; i < m - k; i += 64) t += Lg[k + i + (size_t)j * m] * xu[i];
+            for (int i = lane; i < m - k; i += 64) t += Lg[k + i + (size_t)j * M.ldp] * xu[i];
             t = wave_sum(t);
             if (lane == 0) ws[j] -= t;
         }
@@ -920,10 +706,10 @@ __global__ __launch_bounds__(256) void k_fwd_big_upd(DevView V, int list_off)
     double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
     int j = 0;
     for (; j + 3 < k; j += 4) {
-        t0 += Lg[(size_t)j * m] * ys[j]; t1 += Lg[(size_t)(j + 1) * m] * ys[j + 1];
-        t2 += Lg[(size_t)(j + 2) * m] * ys[j + 2]; t3 += Lg[(size_t)(j + 3) * m] * ys[j + 3];
+        t0 += Lg[(size_t)j * M.ldp] * ys[j]; t1 += Lg[(size_t)(j + 1) * M.ldp] * ys[j + 1];
+        t2 += Lg[(size_t)(j + 2) * M.ldp] * ys[j + 2]; t3 += Lg[(size_t)(j + 3) * M.ldp] * ys[j + 3];
     }
-    for (; j < k; ++j) t0 += Lg[(size_t)j * m] * ys[j];
+    for (; j < k; ++j) t0 += Lg[(size_t)j * M.ldp] * ys[j];
     V.cvec[r0 + i] -= (t0 + t1) + (t2 + t3);
 }
 // big fronts, backward part 1: partial(chunk, j) = sum_{i in chunk} L21(i,j) x(rows(i)), 256 rows per workgroup
@@ -942,7 +728,7 @@ __global__ __launch_bounds__(256) void k_bwd_big_dot(DevView V, int list_off)
     double* part = V.wbuf + V.wb_off[s] + (size_t)blockIdx.x * k;
     for (int j = wave; j < k; j += 4) {
         double t = 0.0;
-        for (int i = lane; i < nrow; i += 64) t += Lg[i + (size_t)j * m] * xs[i];
+        for (int i = lane; i < nrow; i += 64) t += Lg[i + (size_t)j * M.ldp] * xs[i];
         t = wave_sum(t);
         if (lane == 0) part[j] = t;
     }
@@ -962,7 +748,7 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
-    const int mu = m - k;
+    (void)0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fc = blockIdx.x * 4 + wave;                 // front column owned by this wavefront
     const bool active = fc < m;
@@ -971,11 +757,13 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
     const bool skip_owned = top_mode && V.arena;                           // rank-owned children are inside the arena
     if (active) {
         const double* Ar = from_arena ? V.arena + V.arena_off[s] + (size_t)fc * m : nullptr;   // all-reduced square, lower part
-        if (fc < k) {
-            col = V.L + M.panel_off + (size_t)fc * m;
+        if (fc < k) col = V.L + M.panel_off + (size_t)fc * M.ldp;
+        else        col = V.cb + M.cb_off + (size_t)(fc - k) * M.ldt - k;
+        if (M.alias) {          // the front already sits in its chain child's contribution block: nothing to clear or copy
+            if (from_arena) for (int i = fc + lane; i < m; i += 64) col[i] += Ar[i];
+        } else if (fc < k) {
             for (int i = lane; i < m; i += 64) col[i] = (from_arena && i >= fc) ? Ar[i] : 0.0;
         } else {
-            col = V.cb + M.cb_off + (size_t)(fc - k) * mu - k;
             for (int i = fc + lane; i < m; i += 64) col[i] = from_arena ? Ar[i] : 0.0;
         }
     }
@@ -988,45 +776,18 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
         const ChildMeta Cm = V.cmeta[cp];
         const int ch = Cm.ch; (void)ch;
-        if (active && !(skip_owned && Cm.owner >= 0)) {
+        if (active && !Cm.aliased && !(skip_owned && Cm.owner >= 0)) {
             const int mc = Cm.mc;
             const int* relc = V.rel + Cm.relbase;
             int lo = 0, hi = mc;                           // first b with relc[b] >= fc (relc is increasing)
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
             if (lo < mc && relc[lo] == fc) {
-                const double* C = V.cb + Cm.cb_off + (size_t)lo * mc;
+                const double* C = V.cb + Cm.cb_off + (size_t)lo * Cm.ldt;
                 for (int a = lo + lane; a < mc; a += 64) col[relc[a]] += C[a];
             }
         }
         __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(256) void k_big_diag(DevView V, int list_off)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x;
-    const int s = V.level_sn[list_off + blockIdx.x];
-    const int c0 = V.sn_colptr[s], k = V.sn_colptr[s + 1] - c0;
-    const int m = V.sn_rowptr[s + 1] - V.sn_rowptr[s];
-    const int ld = k | 1;
-    double* F = reinterpret_cast<double*>(smem_raw);
-    double* lc0 = F + (size_t)ld * k; double* lc1 = lc0 + k; double* dinv_s = lc1 + k; double* doff_s = dinv_s + k;
-    double* redv = doff_s + k; int* redi = reinterpret_cast<int*>(redv + 4); int* lp = redi + 4; int* pt_s = lp + k;
-    double* P = V.L + V.panel_off[s];
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; F[i + c * ld] = (i >= c) ? P[i + (size_t)c * m] : 0.0; }
-    for (int j = tid; j < k; j += 256) lp[j] = j;
-    __syncthreads();
-    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
-    ldlt_lds<256>(F, ld, k, k, lc0, lc1, dinv_s, doff_s, pt_s, lp, redv, redi, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
-    __syncthreads();
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; P[i + (size_t)c * m] = (i >= c) ? F[i + c * ld] : 0.0; }
-    for (int j = tid; j < k; j += 256) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = lp[j]; }
-    if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
-    __syncthreads();
-    invert_unit_lower<256>(F, ld, k);
-    double* Mg = V.minv + V.minv_off[s];
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? F[i + c * ld] : (i == c ? 1.0 : 0.0); }
 }
 
 // rows below the pivot block:  W21 = (A21 P) L11^{-T}  as a GEMM with the stored inverse (fp64 MFMA, no
@@ -1046,12 +807,13 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     double* As = Ms + (size_t)ldm * kp;                       // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
     double* Ws = As + (size_t)65 * kp;                        // 64 x k : Ws[r + j*65]
     double* P = V.L + M.panel_off;
+    const size_t ldp = (size_t)M.ldp;
     double* W = V.wbuf + V.wb_off[s];
     const double* Mg = V.minv + M.minv_off;
     for (int idx = tid; idx < k * kp; idx += 256) { const int j = idx % k, p = idx / k; Ms[j + p * ldm] = (p < k) ? Mg[j + (size_t)p * k] : 0.0; }
     for (int idx = tid; idx < 64 * kp; idx += 256) {
         const int r = idx & 63, p = idx >> 6;
-        As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)V.lperm[c0 + p] * m] : 0.0;
+        As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)V.lperm[c0 + p] * ldp] : 0.0;
     }
     __syncthreads();
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1079,7 +841,7 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
         if (pt == 1) l = wj * V.dinv[c0 + j];
         else if (pt == 2) l = V.dinv[c0 + j] * wj + V.doff[c0 + j] * Ws[r + (j + 1) * 65];
         else l = V.doff[c0 + j - 1] * Ws[r + (j - 1) * 65] + V.dinv[c0 + j] * wj;
-        if (i < m) { W[i + (size_t)j * m] = wj; P[i + (size_t)j * m] = l; lmax = fmax(lmax, fabs(l)); }
+        if (i < m) { W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l; lmax = fmax(lmax, fabs(l)); }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
@@ -1117,11 +879,11 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
     for (int p = 0; p < k; p += 4) {
         const int pk = p + l4;
         const bool v = pk < k;
-        const size_t off = (size_t)pk * m;
+        const size_t off = (size_t)pk * m, offp = (size_t)pk * M.ldp;
         const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
         const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
-        const double b0 = (v && ia < mu) ? Lp[ia + off] : 0.0;
-        const double b1 = (v && ib < mu) ? Lp[ib + off] : 0.0;
+        const double b0 = (v && ia < mu) ? Lp[ia + offp] : 0.0;
+        const double b1 = (v && ib < mu) ? Lp[ib + offp] : 0.0;
         acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
         acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
@@ -1136,7 +898,7 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
             for (int g = 0; g < 4; ++g) {
                 const int c = cc0 + r * 16 + l4 + 4 * g;      // D row index  -> T column
                 const int i = i0 + q * 16 + l15;              // D column index -> T row
-                if (i < mu && c < mu && i >= c) T[i + (size_t)c * mu] -= acc[r][q][g];
+                if (i < mu && c < mu && i >= c) T[i + (size_t)c * M.ldt] -= acc[r][q][g];
             }
 }
 
@@ -1164,7 +926,7 @@ __global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off)
             int lo = 0, hi = mc;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
             if (lo < mc && relc[lo] == fc) {
-                const double* C = V.cb + Cm.cb_off + (size_t)lo * mc;
+                const double* C = V.cb + Cm.cb_off + (size_t)lo * Cm.ldt;
                 for (int a = lo + lane; a < mc; a += 64) col[relc[a]] += C[a];
             }
         }
@@ -1229,7 +991,6 @@ public:
     int join_list_base = 0, join_count = 0, join_maxm = 0;   // replicated fronts with a rank-owned child (arena squares)
     long long arena_doubles = 0, toprhs_doubles = 0;
     bool multi = false;
-    bool legacy = false;          // MI355X_KKT_LEGACY=1: the LDS-resident LDL^T kernels (A/B comparisons)
 
     // ---- per-kernel-kind timing (bench.py roofline): hip events around every launch, eager mode ----
     bool prof_on = false;
@@ -1285,7 +1046,6 @@ public:
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
-        { const char* e = getenv("MI355X_KKT_LEGACY"); legacy = e && e[0] == '1'; }
         std::vector<int> lvl_list(Sy.level_sn);
         std::vector<long long> aoff(Sy.num_sn, -1), troff(Sy.num_sn, -1);
         std::vector<int> colown(Sy.n, 0);
@@ -1327,15 +1087,18 @@ public:
             const int sn = lvl_list[q];
             FrontMeta& M = fm[q];
             M.s = sn; M.c0 = Sy.sn_colptr[sn]; M.k = Sy.sn_colptr[sn + 1] - M.c0; M.r0 = Sy.sn_rowptr[sn]; M.m = Sy.sn_rowptr[sn + 1] - M.r0;
-            M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.pad = 0;
+            M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.alias = Sy.alias_child[sn] >= 0 ? 1 : 0;
+            M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
             M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
         }
         std::vector<ChildMeta> cm(Sy.child_idx.size());
         for (size_t q = 0; q < cm.size(); ++q) {
             const int ch = Sy.child_idx[q]; const int kc = Sy.sn_colptr[ch + 1] - Sy.sn_colptr[ch];
             cm[q].ch = ch; cm[q].relbase = Sy.sn_rowptr[ch] + kc; cm[q].mc = Sy.sn_rowptr[ch + 1] - cm[q].relbase;
-            cm[q].owner = Sy.sn_owner[ch]; cm[q].cb_off = Sy.cb_off[ch];
+            cm[q].owner = Sy.sn_owner[ch]; cm[q].cb_off = Sy.cb_off[ch]; cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0;
         }
+        for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0)
+            for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) if (Sy.child_idx[q] == Sy.alias_child[sn]) cm[q].aliased = 1;
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta)) return false;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
@@ -1347,18 +1110,16 @@ public:
         double* tv = nullptr;
         if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
         if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
-            !dalloc(&V.L, (size_t)Sy.l_doubles) || !dalloc(&V.cb, (size_t)Sy.cb_doubles) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
+            !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
             !dalloc(&d_stats, 4)) return false;
+        V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
         if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 16)) return false; }
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
         V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
-        HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<64>,  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_front_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1391,24 +1152,20 @@ public:
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
 
-    // one (level, class) bucket of fronts: register-tiled kernels by default, LDS-resident ones with MI355X_KKT_LEGACY=1
+    // one (level, class) bucket of fronts
     bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk) {
         const int nb = b1 - b0;
         const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
         if (fc == FC_WAVE) {
-            if (legacy) LAUNCH(KK_FRONT_WAVE, k_front_lds<64>, dim3(nb), dim3(64), front_lds_bytes(32, 32), stream, V, b0, top_mode);
-            else        LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
+            LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
         } else if (fc == FC_LDS64) {
-            if (legacy) LAUNCH(KK_FRONT_LDS64, k_front_lds<64>, dim3(nb), dim3(64), front_lds_bytes(64, 64), stream, V, b0, top_mode);
-            else        LAUNCH(KK_FRONT_LDS64, (k_front_reg<64, 8>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
+            LAUNCH(KK_FRONT_LDS64, (k_front_reg<64, 8>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
         } else if (fc == FC_LDS128) {
-            if (legacy) LAUNCH(KK_FRONT_LDS128, k_front_lds<256>, dim3(nb), dim3(256), front_lds_bytes(128, 128), stream, V, b0, top_mode);
-            else        LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb), dim3(256), rl, stream, V, b0, top_mode);
+            LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb), dim3(256), rl, stream, V, b0, top_mode);
         } else {
             const int nt = (mm - 1 + 63) / 64;
             LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
-            if (legacy) LAUNCH(KK_BIG_DIAG, k_big_diag, dim3(nb), dim3(256), front_lds_bytes(kk, kk), stream, V, b0);
-            else        LAUNCH(KK_BIG_DIAG, k_big_diag_reg, dim3(nb), dim3(256), (size_t)(2 * (kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+            LAUNCH(KK_BIG_DIAG, k_big_diag_reg, dim3(nb), dim3(256), (size_t)(2 * (kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
             LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
             LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, nb), dim3(256), 0, stream, V, b0);
         }
@@ -1576,7 +1333,6 @@ public:
     }
     bool factor_local(const double* dvals) {
         if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
-        if (legacy) { err_ = "MI355X_KKT_LEGACY kernels do not implement the multi-GPU top mode"; return false; }
         const Symbolic& Sy = *S; const int n = Sy.n;
         V.pivtol = opt.pivtol; V.small = opt.small;
         if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));

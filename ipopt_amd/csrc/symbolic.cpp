@@ -629,19 +629,15 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     S.sn_level.assign(nsn, 0);
     for (int s = 0; s < nsn; ++s) { int p = S.sn_parent[s]; if (p >= 0) S.sn_level[p] = std::max(S.sn_level[p], S.sn_level[s] + 1); }
     S.num_levels = 0; for (int s = 0; s < nsn; ++s) S.num_levels = std::max(S.num_levels, S.sn_level[s] + 1);
-    S.sn_class.resize(nsn); S.panel_off.resize(nsn); S.cb_off.resize(nsn);
-    int64_t loff = 0, coff = 0;
+    S.sn_class.resize(nsn);
     for (int s = 0; s < nsn; ++s) {
         int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
         S.sn_class[s] = m <= 32 ? FC_WAVE : (m <= 64 ? FC_LDS64 : (m <= 128 ? FC_LDS128 : FC_BIG));
         if (S.sn_class[s] == FC_BIG) S.num_big++;
-        S.panel_off[s] = loff; loff += m * k;
-        S.cb_off[s] = coff; coff += (m - k) * (m - k);
         S.nnz_l += k * m - k * (k - 1) / 2;
         for (int64_t j = 0; j < k; ++j) { int64_t c = m - j; S.flops_factor += (c - 1) * (c + 2); }
         S.maxfront = std::max<int>(S.maxfront, (int)m); S.maxsupernode = std::max<int>(S.maxsupernode, (int)k);
     }
-    S.l_doubles = loff; S.cb_doubles = coff;
     S.minv_off.resize(nsn);
     { int64_t mo = 0; for (int s = 0; s < nsn; ++s) { int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s]; S.minv_off[s] = mo; mo += k * k; } S.minv_doubles = mo; }
     {   // per-level scratch for the W = L*D panels of the blocked (big-front) path
@@ -701,6 +697,34 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             else if (S.sn_parent[s] >= 0 && S.sn_owner[S.sn_parent[s]] >= 0) S.sn_owner[s] = S.sn_owner[S.sn_parent[s]];
             else S.sn_owner[s] = -1;
         }
+    }
+    // ---- 12. storage: panels, contribution blocks, in-place separator chains (needs the ownership map) ----
+    S.panel_off.assign(nsn, 0); S.cb_off.assign(nsn, 0); S.sn_ldp.assign(nsn, 0); S.sn_ldt.assign(nsn, 0); S.alias_child.assign(nsn, -1);
+    {
+        auto K = [&](int s) { return (int64_t)(S.sn_colptr[s + 1] - S.sn_colptr[s]); };
+        auto Mf = [&](int s) { return (int64_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]); };
+        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG)
+            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+                const int c = S.child_idx[q];
+                if (S.sn_class[c] == FC_BIG && Mf(c) - K(c) == Mf(s) && S.sn_owner[c] == S.sn_owner[s]) { S.alias_child[s] = c; break; }
+            }
+        int64_t loff = 0, coff = 0;
+        for (int s = 0; s < nsn; ++s) if (S.alias_child[s] < 0) loff += Mf(s) * K(s);
+        S.l_doubles = loff;
+        loff = 0;
+        for (int s = 0; s < nsn; ++s) {
+            const int64_t k = K(s), m = Mf(s), mu = m - k;
+            const int ac = S.alias_child[s];
+            if (ac < 0) {
+                S.panel_off[s] = loff; loff += m * k; S.sn_ldp[s] = (int)m;
+                S.cb_off[s] = coff; coff += mu * mu; S.sn_ldt[s] = (int)mu;
+            } else {        // children precede parents, so the child's placement is final
+                const int64_t ldc = S.sn_ldt[ac];
+                S.panel_off[s] = S.l_doubles + S.cb_off[ac]; S.sn_ldp[s] = (int)ldc;
+                S.cb_off[s] = S.cb_off[ac] + k * ldc + k; S.sn_ldt[s] = (int)ldc;
+            }
+        }
+        S.cb_doubles = coff;
     }
     S.time_analyse = now_s() - t0;
     if (opt.verbose)

@@ -59,7 +59,13 @@ struct Symbolic {
     std::vector<int> sn_level;             // height-based level (leaves = 0)
     std::vector<int> sn_class;             // FrontClass
     std::vector<int64_t> panel_off;        // [num_sn] offset (doubles) of the m x k panel in L storage (ld = m)
-    std::vector<int64_t> cb_off;           // [num_sn] offset (doubles) of the (m-k)^2 contribution block (ld = m-k)
+    std::vector<int64_t> cb_off;           // [num_sn] offset (doubles) of the (m-k)^2 contribution block (ld = sn_ldt)
+    // In-place separator chains: a BIG front whose row set equals the update rows of a BIG child is not re-assembled -- it
+    // LIVES in that child's contribution block (panel = its first k columns, own contribution block = the trailing part),
+    // i.e. a right-looking blocked LDL^T of the separator front.  panel_off of such a front points into the cb pool
+    // (offset >= l_doubles; L and cb are one allocation) and both leading dimensions are inherited from the child.
+    std::vector<int> sn_ldp, sn_ldt;       // leading dimensions of the panel / of the contribution block
+    std::vector<int> alias_child;          // the child whose contribution block this front lives in, or -1
     std::vector<int64_t> wb_off;           // [num_sn] offset (doubles) of the m x k scaled-panel copy W = L*D of a BIG front
                                            // inside the per-level scratch (reused level after level), -1 otherwise
     int64_t wbuf_doubles = 0;
