@@ -90,39 +90,6 @@ struct DevView {
 // ------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------
-struct MaxIdx { double v; int i; };
-__device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
-
-template <int NT>
-__device__ __forceinline__ MaxIdx block_argmax(MaxIdx x, double* redv, int* redi)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { MaxIdx o; o.v = __shfl_xor(x.v, off); o.i = __shfl_xor(x.i, off); x = better(x, o); }
-    if (NT == 64) return x;
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { redv[w] = x.v; redi[w] = x.i; }
-    __syncthreads();
-    MaxIdx r; r.v = redv[0]; r.i = redi[0];
-#pragma unroll
-    for (int q = 1; q < NT / 64; ++q) { MaxIdx o; o.v = redv[q]; o.i = redi[q]; r = better(r, o); }
-    __syncthreads();
-    return r;
-}
-template <int NT>
-__device__ __forceinline__ double block_max(double x, double* redv)
-{
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) x = fmax(x, __shfl_xor(x, off));
-    if (NT == 64) return x;
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) redv[w] = x;
-    __syncthreads();
-    double r = redv[0];
-#pragma unroll
-    for (int q = 1; q < NT / 64; ++q) r = fmax(r, redv[q]);
-    __syncthreads();
-    return r;
-}
 // ---- wavefront reductions on the DPP path (row-local butterflies, then 4 readlanes): ~10x lower latency than the
 // ds_bpermute shuffles on the serial pivot chain.  Results are wave-uniform. ----
 template <int CTRL>
@@ -553,9 +520,10 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_reduce_stats(const int4* fstat, const int* owner, int nsn, int rank_filter, int* out)
 {
+    // integer sums: order-independent, so a grid of partial sums + atomicAdd stays deterministic
     __shared__ int sh[4][256];
     int a = 0, b = 0, c = 0, d = 0;
-    for (int s = threadIdx.x; s < nsn; s += 256) {
+    for (int s = blockIdx.x * 256 + threadIdx.x; s < nsn; s += gridDim.x * 256) {
         if (rank_filter >= -1 && owner[s] != rank_filter) continue;
         const int4 v = fstat[s]; a += v.x; b += v.y; c += v.z; d += v.w;
     }
@@ -565,8 +533,9 @@ __global__ void k_reduce_stats(const int4* fstat, const int* owner, int nsn, int
         if (threadIdx.x < off) for (int q = 0; q < 4; ++q) sh[q][threadIdx.x] += sh[q][threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x < 4) out[threadIdx.x] = sh[threadIdx.x][0];
+    if (threadIdx.x < 4 && sh[threadIdx.x][0] != 0) atomicAdd(&out[threadIdx.x], sh[threadIdx.x][0]);
 }
+__global__ void k_zero_i32(int* p, int n) { if (threadIdx.x < n) p[threadIdx.x] = 0; }
 
 // ------------------------------------------------------------------------------------------------
 // solves
@@ -1145,10 +1114,6 @@ public:
         ready = true; return true;
     }
 
-    static size_t front_lds_bytes(int mmax, int kmax) {
-        size_t ld = (size_t)mmax | 1;
-        return (ld * mmax + 2 * (size_t)mmax + 2 * (size_t)kmax + 4) * sizeof(double) + (4 + 2 * (size_t)kmax) * sizeof(int) + 16;
-    }
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
 
@@ -1192,7 +1157,8 @@ public:
                 launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv]);
             }
         }
-        LAUNCH(KK_STATS, k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
+        LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
+        LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());
         return true;
     }
@@ -1363,11 +1329,13 @@ public:
         HIPCHK(hipEventRecord(ev0, stream));
         if (!launch_fronts(sch_top, 1)) return false;
         // this rank reports its own subtrees; rank 0 also the replicated top => the sum over ranks is the inertia
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
         hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
         HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3];
         if (opt.rank == 0) {
+            hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
             hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
             HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
