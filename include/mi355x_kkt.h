@@ -72,7 +72,9 @@ typedef struct mi355x_kkt_options {
     int    verbose;         /* 0 silent                                                                 */
     int    leaf_cols;       /* whole elimination subtrees of <= this many columns become one supernode  */
                             /* (default 0 = off; measured: not a win)                                               */
-    int    reserved[7];
+    int    tree_merge;      /* tree amalgamation of small non-contiguous supernodes: 1 on, 0 off,        */
+                            /* -1 = on when n <= 400 000.  Default 0: measured NOT to pay    */
+    int    reserved[6];
 } mi355x_kkt_options;
 
 typedef struct mi355x_kkt_info {

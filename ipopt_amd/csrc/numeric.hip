@@ -60,6 +60,7 @@ struct DevView {
     const long long* panel_off; const long long* cb_off; const long long* wb_off; const long long* minv_off;
     const int* acolptr; const int* apos; const int* arow; const int* acol;
     const int* dup_ptr; const int* dup_src;
+    const int* rslot_ptr; const int* rslot_idx;
     const int* level_sn;
     const FrontMeta* fmeta;   // parallel to level_sn
     const ChildMeta* cmeta;   // parallel to child_idx
@@ -68,6 +69,7 @@ struct DevView {
     const double* tvals;    // triplet values (device copy)
     double* aval;           // summed + scaled values, permuted lower CSC order
     double* scale;          // symmetric scaling, permuted numbering
+    double* scale2;         // second buffer (Jacobi-style equilibration sweeps)
     unsigned long long* rowmax;  // scratch for equilibration (bit pattern of non-negative doubles)
     double* L;              // panels
     double* cb;             // contribution blocks
@@ -149,24 +151,21 @@ __global__ void k_zero_u64(unsigned long long* p, int n)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
 }
-// one Ruiz sweep, part 1: rowmax_i = max_j |a_ij| s_i s_j  (max is order independent => deterministic)
-__global__ void k_ruiz_rowmax(DevView V)
-{
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < V.nnz_a; q += gridDim.x * blockDim.x) {
-        const int r = V.arow[q], c = V.acol[q];
-        const double v = fabs(V.aval[q]) * V.scale[r] * V.scale[c];
-        if (v > 0.0) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(v);
-            atomicMax(&V.rowmax[r], b);
-            if (r != c) atomicMax(&V.rowmax[c], b);
-        }
-    }
-}
-__global__ void k_ruiz_update(DevView V)
+// one Ruiz sweep as a gather: s_new(i) = s(i) / sqrt( max_j |a_ij| s(i) s(j) ), one thread per row walking the symmetric
+// row view of the pattern (no atomics, Jacobi style: reads the previous sweep's factors) => deterministic, 1 launch/sweep
+__global__ void k_ruiz_sweep(DevView V, const double* sin, double* sout)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) {
-        const double m = __longlong_as_double((long long)V.rowmax[i]);
-        if (m > 0.0) V.scale[i] *= 1.0 / sqrt(m);
+        const double si = sin[i];
+        double mx = 0.0;
+        for (int p = V.rslot_ptr[i]; p < V.rslot_ptr[i + 1]; ++p) {
+            const int q = V.rslot_idx[p];
+            const int r = V.arow[q], c = V.acol[q];
+            const double sj = sin[r == i ? c : r];
+            mx = fmax(mx, fabs(V.aval[q]) * sj);
+        }
+        mx *= si;
+        sout[i] = mx > 0.0 ? si / sqrt(mx) : si;
     }
 }
 __global__ void k_apply_scale(DevView V)
@@ -378,7 +377,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
 // write-back of the pivot-ordered panel, the contribution block (straight from registers), pivot data and L11^{-1}.
 template <int NT, int TS>
-__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : 1) void k_front_reg(DevView V, int list_off, int top_mode)
+__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS == 2) ? 6 : 1)) void k_front_reg(DevView V, int list_off, int top_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = (NT == 64) ? 8 : 16;
@@ -952,6 +951,7 @@ public:
     bool scale_identity = true;
     std::vector<int> big_maxm, big_maxk;
     std::vector<size_t> reg_lds;
+    std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
     struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk; };
@@ -1051,6 +1051,17 @@ public:
             }
             for (int s = 0; s < Sy.num_sn; ++s) for (int j = Sy.sn_colptr[s]; j < Sy.sn_colptr[s + 1]; ++j) colown[j] = Sy.sn_owner[s];
         }
+        // inside every (level, FC_WAVE) bucket of the single-GPU schedule: fronts of order <= 16 first.  When there are many of
+        // them (throughput regime) they run on the 2x2-tile instantiation, whose small register footprint doubles the
+        // number of resident wavefronts.
+        tiny_split.assign(Sy.num_levels, 0);
+        for (int lv = 0; lv < Sy.num_levels; ++lv) {
+            const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE + 1];
+            auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
+            std::stable_sort(lvl_list.begin() + b0, lvl_list.begin() + b1, [&](int a, int b) { return order_of(a) < order_of(b); });
+            int q = b0; while (q < b1 && order_of(lvl_list[q]) <= 16) ++q;
+            tiny_split[lv] = (q - b0 >= 2048) ? q - b0 : 0;
+        }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -1073,12 +1084,12 @@ public:
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
             !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) || !upload(moff, &V.minv_off) ||
             !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
-            !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(lvl_list, &V.level_sn) ||
+            !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.rslot_ptr, &V.rslot_ptr) || !upload(Sy.rslot_idx, &V.rslot_idx) || !upload(lvl_list, &V.level_sn) ||
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
             !upload(Sy.perm, &V.perm)) return false;
         double* tv = nullptr;
         if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
-        if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
+        if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.scale2, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
@@ -1090,6 +1101,7 @@ public:
         V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1122,7 +1134,9 @@ public:
         const int nb = b1 - b0;
         const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
         if (fc == FC_WAVE) {
-            LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
+            const int nt = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_WAVE]) ? tiny_split[lv] : 0;     // single-GPU schedule only
+            if (nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 2>), dim3(nt), dim3(64), rl, stream, V, b0, top_mode);
+            if (nb - nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb - nt), dim3(64), rl, stream, V, b0 + nt, top_mode);
         } else if (fc == FC_LDS64) {
             LAUNCH(KK_FRONT_LDS64, (k_front_reg<64, 8>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
         } else if (fc == FC_LDS128) {
@@ -1143,11 +1157,11 @@ public:
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (opt.scaling) {
-            for (int it = 0; it < 3; ++it) {
-                LAUNCH(KK_GATHER_SCALE, k_zero_u64, dim3(grid1d(n)), dim3(256), 0, stream, V.rowmax, n);
-                LAUNCH(KK_GATHER_SCALE, k_ruiz_rowmax, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-                LAUNCH(KK_GATHER_SCALE, k_ruiz_update, dim3(grid1d(n)), dim3(256), 0, stream, V);
-            }
+            // 3 sweeps: scale -> scale2 -> scale -> scale2, then scale2 is copied back by the last sweep's roles being swapped
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
             LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         }
         for (int lv = 0; lv < Sy.num_levels; ++lv) {
@@ -1308,11 +1322,10 @@ public:
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (opt.scaling) {
-            for (int it = 0; it < 3; ++it) {
-                hipLaunchKernelGGL(k_zero_u64, dim3(grid1d(n)), dim3(256), 0, stream, V.rowmax, n);
-                hipLaunchKernelGGL(k_ruiz_rowmax, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-                hipLaunchKernelGGL(k_ruiz_update, dim3(grid1d(n)), dim3(256), 0, stream, V);
-            }
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
             hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         }
         if (!launch_fronts(sch_local, 0)) return false;

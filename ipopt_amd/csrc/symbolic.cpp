@@ -335,7 +335,8 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int* ri, const int* ci,
              int format, const double* vals)
 {
-    double t0 = now_s();
+    double t0 = now_s(), tl = t0;
+    auto lap = [&](const char* what) { if (opt.verbose >= 2) { double t = now_s(); fprintf(stderr, "[mi355x_kkt]   %-28s %.3f s\n", what, t - tl); tl = t; } };
     S = Symbolic();
     S.n = n; S.nnz_in = nnz;
     if (n < 0 || nnz < 0) { S.error = "analyse: negative size"; return false; }
@@ -347,11 +348,13 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     vector<int> xadj, adj;
     build_adjacency(n, P.colptr, P.row, xadj, adj);
 
+    lap("pattern+adjacency");
     // ---- 2. pairing ----
     vector<char> zrow(n, 0);
     if (opt.matching) zero_diag_matching(n, P, xadj, adj, vals, nnz, S.pair_of, S.num_pairs, zrow);
     else S.pair_of.assign(n, -1);
 
+    lap("pairing");
     // ---- 3. compressed graph ----
     vector<int> cid(n, -1); int nc = 0;
     vector<int> cfirst; cfirst.reserve(n);   // representative (first member) of each compressed node
@@ -373,6 +376,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         CG.adj = std::move(tmp);
     }
 
+    lap("compressed graph");
     // ---- 4. ordering ----
     vector<int> corder(nc);
     if (opt.ordering == 2) std::iota(corder.begin(), corder.end(), 0);
@@ -388,6 +392,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     vector<int> iperm(n);
     for (int k = 0; k < n; ++k) iperm[perm[k]] = k;
 
+    lap("ordering (ND+MD)");
     // ---- 5. elimination tree + postorder (pairs stay adjacent) ----
     vector<int> parent(n, -1);
     {
@@ -441,7 +446,9 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     }
     S.perm = perm; S.iperm = iperm;
 
-    // ---- 6. permuted lower CSC + maps ----
+    lap("etree+postorder");
+    // ---- 6. permuted lower CSC + maps (re-run when the tree amalgamation of step 8b renumbers columns) ----
+    auto build_permuted_csc = [&]()
     {
         const int nnzA = (int)P.row.size();
         vector<int> pc(nnzA), pr(nnzA);
@@ -469,8 +476,9 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         S.dup_src.resize(nnz);
         { vector<int> pos(S.dup_ptr.begin(), S.dup_ptr.end() - 1);
           for (int t = 0; t < nnz; ++t) S.dup_src[pos[S.trip2slot[t]]++] = t; }
-    }
-
+    };
+    build_permuted_csc();
+    lap("permuted CSC + maps");
     // ---- 7. column counts (skeleton matrix / least common ancestors; matrix is postordered) ----
     vector<int> cc(n, 0);
     {
@@ -494,6 +502,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         for (int j = 0; j < n; ++j) if (parent[j] != -1) cc[parent[j]] += cc[j];
     }
 
+    lap("column counts");
     // ---- 8. supernodes: fundamental + forced pairs, then relaxed amalgamation of chains ----
     const int maxcols = std::max(2, opt.max_sn_cols);
     // (a) whole small subtrees become one dense supernode: in the latency-bound regime (fronts of a few rows) dense
@@ -559,10 +568,81 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         for (int s = 0; s < S.num_sn; ++s) S.sn_colptr[s] = st[s].c0;
         S.sn_colptr[S.num_sn] = n;
     }
+    // ---- 8b. tree amalgamation: merge small sibling/child supernodes into their parent even when their columns are
+    //      not contiguous (the chain pass above only joins neighbours).  In the latency-bound regime every tree level is
+    //      a kernel launch plus a few dependent HBM round trips, so a 3-separator node of ~16 columns beats three levels of
+    //      ~5 columns.  Columns are renumbered by a postorder of the merged tree (any topological order of the elimination
+    //      tree is an equivalent elimination order), then the permuted pattern is rebuilt once.
+    {
+        const bool on = opt.tree_merge > 0 || (opt.tree_merge < 0 && n <= 400000);
+        const int nsn0 = S.num_sn;
+        if (on && nsn0 > 1) {
+            const int KM = 20, MM = 32;
+            vector<int> snof0(n), par0(nsn0, -1), gk(nsn0), gm(nsn0), grp(nsn0);
+            for (int s = 0; s < nsn0; ++s) for (int j = S.sn_colptr[s]; j < S.sn_colptr[s + 1]; ++j) snof0[j] = s;
+            for (int s = 0; s < nsn0; ++s) {
+                const int last = S.sn_colptr[s + 1] - 1;
+                gk[s] = S.sn_colptr[s + 1] - S.sn_colptr[s]; gm[s] = gk[s] + cc[last] - 1; grp[s] = s;
+                if (parent[last] >= 0) par0[s] = snof0[parent[last]];
+            }
+            int merges = 0;
+            for (int s = 0; s < nsn0; ++s) {
+                const int p = par0[s];
+                if (p < 0) continue;
+                const int newk = gk[s] + gk[p], newm = gk[s] + gm[p];
+                if (newk > KM || newm > MM) continue;
+                const double z = (double)gk[s] * (double)(newm - gm[s]);
+                if (z > 0.6 * (double)newk * newm) continue;
+                grp[s] = p; gk[p] = newk; gm[p] = newm; ++merges;
+            }
+            if (merges > 0) {
+                auto find = [&](int s) { while (grp[s] != s) s = grp[s]; return s; };
+                vector<int> rep(nsn0);
+                for (int s = nsn0 - 1; s >= 0; --s) rep[s] = (grp[s] == s) ? s : rep[grp[s]];     // parents have larger indices
+                (void)find;
+                // members of each group (ascending) and child groups
+                vector<int> mhead(nsn0, -1), mnext(nsn0, -1), chead(nsn0, -1), cnext(nsn0, -1);
+                for (int s = nsn0 - 1; s >= 0; --s) { const int g = rep[s]; mnext[s] = mhead[g]; mhead[g] = s; }
+                vector<int> roots;
+                for (int s = nsn0 - 1; s >= 0; --s) if (rep[s] == s) {
+                    // parent group = group of the parent of the group's top member s
+                    const int p = par0[s];
+                    if (p < 0) roots.push_back(s); else { const int pg = rep[p]; cnext[s] = chead[pg]; chead[pg] = s; }
+                }
+                // postorder over groups (child lists are ascending because of the descending insertion), emit columns
+                vector<int> newpos; newpos.reserve(n);            // newpos[t] = old column at new position t
+                vector<int> newstart;                             // first new column of each group
+                vector<int> stack, itc(nsn0);
+                for (int s = 0; s < nsn0; ++s) itc[s] = chead[s];
+                std::sort(roots.begin(), roots.end());
+                for (int r : roots) {
+                    stack.push_back(r);
+                    while (!stack.empty()) {
+                        const int g = stack.back();
+                        if (itc[g] != -1) { const int c = itc[g]; itc[g] = cnext[c]; stack.push_back(c); continue; }
+                        stack.pop_back();
+                        newstart.push_back((int)newpos.size());
+                        for (int ms = mhead[g]; ms != -1; ms = mnext[ms])
+                            for (int j = S.sn_colptr[ms]; j < S.sn_colptr[ms + 1]; ++j) newpos.push_back(j);
+                    }
+                }
+                // renumber: perm, iperm; the column etree / counts are not needed any more
+                vector<int> perm2(n);
+                for (int t = 0; t < n; ++t) perm2[t] = perm[newpos[t]];
+                perm.swap(perm2);
+                for (int t = 0; t < n; ++t) iperm[perm[t]] = t;
+                S.perm = perm; S.iperm = iperm;
+                S.num_sn = (int)newstart.size();
+                S.sn_colptr = newstart; S.sn_colptr.push_back(n);
+                build_permuted_csc();
+            }
+        }
+    }
     const int nsn = S.num_sn;
     S.sn_of.resize(n);
     for (int s = 0; s < nsn; ++s) for (int j = S.sn_colptr[s]; j < S.sn_colptr[s + 1]; ++j) S.sn_of[j] = s;
 
+    lap("supernodes");
     // ---- 9. supernodal row structures ----
     S.sn_rowptr.assign(nsn + 1, 0); S.sn_parent.assign(nsn, -1);
     S.sn_rows.clear(); S.sn_rows.reserve((size_t)n * 4);
@@ -595,6 +675,16 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     { vector<int> pos(S.child_ptr.begin(), S.child_ptr.end() - 1);
       for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_idx[pos[S.sn_parent[s]]++] = s; }
 
+    lap("row structures");
+    {   // symmetric row view of the permuted pattern (equilibration gather)
+        const int nnzA = S.nnz_a;
+        S.rslot_ptr.assign(n + 1, 0);
+        for (int q = 0; q < nnzA; ++q) { S.rslot_ptr[S.arow[q] + 1]++; if (S.arow[q] != S.acol[q]) S.rslot_ptr[S.acol[q] + 1]++; }
+        for (int i = 0; i < n; ++i) S.rslot_ptr[i + 1] += S.rslot_ptr[i];
+        S.rslot_idx.resize(S.rslot_ptr[n]);
+        vector<int> pos(S.rslot_ptr.begin(), S.rslot_ptr.end() - 1);
+        for (int q = 0; q < nnzA; ++q) { S.rslot_idx[pos[S.arow[q]]++] = q; if (S.arow[q] != S.acol[q]) S.rslot_idx[pos[S.acol[q]]++] = q; }
+    }
     // ---- 10. relative indices, A scatter positions, levels, offsets, stats ----
     S.rel.assign(S.sn_rows.size(), -1);
     for (int s = 0; s < nsn; ++s) {
@@ -657,6 +747,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     { vector<int> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
       for (int s = 0; s < nsn; ++s) S.level_sn[pos[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s]]++] = s; }
 
+    lap("rel/apos/levels");
     // ---- 11. multi-GPU ownership: proportional subtree-to-rank mapping ----
     S.sn_owner.assign(nsn, opt.nranks > 1 ? -1 : 0);
     if (opt.nranks > 1) {
@@ -698,6 +789,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             else S.sn_owner[s] = -1;
         }
     }
+    lap("ownership");
     // ---- 12. storage: panels, contribution blocks, in-place separator chains (needs the ownership map) ----
     S.panel_off.assign(nsn, 0); S.cb_off.assign(nsn, 0); S.sn_ldp.assign(nsn, 0); S.sn_ldt.assign(nsn, 0); S.alias_child.assign(nsn, -1);
     {

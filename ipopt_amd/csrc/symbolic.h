@@ -23,6 +23,7 @@ struct SymbolicOptions {
     int    nemin       = 8;
     int    max_sn_cols = 64;
     int    leaf_cols   = 0;    // whole elimination subtrees with at most this many columns become ONE supernode
+    int    tree_merge  = 0;    // merge small non-contiguous child supernodes into the parent: 1 on, 0 off (default), -1 auto (n <= 4e5)
     int    nranks      = 1;
     int    verbose     = 0;
 };
@@ -47,6 +48,9 @@ struct Symbolic {
     std::vector<int> dup_ptr, dup_src;     // [nnz_a+1], [nnz_in]
     // symmetric index pairs for scaling: slot -> (row,col) are arow / column of slot
     std::vector<int> acol;                 // [nnz_a] column of each slot (permuted numbering)
+    // full symmetric row view of the pattern: for every row i the slots (q) that carry an entry of row i, i.e. column i's
+    // own slots and the slots (i, c < i) of earlier columns; lets the equilibration run as a gather (no atomics)
+    std::vector<int> rslot_ptr, rslot_idx; // [n+1], [2*nnz_a - n]
     // supernodes
     int num_sn = 0;
     std::vector<int> sn_colptr;            // [num_sn+1] pivot column ranges (permuted numbering)
