@@ -64,8 +64,8 @@ typedef struct mi355x_kkt_options {
     double pivtol;          /* relative pivot threshold u (default 1e-8, cf. ma97_u)                    */
     double pivtolmax;       /* upper bound for set_pivtol escalation (default 1e-4)                     */
     double small;           /* |pivot| below this (after scaling) counts as zero (default 1e-20)        */
-    int    refine_steps;    /* RESERVED (ignored): internal iterative refinement is not built; Ipopt    */
-                            /* runs its own refinement loop (IpPDFullSpaceSolver.cpp:256-346)           */
+    int    refine_steps;    /* internal iterative-refinement steps per solve, fp64 residual on device    */
+                            /* (default 0: Ipopt runs its own loop, IpPDFullSpaceSolver.cpp:256-346)     */
     int    use_graph;       /* 1 (default) = replay factor/solve launch sequences as hipGraphs          */
     int    nranks;          /* multi-GPU: number of ranks sharing one matrix (default 1)                */
     int    rank;            /* multi-GPU: this rank                                                     */

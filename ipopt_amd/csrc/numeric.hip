@@ -79,6 +79,7 @@ struct DevView {
     int4*   fstat;          // per front {neg, zero, two, small}
     double* xw;             // work vector (permuted, scaled)
     double* cvec;           // forward-solve contributions, aligned with sn_rows
+    double* bw; double* xacc;   // iterative refinement: scaled right-hand side and accumulated solution (permuted numbering)
     double* ybuf;           // y of the pivot rows (big fronts: the update rows are handled by a second, multi-workgroup launch)
     // multi-GPU top arena (full m x m squares per replicated front), null on 1 GPU
     double* arena; const long long* arena_off;
@@ -547,6 +548,28 @@ __global__ void k_store_sol(DevView V, double* b)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) b[V.perm[i]] = V.scale[i] * V.xw[i];
 }
+
+// iterative refinement in the scaled, permuted space:  xacc += xw;  xw <- bw - K xacc   (K = scaled matrix, symmetric row
+// view => gather, no atomics).  first != 0: xacc = xw (no accumulation yet).  The residual is then solved for again.
+__global__ void k_refine_residual(DevView V, int first)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x)
+        V.xacc[i] = first ? V.xw[i] : V.xacc[i] + V.xw[i];
+}
+__global__ void k_refine_spmv(DevView V)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) {
+        double acc = 0.0;
+        for (int p = V.rslot_ptr[i]; p < V.rslot_ptr[i + 1]; ++p) {
+            const int q = V.rslot_idx[p];
+            const int r = V.arow[q], c = V.acol[q];
+            acc += V.aval[q] * V.xacc[r == i ? c : r];
+        }
+        V.xw[i] = V.bw[i] - acc;
+    }
+}
+__global__ void k_save_rhs(DevView V) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) V.bw[i] = V.xw[i]; }
+__global__ void k_refine_finish(DevView V) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) V.xw[i] += V.xacc[i]; }
 
 // forward: y = L11^{-1} P b for the pivot rows (a k x k mat-vec with the stored inverse: no substitution chain),
 // z = D^{-1} y, and the contribution  c = (children) - L21 y  for the ancestors is left in cvec (the parent
@@ -1092,7 +1115,7 @@ public:
         if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.scale2, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
-            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
+            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
             !dalloc(&d_stats, 4)) return false;
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
@@ -1219,27 +1242,36 @@ public:
         const Symbolic& Sy = *S;
         const int n = Sy.n;
         LAUNCH(KK_SOLVE_PERM, k_load_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V, dsrc);
-        auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
-        for (int lv = 0; lv < Sy.num_levels; ++lv)
-            for (int fc = 0; fc < FC_COUNT; ++fc) {
-                const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
-                if (b1 == b0) continue;
-                if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
-                else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
-                else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
-                else { LAUNCH(KK_FWD_BIG, (k_fwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0, 0);
-                       LAUNCH(KK_FWD_BIG, k_fwd_big_upd, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0); }
+        const int nref = opt.refine_steps > 0 ? opt.refine_steps : 0;
+        if (nref > 0) LAUNCH(KK_SOLVE_PERM, k_save_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V);
+        for (int pass = 0; pass <= nref; ++pass) {
+            if (pass > 0) {      // xacc (+)= xw ; xw = bw - K xacc ; solve again for the correction
+                LAUNCH(KK_SOLVE_PERM, k_refine_residual, dim3(grid1d(n)), dim3(256), 0, stream, V, pass == 1 ? 1 : 0);
+                LAUNCH(KK_SOLVE_PERM, k_refine_spmv, dim3(grid1d(n)), dim3(256), 0, stream, V);
             }
-        for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
-            for (int fc = 0; fc < FC_COUNT; ++fc) {
-                const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
-                if (b1 == b0) continue;
-                if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
-                else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
-                else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
-                else { LAUNCH(KK_BWD_BIG, k_bwd_big_dot, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0);
-                       LAUNCH(KK_BWD_BIG, (k_bwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0); }
-            }
+            auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
+            for (int lv = 0; lv < Sy.num_levels; ++lv)
+                for (int fc = 0; fc < FC_COUNT; ++fc) {
+                    const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
+                    if (b1 == b0) continue;
+                    if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
+                    else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
+                    else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
+                    else { LAUNCH(KK_FWD_BIG, (k_fwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0, 0);
+                           LAUNCH(KK_FWD_BIG, k_fwd_big_upd, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0); }
+                }
+            for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
+                for (int fc = 0; fc < FC_COUNT; ++fc) {
+                    const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
+                    if (b1 == b0) continue;
+                    if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                    else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
+                    else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
+                    else { LAUNCH(KK_BWD_BIG, k_bwd_big_dot, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0);
+                           LAUNCH(KK_BWD_BIG, (k_bwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0); }
+                }
+        }
+        if (nref > 0) LAUNCH(KK_SOLVE_PERM, k_refine_finish, dim3(grid1d(n)), dim3(256), 0, stream, V);
         LAUNCH(KK_SOLVE_PERM, k_store_sol, dim3(grid1d(n)), dim3(256), 0, stream, V, drhs);
         HIPCHK(hipGetLastError());
         return true;

@@ -14,11 +14,23 @@
 #include <numeric>
 #include <set>
 #include <cstdio>
+#include <thread>
+#include <atomic>
+#include <functional>
 
 namespace mi355x {
 namespace {
 
 using std::vector;
+
+// static-chunk parallel loop on std::thread (the analysis is the only multi-threaded host code; T <= 16)
+int analysis_threads() { unsigned h = std::thread::hardware_concurrency(); int t = h ? (int)h : 1; const char* e = getenv("MI355X_KKT_THREADS"); if (e) t = atoi(e); return std::max(1, std::min(t, 16)); }
+template <class F> void parallel_chunks(long long n, int T, F fn) {
+    if (T <= 1 || n < 4096) { fn(0LL, n, 0); return; }
+    std::vector<std::thread> th; th.reserve(T);
+    for (int t = 0; t < T; ++t) { long long b = n * t / T, e = n * (t + 1) / T; th.emplace_back([=, &fn] { fn(b, e, t); }); }
+    for (auto& x : th) x.join();
+}
 
 // ---------------------------------------------------------------------------------------
 // 1. canonical lower pattern in the ORIGINAL numbering (col = min, row = max), dedup
@@ -54,23 +66,36 @@ bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int f
     vector<int> order(nnz);
     { vector<int> pos(cnt.begin(), cnt.end() - 1);
       for (int t = 0; t < nnz; ++t) order[pos[lo[t]]++] = t; }
-    P.colptr.assign(n + 1, 0);
-    P.row.clear(); P.row.reserve((size_t)nnz + n);
-    P.t2slot.assign(nnz, -1);
-    vector<std::pair<int,int>> tmp;
-    for (int j = 0; j < n; ++j) {
-        tmp.clear();
-        for (int p = cnt[j]; p < cnt[j + 1]; ++p) tmp.emplace_back(hi[order[p]], order[p]);
-        std::sort(tmp.begin(), tmp.end());
-        P.colptr[j] = (int)P.row.size();
-        // diagonal first, always present
-        P.row.push_back(j);
-        int last = j;
-        for (auto& e : tmp) {
-            if (e.first != last) { P.row.push_back(e.first); last = e.first; }
-            P.t2slot[e.second] = (int)P.row.size() - 1;
+    // per column: sort the (row, triplet) pairs, count distinct rows (+ the always-present diagonal) -- columns are
+    // independent, so both passes run on threads; the prefix sum in between is sequential
+    const int T = analysis_threads();
+    vector<int> sorted_hi(nnz), sorted_t(nnz), ndist(n, 0);
+    parallel_chunks(n, T, [&](long long jb, long long je, int) {
+        vector<std::pair<int,int>> tmp;
+        for (int j = (int)jb; j < (int)je; ++j) {
+            tmp.clear();
+            for (int p = cnt[j]; p < cnt[j + 1]; ++p) tmp.emplace_back(hi[order[p]], order[p]);
+            if (tmp.size() > 1) std::sort(tmp.begin(), tmp.end());
+            int last = j, d = 1;
+            for (size_t q = 0; q < tmp.size(); ++q) { sorted_hi[cnt[j] + q] = tmp[q].first; sorted_t[cnt[j] + q] = tmp[q].second; if (tmp[q].first != last) { ++d; last = tmp[q].first; } }
+            ndist[j] = d;
         }
-    }
+    });
+    P.colptr.assign(n + 1, 0);
+    for (int j = 0; j < n; ++j) P.colptr[j + 1] = P.colptr[j] + ndist[j];
+    P.row.assign(P.colptr[n], 0);
+    P.t2slot.assign(nnz, -1);
+    parallel_chunks(n, T, [&](long long jb, long long je, int) {
+        for (int j = (int)jb; j < (int)je; ++j) {
+            int w = P.colptr[j];
+            P.row[w] = j;                       // diagonal first, always present
+            int last = j;
+            for (int p = cnt[j]; p < cnt[j + 1]; ++p) {
+                if (sorted_hi[p] != last) { P.row[++w] = sorted_hi[p]; last = sorted_hi[p]; }
+                P.t2slot[sorted_t[p]] = w;
+            }
+        }
+    });
     P.colptr[n] = (int)P.row.size();
     return true;
 }
@@ -234,19 +259,20 @@ private:
 class NestedDissection {
 public:
     NestedDissection(const Graph& g, int leaf) : G(g), leaf_(std::max(leaf, 8)), md(g), tag(g.n, -1), lev(g.n, -1) {}
-    void run(vector<int>& order, bool md_only) {
-        order.assign(G.n, -1);
-        vector<int> all(G.n); std::iota(all.begin(), all.end(), 0);
-        if (md_only) { md.order(all, order.data()); return; }
-        struct Task { vector<int> nodes; int start; };
-        vector<Task> st; st.push_back({std::move(all), 0});
-        int stamp = 0;
-        vector<int> queue, small;
-        while (!st.empty()) {
-            Task t = std::move(st.back()); st.pop_back();
+    MinDegree& mindeg() { return md; }
+    struct Task { vector<int> nodes; int start; };
+    // splits (or orders) every task on the stack until it is empty; with `budget` > 0 stops as soon as the stack holds
+    // that many pending tasks (they are then handed to worker threads, each with its own NestedDissection state)
+    void drain(vector<Task>& st, vector<int>& order) {
+        while (!st.empty()) { Task t = std::move(st.back()); st.pop_back(); step(std::move(t), st, order); }
+    }
+    int leaf() const { return leaf_; }
+    // one task: order it (leaf / unsplittable) or split it into sub-tasks pushed onto st
+    void step(Task t, vector<Task>& st, vector<int>& order) {
+        {
             int m = (int)t.nodes.size();
-            if (m == 0) continue;
-            if (m <= leaf_) { md.order(t.nodes, order.data() + t.start); continue; }
+            if (m == 0) return;
+            if (m <= leaf_) { md.order(t.nodes, order.data() + t.start); return; }
             // connected components of the induced subgraph
             ++stamp; for (int v : t.nodes) tag[v] = stamp;
             int cstamp = ++stamp;   // visited marker
@@ -268,7 +294,7 @@ public:
                     }
                 }
                 if (!small.empty()) { md.order(small, order.data() + pos); pos += (int)small.size(); small.clear(); }
-                continue;
+                return;
             }
             // one connected component: level structure from a pseudo-peripheral node
             vector<int>& comp = comps[0];
@@ -283,19 +309,19 @@ public:
                 nlev = nl; if (best == root) break; root = best;
             }
             nlev = bfs_levels(root, cstamp, ++stamp, queue); cstamp = stamp;
-            if (nlev < 3) { md.order(t.nodes, order.data() + t.start); continue; }
+            if (nlev < 3) { md.order(t.nodes, order.data() + t.start); return; }
             vector<int> lsize(nlev, 0);
             for (int v : queue) lsize[lev[v]]++;
             // choose the separator level: small and balanced
             int bestl = -1; double bests = 1e300; int below = lsize[0];
             for (int l = 1; l <= nlev - 2; ++l) {
                 int a = below, s = lsize[l], b = m - a - s; below += s;
-                if (a == 0 || b == 0) continue;
+                if (a == 0 || b == 0) return;
                 double imb = std::fabs((double)a - b) / (double)(a + b);
                 double score = (double)s * (1.0 + 4.0 * imb * imb) + 0.05 * m * imb;
                 if (score < bests) { bests = score; bestl = l; }
             }
-            if (bestl < 0) { md.order(t.nodes, order.data() + t.start); continue; }
+            if (bestl < 0) { md.order(t.nodes, order.data() + t.start); return; }
             vector<int> A, B, S;
             for (int v : queue) {
                 int l = lev[v];
@@ -307,7 +333,7 @@ public:
                     if (touchesB) S.push_back(v); else A.push_back(v);
                 }
             }
-            if (A.empty() || B.empty() || (int)S.size() * 2 > m) { md.order(t.nodes, order.data() + t.start); continue; }
+            if (A.empty() || B.empty() || (int)S.size() * 2 > m) { md.order(t.nodes, order.data() + t.start); return; }
             int sa = (int)A.size(), sb = (int)B.size();
             // separator last; inside S keep BFS order (dense clique anyway)
             for (size_t i = 0; i < S.size(); ++i) order[t.start + sa + sb + (int)i] = S[i];
@@ -315,6 +341,8 @@ public:
             st.push_back({std::move(B), t.start + sa});
         }
     }
+    int stamp = 0;
+    vector<int> queue, small;
 private:
     // BFS restricted to nodes with tag == in_stamp; re-tags visited with out_stamp; returns #levels
     int bfs_levels(int root, int in_stamp, int out_stamp, vector<int>& queue) {
@@ -380,7 +408,36 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     // ---- 4. ordering ----
     vector<int> corder(nc);
     if (opt.ordering == 2) std::iota(corder.begin(), corder.end(), 0);
-    else { NestedDissection nd(CG, opt.nd_leaf); nd.run(corder, opt.ordering == 1); }
+    else if (opt.ordering == 1) { NestedDissection nd(CG, opt.nd_leaf); vector<int> all(nc); std::iota(all.begin(), all.end(), 0); nd.mindeg().order(all, corder.data()); }
+    else {
+        // nested dissection; the recursion is task parallel: the main thread splits the largest pending piece until there
+        // are enough pieces, then worker threads (each with private scratch) finish them -- output ranges are disjoint
+        const int T = analysis_threads();
+        NestedDissection nd(CG, opt.nd_leaf);
+        vector<NestedDissection::Task> st;
+        { vector<int> all(nc); std::iota(all.begin(), all.end(), 0); st.push_back({std::move(all), 0}); }
+        std::fill(corder.begin(), corder.end(), -1);
+        if (T <= 1 || nc < 50000) nd.drain(st, corder);
+        else {
+            const size_t budget = (size_t)8 * T;
+            while (st.size() < budget) {
+                size_t big = 0; for (size_t q = 1; q < st.size(); ++q) if (st[q].nodes.size() > st[big].nodes.size()) big = q;
+                if ((int)st[big].nodes.size() <= std::max(nd.leaf(), nc / (int)(4 * budget))) break;
+                NestedDissection::Task t = std::move(st[big]); st.erase(st.begin() + big);
+                nd.step(std::move(t), st, corder);
+                if (st.empty()) break;
+            }
+            std::sort(st.begin(), st.end(), [](const NestedDissection::Task& a, const NestedDissection::Task& b) { return a.nodes.size() > b.nodes.size(); });
+            std::atomic<size_t> next(0);
+            std::vector<std::thread> th;
+            for (int w = 0; w < T; ++w) th.emplace_back([&] {
+                NestedDissection local(CG, opt.nd_leaf);
+                vector<NestedDissection::Task> mine;
+                for (;;) { size_t q = next.fetch_add(1); if (q >= st.size()) break; mine.clear(); mine.push_back(std::move(st[q])); local.drain(mine, corder); }
+            });
+            for (auto& x : th) x.join();
+        }
+    }
     // expand: within a pair the non-zero-diagonal member (the "variable") comes first, the
     // zero-diagonal row (the "constraint") second.
     vector<int> perm; perm.reserve(n);
@@ -451,25 +508,36 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     auto build_permuted_csc = [&]()
     {
         const int nnzA = (int)P.row.size();
+        const int T = analysis_threads();
         vector<int> pc(nnzA), pr(nnzA);
+        parallel_chunks(n, T, [&](long long jb, long long je, int) {
+            for (int j = (int)jb; j < (int)je; ++j)
+                for (int p = P.colptr[j]; p < P.colptr[j + 1]; ++p) {
+                    const int a = iperm[P.row[p]], b = iperm[j];
+                    pc[p] = std::min(a, b); pr[p] = std::max(a, b);
+                }
+        });
         vector<int> cnt(n + 1, 0);
-        for (int j = 0; j < n; ++j)
-            for (int p = P.colptr[j]; p < P.colptr[j + 1]; ++p) {
-                int a = iperm[P.row[p]], b = iperm[j];
-                pc[p] = std::min(a, b); pr[p] = std::max(a, b); cnt[pc[p] + 1]++;
-            }
+        for (int p = 0; p < nnzA; ++p) cnt[pc[p] + 1]++;
         for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
         S.acolptr = cnt;
-        // sort by row within column: bucket by row first (stable), then by column
-        vector<int> byrow(nnzA);
-        { vector<int> rc(n + 1, 0); for (int p = 0; p < nnzA; ++p) rc[pr[p] + 1]++; for (int i = 0; i < n; ++i) rc[i + 1] += rc[i];
-          for (int p = 0; p < nnzA; ++p) byrow[rc[pr[p]]++] = p; }
+        // place every entry into its (new) column, then sort the rows of each column -- columns are independent
+        vector<int> src(nnzA);
+        { vector<int> pos(cnt.begin(), cnt.end() - 1); for (int p = 0; p < nnzA; ++p) src[pos[pc[p]]++] = p; }
         vector<int> old2new(nnzA); S.arow.resize(nnzA); S.acol.resize(nnzA);
-        { vector<int> pos(cnt.begin(), cnt.end() - 1);
-          for (int q = 0; q < nnzA; ++q) { int p = byrow[q]; int dst = pos[pc[p]]++; old2new[p] = dst; S.arow[dst] = pr[p]; S.acol[dst] = pc[p]; } }
+        parallel_chunks(n, T, [&](long long jb, long long je, int) {
+            vector<std::pair<int,int>> tmp;
+            for (int j = (int)jb; j < (int)je; ++j) {
+                const int q0 = cnt[j], q1 = cnt[j + 1];
+                tmp.clear();
+                for (int q = q0; q < q1; ++q) tmp.emplace_back(pr[src[q]], src[q]);
+                if (q1 - q0 > 1) std::sort(tmp.begin(), tmp.end());
+                for (int q = q0; q < q1; ++q) { S.arow[q] = tmp[q - q0].first; S.acol[q] = j; old2new[tmp[q - q0].second] = q; }
+            }
+        });
         S.nnz_a = nnzA;
         S.trip2slot.resize(nnz);
-        for (int t = 0; t < nnz; ++t) S.trip2slot[t] = old2new[P.t2slot[t]];
+        parallel_chunks(nnz, T, [&](long long tb, long long te, int) { for (long long t = tb; t < te; ++t) S.trip2slot[t] = old2new[P.t2slot[t]]; });
         S.dup_ptr.assign(nnzA + 1, 0);
         for (int t = 0; t < nnz; ++t) S.dup_ptr[S.trip2slot[t] + 1]++;
         for (int q = 0; q < nnzA; ++q) S.dup_ptr[q + 1] += S.dup_ptr[q];

@@ -172,3 +172,16 @@ def test_full_size_properties_config_sized():
     assert np.abs(x12 - (x1 + 2.0 * x2)).max() <= 1e-9 * np.abs(x12).max()
     x1b = b1.copy(); s.multi_solve(True, x1b)
     assert np.array_equal(x1, x1b)
+
+
+def test_internal_refinement_improves_an_ill_conditioned_solve():
+    """refine_steps > 0: fp64 residual + correction solves on the device (the option Ipopt does not need -- it runs its own
+    loop -- but a stand-alone caller of the C ABI does)."""
+    n, r, c, v, neg = kktgen.grid_kkt(40, 40, dof=2, ncon=2, seed=17, sigma_exp=8.0)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    _, st0, x0 = gpu_factor_solve(n, r, c, v, b)
+    _, st2, x2 = gpu_factor_solve(n, r, c, v, b, refine_steps=2)
+    assert st0 == 0 and st2 == 0
+    e0, e2 = np.abs(x0 - 1).max(), np.abs(x2 - 1).max()
+    assert sres(K, x2, b) <= RES_TOL and e2 <= max(e0, 1e-12)
