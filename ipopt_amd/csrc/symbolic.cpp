@@ -831,12 +831,14 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         double total = 0;
         for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] < 0) { front.insert({work[s], s}); total += work[s]; }
         const double target = total / opt.nranks;
+        auto total_sub = [](const std::set<std::pair<double,int>, std::greater<std::pair<double,int>>>& f) { double t = 0; for (auto& e : f) t += e.first; return t; };
         int guard = 0;
         while (!front.empty() && guard++ < nsn) {
             auto top = *front.begin();
             // split the heaviest frontier subtree until there are >= 2 pieces per rank and none is heavier than 60% of a
             // rank's share: deeper cuts only move work into the REPLICATED top, which every rank repeats (Amdahl)
-            bool enough = (int)front.size() >= 2 * opt.nranks && top.first <= 0.6 * target;
+            bool enough = ((int)front.size() >= 2 * opt.nranks && top.first <= 0.6 * target) ||
+                          ((int)front.size() >= opt.nranks && top.first <= 1.15 * (total_sub(front) / opt.nranks));
             if (enough) break;
             int s = top.second;
             if (S.child_ptr[s + 1] == S.child_ptr[s]) {   // leaf: cannot split; stop if it is the biggest
