@@ -74,7 +74,8 @@ typedef struct mi355x_kkt_options {
                             /* (default 0 = off; measured: not a win)                                               */
     int    tree_merge;      /* tree amalgamation of small non-contiguous supernodes: 1 on, 0 off,        */
                             /* -1 = on when n <= 400 000.  Default 0: measured NOT to pay    */
-    int    reserved[6];
+    int    wide_panels;     /* 1: 128-column panels on separator fronts of order >= 512 (default 0)      */
+    int    reserved[5];
 } mi355x_kkt_options;
 
 typedef struct mi355x_kkt_info {

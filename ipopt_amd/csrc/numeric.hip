@@ -244,7 +244,7 @@ __device__ __forceinline__ double fast_rcp(double d)
     return r;
 }
 
-template <int NT, int TS>
+template <int NT, int TS, bool WIDE>
 __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const int k, double* Lbuf, const int ldL, double* colbuf,
                                          double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double small,
                                          int& nneg, int& nzero, int& ntwo, int& nsmall)
@@ -262,34 +262,43 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 #pragma unroll
     for (int x = 0; x < TS; ++x) if (row0 + x < m) rowvalid |= 1u << x;
     const unsigned long long lanebit = 1ull << lane;
-    unsigned long long alive = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);     // fully-summed rows not yet eliminated (k <= 64)
+    // fully-summed rows not yet eliminated: rows 0..63 in alive, rows 64..127 in alive1 (WIDE: pivot blocks of <= 128 columns)
+    unsigned long long alive = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
+    unsigned long long alive1 = (WIDE && k > 64) ? ((k >= 128) ? ~0ull : ((1ull << (k - 64)) - 1ull)) : 0ull;
+    auto clear_row = [&](int r) { if (!WIDE || r < 64) alive &= ~(1ull << r); else alive1 &= ~(1ull << (r - 64)); };
     unsigned long long bigmask = 0ull;
     int step = 0, bufsel = 0;
-    while (alive != 0ull) {
+    while ((alive | alive1) != 0ull) {
         double* colA = colbuf + bufsel * 2 * MAXM; bufsel ^= 1;
         double* colB = colA + MAXM;
-        const int j = __builtin_amdgcn_readfirstlane(__ffsll((long long)alive) - 1);
+        const int j = __builtin_amdgcn_readfirstlane(alive != 0ull ? __ffsll((long long)alive) - 1 : 64 + __ffsll((long long)alive1) - 1);
         if (tj == j / TS) publish_col<TS>(colA, t, row0, j % TS);
         __syncthreads();
         // every LDS read of the common case (1x1 pivot on row j) is issued here, in ONE round trip
         const double djj = colA[j];
         const double avr = colA[lane];
+        const double avr1 = WIDE ? colA[(lane + 64) & (MAXM - 1)] : 0.0;
         double rv[TS], cv[TS];
 #pragma unroll
         for (int x = 0; x < TS; ++x) { rv[x] = colA[row0 + x]; cv[x] = colA[col0 + x]; }
         const double ajj = fabs(djj);
         const bool cand = (alive & lanebit) != 0ull && lane != j;
-        const double av = cand ? fabs(avr) : -1.0;
+        const bool cand1 = WIDE && (alive1 & lanebit) != 0ull && lane + 64 != j;
+        const double av0 = cand ? fabs(avr) : -1.0, av1 = cand1 ? fabs(avr1) : -1.0;
+        const double av = fmax(av0, av1);
+        const int bi = (av1 > av0) ? lane + 64 : lane;       // this lane's best candidate row
         int p = j, q = -1;                 // 1x1 pivot p, or 2x2 pivot (p, q)
         double dpiv = djj;
         if (__ballot(av * BK_ALPHA > ajj) != 0ull) {          // some |a_ij| > |a_jj| / alpha: run the full Bunch-Kaufman test
             const double lam = wave_max_all(av);
             const unsigned long long hit = __ballot(av == lam);
-            const int r = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+            const int r = __builtin_amdgcn_readlane(bi, src);
             if (tj == r / TS) publish_col<TS>(colB, t, row0, r % TS);
             __syncthreads();
             const bool cs = (alive & lanebit) != 0ull && lane != r;
-            const double sig = wave_max_all(cs ? fabs(colB[lane]) : 0.0);
+            const bool cs1 = WIDE && (alive1 & lanebit) != 0ull && lane + 64 != r;
+            const double sig = wave_max_all(fmax(cs ? fabs(colB[lane]) : 0.0, cs1 ? fabs(colB[(lane + 64) & (MAXM - 1)]) : 0.0));
             const double arr = fabs(colB[r]);
             if (ajj * sig >= BK_ALPHA * lam * lam) { /* 1x1 at j */ }
             else if (arr >= BK_ALPHA * sig) {
@@ -305,7 +314,6 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             if (fabs(det) <= small) q = -1;            // degenerate block: (perturbed) 1x1 at j instead
             else {
                 const double idet = fast_rcp(det);
-                const unsigned long long keep = alive & ~(1ull << p) & ~(1ull << q);
                 double l0[TS], l1[TS], w0[TS], w1[TS];
 #pragma unroll
                 for (int x = 0; x < TS; ++x) {
@@ -329,7 +337,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                     dinv_s[step] = c * idet; dinv_s[step + 1] = a * idet; doff_s[step] = -b * idet; doff_s[step + 1] = 0.0;
                 }
                 if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
-                ntwo++; alive = keep; step += 2;
+                ntwo++; clear_row(p); clear_row(q); step += 2;
                 continue;
             }
         }
@@ -337,7 +345,6 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             double d = dpiv;
             if (fabs(d) <= small) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
             const double di = fast_rcp(d);
-            const unsigned long long keep = alive & ~(1ull << p);
             // No masking of dead rows / columns: the rank-1 update itself annihilates row and column p (l_p = 1 up to
             // rounding), padding rows are exact zeros, and whatever residue is left in dead positions is never read
             // (alive mask in the search, (i > c) filter at write-back).  That removes ~50 instructions per pivot.
@@ -358,7 +365,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             }
             if (tid == 0) { ord[step] = p; pt_s[step] = 1; dinv_s[step] = di; doff_s[step] = 0.0; }
             if (d < 0.0) nneg++;
-            alive = keep; step += 1;
+            clear_row(p); step += 1;
         }
     }
     bigmask = wave_or_all(bigmask);
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     // ---- (d) LDL^T ----
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
     DBGSTAMP(5);
-    ldlt_reg<NT, TS>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
     __syncthreads();
     DBGSTAMP(6);
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[14] = (unsigned long long)k * 1000 + m;
@@ -469,18 +476,18 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ldi] : (i == c ? 1.0 : 0.0); }
 }
 
-// pivot block (k <= 64 columns) of a BIG front on the register-tiled core
+// pivot block of a BIG front on the register-tiled core: TS = 4 for k <= 64, TS = 8 (two-word alive mask) for k <= 128
+template <int TS>
 __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int TS = 4, G = 16, MAXM = 64;
+    constexpr int G = 16, MAXM = G * TS;
     const int tid = threadIdx.x;
     const FrontMeta M = V.fmeta[list_off + blockIdx.x];
-    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k; (void)m;
+    const int s = M.s, c0 = M.c0, k = M.k;
     const int ld = k | 1;
-    double* Lb     = reinterpret_cast<double*>(smem_raw);   // k x k L columns (physical rows)
-    double* Li     = Lb + (size_t)ld * k;                    // k x k pivot-ordered copy / inverse
-    double* colbuf = Li + (size_t)ld * k;
+    double* Lb     = reinterpret_cast<double*>(smem_raw);   // k x k L columns (physical rows); later the pivot-ordered block / its inverse
+    double* colbuf = Lb + (size_t)ld * k;
     double* dinv_s = colbuf + 4 * MAXM; double* doff_s = dinv_s + k;
     int* ord = reinterpret_cast<int*>(doff_s + k); int* pt_s = ord + k;
     double* P = V.L + M.panel_off;
@@ -496,22 +503,22 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
         }
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
     DBGSTAMP(0);
-    ldlt_reg<256, TS>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    ldlt_reg<256, TS, (TS == 8)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
     __syncthreads();
     DBGSTAMP(1);
-    for (int idx = tid; idx < k * k; idx += 256) {
-        const int i = idx % k, c = idx / k;
-        const double v = (i > c) ? Lb[ord[i] + c * ld] : 0.0;
-        P[i + (size_t)c * ldp] = v; Li[i + c * ld] = v;
-    }
+    // pivot-ordered unit-lower block -> panel (global), then back into the same LDS block for the inversion: the global
+    // round trip (L2 hits, same workgroup) avoids a second k x k LDS buffer, which does not fit at k = 128
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; P[i + (size_t)c * ldp] = (i > c) ? Lb[ord[i] + c * ld] : 0.0; }
+    __syncthreads();
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Lb[i + c * ld] = P[i + (size_t)c * ldp]; }
     for (int j = tid; j < k; j += 256) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
     __syncthreads();
     DBGSTAMP(2);
-    invert_unit_lower<256>(Li, ld, k);
+    invert_unit_lower<256>(Lb, ld, k);
     DBGSTAMP(3);
     double* Mg = V.minv + M.minv_off;
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ld] : (i == c ? 1.0 : 0.0); }
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Lb[i + c * ld] : (i == c ? 1.0 : 0.0); }
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[15] = (unsigned long long)k;
 }
 
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
 // big fronts, forward part 2: c(i) -= sum_j L21(i,j) y_j, one thread per update row, 256 rows per workgroup
 __global__ __launch_bounds__(256) void k_fwd_big_upd(DevView V, int list_off)
 {
-    __shared__ double ys[72];
+    __shared__ double ys[136];
     const int tid = threadIdx.x;
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
@@ -781,27 +788,28 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
     }
 }
 
-// rows below the pivot block:  W21 = (A21 P) L11^{-T}  as a GEMM with the stored inverse (fp64 MFMA, no
-// substitution chain), then L21 = W21 D^{-1}.  64 rows per workgroup, 16 rows per wavefront; the product is formed
-// transposed (A operand = rows of L11^{-1}, B operand = rows of A21 P) so that lanes hold consecutive rows.
+// rows below the pivot block:  W21 = (A21 P) L11^{-T}  as a GEMM with the stored inverse (fp64 MFMA, no substitution chain),
+// then L21 = W21 D^{-1}.  64 rows per workgroup, 16 rows per wavefront; A21 P is staged in LDS, the rows of L11^{-1} needed
+// by a 16-column tile are pulled straight into registers (<= 32 values per lane, L2 resident); the product is formed
+// transposed (A operand = rows of L11^{-1}, B operand = rows of A21 P) so that lanes hold consecutive rows.  k <= 128.
 __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
-    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
+    const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
     const int ibase = k + blockIdx.x * 64;
     if (ibase >= m) return;
     const int kp = (k + 3) & ~3;                              // K padded to the MFMA depth
-    const int ldm = k | 1;
-    double* Ms = reinterpret_cast<double*>(smem_raw);         // k x kp : Ms[j + p*ldm] = Minv(j,p)
-    double* As = Ms + (size_t)ldm * kp;                       // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
+    double* As = reinterpret_cast<double*>(smem_raw);         // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
     double* Ws = As + (size_t)65 * kp;                        // 64 x k : Ws[r + j*65]
+    double* Ds = Ws + (size_t)65 * k;                         // dinv[k], doff[k]
+    int*    Ts = reinterpret_cast<int*>(Ds + 2 * k);          // ptype[k]
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
     double* W = V.wbuf + V.wb_off[s];
     const double* Mg = V.minv + M.minv_off;
-    for (int idx = tid; idx < k * kp; idx += 256) { const int j = idx % k, p = idx / k; Ms[j + p * ldm] = (p < k) ? Mg[j + (size_t)p * k] : 0.0; }
+    for (int j = tid; j < k; j += 256) { Ds[j] = V.dinv[c0 + j]; Ds[k + j] = V.doff[c0 + j]; Ts[j] = V.ptype[c0 + j]; }
     for (int idx = tid; idx < 64 * kp; idx += 256) {
         const int r = idx & 63, p = idx >> 6;
         As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)V.lperm[c0 + p] * ldp] : 0.0;
@@ -810,14 +818,14 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     const int l15 = lane & 15, l4 = lane >> 4;
     const int r16 = wave * 16;
     for (int c16 = 0; c16 < k; c16 += 16) {
-        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
         const int col = c16 + l15;
-        const int pend = min(kp, (c16 + 16 + 3) & ~3);        // Minv(col,p) = 0 for p > col
-        for (int p = 0; p < pend; p += 4) {
-            const double a = (col < k) ? Ms[col + (p + l4) * ldm] : 0.0;
-            const double b = As[r16 + l15 + (p + l4) * 65];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-        }
+        const int pend = min(kp, c16 + 16);                   // Minv(col,p) = 0 for p > col
+        double mreg[32];                                      // Minv(col, p + l4), p = 0, 4, ..., pend-4
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int p = 4 * u + l4; mreg[u] = (4 * u < pend && col < k && p < k) ? Mg[col + (size_t)p * k] : 0.0; }
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 32; ++u) if (4 * u < pend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[u], As[r16 + l15 + (4 * u + l4) * 65], acc, 0, 0, 0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) { const int cc = c16 + l4 + 4 * g; if (cc < k) Ws[r16 + l15 + cc * 65] = acc[g]; }
     }
@@ -826,12 +834,12 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     for (int idx = tid; idx < 64 * k; idx += 256) {
         const int r = idx & 63, j = idx >> 6;
         const int i = ibase + r;
-        const int pt = V.ptype[c0 + j];
+        const int pt = Ts[j];
         const double wj = Ws[r + j * 65];
         double l;
-        if (pt == 1) l = wj * V.dinv[c0 + j];
-        else if (pt == 2) l = V.dinv[c0 + j] * wj + V.doff[c0 + j] * Ws[r + (j + 1) * 65];
-        else l = V.doff[c0 + j - 1] * Ws[r + (j - 1) * 65] + V.dinv[c0 + j] * wj;
+        if (pt == 1) l = wj * Ds[j];
+        else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * Ws[r + (j + 1) * 65];
+        else l = Ds[k + j - 1] * Ws[r + (j - 1) * 65] + Ds[j] * wj;
         if (i < m) { W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l; lmax = fmax(lmax, fabs(l)); }
     }
 #pragma unroll
@@ -1123,7 +1131,8 @@ public:
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
         V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
-        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1167,8 +1176,9 @@ public:
         } else {
             const int nt = (mm - 1 + 63) / 64;
             LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
-            LAUNCH(KK_BIG_DIAG, k_big_diag_reg, dim3(nb), dim3(256), (size_t)(2 * (kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-            LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(((kk | 1) + 65) * ((kk + 3) & ~3) + 65 * kk) * sizeof(double) + 16, stream, V, b0);
+            if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+            else          LAUNCH(KK_BIG_DIAG, k_big_diag_reg<8>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+            LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
             LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, nb), dim3(256), 0, stream, V, b0);
         }
         return true;

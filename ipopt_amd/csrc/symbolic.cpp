@@ -573,6 +573,9 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     lap("column counts");
     // ---- 8. supernodes: fundamental + forced pairs, then relaxed amalgamation of chains ----
     const int maxcols = std::max(2, opt.max_sn_cols);
+    // fronts of order >= wide_from (the separator chains of the blocked path) get panels of 2*maxcols columns: half as many
+    // tree levels and twice the arithmetic intensity of the Schur update (the pivot-block kernels handle <= 128 columns)
+    const int wide_from = opt.wide_panels > 0 ? 512 : (1 << 30);     // default off: measured slower (pivot block of 128 costs more than it saves)
     // (a) whole small subtrees become one dense supernode: in the latency-bound regime (fronts of a few rows) dense
     //     arithmetic on <= leaf_cols columns is free, while every tree level costs a kernel launch and a dependent
     //     HBM round trip.  A subtree is a contiguous column range in the postorder.
@@ -599,7 +602,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             else if (!forced_start[j] && j > 0 && parent[j - 1] == j) {
                 bool pair = (S.pair_of[perm[j]] == perm[j - 1]);
                 if (pair) join = true;
-                else if (cc[j - 1] == cc[j] + 1 && len < maxcols - 1) join = true;   // -1: a forced pair may still add one column
+                else if (cc[j - 1] == cc[j] + 1 && len < (cc[j] >= wide_from ? 2 * maxcols : maxcols) - 1) join = true;   // -1: a forced pair may still add one column
             }
             if (!join) { fstart.push_back(j); len = 1; } else ++len;
         }
@@ -620,7 +623,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
                 int pcol = parent[lastc];
                 if (pcol < cur.c0 || pcol >= cur.c0 + cur.k) break;          // not a child of cur
                 int knew = ch.k + cur.k;
-                if (knew > maxcols) break;
+                if (knew > (cur.m >= wide_from ? 2 * maxcols : maxcols)) break;
                 int mnew = ch.k + cur.m;
                 double znew = ch.z + cur.z + (double)ch.k * (double)(ch.k + cur.m - ch.m);
                 double total = (double)knew * mnew - 0.5 * knew * (knew - 1);

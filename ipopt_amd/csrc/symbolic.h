@@ -24,6 +24,7 @@ struct SymbolicOptions {
     int    max_sn_cols = 64;
     int    leaf_cols   = 0;    // whole elimination subtrees with at most this many columns become ONE supernode
     int    tree_merge  = 0;    // merge small non-contiguous child supernodes into the parent: 1 on, 0 off (default), -1 auto (n <= 4e5)
+    int    wide_panels = 0;    // 1: separator fronts of order >= 512 get 128-column panels (kernels support it; default off)
     int    nranks      = 1;
     int    verbose     = 0;
 };

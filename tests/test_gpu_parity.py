@@ -185,3 +185,15 @@ def test_internal_refinement_improves_an_ill_conditioned_solve():
     assert st0 == 0 and st2 == 0
     e0, e2 = np.abs(x0 - 1).max(), np.abs(x2 - 1).max()
     assert sres(K, x2, b) <= RES_TOL and e2 <= max(e0, 1e-12)
+
+
+@pytest.mark.parametrize("opts", [dict(wide_panels=1), dict(tree_merge=1), dict(leaf_cols=32), dict(ordering=1), dict(scaling=0), dict(use_graph=0)],
+                         ids=["wide_panels", "tree_merge", "leaf_cols", "md_ordering", "no_scaling", "no_graph"])
+def test_optional_code_paths_stay_exact(opts):
+    """every non-default analysis / kernel option must give the same inertia and a converged solve"""
+    n, r, c, v, neg = kktgen.grid_kkt(48, 44, dof=3, ncon=2, seed=23)      # separator fronts > 512 rows: 128-column panels kick in
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg, **opts)
+    assert st == 0 and s.number_of_neg_evals() == neg
+    assert sres(K, x, b) <= RES_TOL
