@@ -75,7 +75,9 @@ typedef struct mi355x_kkt_options {
     int    tree_merge;      /* tree amalgamation of small non-contiguous supernodes: 1 on, 0 off,        */
                             /* -1 = on when n <= 400 000.  Default 0: measured NOT to pay    */
     int    wide_panels;     /* 1: 128-column panels on separator fronts of order >= 512 (default 0)      */
-    int    reserved[5];
+    int    chain_group;     /* links of an in-place separator chain per update/solve unit, 1..4 (default 4) */
+    int    solve_group;     /* 1: triangular solves per chain group instead of per link (default 0)       */
+    int    reserved[3];
 } mi355x_kkt_options;
 
 typedef struct mi355x_kkt_info {
@@ -174,7 +176,9 @@ int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t ca
 #define MI355X_KKT_KERNEL_BWD_WAVE     13
 #define MI355X_KKT_KERNEL_BWD_LDS      14
 #define MI355X_KKT_KERNEL_BWD_BIG      15
-#define MI355X_KKT_KERNEL_COUNT        16
+#define MI355X_KKT_KERNEL_FWD_BIG_UPD 16   /* chain groups: update of the entries beyond the group (many workgroups) */
+#define MI355X_KKT_KERNEL_BWD_BIG_DOT 17   /* chain groups: partial L21^T x of the rows beyond the group             */
+#define MI355X_KKT_KERNEL_COUNT        18
 int  mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches, int capacity);
 
 /* ---- multi-GPU (one process per GPU; subtrees sharded, top of the tree replicated) ---- */

@@ -37,7 +37,7 @@ public:
     double last_factor_ms() const;
     double last_solve_ms() const;
     const std::string& error() const;
-    static constexpr int kNumKernelKinds = 16;
+    static constexpr int kNumKernelKinds = 18;
     bool   profile(int reps, double* ms, int* launches);
     bool   debug_clocks(unsigned long long* out16);        // development aid (MI355X_KKT_DEBUG_CLOCKS=1)   // per-kernel-kind device time (hip events), eager launches
     // multi-GPU pieces

@@ -38,7 +38,7 @@ namespace mi355x {
 
 // kernel kinds for the profiling entry point (order = include/mi355x_kkt.h MI355X_KKT_KERNEL_*)
 enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_LDS128, KK_BIG_ASSEMBLE, KK_BIG_DIAG, KK_BIG_TRSM,
-                  KK_BIG_SCHUR, KK_STATS, KK_SOLVE_PERM, KK_FWD_WAVE, KK_FWD_LDS, KK_FWD_BIG, KK_BWD_WAVE, KK_BWD_LDS, KK_BWD_BIG, KK_COUNT };
+                  KK_BIG_SCHUR, KK_STATS, KK_SOLVE_PERM, KK_FWD_WAVE, KK_FWD_LDS, KK_FWD_BIG, KK_BWD_WAVE, KK_BWD_LDS, KK_BWD_BIG, KK_FWD_BIG_UPD, KK_BWD_BIG_DOT, KK_COUNT };
 #define DBGSTAMP(slot) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { V.dbg[2 * (slot)] = clock64(); V.dbg[2 * (slot) + 1] = wall_clock64(); } } while (0)
 #define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); } while (0)
 
@@ -50,8 +50,11 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // ------------------------------------------------------------------------------------------------
 // per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
-struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt; };
-struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; };
+struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt;
+                   long long cv, wb, gpart; int gbase, gpos, grem, gcols; };
+struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase; };
+// one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
+struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
 
 struct DevView {
     // symbolic
@@ -60,9 +63,10 @@ struct DevView {
     const long long* panel_off; const long long* cb_off; const long long* wb_off; const long long* minv_off;
     const int* acolptr; const int* apos; const int* arow; const int* acol;
     const int* dup_ptr; const int* dup_src;
-    const int* rslot_ptr; const int* rslot_idx;
+    const int* rslot_ptr; const int* rslot_idx; const int* rslot_col; int rslot_len;
     const int* level_sn;
     const FrontMeta* fmeta;   // parallel to level_sn
+    const GroupLink* gtab;    // links of the chain groups (FrontMeta::gbase .. gbase + gpos)
     const ChildMeta* cmeta;   // parallel to child_idx
     const int* perm;
     // numeric
@@ -70,6 +74,7 @@ struct DevView {
     double* aval;           // summed + scaled values, permuted lower CSC order
     double* scale;          // symmetric scaling, permuted numbering
     double* scale2;         // second buffer (Jacobi-style equilibration sweeps)
+    double* arv;            // |values| in symmetric row-view order (equilibration sweeps stream it)
     unsigned long long* rowmax;  // scratch for equilibration (bit pattern of non-negative doubles)
     double* L;              // panels
     double* cb;             // contribution blocks
@@ -80,6 +85,7 @@ struct DevView {
     double* xw;             // work vector (permuted, scaled)
     double* cvec;           // forward-solve contributions, aligned with sn_rows
     double* bw; double* xacc;   // iterative refinement: scaled right-hand side and accumulated solution (permuted numbering)
+    double* gpart;          // partial sums of the backward dot products of the chain groups
     double* ybuf;           // y of the pivot rows (big fronts: the update rows are handled by a second, multi-workgroup launch)
     // multi-GPU top arena (full m x m squares per replicated front), null on 1 GPU
     double* arena; const long long* arena_off;
@@ -152,21 +158,25 @@ __global__ void k_zero_u64(unsigned long long* p, int n)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0ull;
 }
-// one Ruiz sweep as a gather: s_new(i) = s(i) / sqrt( max_j |a_ij| s(i) s(j) ), one thread per row walking the symmetric
-// row view of the pattern (no atomics, Jacobi style: reads the previous sweep's factors) => deterministic, 1 launch/sweep
+// Ruiz equilibration as gathers over the symmetric row view of the pattern (no atomics, Jacobi style => deterministic):
+//   k_abs_rowview   arv(p) = |a(slot(p))|, the one pass with scattered reads; every sweep then streams arv
+//   k_ruiz_sweep    s_new(i) = s(i) / sqrt( s(i) max_p arv(p) s(col(p)) ), 8 lanes per row, shuffle max; sin == null means 1
+__global__ void k_abs_rowview(DevView V)
+{
+    const int total = V.rslot_len;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) V.arv[p] = fabs(V.aval[V.rslot_idx[p]]);
+}
 __global__ void k_ruiz_sweep(DevView V, const double* sin, double* sout)
 {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) {
-        const double si = sin[i];
+    const int sub = threadIdx.x & 7;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < ((V.n + 7) & ~7) + 0; i += (gridDim.x * blockDim.x) >> 3) {
         double mx = 0.0;
-        for (int p = V.rslot_ptr[i]; p < V.rslot_ptr[i + 1]; ++p) {
-            const int q = V.rslot_idx[p];
-            const int r = V.arow[q], c = V.acol[q];
-            const double sj = sin[r == i ? c : r];
-            mx = fmax(mx, fabs(V.aval[q]) * sj);
+        if (i < V.n) {
+            const int p1 = V.rslot_ptr[i + 1];
+            for (int p = V.rslot_ptr[i] + sub; p < p1; p += 8) mx = fmax(mx, V.arv[p] * (sin ? sin[V.rslot_col[p]] : 1.0));
         }
-        mx *= si;
-        sout[i] = mx > 0.0 ? si / sqrt(mx) : si;
+        mx = fmax(mx, __shfl_xor(mx, 1)); mx = fmax(mx, __shfl_xor(mx, 2)); mx = fmax(mx, __shfl_xor(mx, 4));
+        if (i < V.n && sub == 0) { const double si = sin ? sin[i] : 1.0; mx *= si; sout[i] = mx > 0.0 ? si / sqrt(mx) : si; }
     }
 }
 __global__ void k_apply_scale(DevView V)
@@ -594,12 +604,12 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
     double* bp = ys + k;                                // k   pivot rows in pivot order
     double* xu = bp + k;                                // m-k update-row accumulators (LDS classes only)
     for (int i = tid; i < k; i += NT) xp[i] = V.xw[c0 + i];
-    if (BIG) { for (int i = k + tid; i < m; i += NT) V.cvec[r0 + i] = 0.0; }
+    if (BIG) { for (int i = k + tid; i < m; i += NT) V.cvec[M.cv + i] = 0.0; }
     else     { for (int i = k + tid; i < m; i += NT) xu[i - k] = 0.0; }
     if (top_mode && V.top_rhs) {
         const double* tr = V.top_rhs + V.top_rhs_off[s];
         __syncthreads();
-        for (int i = tid; i < m; i += NT) { if (i < k) xp[i] += tr[i]; else if (BIG) V.cvec[r0 + i] += tr[i]; else xu[i - k] += tr[i]; }
+        for (int i = tid; i < m; i += NT) { if (i < k) xp[i] += tr[i]; else if (BIG) V.cvec[M.cv + i] += tr[i]; else xu[i - k] += tr[i]; }
     }
     __syncthreads();
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
@@ -608,8 +618,8 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         if (top_mode && V.top_rhs && Cm.owner >= 0) continue;
         const int base = Cm.relbase, mc = Cm.mc;
         for (int t = tid; t < mc; t += NT) {
-            const int tg = V.rel[base + t]; const double v = V.cvec[base + t];
-            if (tg < k) xp[tg] += v; else if (BIG) V.cvec[r0 + tg] += v; else xu[tg - k] += v;
+            const int tg = V.rel[base + t]; const double v = V.cvec[Cm.cvbase + t];
+            if (tg < k) xp[tg] += v; else if (BIG) V.cvec[M.cv + tg] += v; else xu[tg - k] += v;
         }
         __syncthreads();
     }
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
             int j = 0;
             for (; j + 1 < k; j += 2) { t0 += Lg[i + (size_t)j * M.ldp] * ys[j]; t1 += Lg[i + (size_t)(j + 1) * M.ldp] * ys[j + 1]; }
             if (j < k) t0 += Lg[i + (size_t)j * M.ldp] * ys[j];
-            V.cvec[r0 + i] = xu[i - k] - (t0 + t1);
+            V.cvec[M.cv + i] = xu[i - k] - (t0 + t1);
         }
     }
     for (int j = tid; j < k; j += NT) {
@@ -688,6 +698,230 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
 }
 
 
+
+// ================================================================================================
+// BIG fronts in the triangular solves: a CHAIN GROUP (<= 4 links of an in-place separator chain, <= 256 columns) is one
+// unit, handled at its LAST link (FrontMeta::grem == 0; the other links return at once).  All links of a chain share one
+// forward vector (cvec + cv): the update entries of a link ARE the entries of the next link, nothing is copied.
+//   k_fwd_grp      one workgroup: children gathered into the chain vector; per link  y = L11^{-1} P b, z = D^{-1} y, and
+//                  the entries of the group's later pivots updated (<= 192 rows)
+//   k_fwd_grp_upd  256 rows per workgroup: entries beyond the group  -=  sum over links  L21 y   (<= 256 columns in one pass)
+//   k_bwd_grp_dot  256 rows per workgroup: partial  L21^T x  of the rows beyond the group, for all the group's columns
+//   k_bwd_grp      one workgroup: per link (last to first)  x = P^T L11^{-T} ( z - partials - L(group rows)^T x )
+// ================================================================================================
+__global__ __launch_bounds__(256) void k_fwd_grp(DevView V, int list_off, int top_mode)
+{
+    __shared__ double bp[128], ys[128];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    if (M.grem != 0) return;
+    const int tid = threadIdx.x;
+    const int nl = M.gpos + 1;
+    for (int j = 0; j < nl; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        double* cv = V.cvec + G.cv;
+        if (!G.alias) { for (int i = tid; i < G.m; i += 256) cv[i] = 0.0; __syncthreads(); }
+        if (top_mode && V.top_rhs && G.tr >= 0) {
+            const double* tr = V.top_rhs + G.tr;
+            for (int i = tid; i < G.m; i += 256) cv[i] += tr[i];
+            __syncthreads();
+        }
+        for (int cp = G.ch0; cp < G.ch1; ++cp) {
+            const ChildMeta Cm = V.cmeta[cp];
+            if (Cm.aliased) continue;
+            if (top_mode && V.top_rhs && Cm.owner >= 0) continue;
+            const int base = Cm.relbase, mc = Cm.mc;
+            for (int t = tid; t < mc; t += 256) cv[V.rel[base + t]] += V.cvec[Cm.cvbase + t];
+            __syncthreads();
+        }
+    }
+    int done = 0;
+    for (int j = 0; j < nl; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        double* cv = V.cvec + G.cv;
+        const int k = G.k, c0 = G.c0;
+        done += k;
+        const int rem = M.gcols - done;
+        for (int p = tid; p < k; p += 256) { const int lp = V.lperm[c0 + p]; bp[p] = V.xw[c0 + lp] + cv[lp]; }
+        __syncthreads();
+        const double* Mg = V.minv + G.minv_off;
+        {   // y = Minv (P b): 4 threads per row (columns p = part, part + 4, ...), combined through LDS
+            const int q = tid >> 2, part = tid & 3;
+            double a = 0.0;
+            for (int q2 = q; q2 < k; q2 += 64) {
+                a = 0.0;
+                int p = part;
+                for (; p + 12 <= q2; p += 16) {
+                    const double m0 = Mg[q2 + (size_t)p * k], m1 = Mg[q2 + (size_t)(p + 4) * k], m2 = Mg[q2 + (size_t)(p + 8) * k], m3 = Mg[q2 + (size_t)(p + 12) * k];
+                    a += m0 * bp[p] + m1 * bp[p + 4] + m2 * bp[p + 8] + m3 * bp[p + 12];
+                }
+                for (; p <= q2; p += 4) a += Mg[q2 + (size_t)p * k] * bp[p];
+                a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+                if (part == 0) ys[q2] = a;
+            }
+        }
+        __syncthreads();
+        for (int q = tid; q < k; q += 256) {
+            const int pt = V.ptype[c0 + q];
+            double z;
+            if (pt == 1) z = ys[q] * V.dinv[c0 + q];
+            else if (pt == 2) z = V.dinv[c0 + q] * ys[q] + V.doff[c0 + q] * ys[q + 1];
+            else z = V.doff[c0 + q - 1] * ys[q - 1] + V.dinv[c0 + q] * ys[q];
+            V.xw[c0 + q] = z;
+            V.ybuf[c0 + q] = ys[q];
+        }
+        const double* Lg = V.L + G.panel_off;
+        for (int i = k + tid; i < k + rem; i += 256) {
+            double t0 = 0.0, t1 = 0.0;
+            int p = 0;
+            for (; p + 7 < k; p += 8) {                      // 8 independent loads in flight per thread
+                double l[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) l[u] = Lg[i + (size_t)(p + u) * G.ldp];
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) { t0 += l[u] * ys[p + u]; t1 += l[u + 1] * ys[p + u + 1]; }
+            }
+            for (; p < k; ++p) t0 += Lg[i + (size_t)p * G.ldp] * ys[p];
+            cv[i] -= t0 + t1;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fwd_grp_upd(DevView V, int list_off)
+{
+    // 64 rows per workgroup (one per lane); the group's columns are dealt to the 4 wavefronts in blocks of 8 (8 coalesced
+    // loads in flight per lane), the 4 partial sums are combined through LDS in fixed order
+    __shared__ double ys[256];
+    __shared__ double red[4][64];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    if (M.grem != 0) return;
+    if (M.k + blockIdx.x * 64 >= M.m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nl = M.gpos + 1;
+    int cb = 0;
+    for (int j = 0; j < nl; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        for (int p = tid; p < G.k; p += 256) ys[cb + p] = V.ybuf[G.c0 + p];
+        cb += G.k;
+    }
+    __syncthreads();
+    const int i = M.k + blockIdx.x * 64 + lane;
+    const bool ok = i < M.m;
+    double t0 = 0.0, t1 = 0.0;
+    cb = 0;
+    for (int j = 0; j < nl; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        const double* Lg = V.L + G.panel_off + (G.m - M.m) + (ok ? i : M.k);
+        const double* y = ys + cb;
+        const int k = G.k;
+        for (int p = wave * 8; p < k; p += 32) {
+            double l[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) l[u] = (p + u < k) ? Lg[(size_t)(p + u) * G.ldp] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) { t0 += l[u] * ((p + u < k) ? y[p + u] : 0.0); t1 += l[u + 1] * ((p + u + 1 < k) ? y[p + u + 1] : 0.0); }
+        }
+        cb += k;
+    }
+    red[wave][lane] = t0 + t1;
+    __syncthreads();
+    if (wave == 0 && ok) V.cvec[M.cv + i] -= (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+__global__ __launch_bounds__(256) void k_bwd_grp_dot(DevView V, int list_off)
+{
+    // 256 rows per workgroup (4 per lane); column blocks of 4 are dealt to the wavefronts: 16 loads in flight per lane
+    __shared__ double xs[256];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    if (M.grem != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ibase = M.k + blockIdx.x * 256;
+    if (ibase >= M.m) return;
+    const int nrow = min(256, M.m - ibase);
+    xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[M.r0 + ibase + tid]] : 0.0;
+    __syncthreads();
+    double* part = V.gpart + M.gpart + (size_t)blockIdx.x * M.gcols;
+    const int nl = M.gpos + 1;
+    const double x0 = xs[lane], x1 = xs[lane + 64], x2 = xs[lane + 128], x3 = xs[lane + 192];
+    const bool v0 = lane < nrow, v1 = lane + 64 < nrow, v2 = lane + 128 < nrow, v3 = lane + 192 < nrow;
+    int cb = 0;
+    for (int j = 0; j < nl; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        const double* Lg = V.L + G.panel_off + (G.m - M.m) + ibase + lane;
+        const int k = G.k;
+        for (int pb = wave * 4; pb < k; pb += 16) {
+            double t[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool cv = pb + u < k;
+                const double* c = Lg + (size_t)(pb + u) * G.ldp;
+                const double a0 = (cv && v0) ? c[0] : 0.0, a1 = (cv && v1) ? c[64] : 0.0, a2 = (cv && v2) ? c[128] : 0.0, a3 = (cv && v3) ? c[192] : 0.0;
+                t[u] = (a0 * x0 + a1 * x1) + (a2 * x2 + a3 * x3);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { t[u] = wave_sum(t[u]); if (lane == 0 && pb + u < k) part[cb + pb + u] = t[u]; }
+        }
+        cb += k;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bwd_grp(DevView V, int list_off)
+{
+    __shared__ double ws[128], xs[256];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    if (M.grem != 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nch = (M.m - M.k + 255) / 256;
+    const double* part = V.gpart + M.gpart;
+    int cb = M.gcols;
+    for (int j = M.gpos; j >= 0; --j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        const int k = G.k, c0 = G.c0;
+        cb -= k;                                           // first group column of this link
+        const int rem = M.gcols - cb - k;                  // pivots of the later links = this link's first update rows
+        for (int p = tid; p < k; p += 256) {
+            double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+            int c = 0;
+            for (; c + 3 < nch; c += 4) { t0 += part[(size_t)c * M.gcols + cb + p]; t1 += part[(size_t)(c + 1) * M.gcols + cb + p];
+                                          t2 += part[(size_t)(c + 2) * M.gcols + cb + p]; t3 += part[(size_t)(c + 3) * M.gcols + cb + p]; }
+            for (; c < nch; ++c) t0 += part[(size_t)c * M.gcols + cb + p];
+            ws[p] = V.xw[c0 + p] - ((t0 + t1) + (t2 + t3));
+        }
+        for (int i = tid; i < rem; i += 256) xs[i] = V.xw[V.sn_rows[G.r0 + k + i]];
+        __syncthreads();
+        if (rem > 0) {
+            const double* Lg = V.L + G.panel_off + k;
+            for (int pb = wave * 4; pb < k; pb += 16) {           // 4 columns per pass: their loads are all in flight together
+                double t[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int i = lane; i < rem; i += 64) {
+                    const double x = xs[i];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (pb + u < k) t[u] += Lg[i + (size_t)(pb + u) * G.ldp] * x;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { t[u] = wave_sum(t[u]); if (lane == 0 && pb + u < k) ws[pb + u] -= t[u]; }
+            }
+            __syncthreads();
+        }
+        const double* Mg = V.minv + G.minv_off;
+        {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column (contiguous quarter-interleaved walk), combined by shuffles
+            const int part = tid & 3;
+            for (int p = tid >> 2; p < k; p += 64) {
+                double a = 0.0;
+                int q = p + part;
+                for (; q + 12 < k; q += 16) {
+                    const double m0 = Mg[q + (size_t)p * k], m1 = Mg[q + 4 + (size_t)p * k], m2 = Mg[q + 8 + (size_t)p * k], m3 = Mg[q + 12 + (size_t)p * k];
+                    a += m0 * ws[q] + m1 * ws[q + 4] + m2 * ws[q + 8] + m3 * ws[q + 12];
+                }
+                for (; q < k; q += 4) a += Mg[q + (size_t)p * k] * ws[q];
+                a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+                if (part == 0) V.xw[c0 + V.lperm[c0 + p]] = a;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // big fronts, forward part 2: c(i) -= sum_j L21(i,j) y_j, one thread per update row, 256 rows per workgroup
 __global__ __launch_bounds__(256) void k_fwd_big_upd(DevView V, int list_off)
 {
@@ -708,7 +942,7 @@ __global__ __launch_bounds__(256) void k_fwd_big_upd(DevView V, int list_off)
         t2 += Lg[(size_t)(j + 2) * M.ldp] * ys[j + 2]; t3 += Lg[(size_t)(j + 3) * M.ldp] * ys[j + 3];
     }
     for (; j < k; ++j) t0 += Lg[(size_t)j * M.ldp] * ys[j];
-    V.cvec[r0 + i] -= (t0 + t1) + (t2 + t3);
+    V.cvec[M.cv + i] -= (t0 + t1) + (t2 + t3);
 }
 // big fronts, backward part 1: partial(chunk, j) = sum_{i in chunk} L21(i,j) x(rows(i)), 256 rows per workgroup
 __global__ __launch_bounds__(256) void k_bwd_big_dot(DevView V, int list_off)
@@ -807,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     int*    Ts = reinterpret_cast<int*>(Ds + 2 * k);          // ptype[k]
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
-    double* W = V.wbuf + V.wb_off[s];
+    double* W = V.wbuf + M.wb;
     const double* Mg = V.minv + M.minv_off;
     for (int j = tid; j < k; j += 256) { Ds[j] = V.dinv[c0 + j]; Ds[k + j] = V.doff[c0 + j]; Ts[j] = V.ptype[c0 + j]; }
     for (int idx = tid; idx < 64 * kp; idx += 256) {
@@ -851,42 +1085,56 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 // 2x2 v_mfma_f64_16x16x4_f64 accumulators.  The product is formed TRANSPOSED (A operand = W rows, B operand = L rows)
 // so that the 16 lanes sharing an accumulator register hold 16 consecutive ROWS of the column-major T => 128-byte
 // coalesced read-modify-write segments.
+// Chain groups: a link that is not the last of its group only updates the group's remaining `grem` columns (the panels
+// of the later links); the LAST link applies the update of ALL the group's panels to its contribution block in one
+// pass (K = sum of the links' columns, <= 256), so the block is read and written once per group instead of once per link.
 __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
-    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
+    const int k = M.k, m = M.m;
     const int mu = m - k;
     const int nt = (mu + 63) >> 6;
     const int t = blockIdx.x;
-    if (t >= nt * (nt + 1) / 2) return;
-    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-    while (ti * (ti + 1) / 2 > t) --ti;
-    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-    const int tc = t - ti * (ti + 1) / 2;
+    int ti, tc, climit, j0;
+    if (M.grem > 0) {
+        const int ntc = (M.grem + 63) >> 6;
+        if (t >= nt * ntc) return;
+        ti = t / ntc; tc = t - ti * ntc; climit = M.grem; j0 = M.gpos;
+    } else {
+        if (t >= nt * (nt + 1) / 2) return;
+        ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > t) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        tc = t - ti * (ti + 1) / 2; climit = mu; j0 = 0;
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
-    if (i0 + 31 < cc0) return;
+    if (i0 + 31 < cc0 || cc0 >= climit) return;
     const int l15 = lane & 15, l4 = lane >> 4;
-    const double* Lp = V.L + M.panel_off + k;
-    const double* Wp = V.wbuf + V.wb_off[s] + k;
     v4f64 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int q = 0; q < 2; ++q) acc[r][q] = (v4f64){0.0, 0.0, 0.0, 0.0};
     const int ca = cc0 + l15, cb_ = cc0 + 16 + l15, ia = i0 + l15, ib = i0 + 16 + l15;
-    for (int p = 0; p < k; p += 4) {
-        const int pk = p + l4;
-        const bool v = pk < k;
-        const size_t off = (size_t)pk * m, offp = (size_t)pk * M.ldp;
-        const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
-        const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
-        const double b0 = (v && ia < mu) ? Lp[ia + offp] : 0.0;
-        const double b1 = (v && ib < mu) ? Lp[ib + offp] : 0.0;
-        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+    for (int j = j0; j <= M.gpos; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        const int kj = G.k;
+        const double* Lp = V.L + G.panel_off + (G.m - mu);           // rows of this front's contribution block inside link j
+        const double* Wp = V.wbuf + G.wb + (G.m - mu);
+        for (int p = 0; p < kj; p += 4) {
+            const int pk = p + l4;
+            const bool v = pk < kj;
+            const size_t off = (size_t)pk * G.m, offp = (size_t)pk * G.ldp;
+            const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
+            const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
+            const double b0 = (v && ia < mu) ? Lp[ia + offp] : 0.0;
+            const double b1 = (v && ib < mu) ? Lp[ib + offp] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
     }
     double* T = V.cb + M.cb_off;
 #pragma unroll
@@ -897,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
             for (int g = 0; g < 4; ++g) {
                 const int c = cc0 + r * 16 + l4 + 4 * g;      // D row index  -> T column
                 const int i = i0 + q * 16 + l15;              // D column index -> T row
-                if (i < mu && c < mu && i >= c) T[i + (size_t)c * M.ldt] -= acc[r][q][g];
+                if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] -= acc[r][q][g];
             }
 }
 
@@ -945,7 +1193,7 @@ __global__ __launch_bounds__(256) void k_top_rhs_assemble(DevView V, int list_of
         const int ch = Cm.ch; (void)ch;
         if (Cm.owner == V.rank) {
             const int base = Cm.relbase, mc = Cm.mc;
-            for (int t = threadIdx.x; t < mc; t += 256) tr[V.rel[base + t]] += V.cvec[base + t];
+            for (int t = threadIdx.x; t < mc; t += 256) tr[V.rel[base + t]] += V.cvec[Cm.cvbase + t];
         }
         __syncthreads();
     }
@@ -980,12 +1228,12 @@ public:
     double* d_rhs = nullptr; size_t d_rhs_cap = 0;
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
-    std::vector<int> big_maxm, big_maxk;
+    std::vector<int> big_maxm, big_maxk, big_tiles, big_last0, big_last1;
     std::vector<size_t> reg_lds;
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
-    struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk; };
+    struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk, tiles, last0, last1; };   // last0/1: per level, the group-last BIG fronts (solve units)
     Sched sch_local, sch_top;
     int top_list_base = 0, top_count = 0, top_maxm = 0;      // all replicated fronts (top-rhs assembly)
     int join_list_base = 0, join_count = 0, join_maxm = 0;   // replicated fronts with a rank-owned child (arena squares)
@@ -1047,21 +1295,29 @@ public:
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
         std::vector<int> lvl_list(Sy.level_sn);
+        std::vector<char> solve_entry;      // parallel to lvl_list: 1 = entry of a solve-unit list
         std::vector<long long> aoff(Sy.num_sn, -1), troff(Sy.num_sn, -1);
         std::vector<int> colown(Sy.n, 0);
         if (multi) {
             auto build = [&](Sched& sc, bool top) {
                 sc.ptr.assign((size_t)Sy.num_levels * FC_COUNT + 1, 0); sc.base = (int)lvl_list.size();
-                sc.maxm.assign(Sy.num_levels, 0); sc.maxk.assign(Sy.num_levels, 0);
+                sc.maxm.assign(Sy.num_levels, 0); sc.maxk.assign(Sy.num_levels, 0); sc.tiles.assign(Sy.num_levels, 0);
                 std::vector<std::vector<int>> bucket((size_t)Sy.num_levels * FC_COUNT);
                 for (int s = 0; s < Sy.num_sn; ++s) {
                     const bool mine = top ? (Sy.sn_owner[s] < 0) : (Sy.sn_owner[s] == opt.rank);
                     if (!mine) continue;
                     bucket[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]].push_back(s);
                     if (Sy.sn_class[s] == FC_BIG) { sc.maxm[Sy.sn_level[s]] = std::max(sc.maxm[Sy.sn_level[s]], Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]);
-                                                    sc.maxk[Sy.sn_level[s]] = std::max(sc.maxk[Sy.sn_level[s]], Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]); }
+                                                    sc.maxk[Sy.sn_level[s]] = std::max(sc.maxk[Sy.sn_level[s]], Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
+                                                    sc.tiles[Sy.sn_level[s]] = std::max(sc.tiles[Sy.sn_level[s]], schur_tiles(Sy, s)); }
                 }
                 for (size_t b = 0; b < bucket.size(); ++b) { sc.ptr[b + 1] = sc.ptr[b] + (int)bucket[b].size(); lvl_list.insert(lvl_list.end(), bucket[b].begin(), bucket[b].end()); }
+                sc.last0.assign(Sy.num_levels, 0); sc.last1.assign(Sy.num_levels, 0);
+                for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                    sc.last0[lv] = (int)lvl_list.size();
+                    for (int sn : bucket[(size_t)lv * FC_COUNT + FC_BIG]) if (Sy.grp_rem[sn] == 0 || !Sy.solve_group) { lvl_list.push_back(sn); solve_entry.resize(lvl_list.size(), 0); solve_entry.back() = 1; }
+                    sc.last1[lv] = (int)lvl_list.size();
+                }
             };
             build(sch_local, false); build(sch_top, true);
             // top-rhs accumulators for every replicated front; arena squares only for those that have a child owned by some
@@ -1093,6 +1349,32 @@ public:
             int q = b0; while (q < b1 && order_of(lvl_list[q]) <= 16) ++q;
             tiny_split[lv] = (q - b0 >= 2048) ? q - b0 : 0;
         }
+        // single-GPU schedule: per level the group-last BIG fronts (the units of the triangular solves)
+        big_last0.assign(Sy.num_levels, 0); big_last1.assign(Sy.num_levels, 0);
+        for (int lv = 0; lv < Sy.num_levels; ++lv) {
+            big_last0[lv] = (int)lvl_list.size();
+            for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1]; ++q)
+                if (Sy.grp_rem[Sy.level_sn[q]] == 0 || !Sy.solve_group) { lvl_list.push_back(Sy.level_sn[q]); solve_entry.resize(lvl_list.size(), 0); solve_entry.back() = 1; }
+            big_last1[lv] = (int)lvl_list.size();
+        }
+        // chain-group tables: for every BIG front the links of its group up to and including itself
+        std::vector<GroupLink> gt;
+        std::vector<int> gbase_of(Sy.num_sn, 0), gcols_of(Sy.num_sn, 0);
+        for (int sn = 0; sn < Sy.num_sn; ++sn) {
+            gcols_of[sn] = Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn];
+            if (Sy.sn_class[sn] != FC_BIG) continue;
+            std::vector<int> links(Sy.grp_pos[sn] + 1);
+            int cur = sn;
+            for (int j = Sy.grp_pos[sn]; j >= 0; --j) { links[j] = cur; if (j > 0) cur = Sy.alias_child[cur]; }
+            gbase_of[sn] = (int)gt.size(); gcols_of[sn] = 0;
+            for (int l : links) {
+                GroupLink G;
+                G.panel_off = Sy.panel_off[l]; G.wb = Sy.wb_off[l]; G.minv_off = Sy.minv_off[l]; G.cv = Sy.cv_off[l]; G.tr = troff[l];
+                G.c0 = Sy.sn_colptr[l]; G.k = Sy.sn_colptr[l + 1] - G.c0; G.r0 = Sy.sn_rowptr[l]; G.m = Sy.sn_rowptr[l + 1] - G.r0;
+                G.ldp = Sy.sn_ldp[l]; G.ch0 = Sy.child_ptr[l]; G.ch1 = Sy.child_ptr[l + 1]; G.alias = Sy.alias_child[l] >= 0 ? 1 : 0;
+                gt.push_back(G); gcols_of[sn] += G.k;
+            }
+        }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -1101,29 +1383,35 @@ public:
             M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.alias = Sy.alias_child[sn] >= 0 ? 1 : 0;
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
             M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
+            M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
+            M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn];
+            if (q < solve_entry.size() && solve_entry[q] && !Sy.solve_group) {     // per-link solves: every front is its own unit
+                M.gbase += M.gpos; M.gpos = 0; M.grem = 0; M.gcols = M.k;
+            }
         }
         std::vector<ChildMeta> cm(Sy.child_idx.size());
         for (size_t q = 0; q < cm.size(); ++q) {
             const int ch = Sy.child_idx[q]; const int kc = Sy.sn_colptr[ch + 1] - Sy.sn_colptr[ch];
             cm[q].ch = ch; cm[q].relbase = Sy.sn_rowptr[ch] + kc; cm[q].mc = Sy.sn_rowptr[ch + 1] - cm[q].relbase;
-            cm[q].owner = Sy.sn_owner[ch]; cm[q].cb_off = Sy.cb_off[ch]; cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0;
+            cm[q].owner = Sy.sn_owner[ch]; cm[q].cb_off = Sy.cb_off[ch]; cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0; cm[q].cvbase = Sy.cv_off[ch] + kc;
         }
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0)
             for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) if (Sy.child_idx[q] == Sy.alias_child[sn]) cm[q].aliased = 1;
-        if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta)) return false;
+        if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
             !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) || !upload(moff, &V.minv_off) ||
             !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
-            !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.rslot_ptr, &V.rslot_ptr) || !upload(Sy.rslot_idx, &V.rslot_idx) || !upload(lvl_list, &V.level_sn) ||
+            !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.rslot_ptr, &V.rslot_ptr) || !upload(Sy.rslot_idx, &V.rslot_idx) || !upload(Sy.rslot_col, &V.rslot_col) || !upload(lvl_list, &V.level_sn) ||
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
             !upload(Sy.perm, &V.perm)) return false;
         double* tv = nullptr;
         if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
-        if (!dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.scale2, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
+        V.rslot_len = (int)Sy.rslot_idx.size();
+        if (!dalloc(&V.arv, Sy.rslot_idx.size()) || !dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.scale2, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
-            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.sum_sn_rows) ||
+            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 4)) return false;
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
@@ -1149,20 +1437,28 @@ public:
         }
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
-        big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0);
+        big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
             const int lv = Sy.sn_level[s];
             big_maxm[lv] = std::max(big_maxm[lv], Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]);
             big_maxk[lv] = std::max(big_maxk[lv], Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
+            big_tiles[lv] = std::max(big_tiles[lv], schur_tiles(Sy, s));
         }
         ready = true; return true;
     }
 
+    // 64x64 tiles of the trailing update of front s: the whole lower triangle, or (not the last link of a chain group) only
+    // the tile columns of the group's remaining panels
+    static int schur_tiles(const Symbolic& Sy, int s) {
+        const int mu = (Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]) - (Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
+        const int nt = (mu + 63) / 64;
+        return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 63) / 64) : nt * (nt + 1) / 2;
+    }
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
 
     // one (level, class) bucket of fronts
-    bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk) {
+    bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk, int tiles) {
         const int nb = b1 - b0;
         const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
         if (fc == FC_WAVE) {
@@ -1174,12 +1470,11 @@ public:
         } else if (fc == FC_LDS128) {
             LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb), dim3(256), rl, stream, V, b0, top_mode);
         } else {
-            const int nt = (mm - 1 + 63) / 64;
             LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
             if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
             else          LAUNCH(KK_BIG_DIAG, k_big_diag_reg<8>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
             LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
-            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(nt * (nt + 1) / 2, nb), dim3(256), 0, stream, V, b0);
+            if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(256), 0, stream, V, b0);
         }
         return true;
     }
@@ -1188,20 +1483,19 @@ public:
         const Symbolic& Sy = *S;
         const int n = Sy.n;
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
-        if (opt.scaling) {
-            // 3 sweeps: scale -> scale2 -> scale -> scale2, then scale2 is copied back by the last sweep's roles being swapped
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+        if (opt.scaling) {      // 4 sweeps, ping-pong between the two buffers, ending in V.scale
+            LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
             LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        }
+        } else LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         for (int lv = 0; lv < Sy.num_levels; ++lv) {
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv]);
+                launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv]);
             }
         }
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
@@ -1267,8 +1561,10 @@ public:
                     if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
                     else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
                     else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
-                    else { LAUNCH(KK_FWD_BIG, (k_fwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0, 0);
-                           LAUNCH(KK_FWD_BIG, k_fwd_big_upd, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0); }
+                    else if (big_last1[lv] > big_last0[lv]) {
+                           const int g0 = big_last0[lv], ng = big_last1[lv] - g0;
+                           LAUNCH(KK_FWD_BIG, k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, 0);
+                           LAUNCH(KK_FWD_BIG_UPD, k_fwd_grp_upd, dim3((big_maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); }
                 }
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -1277,8 +1573,10 @@ public:
                     if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
                     else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
                     else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
-                    else { LAUNCH(KK_BWD_BIG, k_bwd_big_dot, dim3((big_maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0);
-                           LAUNCH(KK_BWD_BIG, (k_bwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, big_maxk[lv]), stream, V, b0); }
+                    else if (big_last1[lv] > big_last0[lv]) {
+                           const int g0 = big_last0[lv], ng = big_last1[lv] - g0;
+                           LAUNCH(KK_BWD_BIG_DOT, k_bwd_grp_dot, dim3((big_maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
+                           LAUNCH(KK_BWD_BIG, k_bwd_grp, dim3(ng), dim3(256), 0, stream, V, g0); }
                 }
         }
         if (nref > 0) LAUNCH(KK_SOLVE_PERM, k_refine_finish, dim3(grid1d(n)), dim3(256), 0, stream, V);
@@ -1322,7 +1620,7 @@ public:
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc], b1 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                launch_bucket(lv, fc, b0, b1, top_mode, sc.maxm[lv], sc.maxk[lv]);
+                launch_bucket(lv, fc, b0, b1, top_mode, sc.maxm[lv], sc.maxk[lv], sc.tiles[lv]);
             }
         HIPCHK(hipGetLastError());
         return true;
@@ -1339,14 +1637,18 @@ public:
                     if (fc == FC_WAVE)        hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, top_mode);
                     else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, top_mode);
                     else if (fc == FC_LDS128) hipLaunchKernelGGL((k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, top_mode);
-                    else { hipLaunchKernelGGL((k_fwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0, top_mode);
-                           hipLaunchKernelGGL(k_fwd_big_upd, dim3((sc.maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0); }
+                    else if (sc.last1[lv] > sc.last0[lv]) {
+                           const int g0 = sc.last0[lv], ng = sc.last1[lv] - g0;
+                           hipLaunchKernelGGL(k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, top_mode);
+                           hipLaunchKernelGGL(k_fwd_grp_upd, dim3((sc.maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); }
                 } else {
                     if (fc == FC_WAVE)        hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
                     else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
                     else if (fc == FC_LDS128) hipLaunchKernelGGL((k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
-                    else { hipLaunchKernelGGL(k_bwd_big_dot, dim3((sc.maxm[lv] + 255) / 256, b1 - b0), dim3(256), 0, stream, V, b0);
-                           hipLaunchKernelGGL((k_bwd<256, true>), dim3(b1 - b0), dim3(256), lds_solve(0, sc.maxk[lv]), stream, V, b0); }
+                    else if (sc.last1[lv] > sc.last0[lv]) {
+                           const int g0 = sc.last0[lv], ng = sc.last1[lv] - g0;
+                           hipLaunchKernelGGL(k_bwd_grp_dot, dim3((sc.maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
+                           hipLaunchKernelGGL(k_bwd_grp, dim3(ng), dim3(256), 0, stream, V, g0); }
                 }
             }
         }
@@ -1362,14 +1664,14 @@ public:
         have_values = true;
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (opt.scaling) {
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+            hipLaunchKernelGGL(k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
+            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
             hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        }
+        } else hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (!launch_fronts(sch_local, 0)) return false;
         HIPCHK(hipMemsetAsync(V.arena, 0, (size_t)arena_doubles * sizeof(double), stream));
         if (join_count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((join_maxm + 3) / 4, join_count), dim3(256), 0, stream, V, join_list_base);

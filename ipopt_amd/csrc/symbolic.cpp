@@ -754,7 +754,12 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         for (int i = 0; i < n; ++i) S.rslot_ptr[i + 1] += S.rslot_ptr[i];
         S.rslot_idx.resize(S.rslot_ptr[n]);
         vector<int> pos(S.rslot_ptr.begin(), S.rslot_ptr.end() - 1);
-        for (int q = 0; q < nnzA; ++q) { S.rslot_idx[pos[S.arow[q]]++] = q; if (S.arow[q] != S.acol[q]) S.rslot_idx[pos[S.acol[q]]++] = q; }
+        S.rslot_col.resize(S.rslot_ptr[n]);
+        for (int q = 0; q < nnzA; ++q) {
+            const int r = S.arow[q], c = S.acol[q];
+            S.rslot_col[pos[r]] = c; S.rslot_idx[pos[r]++] = q;
+            if (r != c) { S.rslot_col[pos[c]] = r; S.rslot_idx[pos[c]++] = q; }
+        }
     }
     // ---- 10. relative indices, A scatter positions, levels, offsets, stats ----
     S.rel.assign(S.sn_rows.size(), -1);
@@ -801,15 +806,6 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     }
     S.minv_off.resize(nsn);
     { int64_t mo = 0; for (int s = 0; s < nsn; ++s) { int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s]; S.minv_off[s] = mo; mo += k * k; } S.minv_doubles = mo; }
-    {   // per-level scratch for the W = L*D panels of the blocked (big-front) path
-        S.wb_off.assign(nsn, -1);
-        vector<int64_t> lvl_used(S.num_levels, 0);
-        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) {
-            int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
-            S.wb_off[s] = lvl_used[S.sn_level[s]]; lvl_used[S.sn_level[s]] += m * k;
-        }
-        for (int64_t u : lvl_used) S.wbuf_doubles = std::max(S.wbuf_doubles, u);
-    }
     // level schedule buckets (level, class)
     S.level_ptr.assign((size_t)S.num_levels * FC_COUNT + 1, 0);
     for (int s = 0; s < nsn; ++s) S.level_ptr[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s] + 1]++;
@@ -890,6 +886,46 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             }
         }
         S.cb_doubles = coff;
+        // chain groups: up to `chain_group` consecutive links of an in-place chain (<= 256 columns, consecutive levels) are
+        // ONE unit for the trailing update (a single rank-(sum k) update at the last link; the links before it only update
+        // the group's own remaining columns) and for the triangular solves (one launch pair per group).
+        const int gmax = std::max(1, std::min(opt.chain_group, 4));
+        S.solve_group = opt.solve_group;
+        S.grp_pos.assign(nsn, 0); S.grp_rem.assign(nsn, 0);
+        vector<int> gcols(nsn, 0), alias_parent(nsn, -1);
+        for (int s = 0; s < nsn; ++s) {
+            const int ac = S.alias_child[s];
+            gcols[s] = (int)K(s);
+            if (ac >= 0 && S.grp_pos[ac] + 1 < gmax && gcols[ac] + K(s) <= 256 && S.sn_level[s] == S.sn_level[ac] + 1) {
+                S.grp_pos[s] = S.grp_pos[ac] + 1; gcols[s] = gcols[ac] + (int)K(s); alias_parent[ac] = s;
+            }
+        }
+        for (int s = nsn - 1; s >= 0; --s) { const int p = alias_parent[s]; if (p >= 0) S.grp_rem[s] = S.grp_rem[p] + (int)K(p); }
+        // forward-solve vectors: an in-place chain shares ONE vector (the parent's entries are the child's update entries)
+        S.cv_off.assign(nsn, 0);
+        int64_t cvo = 0;
+        for (int s = 0; s < nsn; ++s) {
+            const int ac = S.alias_child[s];
+            if (ac >= 0) S.cv_off[s] = S.cv_off[ac] + K(ac);
+            else { S.cv_off[s] = cvo; cvo += Mf(s); }
+        }
+        S.cvec_doubles = cvo;
+        // W = L*D panels of the BIG fronts: per-level scratch in 4 banks (level mod 4) so that the panels of a chain group
+        // (<= 4 consecutive levels) are all alive at the group's trailing update; partial sums of the backward dot products
+        S.wb_off.assign(nsn, -1); S.gpart_off.assign(nsn, -1);
+        vector<int64_t> lvl_used(S.num_levels, 0), lvl_part(S.num_levels, 0);
+        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) {
+            const int lv = S.sn_level[s];
+            S.wb_off[s] = lvl_used[lv]; lvl_used[lv] += Mf(s) * K(s);
+            S.gpart_off[s] = lvl_part[lv]; lvl_part[lv] += ((Mf(s) - K(s) + 255) / 256 + 1) * (int64_t)gcols[s];
+        }
+        int64_t bank[4] = {0, 0, 0, 0};
+        for (int lv = 0; lv < S.num_levels; ++lv) bank[lv & 3] = std::max(bank[lv & 3], lvl_used[lv]);
+        const int64_t bank_base[4] = {0, bank[0], bank[0] + bank[1], bank[0] + bank[1] + bank[2]};
+        for (int s = 0; s < nsn; ++s) if (S.wb_off[s] >= 0) S.wb_off[s] += bank_base[S.sn_level[s] & 3];
+        S.wbuf_doubles = bank[0] + bank[1] + bank[2] + bank[3];
+        S.gpart_doubles = 0;
+        for (int64_t u : lvl_part) S.gpart_doubles = std::max(S.gpart_doubles, u);
     }
     S.time_analyse = now_s() - t0;
     if (opt.verbose)

@@ -24,6 +24,8 @@ struct SymbolicOptions {
     int    max_sn_cols = 64;
     int    leaf_cols   = 0;    // whole elimination subtrees with at most this many columns become ONE supernode
     int    tree_merge  = 0;    // merge small non-contiguous child supernodes into the parent: 1 on, 0 off (default), -1 auto (n <= 4e5)
+    int    solve_group = 0;    // 1: the triangular solves also work per chain group (default: per link, measured faster)
+    int    chain_group = 4;    // links of an in-place separator chain handled as one unit (1 = off, max 4)
     int    wide_panels = 0;    // 1: separator fronts of order >= 512 get 128-column panels (kernels support it; default off)
     int    nranks      = 1;
     int    verbose     = 0;
@@ -51,7 +53,8 @@ struct Symbolic {
     std::vector<int> acol;                 // [nnz_a] column of each slot (permuted numbering)
     // full symmetric row view of the pattern: for every row i the slots (q) that carry an entry of row i, i.e. column i's
     // own slots and the slots (i, c < i) of earlier columns; lets the equilibration run as a gather (no atomics)
-    std::vector<int> rslot_ptr, rslot_idx; // [n+1], [2*nnz_a - n]
+    std::vector<int> rslot_ptr, rslot_idx; // [n+1], [2*nnz_a - n]  symmetric row view: slots of the entries of row i (both triangles)
+    std::vector<int> rslot_col;            // [2*nnz_a - n] the other index of each of them
     // supernodes
     int num_sn = 0;
     std::vector<int> sn_colptr;            // [num_sn+1] pivot column ranges (permuted numbering)
@@ -71,6 +74,11 @@ struct Symbolic {
     // (offset >= l_doubles; L and cb are one allocation) and both leading dimensions are inherited from the child.
     std::vector<int> sn_ldp, sn_ldt;       // leading dimensions of the panel / of the contribution block
     std::vector<int> alias_child;          // the child whose contribution block this front lives in, or -1
+    std::vector<int> grp_pos, grp_rem;     // chain groups: position of the front in its group; columns of the LATER links (0 = last link)
+    std::vector<int64_t> cv_off;           // [num_sn] offset of the front's forward-solve vector (in-place chains share one)
+    std::vector<int64_t> gpart_off;        // [num_sn] (group-last BIG fronts) offset of the backward partial sums
+    int64_t cvec_doubles = 0, gpart_doubles = 0;
+    int solve_group = 0;                   // copy of the option: solves per chain group (1) or per link (0)
     std::vector<int64_t> wb_off;           // [num_sn] offset (doubles) of the m x k scaled-panel copy W = L*D of a BIG front
                                            // inside the per-level scratch (reused level after level), -1 otherwise
     int64_t wbuf_doubles = 0;

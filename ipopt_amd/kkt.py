@@ -29,7 +29,7 @@ class _Options(C.Structure):
                 ("scaling", C.c_int), ("nd_leaf", C.c_int), ("nemin", C.c_int), ("max_sn_cols", C.c_int),
                 ("pivtol", C.c_double), ("pivtolmax", C.c_double), ("small", C.c_double),
                 ("refine_steps", C.c_int), ("use_graph", C.c_int), ("nranks", C.c_int), ("rank", C.c_int),
-                ("verbose", C.c_int), ("leaf_cols", C.c_int), ("tree_merge", C.c_int), ("wide_panels", C.c_int), ("reserved", C.c_int * 5)]
+                ("verbose", C.c_int), ("leaf_cols", C.c_int), ("tree_merge", C.c_int), ("wide_panels", C.c_int), ("chain_group", C.c_int), ("solve_group", C.c_int), ("reserved", C.c_int * 3)]
 
 
 class _Info(C.Structure):
@@ -65,7 +65,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
-                "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big"]
+                "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big", "fwd_big_upd", "bwd_big_dot"]
 
 
 def load_library():

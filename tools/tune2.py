@@ -13,8 +13,8 @@ def run(wl, **opts):
     I = s.info()
     res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
     pr = s.profile(3)
-    top = sorted(((k_, v_[0] / 3) for k_, v_ in pr.items() if v_[1] > 0), key=lambda t: -t[1])[:6]
+    top = sorted(((k_, v_[0] / 3) for k_, v_ in pr.items() if v_[1] > 0), key=lambda t: -t[1])[:int(os.environ.get('TOPK', '6'))]
     print(f"{wl:12s} {str(opts):40s} st={st} res={res:.1e} small={I.num_small} lev={I.num_levels:3d} nsn={I.num_sn:7d} maxfront={I.maxfront:5d} flops={I.flops_factor:.3g} factor_ms={min(tf):8.3f} solve_ms={min(ts):7.3f} | " + " ".join(f"{a}={b:.3f}" for a, b in top), flush=True)
 for wl in sys.argv[1:]:
-    for opts in [dict(), dict(leaf_cols=0), dict(leaf_cols=16)]:
+    for opts in [dict()] + [eval(o) for o in os.environ.get('OPTS', '').split(';') if o]:
         run(wl, **opts)
