@@ -395,7 +395,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
 // write-back of the pivot-ordered panel, the contribution block (straight from registers), pivot data and L11^{-1}.
 template <int NT, int TS>
-__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS == 2) ? 6 : 1)) void k_front_reg(DevView V, int list_off, int top_mode)
+__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS == 2) ? 6 : ((NT == 256 && TS == 6) ? 2 : 1))) void k_front_reg(DevView V, int list_off, int top_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = (NT == 64) ? 8 : 16;
@@ -1015,7 +1015,14 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
             if (lo < mc && relc[lo] == fc) {
                 const double* C = V.cb + Cm.cb_off + (size_t)lo * Cm.ldt;
-                for (int a = lo + lane; a < mc; a += 64) col[relc[a]] += C[a];
+                int a = lo + lane;
+                for (; a + 192 < mc; a += 256) {             // 4 independent gather-add chains in flight per lane
+                    const int r0_ = relc[a], r1_ = relc[a + 64], r2_ = relc[a + 128], r3_ = relc[a + 192];
+                    const double c0_ = C[a], c1_ = C[a + 64], c2_ = C[a + 128], c3_ = C[a + 192];
+                    const double t0 = col[r0_], t1 = col[r1_], t2 = col[r2_], t3 = col[r3_];
+                    col[r0_] = t0 + c0_; col[r1_] = t1 + c1_; col[r2_] = t2 + c2_; col[r3_] = t3 + c3_;
+                }
+                for (; a < mc; a += 64) col[relc[a]] += C[a];
             }
         }
         __syncthreads();
@@ -1088,18 +1095,25 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 // Chain groups: a link that is not the last of its group only updates the group's remaining `grem` columns (the panels
 // of the later links); the LAST link applies the update of ALL the group's panels to its contribution block in one
 // pass (K = sum of the links' columns, <= 256), so the block is read and written once per group instead of once per link.
-__global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
+__global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off)
 {
+    // 128 x 128 tile per workgroup of 16 wavefronts (32 x 32 each = 2 x 2 accumulators of v_mfma_f64_16x16x4_f64).  The
+    // operands are staged through LDS in chunks of 16 panel columns (double buffered, one barrier per chunk): every panel
+    // entry is fetched from L2 once per tile instead of once per wavefront, and 4 wavefronts per SIMD hide the LDS latency.
+    constexpr int KC = 16, LD = 132;
+    __shared__ double As[2][KC][LD];      // W rows (-> T columns) of the tile
+    __shared__ double Bs[2][KC][LD];      // L rows (-> T rows)
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
     const int k = M.k, m = M.m;
     const int mu = m - k;
-    const int nt = (mu + 63) >> 6;
+    const int nt = (mu + 127) >> 7;
     const int t = blockIdx.x;
     int ti, tc, climit, j0;
     if (M.grem > 0) {
-        const int ntc = (M.grem + 63) >> 6;
+        const int ntc = (M.grem + 127) >> 7;
         if (t >= nt * ntc) return;
         ti = t / ntc; tc = t - ti * ntc; climit = M.grem; j0 = M.gpos;
+        if (ti < tc) return;
     } else {
         if (t >= nt * (nt + 1) / 2) return;
         ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -1107,45 +1121,83 @@ __global__ __launch_bounds__(256) void k_big_schur(DevView V, int list_off)
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         tc = t - ti * (ti + 1) / 2; climit = mu; j0 = 0;
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
-    if (i0 + 31 < cc0 || cc0 >= climit) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
+    const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;             // this wavefront's 32 x 32 block inside the tile
+    const int i0 = ti * 128, cc0 = tc * 128;
+    const bool work = (i0 + wr + 31 >= cc0 + wc) && (cc0 + wc < climit) && (i0 + wr < mu);
     v4f64 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int q = 0; q < 2; ++q) acc[r][q] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int ca = cc0 + l15, cb_ = cc0 + 16 + l15, ia = i0 + l15, ib = i0 + 16 + l15;
-    for (int j = j0; j <= M.gpos; ++j) {
+    // staging role of this thread: row (tid & 127) of the tile, panel columns (tid >> 7) and (tid >> 7) + 8 of the chunk
+    const int srow = tid & 127, scol = tid >> 7;
+    const bool arow_ok = cc0 + srow < mu, brow_ok = i0 + srow < mu;
+    double ga[2], gb[2];
+    auto fetch = [&](int j, int p0) -> int {
         const GroupLink G = V.gtab[M.gbase + j];
-        const int kj = G.k;
-        const double* Lp = V.L + G.panel_off + (G.m - mu);           // rows of this front's contribution block inside link j
-        const double* Wp = V.wbuf + G.wb + (G.m - mu);
-        for (int p = 0; p < kj; p += 4) {
-            const int pk = p + l4;
-            const bool v = pk < kj;
-            const size_t off = (size_t)pk * G.m, offp = (size_t)pk * G.ldp;
-            const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
-            const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
-            const double b0 = (v && ia < mu) ? Lp[ia + offp] : 0.0;
-            const double b1 = (v && ib < mu) ? Lp[ib + offp] : 0.0;
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        const double* Lp = V.L + G.panel_off + (G.m - mu) + i0 + srow;
+        const double* Wp = V.wbuf + G.wb + (G.m - mu) + cc0 + srow;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pk = p0 + scol + 8 * u;
+            const bool v = pk < G.k;
+            ga[u] = (v && arow_ok) ? Wp[(size_t)pk * G.m] : 0.0;
+            gb[u] = (v && brow_ok) ? Lp[(size_t)pk * G.ldp] : 0.0;
         }
+        return G.k;
+    };
+    int j = j0, p0 = 0, buf = 0;
+    int kcur = fetch(j, p0);
+    As[0][scol][srow] = ga[0]; As[0][scol + 8][srow] = ga[1]; Bs[0][scol][srow] = gb[0]; Bs[0][scol + 8][srow] = gb[1];
+    __syncthreads();
+    while (true) {
+        int jn = j, pn = p0 + KC;
+        if (pn >= kcur) { jn = j + 1; pn = 0; }
+        const bool more = jn <= M.gpos;
+        int knext = kcur;
+        if (more) knext = fetch(jn, pn);
+        if (work) {
+#pragma unroll
+            for (int st = 0; st < KC / 4; ++st) {
+                const int kk = 4 * st + l4;
+                const double a0 = As[buf][kk][wc + l15], a1 = As[buf][kk][wc + 16 + l15];
+                const double b0 = Bs[buf][kk][wr + l15], b1 = Bs[buf][kk][wr + 16 + l15];
+                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (!more) break;
+        buf ^= 1;
+        As[buf][scol][srow] = ga[0]; As[buf][scol + 8][srow] = ga[1]; Bs[buf][scol][srow] = gb[0]; Bs[buf][scol + 8][srow] = gb[1];
+        __syncthreads();
+        j = jn; p0 = pn; kcur = knext;
     }
+    if (!work) return;
     double* T = V.cb + M.cb_off;
+    double tv[2][2][4];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int c = cc0 + r * 16 + l4 + 4 * g;      // D row index  -> T column
-                const int i = i0 + q * 16 + l15;              // D column index -> T row
-                if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] -= acc[r][q][g];
+                const int c = cc0 + wc + r * 16 + l4 + 4 * g;      // D row index  -> T column
+                const int i = i0 + wr + q * 16 + l15;              // D column index -> T row
+                tv[r][q][g] = (i < mu && c < climit && i >= c) ? T[i + (size_t)c * M.ldt] : 0.0;
+            }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + wc + r * 16 + l4 + 4 * g;
+                const int i = i0 + wr + q * 16 + l15;
+                if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] = tv[r][q][g] - acc[r][q][g];
             }
 }
 
@@ -1230,6 +1282,7 @@ public:
     bool scale_identity = true;
     std::vector<int> big_maxm, big_maxk, big_tiles, big_last0, big_last1;
     std::vector<size_t> reg_lds;
+    std::vector<int> mid_split; std::vector<size_t> mid_lds;   // per level: leading FC_LDS128 fronts of order <= 96 (6x6-tile kernel, 2 workgroups per CU) and their LDS need
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
@@ -1349,6 +1402,22 @@ public:
             int q = b0; while (q < b1 && order_of(lvl_list[q]) <= 16) ++q;
             tiny_split[lv] = (q - b0 >= 2048) ? q - b0 : 0;
         }
+        // same for the (level, FC_LDS128) buckets: fronts of order <= 96 first; they run on the 6x6-tile instantiation (half the
+        // registers and LDS of the 8x8 one => two workgroups per CU)
+        mid_split.assign(Sy.num_levels, 0); mid_lds.assign(Sy.num_levels, 0);
+        for (int lv = 0; lv < Sy.num_levels; ++lv) {
+            const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_LDS128], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_LDS128 + 1];
+            auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
+            std::stable_sort(lvl_list.begin() + b0, lvl_list.begin() + b1, [&](int a, int b) { return order_of(a) < order_of(b); });
+            int q = b0;
+            while (q < b1 && order_of(lvl_list[q]) <= 96) {
+                const int sn = lvl_list[q];
+                const size_t m = order_of(sn), k = Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn], ld = m | 1, ldi = k | 1;
+                mid_lds[lv] = std::max(mid_lds[lv], (std::max(ld * m, k * ld + k * ldi) + 4 * 96 + 2 * k) * sizeof(double) + 2 * k * sizeof(int) + 64);
+                ++q;
+            }
+            mid_split[lv] = (q - b0 >= 256) ? q - b0 : 0;
+        }
         // single-GPU schedule: per level the group-last BIG fronts (the units of the triangular solves)
         big_last0.assign(Sy.num_levels, 0); big_last1.assign(Sy.num_levels, 0);
         for (int lv = 0; lv < Sy.num_levels; ++lv) {
@@ -1425,6 +1494,7 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // exact LDS need of the register-tiled front kernel per (level, class) bucket
         reg_lds.assign((size_t)Sy.num_levels * FC_COUNT, 0);
         for (int s = 0; s < Sy.num_sn; ++s) {
@@ -1447,12 +1517,12 @@ public:
         ready = true; return true;
     }
 
-    // 64x64 tiles of the trailing update of front s: the whole lower triangle, or (not the last link of a chain group) only
+    // 128x128 tiles of the trailing update of front s: the whole lower triangle, or (not the last link of a chain group) only
     // the tile columns of the group's remaining panels
     static int schur_tiles(const Symbolic& Sy, int s) {
         const int mu = (Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]) - (Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
-        const int nt = (mu + 63) / 64;
-        return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 63) / 64) : nt * (nt + 1) / 2;
+        const int nt = (mu + 127) / 128;
+        return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 127) / 128) : nt * (nt + 1) / 2;
     }
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
@@ -1468,13 +1538,15 @@ public:
         } else if (fc == FC_LDS64) {
             LAUNCH(KK_FRONT_LDS64, (k_front_reg<64, 8>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
         } else if (fc == FC_LDS128) {
-            LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb), dim3(256), rl, stream, V, b0, top_mode);
+            const int nm = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_LDS128]) ? mid_split[lv] : 0;    // single-GPU schedule only
+            if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
+            if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
         } else {
             LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
             if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
             else          LAUNCH(KK_BIG_DIAG, k_big_diag_reg<8>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
             LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
-            if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(256), 0, stream, V, b0);
+            if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0);
         }
         return true;
     }
