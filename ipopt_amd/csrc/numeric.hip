@@ -51,7 +51,7 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
 struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt;
-                   long long cv, wb, gpart; int gbase, gpos, grem, gcols; };
+                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, pad_; };
 struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase; };
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
 struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
@@ -1095,31 +1095,40 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 // Chain groups: a link that is not the last of its group only updates the group's remaining `grem` columns (the panels
 // of the later links); the LAST link applies the update of ALL the group's panels to its contribution block in one
 // pass (K = sum of the links' columns, <= 256), so the block is read and written once per group instead of once per link.
-__global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off)
+// Look-ahead: the update of a group-last front whose chain continues may be SPLIT (FrontMeta::split): part 1 = the first two
+// tile columns (all that the next group's panels, pivot blocks and narrow updates touch) stays on the main stream, part 2 =
+// the rest runs on a second stream, overlapped with the latency-bound pivot chains of the next group.  part 0 = everything.
+constexpr int SCHUR_KC = 16, SCHUR_LD = 132;
+__device__ __forceinline__ void schur_tile(const DevView& V, const FrontMeta& M, const int t, const int part,
+                                           double (&As)[2][SCHUR_KC][SCHUR_LD], double (&Bs)[2][SCHUR_KC][SCHUR_LD])
 {
     // 128 x 128 tile per workgroup of 16 wavefronts (32 x 32 each = 2 x 2 accumulators of v_mfma_f64_16x16x4_f64).  The
     // operands are staged through LDS in chunks of 16 panel columns (double buffered, one barrier per chunk): every panel
     // entry is fetched from L2 once per tile instead of once per wavefront, and 4 wavefronts per SIMD hide the LDS latency.
-    constexpr int KC = 16, LD = 132;
-    __shared__ double As[2][KC][LD];      // W rows (-> T columns) of the tile
-    __shared__ double Bs[2][KC][LD];      // L rows (-> T rows)
-    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    constexpr int KC = SCHUR_KC;
     const int k = M.k, m = M.m;
     const int mu = m - k;
     const int nt = (mu + 127) >> 7;
-    const int t = blockIdx.x;
     int ti, tc, climit, j0;
+    const bool sp = part != 0 && M.split != 0;
+    if (part == 2 && !sp) return;
     if (M.grem > 0) {
         const int ntc = (M.grem + 127) >> 7;
         if (t >= nt * ntc) return;
         ti = t / ntc; tc = t - ti * ntc; climit = M.grem; j0 = M.gpos;
         if (ti < tc) return;
+    } else if (sp && part == 1) {
+        if (t >= 2 * nt - 1) return;
+        if (t < nt) { ti = t; tc = 0; } else { ti = t - nt + 1; tc = 1; }
+        climit = mu; j0 = 0;
     } else {
-        if (t >= nt * (nt + 1) / 2) return;
+        const int n2 = sp ? nt - 2 : nt, sh = sp ? 2 : 0;
+        if (t >= n2 * (n2 + 1) / 2) return;
         ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
         while (ti * (ti + 1) / 2 > t) --ti;
         while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
         tc = t - ti * (ti + 1) / 2; climit = mu; j0 = 0;
+        ti += sh; tc += sh;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -1199,6 +1208,17 @@ __global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off)
                 const int i = i0 + wr + q * 16 + l15;
                 if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] = tv[r][q][g] - acc[r][q][g];
             }
+}
+// part 0 / 1: one tile per workgroup.  part 2 (look-ahead, second stream) strides over the tiles, normally also one per
+// workgroup (a persistent grid smaller than the chip was measured: one 16-wave workgroup per CU reaches half the MFMA rate).
+__global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off, int part, int ntiles)
+{
+    __shared__ double As[2][SCHUR_KC][SCHUR_LD];      // W rows (-> T columns) of the tile
+    __shared__ double Bs[2][SCHUR_KC][SCHUR_LD];      // L rows (-> T rows)
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    if (part != 2) { schur_tile(V, M, blockIdx.x, part, As, Bs); return; }
+    if (!M.split) return;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) { schur_tile(V, M, t, part, As, Bs); __syncthreads(); }
 }
 
 
@@ -1281,6 +1301,10 @@ public:
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
     std::vector<int> big_maxm, big_maxk, big_tiles, big_last0, big_last1;
+    // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
+    std::vector<int> la_tiles1, la_tiles2; std::vector<char> la_full;     // la_full: the level has a full (group-last) update
+    std::vector<hipEvent_t> la_evA, la_evB;
+    hipStream_t stream2 = nullptr; bool la_pending = false; hipEvent_t la_last = nullptr; bool lookahead = true; int la_wgs = 1 << 20, la_min_nt = 12;
     std::vector<size_t> reg_lds;
     std::vector<int> mid_split; std::vector<size_t> mid_lds;   // per level: leading FC_LDS128 fronts of order <= 96 (6x6-tile kernel, 2 workgroups per CU) and their LDS need
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
@@ -1319,6 +1343,10 @@ public:
         if (h_stats) { (void)hipHostFree(h_stats); h_stats = nullptr; }
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
         if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        for (auto e : la_evA) if (e) (void)hipEventDestroy(e);
+        for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
+        la_evA.clear(); la_evB.clear();
+        if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         ready = false;
     }
@@ -1341,7 +1369,15 @@ public:
             err_ = "no HIP device available: the MI355X KKT backend has no CPU fallback"; have_device = false; return false; }
         if (opt.device >= 0) HIPCHK(hipSetDevice(opt.device));
         have_device = true;
-        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        {   // the main stream carries the latency-bound pivot chains: highest priority; the look-ahead stream the lowest
+            int plo = 0, phi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+            HIPCHK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
+            HIPCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
+        }
+        lookahead = getenv("MI355X_KKT_NO_LOOKAHEAD") == nullptr;
+        if (const char* e = getenv("MI355X_KKT_LA_WGS")) la_wgs = std::max(1, atoi(e));          // development knobs
+        if (const char* e = getenv("MI355X_KKT_LA_MIN_NT")) la_min_nt = std::max(3, atoi(e));
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
@@ -1444,6 +1480,46 @@ public:
                 gt.push_back(G); gcols_of[sn] += G.k;
             }
         }
+        // look-ahead candidates: group-last BIG fronts (>= 12 tile rows) whose chain continues with a PURE next group (links
+        // whose only child is the chain child: nothing but the chain itself writes into the front before the next full update)
+        std::vector<char> split_of(Sy.num_sn, 0);
+        la_tiles1.assign(Sy.num_levels, 0); la_tiles2.assign(Sy.num_levels, 0); la_full.assign(Sy.num_levels, 0);
+        {
+            std::vector<int> alias_parent(Sy.num_sn, -1);
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0) alias_parent[Sy.alias_child[sn]] = sn;
+            for (int sn = 0; sn < Sy.num_sn; ++sn) {
+                if (Sy.sn_class[sn] != FC_BIG || Sy.grp_rem[sn] != 0) continue;
+                const int lv = Sy.sn_level[sn];
+                la_full[lv] = 1;
+                const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+                const int nt = (mu + 127) / 128;
+                bool ok = lookahead && !multi && nt >= la_min_nt && alias_parent[sn] >= 0;
+                for (int p = alias_parent[sn]; ok && p >= 0; p = alias_parent[p]) {
+                    if (Sy.child_ptr[p + 1] - Sy.child_ptr[p] != 1) ok = false;
+                    if (Sy.grp_rem[p] == 0) break;
+                }
+                split_of[sn] = ok ? 1 : 0;
+                la_tiles1[lv] = std::max(la_tiles1[lv], ok ? 2 * nt - 1 : nt * (nt + 1) / 2);
+                if (ok) la_tiles2[lv] = std::max(la_tiles2[lv], (nt - 2) * (nt - 1) / 2);
+            }
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] != 0)
+                la_tiles1[Sy.sn_level[sn]] = std::max(la_tiles1[Sy.sn_level[sn]], schur_tiles(Sy, sn));
+            if (opt.verbose) {
+                int nsplit = 0, nfull = 0, nimpure = 0, nsmall = 0, nend = 0; long long t2 = 0;
+                for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
+                    ++nfull; nsplit += split_of[sn];
+                    const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+                    const int nt = (mu + 127) / 128;
+                    if (split_of[sn]) t2 += (long long)(nt - 2) * (nt - 1) / 2;
+                    else if (nt < la_min_nt) ++nsmall; else if (alias_parent[sn] < 0) ++nend; else ++nimpure;
+                }
+                fprintf(stderr, "[mi355x_kkt] look-ahead: %d of %d group-end updates split (%lld part-2 tiles); not split: %d small, %d chain ends, %d impure next group\n",
+                        nsplit, nfull, t2, nsmall, nend, nimpure);
+            }
+            la_evA.assign(Sy.num_levels, nullptr); la_evB.assign(Sy.num_levels, nullptr);
+            for (int lv = 0; lv < Sy.num_levels; ++lv) if (la_tiles2[lv] > 0) {
+                HIPCHK(hipEventCreateWithFlags(&la_evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&la_evB[lv], hipEventDisableTiming)); }
+        }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -1453,7 +1529,7 @@ public:
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
             M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
             M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
-            M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn];
+            M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.pad_ = 0;
             if (q < solve_entry.size() && solve_entry[q] && !Sy.solve_group) {     // per-link solves: every front is its own unit
                 M.gbase += M.gpos; M.gpos = 0; M.grem = 0; M.gcols = M.k;
             }
@@ -1546,7 +1622,18 @@ public:
             if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
             else          LAUNCH(KK_BIG_DIAG, k_big_diag_reg<8>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
             LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
-            if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0);
+            const bool single = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_BIG]) && !multi;       // the single-GPU schedule
+            if (single && la_full[lv] && la_pending) {       // a full update may touch what an earlier part 2 is still writing
+                HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false;
+            }
+            if (single && la_tiles2[lv] > 0 && !prof_on) {
+                LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream, V, b0, 1, 0);
+                HIPCHK(hipEventRecord(la_evA[lv], stream));
+                HIPCHK(hipStreamWaitEvent(stream2, la_evA[lv], 0));
+                hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, b0, 2, la_tiles2[lv]);
+                HIPCHK(hipEventRecord(la_evB[lv], stream2));
+                la_last = la_evB[lv]; la_pending = true;
+            } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0, 0, 0);
         }
         return true;
     }
@@ -1570,6 +1657,7 @@ public:
                 launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv]);
             }
         }
+        if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
         LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());

@@ -910,7 +910,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             else { S.cv_off[s] = cvo; cvo += Mf(s); }
         }
         S.cvec_doubles = cvo;
-        // W = L*D panels of the BIG fronts: per-level scratch in 4 banks (level mod 4) so that the panels of a chain group
+        // W = L*D panels of the BIG fronts: per-level scratch in banks (level mod 8) so that the panels of a chain group
         // (<= 4 consecutive levels) are all alive at the group's trailing update; partial sums of the backward dot products
         S.wb_off.assign(nsn, -1); S.gpart_off.assign(nsn, -1);
         vector<int64_t> lvl_used(S.num_levels, 0), lvl_part(S.num_levels, 0);
@@ -919,11 +919,12 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             S.wb_off[s] = lvl_used[lv]; lvl_used[lv] += Mf(s) * K(s);
             S.gpart_off[s] = lvl_part[lv]; lvl_part[lv] += ((Mf(s) - K(s) + 255) / 256 + 1) * (int64_t)gcols[s];
         }
-        int64_t bank[4] = {0, 0, 0, 0};
-        for (int lv = 0; lv < S.num_levels; ++lv) bank[lv & 3] = std::max(bank[lv & 3], lvl_used[lv]);
-        const int64_t bank_base[4] = {0, bank[0], bank[0] + bank[1], bank[0] + bank[1] + bank[2]};
-        for (int s = 0; s < nsn; ++s) if (S.wb_off[s] >= 0) S.wb_off[s] += bank_base[S.sn_level[s] & 3];
-        S.wbuf_doubles = bank[0] + bank[1] + bank[2] + bank[3];
+        // 8 banks: the group after a look-ahead split (numeric.hip) must not overwrite the W panels its predecessor still reads
+        int64_t bank[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bank_base[8];
+        for (int lv = 0; lv < S.num_levels; ++lv) bank[lv & 7] = std::max(bank[lv & 7], lvl_used[lv]);
+        S.wbuf_doubles = 0;
+        for (int b = 0; b < 8; ++b) { bank_base[b] = S.wbuf_doubles; S.wbuf_doubles += bank[b]; }
+        for (int s = 0; s < nsn; ++s) if (S.wb_off[s] >= 0) S.wb_off[s] += bank_base[S.sn_level[s] & 7];
         S.gpart_doubles = 0;
         for (int64_t u : lvl_part) S.gpart_doubles = std::max(S.gpart_doubles, u);
     }

@@ -13,6 +13,12 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 by = collections.defaultdict(list)
 for r in rows:
     by[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in rows)
+ov = 0; cur_end = 0
+for a, b in iv:
+    if a < cur_end: ov += min(b, cur_end) - a
+    cur_end = max(cur_end, b)
+print(f"time with two or more kernels in flight: {ov/1e6:.2f} ms")
 tot = sum(sum(v) for v in by.values())
 print(f"total kernel time {tot/1e3:.1f} ms over {len(rows)} launches")
 for k, v in sorted(by.items(), key=lambda t: -sum(t[1]))[:24]:
