@@ -12,7 +12,9 @@ Workloads (synthetic data of the named shape, inertia known by construction -- t
     lukvle1_1e6   the 10^6-variable target instance (dim 1 999 998)
     grid_1e5      PDE-constrained-like KKT, 160x125 grid, 3 dof + 2 constraints per node (CI-sized sibling of configs[3])
     synth_1e6     BASELINE.json configs[3]: n = 10^6, nnz ~ 2e7 (500x400 grid, 3 dof + 2 constraints per node)
-Default: lukvle1_1e4 at N=1 (the configuration the metric is quoted on), synth_1e6 at N>1 (the multi-GPU config).
+Default: synth_1e6 at every N -- BASELINE.json quotes the GFLOP/s metric on the synthetic n = 10^6 system "at 1, 2, 4 and 8
+GPUs"; it fits one GPU, and the driver's scaling efficiency needs the same workload at every N.  The N=1 line also carries
+the LukVlE1 configurations (configs[1] and the 10^6-variable target) under "also".
 
 Prints ONE JSON line (rank 0).  value = algorithmic GFLOP/s of factor + 2 solves, flop counts as defined
 in SURVEY 8(d): F_fact = sum_j (c_j-1)(c_j+2), F_solve = 4 nnz(L) - 3 n per rhs, for the ordering actually used.
@@ -32,6 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F64_PEAK_TFLOPS = 78.6    # AMD public MI355X spec, fp64 matrix (v_mfma_f64_16x16x4_f64); see DESIGN.md
+MFMA_F64_SUSTAINED_TFLOPS = 47.6   # measured on the box: tools/micro/mfma_f64_peak.hip (back-to-back independent MFMAs, >= 2 waves/SIMD)
 
 
 def make_workload(name):
@@ -71,7 +74,8 @@ def per_kind_work(solver):
     out["big_diag"] = dict(bytes=int((16 * k[big] * k[big]).sum()), flops=int((k[big] ** 3 // 3).sum()))
     out["fwd_wave"] = out["bwd_wave"] = dict(bytes=int(bytes_s[cls == 0].sum()), flops=0)
     out["fwd_lds"] = out["bwd_lds"] = dict(bytes=int(bytes_s[(cls == 1) | (cls == 2)].sum()), flops=0)
-    out["fwd_big"] = out["bwd_big"] = dict(bytes=int(bytes_s[big].sum()), flops=0)
+    out["fwd_big"] = out["bwd_big"] = dict(bytes=int((8 * k[big] * k[big] + 12 * k[big] + 4 * m[big]).sum()), flops=0)          # pivot blocks (stored inverse)
+    out["fwd_big_upd"] = out["bwd_big_dot"] = dict(bytes=int((8 * mu[big] * k[big] + 12 * mu[big]).sum()), flops=0)            # rows below them
     out["gather_scale"] = dict(bytes=int(8 * I.nnz_in + 4 * I.nnz_in + 8 * I.nnz_a * 9), flops=0)
     out["solve_perm"] = dict(bytes=int(2 * 28 * I.n), flops=0)
     out["stats"] = dict(bytes=16 * I.num_sn, flops=0)
@@ -89,9 +93,9 @@ def cpu_baseline(n, r, c, v, b, x_gpu, nsolve):
             path = f.name
         best = None
         ncores = os.cpu_count() or 1
-        for threads in sorted({1, min(16, ncores)}):
+        for threads in sorted({min(16, ncores)} if len(v) > 10_000_000 else {1, min(16, ncores)}):   # (1 thread on the 2e7-entry system alone would take minutes)
             env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads), MKL_DYNAMIC="FALSE")
-            nfac = 4 if n <= 300_000 else 3
+            nfac = 4 if n <= 300_000 else (3 if len(v) <= 10_000_000 else 2)
             try:
                 out = subprocess.run([tool, path, str(nfac), str(nsolve)], capture_output=True, text=True, env=env, timeout=900).stdout
                 j = json.loads(out.strip().splitlines()[-1])
@@ -105,7 +109,7 @@ def cpu_baseline(n, r, c, v, b, x_gpu, nsolve):
             t, threads, j, nfac = best
             return dict(seconds_per_step=t, cores=threads, kind="reference", num_neg=j["num_neg"],
                         sample=f"same KKT system, {nfac - 1} timed factor+{nsolve}-solve steps after one warm-up (symbolic excluded), "
-                               f"reference PardisoMKLSolverInterface on oneMKL PARDISO, best of MKL_NUM_THREADS in {{1,{min(16, ncores)}}}")
+                               f"reference PardisoMKLSolverInterface on oneMKL PARDISO, best of MKL_NUM_THREADS in {{1,{min(16, ncores)}}} (16 only for the 2e7-entry system)")
     # port: the C oracle (scalar, 1 core) on a bounded sample (leading principal sub-band of the workload if it is large)
     from oracle import kkt_oracle as ko
     t0 = time.perf_counter(); ko.factor_solve(n, r, c, v, np.stack([b] * nsolve), u=1e-8); t = time.perf_counter() - t0
@@ -119,6 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("MI355X_KKT_FORCE_MULTI"):
@@ -127,7 +132,7 @@ def main():
 
     import torch
     import ipopt_amd
-    wl = "lukvle1_1e4" if args.workload == "auto" else args.workload
+    wl = "synth_1e6" if args.workload == "auto" else args.workload
     torch.cuda.set_device(0)
     n, r, c, v, neg = make_workload(wl)
     from tests.support import kktgen
@@ -176,12 +181,13 @@ def main():
     w = work.get(dom, dict(bytes=0, flops=0))
     if dom == "big_schur":
         ach = w["flops"] / (dms * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="k_big_schur", achieved=ach, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F64_PEAK_TFLOPS)
+        roof = dict(bound="mfma", kernel="k_big_schur", achieved=ach, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / MFMA_F64_PEAK_TFLOPS,
+                    peak_sustained_measured=MFMA_F64_SUSTAINED_TFLOPS, frac_of_sustained=ach / MFMA_F64_SUSTAINED_TFLOPS)
     else:
         ach = w["bytes"] / (dms * 1e-3) / 1e9
-        kn = {"front_wave": "k_front_reg<64,4>", "front_lds64": "k_front_reg<64,8>", "front_lds128": "k_front_reg<256,8>", "big_diag": "k_big_diag_reg",
+        kn = {"front_wave": "k_front_reg<64,4>", "front_lds64": "k_front_reg<64,8>", "front_lds128": "k_front_reg<256,6|8>", "big_diag": "k_big_diag_reg<4>",
               "fwd_wave": "k_fwd<64,false>", "bwd_wave": "k_bwd<64,false>", "fwd_lds": "k_fwd<*,false>", "bwd_lds": "k_bwd<*,false>",
-              "fwd_big": "k_fwd<256,true>+k_fwd_big_upd", "bwd_big": "k_bwd_big_dot+k_bwd<256,true>"}.get(dom, "k_" + dom)
+              "fwd_big": "k_fwd_grp", "bwd_big": "k_bwd_grp", "fwd_big_upd": "k_fwd_grp_upd", "bwd_big_dot": "k_bwd_grp_dot"}.get(dom, "k_" + dom)
         roof = dict(bound="hbm", kernel=kn, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
     roof.update(launches_per_factor_solve=dlaunch, avg_launch_us=1e3 * dms / max(dlaunch, 1),
                 algorithmic_bytes_per_launch=w["bytes"] / max(dlaunch, 1), algorithmic_flops_per_launch=w["flops"] / max(dlaunch, 1), traffic=None)
@@ -190,7 +196,7 @@ def main():
         try:
             tj = json.load(open(tfile))
             if tj.get("workload") == wl and tj.get("kernel") == roof["kernel"]:
-                roof["traffic"] = tj["hbm_bytes_per_launch"]
+                roof["traffic"] = tj["hbm_bytes_per_factorisation"] / max(dlaunch, 1)     # per launch, like `achieved`
         except Exception:
             pass
     kernel_ms = {kname: round(ms * weight[kname], 4) for kname, (ms, _) in per_rep.items()}
@@ -208,6 +214,37 @@ def main():
         "analyse_s": I.time_analyse,
         "roofline": roof,
     }
+    if args.workload == "auto" and not args.no_also:
+        # the other single-GPU configurations (same step definition, GPU only); the default line stays on the metric's config
+        also = {}
+        del s, dv, db, dx
+        for w2 in ("lukvle1_1e4", "lukvle1_1e6"):
+            try:
+                n2, r2, c2, v2, neg2 = make_workload(w2)
+                s2 = ipopt_amd.KKTSolver(device=0); s2.initialize_structure(n2, r2, c2, vals=v2)
+                K2 = kktgen.to_scipy(n2, r2, c2, v2); b2 = K2 @ np.ones(n2)
+                dv2 = torch.tensor(v2, dtype=torch.float64, device="cuda"); db2 = torch.tensor(b2, dtype=torch.float64, device="cuda"); dx2 = torch.empty_like(db2)
+                torch.cuda.synchronize()
+                def step2():
+                    st_ = s2.factor_device(dv2.data_ptr())
+                    for _ in range(NSOLVE):
+                        s2.solve_device2(db2.data_ptr(), dx2.data_ptr())
+                    return st_
+                for _ in range(3):
+                    st2 = step2()
+                torch.cuda.synchronize(); t1 = time.perf_counter()
+                for _ in range(20):
+                    step2()
+                torch.cuda.synchronize(); dt2 = (time.perf_counter() - t1) / 20
+                x2 = dx2.cpu().numpy(); I2 = s2.info()
+                res2 = float(np.abs(K2 @ x2 - b2).max() / (abs(K2).sum(axis=1).max() * np.abs(x2).max() + np.abs(b2).max()))
+                also[w2] = {"kkt_dim": n2, "ms_per_step": dt2 * 1e3, "GFLOP/s": (I2.flops_factor + NSOLVE * I2.flops_solve) / dt2 / 1e9,
+                            "algorithmic_GBps": (I2.bytes_factor + NSOLVE * I2.bytes_solve) / dt2 / 1e9, "num_neg_ok": bool(st2[0] == 0 and st2[1] == neg2),
+                            "scaled_residual": res2, "device_ms": {"factor": I2.time_factor_ms, "solve": I2.time_solve_ms}}
+                del s2, dv2, db2, dx2
+            except Exception as e:      # never lose the main line over the extras
+                also[w2] = {"error": str(e)[:200]}
+        line["also"] = also
     if not args.no_cpu_baseline:
         cb = cpu_baseline(n, r, c, v, b, x, NSOLVE)
         line["cpu_baseline"] = {"value": flops_step / cb["seconds_per_step"] / 1e9, "unit": "GFLOP/s", "cores": cb["cores"], "kind": cb["kind"],

@@ -27,6 +27,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <map>
 #include <string>
 #include <algorithm>
 #include "numeric.h"
@@ -51,7 +52,7 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
 struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt;
-                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, pad_; };
+                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, pad_; };
 struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase; };
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
 struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
@@ -60,13 +61,14 @@ struct DevView {
     // symbolic
     const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
     const int* child_ptr; const int* child_idx; const int* sn_owner; const int* sn_parent; const int* col_owner;
-    const long long* panel_off; const long long* cb_off; const long long* wb_off; const long long* minv_off;
+    const long long* panel_off; const long long* cb_off; const long long* minv_off;
     const int* acolptr; const int* apos; const int* arow; const int* acol;
     const int* dup_ptr; const int* dup_src;
     const int* rslot_ptr; const int* rslot_idx; const int* rslot_col; int rslot_len;
     const int* level_sn;
     const FrontMeta* fmeta;   // parallel to level_sn
     const GroupLink* gtab;    // links of the chain groups (FrontMeta::gbase .. gbase + gpos)
+    const int* tile_tab;      // XCD-aware tile orders of the large trailing updates ((ti << 16) | tc), see k_big_schur
     const ChildMeta* cmeta;   // parallel to child_idx
     const int* perm;
     // numeric
@@ -590,9 +592,8 @@ __global__ void k_refine_finish(DevView V) { for (int i = blockIdx.x * blockDim.
 
 // forward: y = L11^{-1} P b for the pivot rows (a k x k mat-vec with the stored inverse: no substitution chain),
 // z = D^{-1} y, and the contribution  c = (children) - L21 y  for the ancestors is left in cvec (the parent
-// gathers it: no atomics, deterministic).  One workgroup per front; works for every front size (accumulators
-// of the update rows live in cvec / global when the front is too large for LDS).
-template <int NT, bool BIG>
+// gathers it: no atomics, deterministic).  One workgroup per front of order <= 128 (BIG fronts: k_fwd_grp).
+template <int NT>
 __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -604,12 +605,11 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
     double* bp = ys + k;                                // k   pivot rows in pivot order
     double* xu = bp + k;                                // m-k update-row accumulators (LDS classes only)
     for (int i = tid; i < k; i += NT) xp[i] = V.xw[c0 + i];
-    if (BIG) { for (int i = k + tid; i < m; i += NT) V.cvec[M.cv + i] = 0.0; }
-    else     { for (int i = k + tid; i < m; i += NT) xu[i - k] = 0.0; }
+    for (int i = k + tid; i < m; i += NT) xu[i - k] = 0.0;
     if (top_mode && V.top_rhs) {
         const double* tr = V.top_rhs + V.top_rhs_off[s];
         __syncthreads();
-        for (int i = tid; i < m; i += NT) { if (i < k) xp[i] += tr[i]; else if (BIG) V.cvec[M.cv + i] += tr[i]; else xu[i - k] += tr[i]; }
+        for (int i = tid; i < m; i += NT) { if (i < k) xp[i] += tr[i]; else xu[i - k] += tr[i]; }
     }
     __syncthreads();
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         const int base = Cm.relbase, mc = Cm.mc;
         for (int t = tid; t < mc; t += NT) {
             const int tg = V.rel[base + t]; const double v = V.cvec[Cm.cvbase + t];
-            if (tg < k) xp[tg] += v; else if (BIG) V.cvec[M.cv + tg] += v; else xu[tg - k] += v;
+            if (tg < k) xp[tg] += v; else xu[tg - k] += v;
         }
         __syncthreads();
     }
@@ -635,9 +635,7 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         ys[j] = a0 + a1;
     }
     __syncthreads();
-    if (BIG) {
-        for (int j = tid; j < k; j += NT) V.ybuf[c0 + j] = ys[j];      // update rows: k_fwd_big_upd, many workgroups per front
-    } else {
+    {
         const double* Lg = V.L + M.panel_off;
         for (int i = k + tid; i < m; i += NT) {
             double t0 = 0.0, t1 = 0.0;
@@ -658,7 +656,7 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
 }
 
 // backward: x_piv = P^T L11^{-T} ( z - L21^T x_upd ), written un-permuted
-template <int NT, bool BIG>
+template <int NT>
 __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -668,15 +666,10 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     double* ws = reinterpret_cast<double*>(smem_raw);   // k
     double* xu = ws + k;                                // m-k gathered ancestor values (LDS classes)
-    if (!BIG) { for (int i = k + tid; i < m; i += NT) xu[i - k] = V.xw[V.sn_rows[r0 + i]]; }
+    for (int i = k + tid; i < m; i += NT) xu[i - k] = V.xw[V.sn_rows[r0 + i]];
     for (int j = tid; j < k; j += NT) ws[j] = V.xw[c0 + j];
     __syncthreads();
-    if (BIG) {
-        // L21^T x_upd was formed by k_bwd_big_dot in row chunks of 256: add the partial sums in fixed order
-        const int nch = (m - k + 255) / 256;
-        const double* part = V.wbuf + V.wb_off[s];
-        for (int j = tid; j < k; j += NT) { double t = 0.0; for (int c = 0; c < nch; ++c) t += part[(size_t)c * k + j]; ws[j] -= t; }
-    } else {
+    {
         const double* Lg = V.L + M.panel_off;
         for (int j = wave; j < k; j += NW) {
             double t = 0.0;
@@ -922,50 +915,6 @@ __global__ __launch_bounds__(256) void k_bwd_grp(DevView V, int list_off)
     }
 }
 
-// big fronts, forward part 2: c(i) -= sum_j L21(i,j) y_j, one thread per update row, 256 rows per workgroup
-__global__ __launch_bounds__(256) void k_fwd_big_upd(DevView V, int list_off)
-{
-    __shared__ double ys[136];
-    const int tid = threadIdx.x;
-    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
-    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
-    if (k + blockIdx.x * 256 >= m) return;
-    if (tid < k) ys[tid] = V.ybuf[c0 + tid];
-    __syncthreads();
-    const int i = k + blockIdx.x * 256 + tid;
-    if (i >= m) return;
-    const double* Lg = V.L + M.panel_off + i;
-    double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-    int j = 0;
-    for (; j + 3 < k; j += 4) {
-        t0 += Lg[(size_t)j * M.ldp] * ys[j]; t1 += Lg[(size_t)(j + 1) * M.ldp] * ys[j + 1];
-        t2 += Lg[(size_t)(j + 2) * M.ldp] * ys[j + 2]; t3 += Lg[(size_t)(j + 3) * M.ldp] * ys[j + 3];
-    }
-    for (; j < k; ++j) t0 += Lg[(size_t)j * M.ldp] * ys[j];
-    V.cvec[M.cv + i] -= (t0 + t1) + (t2 + t3);
-}
-// big fronts, backward part 1: partial(chunk, j) = sum_{i in chunk} L21(i,j) x(rows(i)), 256 rows per workgroup
-__global__ __launch_bounds__(256) void k_bwd_big_dot(DevView V, int list_off)
-{
-    __shared__ double xs[256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
-    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
-    const int ibase = k + blockIdx.x * 256;
-    if (ibase >= m) return;
-    const int nrow = min(256, m - ibase);
-    xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[r0 + ibase + tid]] : 0.0;
-    __syncthreads();
-    const double* Lg = V.L + M.panel_off + ibase;
-    double* part = V.wbuf + V.wb_off[s] + (size_t)blockIdx.x * k;
-    for (int j = wave; j < k; j += 4) {
-        double t = 0.0;
-        for (int i = lane; i < nrow; i += 64) t += Lg[i + (size_t)j * M.ldp] * xs[i];
-        t = wave_sum(t);
-        if (lane == 0) part[j] = t;
-    }
-}
-
 // ================================================================================================
 // BIG fronts (order > 128): the front stays in HBM/L2 -- panel (m x k, k <= 66) in the L storage, the
 // (m-k)^2 contribution block in the cb arena -- and is processed by four launches per tree level:
@@ -1123,11 +1072,25 @@ __device__ __forceinline__ void schur_tile(const DevView& V, const FrontMeta& M,
         climit = mu; j0 = 0;
     } else {
         const int n2 = sp ? nt - 2 : nt, sh = sp ? 2 : 0;
-        if (t >= n2 * (n2 + 1) / 2) return;
-        ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while (ti * (ti + 1) / 2 > t) --ti;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        tc = t - ti * (ti + 1) / 2; climit = mu; j0 = 0;
+        const int ntri = n2 * (n2 + 1) / 2;
+        const int tab = sp ? M.ttab2 : M.ttab;
+        if (tab >= 0) {
+            // large update: workgroups are dealt to the 8 XCDs round-robin (linear id mod 8), so XCD x walks the x-th
+            // contiguous eighth of a super-tile ordered list (8 x 8 tile blocks): the ~64 tiles in flight on one XCD share
+            // 16 panel row blocks, which its 4 MB L2 holds, instead of streaming the whole panel from the fabric per tile
+            const int chunk = (ntri + 7) >> 3;
+            const int pos = (t & 7) * chunk + (t >> 3);
+            if ((t >> 3) >= chunk || pos >= ntri) return;
+            const int e = V.tile_tab[tab + pos];
+            ti = e >> 16; tc = e & 0xffff;
+        } else {
+            if (t >= ntri) return;
+            ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+            while (ti * (ti + 1) / 2 > t) --ti;
+            while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+            tc = t - ti * (ti + 1) / 2;
+        }
+        climit = mu; j0 = 0;
         ti += sh; tc += sh;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1381,7 +1344,7 @@ public:
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
-        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), woff(Sy.wb_off.begin(), Sy.wb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
+        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
         std::vector<int> lvl_list(Sy.level_sn);
         std::vector<char> solve_entry;      // parallel to lvl_list: 1 = entry of a solve-unit list
@@ -1499,8 +1462,8 @@ public:
                     if (Sy.grp_rem[p] == 0) break;
                 }
                 split_of[sn] = ok ? 1 : 0;
-                la_tiles1[lv] = std::max(la_tiles1[lv], ok ? 2 * nt - 1 : nt * (nt + 1) / 2);
-                if (ok) la_tiles2[lv] = std::max(la_tiles2[lv], (nt - 2) * (nt - 1) / 2);
+                la_tiles1[lv] = std::max(la_tiles1[lv], ok ? 2 * nt - 1 : tri_tiles(nt));
+                if (ok) la_tiles2[lv] = std::max(la_tiles2[lv], ((nt - 2) * (nt - 1) / 2 + 7) / 8 * 8);
             }
             for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] != 0)
                 la_tiles1[Sy.sn_level[sn]] = std::max(la_tiles1[Sy.sn_level[sn]], schur_tiles(Sy, sn));
@@ -1520,6 +1483,31 @@ public:
             for (int lv = 0; lv < Sy.num_levels; ++lv) if (la_tiles2[lv] > 0) {
                 HIPCHK(hipEventCreateWithFlags(&la_evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&la_evB[lv], hipEventDisableTiming)); }
         }
+        // XCD-aware tile orders for the large (>= 12 tile rows) full updates, one table per triangle size
+        std::vector<int> ttab_of(Sy.num_sn, -1), ttab2_of(Sy.num_sn, -1), tile_tab;
+        {
+            std::map<int, int> tab_at;
+            auto table_for = [&](int n) {
+                auto it = tab_at.find(n);
+                if (it != tab_at.end()) return it->second;
+                const int at = (int)tile_tab.size(), S8 = 8, nst = (n + S8 - 1) / S8;
+                for (int I = 0; I < nst; ++I) for (int J = 0; J <= I; ++J)
+                    for (int a = 0; a < S8; ++a) for (int b = 0; b < S8; ++b) {
+                        const int ti = I * S8 + a, tc = J * S8 + b;
+                        if (ti < n && tc <= ti) tile_tab.push_back((ti << 16) | tc);
+                    }
+                tab_at[n] = at; return at;
+            };
+            const bool xcd_aware = getenv("MI355X_KKT_NO_XCD_TILES") == nullptr;
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (xcd_aware && Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
+                const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+                const int nt = (mu + 127) / 128;
+                if (nt < 12) continue;
+                ttab_of[sn] = table_for(nt);
+                if (split_of[sn]) ttab2_of[sn] = table_for(nt - 2);
+            }
+        }
+        if (!upload(tile_tab, &V.tile_tab)) return false;
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -1529,7 +1517,7 @@ public:
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
             M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
             M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
-            M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.pad_ = 0;
+            M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.ttab = ttab_of[sn]; M.ttab2 = ttab2_of[sn]; M.pad_ = 0;
             if (q < solve_entry.size() && solve_entry[q] && !Sy.solve_group) {     // per-link solves: every front is its own unit
                 M.gbase += M.gpos; M.gpos = 0; M.grem = 0; M.gcols = M.k;
             }
@@ -1545,7 +1533,7 @@ public:
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
-            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(woff, &V.wb_off) || !upload(moff, &V.minv_off) ||
+            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(moff, &V.minv_off) ||
             !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
             !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.rslot_ptr, &V.rslot_ptr) || !upload(Sy.rslot_idx, &V.rslot_idx) || !upload(Sy.rslot_col, &V.rslot_col) || !upload(lvl_list, &V.level_sn) ||
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
@@ -1593,12 +1581,13 @@ public:
         ready = true; return true;
     }
 
+    static int tri_tiles(int nt) { const int t = nt * (nt + 1) / 2; return nt >= 12 ? (t + 7) / 8 * 8 : t; }    // large ones: multiple of 8 (XCD-aware order)
     // 128x128 tiles of the trailing update of front s: the whole lower triangle, or (not the last link of a chain group) only
     // the tile columns of the group's remaining panels
     static int schur_tiles(const Symbolic& Sy, int s) {
         const int mu = (Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]) - (Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
         const int nt = (mu + 127) / 128;
-        return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 127) / 128) : nt * (nt + 1) / 2;
+        return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 127) / 128) : tri_tiles(nt);
     }
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
@@ -1718,9 +1707,9 @@ public:
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
-                    if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
-                    else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
-                    else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
+                    if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
+                    else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
+                    else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
                     else if (big_last1[lv] > big_last0[lv]) {
                            const int g0 = big_last0[lv], ng = big_last1[lv] - g0;
                            LAUNCH(KK_FWD_BIG, k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, 0);
@@ -1730,9 +1719,9 @@ public:
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
-                    if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
-                    else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
-                    else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
+                    if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                    else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
+                    else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
                     else if (big_last1[lv] > big_last0[lv]) {
                            const int g0 = big_last0[lv], ng = big_last1[lv] - g0;
                            LAUNCH(KK_BWD_BIG_DOT, k_bwd_grp_dot, dim3((big_maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
@@ -1794,17 +1783,17 @@ public:
                 const int b0 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc], b1 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
                 if (forward) {
-                    if (fc == FC_WAVE)        hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, top_mode);
-                    else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_fwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, top_mode);
-                    else if (fc == FC_LDS128) hipLaunchKernelGGL((k_fwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, top_mode);
+                    if (fc == FC_WAVE)        hipLaunchKernelGGL((k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, top_mode);
+                    else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, top_mode);
+                    else if (fc == FC_LDS128) hipLaunchKernelGGL((k_fwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, top_mode);
                     else if (sc.last1[lv] > sc.last0[lv]) {
                            const int g0 = sc.last0[lv], ng = sc.last1[lv] - g0;
                            hipLaunchKernelGGL(k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, top_mode);
                            hipLaunchKernelGGL(k_fwd_grp_upd, dim3((sc.maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); }
                 } else {
-                    if (fc == FC_WAVE)        hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
-                    else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_bwd<64, false>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
-                    else if (fc == FC_LDS128) hipLaunchKernelGGL((k_bwd<256, false>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
+                    if (fc == FC_WAVE)        hipLaunchKernelGGL((k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                    else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
+                    else if (fc == FC_LDS128) hipLaunchKernelGGL((k_bwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
                     else if (sc.last1[lv] > sc.last0[lv]) {
                            const int g0 = sc.last0[lv], ng = sc.last1[lv] - g0;
                            hipLaunchKernelGGL(k_bwd_grp_dot, dim3((sc.maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
