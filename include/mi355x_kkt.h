@@ -154,7 +154,9 @@ const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
  *       9 trip2slot[nnz_in] (triplet -> permuted CSC slot), 10 pair_of[n] (old index of the 2x2 partner or -1),
  *       11 sn_owner[num_sn] (multi-GPU rank owning the supernode, -1 = replicated top),
  *       12 apos[nnz_a] (row + col*m position of each permuted-CSC slot inside its supernode panel),
- *       13 level_ptr[num_levels*4+1], 14 level_sn[num_sn] (launch schedule: buckets (level, front class)) */
+ *       13 level_ptr[num_levels*4+1], 14 level_sn[num_sn] (launch schedule: buckets (level, front class)),
+ *       15 grp_pos[num_sn], 16 grp_rem[num_sn] (chain groups: position in the group, columns of the later links),
+ *       17 alias_child[num_sn] (in-place chains: the child whose contribution block hosts this front, or -1) */
 int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t capacity);
 
 /* ---- measurement: device time per kernel kind (hip events on the solver's stream around every launch of an

@@ -169,6 +169,7 @@ int mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t cap
         case 6: v = &S.rel; break;         case 7: v = &S.acolptr; break;    case 8: v = &S.arow; break;
         case 9: v = &S.trip2slot; break;   case 10: v = &S.pair_of; break;   case 11: v = &S.sn_owner; break;
         case 12: v = &S.apos; break;       case 13: v = &S.level_ptr; break; case 14: v = &S.level_sn; break;
+        case 15: v = &S.grp_pos; break;    case 16: v = &S.grp_rem; break;   case 17: v = &S.alias_child; break;
         default: h->err = "get_symbolic: unknown selector"; return MI355X_KKT_FATAL;
     }
     if ((int64_t)v->size() > cap) { h->err = "get_symbolic: buffer too small"; return MI355X_KKT_FATAL; }

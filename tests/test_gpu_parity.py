@@ -187,8 +187,9 @@ def test_internal_refinement_improves_an_ill_conditioned_solve():
     assert sres(K, x2, b) <= RES_TOL and e2 <= max(e0, 1e-12)
 
 
-@pytest.mark.parametrize("opts", [dict(wide_panels=1), dict(tree_merge=1), dict(leaf_cols=32), dict(ordering=1), dict(scaling=0), dict(use_graph=0)],
-                         ids=["wide_panels", "tree_merge", "leaf_cols", "md_ordering", "no_scaling", "no_graph"])
+@pytest.mark.parametrize("opts", [dict(wide_panels=1), dict(tree_merge=1), dict(leaf_cols=32), dict(ordering=1), dict(scaling=0), dict(use_graph=0),
+                          dict(solve_group=1), dict(chain_group=1), dict(chain_group=2, solve_group=1)],
+                         ids=["wide_panels", "tree_merge", "leaf_cols", "md_ordering", "no_scaling", "no_graph", "solve_group", "no_chain_group", "chain_group2"])
 def test_optional_code_paths_stay_exact(opts):
     """every non-default analysis / kernel option must give the same inertia and a converged solve"""
     n, r, c, v, neg = kktgen.grid_kkt(48, 44, dof=3, ncon=2, seed=23)      # separator fronts > 512 rows: 128-column panels kick in

@@ -119,3 +119,36 @@ def test_multigpu_ownership_is_a_subtree_partition(nranks):
         elif p >= 0:
             assert own[p] in (own[sn], -1)          # a subtree never crosses ranks
     assert len(set(own[own >= 0].tolist())) == nranks
+
+
+def test_chain_groups_are_consistent():
+    """in-place chains and chain groups (numeric.hip relies on these invariants): an in-place front has exactly its chain
+    child's update rows; a group is <= 4 consecutive links on consecutive levels with <= 256 columns; grp_rem = columns
+    of the later links of the group"""
+    n, r, c, v, neg = kktgen.grid_kkt(40, 36, dof=3, ncon=2, seed=5)
+    s = ipopt_amd.KKTSolver(device=-1)
+    s.initialize_structure(n, r, c, vals=v)
+    I = s.info(); nsn = I.num_sn
+    cp, rp = s.symbolic(1, nsn + 1), s.symbolic(2, nsn + 1)
+    rows, par, lev = s.symbolic(3, rp[-1]), s.symbolic(4, nsn), s.symbolic(5, nsn)
+    gpos, grem, alias = s.symbolic(15, nsn), s.symbolic(16, nsn), s.symbolic(17, nsn)
+    k, m = np.diff(cp), np.diff(rp)
+    assert (alias >= 0).sum() > 0 and gpos.max() >= 1, "the test matrix must produce separator chains"
+    nxt = {}
+    for p in range(nsn):
+        ch = alias[p]
+        if ch < 0:
+            assert gpos[p] == 0
+            continue
+        assert par[ch] == p and m[p] > 128 and m[ch] > 128
+        assert np.array_equal(rows[rp[ch] + k[ch]:rp[ch + 1]], rows[rp[p]:rp[p + 1]])       # the front IS the child's update block
+        if gpos[p] > 0:
+            assert gpos[p] == gpos[ch] + 1 and lev[p] == lev[ch] + 1
+            nxt[ch] = p
+    for sn in range(nsn):
+        if gpos[sn] == 0:                    # walk the group from its head
+            cols, cur, links = k[sn], sn, 1
+            while cur in nxt:
+                assert grem[cur] == grem[nxt[cur]] + k[nxt[cur]]
+                cur = nxt[cur]; cols += k[cur]; links += 1
+            assert grem[cur] == 0 and links <= 4 and cols <= 256
