@@ -1267,7 +1267,7 @@ public:
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
     std::vector<int> la_tiles1, la_tiles2; std::vector<char> la_full;     // la_full: the level has a full (group-last) update
     std::vector<hipEvent_t> la_evA, la_evB;
-    hipStream_t stream2 = nullptr; bool la_pending = false; hipEvent_t la_last = nullptr; bool lookahead = true; int la_wgs = 1 << 20, la_min_nt = 12;
+    hipStream_t stream2 = nullptr; bool la_pending = false; hipEvent_t la_last = nullptr; bool lookahead = true, la_any = false; int la_wgs = 1 << 20, la_min_nt = 12;
     std::vector<size_t> reg_lds;
     std::vector<int> mid_split; std::vector<size_t> mid_lds;   // per level: leading FC_LDS128 fronts of order <= 96 (6x6-tile kernel, 2 workgroups per CU) and their LDS need
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
@@ -1479,6 +1479,8 @@ public:
                 fprintf(stderr, "[mi355x_kkt] look-ahead: %d of %d group-end updates split (%lld part-2 tiles); not split: %d small, %d chain ends, %d impure next group\n",
                         nsplit, nfull, t2, nsmall, nend, nimpure);
             }
+            la_any = false;
+            for (int lv = 0; lv < Sy.num_levels; ++lv) if (la_tiles2[lv] > 0) la_any = true;
             la_evA.assign(Sy.num_levels, nullptr); la_evB.assign(Sy.num_levels, nullptr);
             for (int lv = 0; lv < Sy.num_levels; ++lv) if (la_tiles2[lv] > 0) {
                 HIPCHK(hipEventCreateWithFlags(&la_evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&la_evB[lv], hipEventDisableTiming)); }
@@ -1663,7 +1665,10 @@ public:
             have_values = true;
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
         HIPCHK(hipEventRecord(ev0, stream));
-        if (opt.use_graph) {
+        // A factorisation with look-ahead forks onto the second stream: it is launched eagerly (measured equal to the graph
+        // replay on these ~10^3-launch sequences, whose kernels are long), because a two-stream hipGraph replays up to 1.5x
+        // slower once another solver's graphs have been created and destroyed in the same process (ROCm 7.2).
+        if (opt.use_graph && !la_any) {
             if (!g_factor || graph_pivtol != V.pivtol) {
                 if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
                 hipGraph_t g = nullptr;
