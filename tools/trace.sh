@@ -20,14 +20,18 @@ for a, b in iv:
     cur_end = max(cur_end, b)
 print(f"time with two or more kernels in flight: {ov/1e6:.2f} ms")
 import os
-focus = os.environ.get("FOCUS", "k_big_assemble")
-fr = [r for r in rows if focus in r["Kernel_Name"]]
-fr.sort(key=lambda r: int(r["Start_Timestamp"]))
-nper = len(fr) // 7 if len(fr) >= 7 else len(fr)            # 7 factorisations in tools/tune2.py
-print(f"-- {focus}: launches of the LAST factorisation, in order (duration us, grid x/y/z in threads)")
-for i, r in enumerate(fr[-nper:]):
-    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    if d > 60: print(f"   #{i:3d} {d:8.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size'))} x {r.get('Grid_Size_Y', '')} x {r.get('Grid_Size_Z', '')}  wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size'))}")
+for focus in os.environ.get("FOCUS", "k_big_assemble").split(","):
+  fr = [r for r in rows if focus in r["Kernel_Name"]]
+  if True:
+    fr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    nper = len(fr) // 7 if len(fr) >= 7 else len(fr)            # 7 factorisations in tools/tune2.py
+    print(f"-- {focus}: first 14 launches of the LAST factorisation (duration us, grid x/y/z in threads), then sum of the rest")
+    rest = 0.0
+    for i, r in enumerate(fr[-nper:]):
+      d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+      if i >= 14: rest += d
+      else: print(f"   #{i:3d} {d:8.1f} us  grid {r.get('Grid_Size_X', r.get('Grid_Size'))} x {r.get('Grid_Size_Y', '')} x {r.get('Grid_Size_Z', '')}  wg {r.get('Workgroup_Size_X', r.get('Workgroup_Size'))}")
+    print(f"   rest: {rest/1e3:.2f} ms")
 tot = sum(sum(v) for v in by.values())
 print(f"total kernel time {tot/1e3:.1f} ms over {len(rows)} launches")
 for k, v in sorted(by.items(), key=lambda t: -sum(t[1]))[:24]:
