@@ -1185,6 +1185,79 @@ __global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off, int
 }
 
 
+// Small-front variant of the trailing update (levels whose largest front has <= 640 rows: thousands of fronts, a handful
+// of tiles each): 64 x 64 tile per 256-thread workgroup, 32 x 32 per wavefront, operands straight from L2.  The 128 x 128
+// LDS-staged kernel above leaves most of its 16 wavefronts idle on such fronts (PMC: 7.6 % MFMA utilisation).
+__global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off)
+{
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int k = M.k, m = M.m;
+    const int mu = m - k;
+    const int nt = (mu + 63) >> 6;
+    const int t = blockIdx.x;
+    int ti, tc, climit, j0;
+    if (M.grem > 0) {
+        const int ntc = (M.grem + 63) >> 6;
+        if (t >= nt * ntc) return;
+        ti = t / ntc; tc = t - ti * ntc; climit = M.grem; j0 = M.gpos;
+    } else {
+        if (t >= nt * (nt + 1) / 2) return;
+        ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > t) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        tc = t - ti * (ti + 1) / 2; climit = mu; j0 = 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
+    if (i0 + 31 < cc0 || cc0 >= climit || i0 >= mu) return;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[r][q] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int ca = cc0 + l15, cb_ = cc0 + 16 + l15, ia = i0 + l15, ib = i0 + 16 + l15;
+    for (int j = j0; j <= M.gpos; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        const int kj = G.k;
+        const double* Lp = V.L + G.panel_off + (G.m - mu);
+        const double* Wp = V.wbuf + G.wb + (G.m - mu);
+        for (int p = 0; p < kj; p += 4) {
+            const int pk = p + l4;
+            const bool v = pk < kj;
+            const size_t off = (size_t)pk * G.m, offp = (size_t)pk * G.ldp;
+            const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
+            const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
+            const double b0 = (v && ia < mu) ? Lp[ia + offp] : 0.0;
+            const double b1 = (v && ib < mu) ? Lp[ib + offp] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    double* T = V.cb + M.cb_off;
+    double tv[2][2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
+                tv[r][q][g] = (i < mu && c < climit && i >= c) ? T[i + (size_t)c * M.ldt] : 0.0;
+            }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
+                if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] = tv[r][q][g] - acc[r][q][g];
+            }
+}
+
 // ================================================================================================
 // multi-GPU pieces (one process per GPU, subtrees sharded, top of the tree replicated)
 // ================================================================================================
@@ -1263,7 +1336,8 @@ public:
     double* d_rhs = nullptr; size_t d_rhs_cap = 0;
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
-    std::vector<int> big_maxm, big_maxk, big_tiles, big_last0, big_last1;
+    std::vector<int> big_maxm, big_maxk, big_tiles, big_tiles64, big_last0, big_last1;
+    std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
     std::vector<int> la_tiles1, la_tiles2; std::vector<char> la_full;     // la_full: the level has a full (group-last) update
     std::vector<hipEvent_t> la_evA, la_evB;
@@ -1273,7 +1347,7 @@ public:
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
-    struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk, tiles, last0, last1; };   // last0/1: per level, the group-last BIG fronts (solve units)
+    struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk, tiles, tiles64, last0, last1; };   // last0/1: per level, the group-last BIG fronts (solve units)
     Sched sch_local, sch_top;
     int top_list_base = 0, top_count = 0, top_maxm = 0;      // all replicated fronts (top-rhs assembly)
     int join_list_base = 0, join_count = 0, join_maxm = 0;   // replicated fronts with a rank-owned child (arena squares)
@@ -1353,7 +1427,7 @@ public:
         if (multi) {
             auto build = [&](Sched& sc, bool top) {
                 sc.ptr.assign((size_t)Sy.num_levels * FC_COUNT + 1, 0); sc.base = (int)lvl_list.size();
-                sc.maxm.assign(Sy.num_levels, 0); sc.maxk.assign(Sy.num_levels, 0); sc.tiles.assign(Sy.num_levels, 0);
+                sc.maxm.assign(Sy.num_levels, 0); sc.maxk.assign(Sy.num_levels, 0); sc.tiles.assign(Sy.num_levels, 0); sc.tiles64.assign(Sy.num_levels, 0);
                 std::vector<std::vector<int>> bucket((size_t)Sy.num_levels * FC_COUNT);
                 for (int s = 0; s < Sy.num_sn; ++s) {
                     const bool mine = top ? (Sy.sn_owner[s] < 0) : (Sy.sn_owner[s] == opt.rank);
@@ -1361,7 +1435,8 @@ public:
                     bucket[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]].push_back(s);
                     if (Sy.sn_class[s] == FC_BIG) { sc.maxm[Sy.sn_level[s]] = std::max(sc.maxm[Sy.sn_level[s]], Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]);
                                                     sc.maxk[Sy.sn_level[s]] = std::max(sc.maxk[Sy.sn_level[s]], Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
-                                                    sc.tiles[Sy.sn_level[s]] = std::max(sc.tiles[Sy.sn_level[s]], schur_tiles(Sy, s)); }
+                                                    sc.tiles[Sy.sn_level[s]] = std::max(sc.tiles[Sy.sn_level[s]], schur_tiles(Sy, s));
+                                                    sc.tiles64[Sy.sn_level[s]] = std::max(sc.tiles64[Sy.sn_level[s]], schur_tiles64(Sy, s)); }
                 }
                 for (size_t b = 0; b < bucket.size(); ++b) { sc.ptr[b + 1] = sc.ptr[b] + (int)bucket[b].size(); lvl_list.insert(lvl_list.end(), bucket[b].begin(), bucket[b].end()); }
                 sc.last0.assign(Sy.num_levels, 0); sc.last1.assign(Sy.num_levels, 0);
@@ -1416,6 +1491,24 @@ public:
                 ++q;
             }
             mid_split[lv] = (q - b0 >= 256) ? q - b0 : 0;
+        }
+        // (level, FC_BIG) buckets of the single-GPU schedule: sorted by order and split at 1024 rows.  The two halves are
+        // launched separately: tighter rectangular grids on heterogeneous levels, and the small fronts (a handful of tiles,
+        // K = 16..64) take the 256-thread 64 x 64 trailing-update kernel while the large ones take the 1024-thread one.
+        big_split.assign(Sy.num_levels, 0);
+        for (int h = 0; h < 2; ++h) { part_mm[h].assign(Sy.num_levels, 0); part_kk[h].assign(Sy.num_levels, 0); part_tiles[h].assign(Sy.num_levels, 0); }
+        for (int lv = 0; lv < Sy.num_levels; ++lv) {
+            const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1];
+            auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
+            std::stable_sort(lvl_list.begin() + b0, lvl_list.begin() + b1, [&](int a, int b) { return order_of(a) < order_of(b); });
+            int q = b0; while (q < b1 && order_of(lvl_list[q]) <= 1024) ++q;
+            big_split[lv] = q - b0;
+            for (int e = b0; e < b1; ++e) {
+                const int sn = lvl_list[e], h = e < q ? 0 : 1;
+                part_mm[h][lv] = std::max(part_mm[h][lv], order_of(sn));
+                part_kk[h][lv] = std::max(part_kk[h][lv], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+                part_tiles[h][lv] = std::max(part_tiles[h][lv], h == 0 ? schur_tiles64(Sy, sn) : schur_tiles(Sy, sn));
+            }
         }
         // single-GPU schedule: per level the group-last BIG fronts (the units of the triangular solves)
         big_last0.assign(Sy.num_levels, 0); big_last1.assign(Sy.num_levels, 0);
@@ -1573,16 +1666,22 @@ public:
         }
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
-        big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0);
+        big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
             const int lv = Sy.sn_level[s];
             big_maxm[lv] = std::max(big_maxm[lv], Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]);
             big_maxk[lv] = std::max(big_maxk[lv], Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
             big_tiles[lv] = std::max(big_tiles[lv], schur_tiles(Sy, s));
+            big_tiles64[lv] = std::max(big_tiles64[lv], schur_tiles64(Sy, s));
         }
         ready = true; return true;
     }
 
+    static int schur_tiles64(const Symbolic& Sy, int s) {
+        const int mu = (Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]) - (Sy.sn_colptr[s + 1] - Sy.sn_colptr[s]);
+        const int nt = (mu + 63) / 64;
+        return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 63) / 64) : nt * (nt + 1) / 2;
+    }
     static int tri_tiles(int nt) { const int t = nt * (nt + 1) / 2; return nt >= 12 ? (t + 7) / 8 * 8 : t; }    // large ones: multiple of 8 (XCD-aware order)
     // 128x128 tiles of the trailing update of front s: the whole lower triangle, or (not the last link of a chain group) only
     // the tile columns of the group's remaining panels
@@ -1595,7 +1694,7 @@ public:
 
 
     // one (level, class) bucket of fronts
-    bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk, int tiles) {
+    bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk, int tiles, int tiles64) {
         const int nb = b1 - b0;
         const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
         if (fc == FC_WAVE) {
@@ -1609,23 +1708,36 @@ public:
             if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
             if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
         } else {
-            LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
-            if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-            else          LAUNCH(KK_BIG_DIAG, k_big_diag_reg<8>, dim3(nb), dim3(256), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-            LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nb), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
             const bool single = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_BIG]) && !multi;       // the single-GPU schedule
-            if (single && la_full[lv] && la_pending) {       // a full update may touch what an earlier part 2 is still writing
-                HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false;
-            }
-            if (single && la_tiles2[lv] > 0 && !prof_on) {
-                LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream, V, b0, 1, 0);
-                HIPCHK(hipEventRecord(la_evA[lv], stream));
-                HIPCHK(hipStreamWaitEvent(stream2, la_evA[lv], 0));
-                hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, b0, 2, la_tiles2[lv]);
-                HIPCHK(hipEventRecord(la_evB[lv], stream2));
-                la_last = la_evB[lv]; la_pending = true;
-            } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0, 0, 0);
+            if (!single) { const bool sm = mm <= 640; return launch_big(lv, b0, sm ? b1 : b0, b1, top_mode, mm, kk, sm ? tiles64 : 0, sm ? 0 : tiles, false); }
+            return launch_big(lv, b0, b0 + big_split[lv], b1, top_mode, mm, kk, part_tiles[0][lv], part_tiles[1][lv], true);
         }
+        return true;
+    }
+    // the big-front launches of one level: assembly, pivot blocks and TRSM over the whole list [b0, b1); the trailing update with
+    // 64 x 64 tiles / 256 threads on the fronts [b0, bs) of order <= 1024 (a handful of tiles, K = 16..64 each) and with
+    // 128 x 128 tiles / 1024 threads on [bs, b1)
+    bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
+        const int nball = b1 - b0;
+        LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
+        if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        else          LAUNCH(KK_BIG_DIAG, k_big_diag_reg<8>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
+        if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0);
+        if (b1 == bs) return true;
+        const int nb = b1 - bs;
+        b0 = bs;
+        if (single && la_full[lv] && la_pending) {       // a full update may touch what an earlier part 2 is still writing
+            HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false;
+        }
+        if (single && la_tiles2[lv] > 0 && !prof_on) {
+            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream, V, b0, 1, 0);
+            HIPCHK(hipEventRecord(la_evA[lv], stream));
+            HIPCHK(hipStreamWaitEvent(stream2, la_evA[lv], 0));
+            hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, b0, 2, la_tiles2[lv]);
+            HIPCHK(hipEventRecord(la_evB[lv], stream2));
+            la_last = la_evB[lv]; la_pending = true;
+        } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0, 0, 0);
         return true;
     }
 
@@ -1645,7 +1757,7 @@ public:
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv]);
+                launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv], big_tiles64[lv]);
             }
         }
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
@@ -1774,7 +1886,7 @@ public:
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc], b1 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                launch_bucket(lv, fc, b0, b1, top_mode, sc.maxm[lv], sc.maxk[lv], sc.tiles[lv]);
+                launch_bucket(lv, fc, b0, b1, top_mode, sc.maxm[lv], sc.maxk[lv], sc.tiles[lv], sc.tiles64[lv]);
             }
         HIPCHK(hipGetLastError());
         return true;
