@@ -52,7 +52,7 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
 struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt;
-                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, pad_; };
+                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, solo; };
 struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase; };
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
 struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
@@ -88,6 +88,7 @@ struct DevView {
     double* cvec;           // forward-solve contributions, aligned with sn_rows
     double* bw; double* xacc;   // iterative refinement: scaled right-hand side and accumulated solution (permuted numbering)
     double* gpart;          // partial sums of the backward dot products of the chain groups
+    double* zb;             // z = D^{-1} y of the forward sweep (pivot order); xw keeps b until the backward sweep writes x
     double* ybuf;           // y of the pivot rows (big fronts: the update rows are handled by a second, multi-workgroup launch)
     // multi-GPU top arena (full m x m squares per replicated front), null on 1 GPU
     double* arena; const long long* arena_off;
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(NT) void k_fwd(DevView V, int list_off, int top_mod
         if (pt == 1) z = ys[j] * V.dinv[c0 + j];
         else if (pt == 2) z = V.dinv[c0 + j] * ys[j] + V.doff[c0 + j] * ys[j + 1];
         else z = V.doff[c0 + j - 1] * ys[j - 1] + V.dinv[c0 + j] * ys[j];
-        V.xw[c0 + j] = z;
+        V.zb[c0 + j] = z;
     }
 }
 
@@ -667,7 +668,7 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
     double* ws = reinterpret_cast<double*>(smem_raw);   // k
     double* xu = ws + k;                                // m-k gathered ancestor values (LDS classes)
     for (int i = k + tid; i < m; i += NT) xu[i - k] = V.xw[V.sn_rows[r0 + i]];
-    for (int j = tid; j < k; j += NT) ws[j] = V.xw[c0 + j];
+    for (int j = tid; j < k; j += NT) ws[j] = V.zb[c0 + j];
     __syncthreads();
     {
         const double* Lg = V.L + M.panel_off;
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(256) void k_fwd_grp(DevView V, int list_off, int to
             if (pt == 1) z = ys[q] * V.dinv[c0 + q];
             else if (pt == 2) z = V.dinv[c0 + q] * ys[q] + V.doff[c0 + q] * ys[q + 1];
             else z = V.doff[c0 + q - 1] * ys[q - 1] + V.dinv[c0 + q] * ys[q];
-            V.xw[c0 + q] = z;
+            V.zb[c0 + q] = z;
             V.ybuf[c0 + q] = ys[q];
         }
         const double* Lg = V.L + G.panel_off;
@@ -777,6 +778,67 @@ __global__ __launch_bounds__(256) void k_fwd_grp(DevView V, int list_off, int to
             cv[i] -= t0 + t1;
         }
         __syncthreads();
+    }
+}
+
+// Fused forward step of a one-link solve unit that has nothing to gather (FrontMeta::solo): block 0 does the pivot part,
+// blocks 1.. each take 64 update rows and recompute y = L11^{-1} P b themselves (64 x 64 mat-vec from L2) instead of
+// waiting for another launch.  b is read from xw, z goes to zb: nothing a sibling block reads is overwritten.
+__global__ __launch_bounds__(256) void k_fwd_solo(DevView V, int list_off)
+{
+    __shared__ double bp[128], ys[128];
+    __shared__ double red[4][64];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int k = M.k, m = M.m, c0 = M.c0;
+    const int rb = (int)blockIdx.x - 1;                       // -1: pivot part
+    if (rb >= 0 && k + rb * 64 >= m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* cv = V.cvec + M.cv;
+    for (int p = tid; p < k; p += 256) { const int lp = V.lperm[c0 + p]; bp[p] = V.xw[c0 + lp] + (M.solo == 1 ? cv[lp] : 0.0); }
+    __syncthreads();
+    const double* Mg = V.minv + M.minv_off;
+    {
+        const int part = tid & 3;
+        for (int q = tid >> 2; q < k; q += 64) {
+            double a = 0.0;
+            int p = part;
+            for (; p + 12 <= q; p += 16) {
+                const double m0 = Mg[q + (size_t)p * k], m1 = Mg[q + (size_t)(p + 4) * k], m2 = Mg[q + (size_t)(p + 8) * k], m3 = Mg[q + (size_t)(p + 12) * k];
+                a += m0 * bp[p] + m1 * bp[p + 4] + m2 * bp[p + 8] + m3 * bp[p + 12];
+            }
+            for (; p <= q; p += 4) a += Mg[q + (size_t)p * k] * bp[p];
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+            if (part == 0) ys[q] = a;
+        }
+    }
+    __syncthreads();
+    if (rb < 0) {
+        for (int q = tid; q < k; q += 256) {
+            const int pt = V.ptype[c0 + q];
+            double z;
+            if (pt == 1) z = ys[q] * V.dinv[c0 + q];
+            else if (pt == 2) z = V.dinv[c0 + q] * ys[q] + V.doff[c0 + q] * ys[q + 1];
+            else z = V.doff[c0 + q - 1] * ys[q - 1] + V.dinv[c0 + q] * ys[q];
+            V.zb[c0 + q] = z;
+        }
+        return;
+    }
+    const int i = k + rb * 64 + lane;
+    const bool ok = i < m;
+    const double* Lg = V.L + M.panel_off + (ok ? i : k);
+    double t0 = 0.0, t1 = 0.0;
+    for (int p = wave * 8; p < k; p += 32) {
+        double l[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) l[u] = (p + u < k) ? Lg[(size_t)(p + u) * M.ldp] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { t0 += l[u] * ((p + u < k) ? ys[p + u] : 0.0); t1 += l[u + 1] * ((p + u + 1 < k) ? ys[p + u + 1] : 0.0); }
+    }
+    red[wave][lane] = t0 + t1;
+    __syncthreads();
+    if (wave == 0 && ok) {
+        const double t = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        cv[i] = (M.solo == 1 ? cv[i] : 0.0) - t;
     }
 }
 
@@ -878,7 +940,7 @@ __global__ __launch_bounds__(256) void k_bwd_grp(DevView V, int list_off)
             for (; c + 3 < nch; c += 4) { t0 += part[(size_t)c * M.gcols + cb + p]; t1 += part[(size_t)(c + 1) * M.gcols + cb + p];
                                           t2 += part[(size_t)(c + 2) * M.gcols + cb + p]; t3 += part[(size_t)(c + 3) * M.gcols + cb + p]; }
             for (; c < nch; ++c) t0 += part[(size_t)c * M.gcols + cb + p];
-            ws[p] = V.xw[c0 + p] - ((t0 + t1) + (t2 + t3));
+            ws[p] = V.zb[c0 + p] - ((t0 + t1) + (t2 + t3));
         }
         for (int i = tid; i < rem; i += 256) xs[i] = V.xw[V.sn_rows[G.r0 + k + i]];
         __syncthreads();
@@ -1337,6 +1399,7 @@ public:
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
     std::vector<int> big_maxm, big_maxk, big_tiles, big_tiles64, big_last0, big_last1;
+    std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
     std::vector<int> la_tiles1, la_tiles2; std::vector<char> la_full;     // la_full: the level has a full (group-last) update
@@ -1518,6 +1581,16 @@ public:
                 if (Sy.grp_rem[Sy.level_sn[q]] == 0 || !Sy.solve_group) { lvl_list.push_back(Sy.level_sn[q]); solve_entry.resize(lvl_list.size(), 0); solve_entry.back() = 1; }
             big_last1[lv] = (int)lvl_list.size();
         }
+        lv_allsolo.assign(Sy.num_levels, 0);
+        if (!Sy.solve_group)
+            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                bool all = big_last1[lv] > big_last0[lv];
+                for (int q = big_last0[lv]; q < big_last1[lv]; ++q) {
+                    const int sn = lvl_list[q], nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
+                    if (!((Sy.alias_child[sn] >= 0 && nch == 1) || (Sy.alias_child[sn] < 0 && nch == 0))) all = false;
+                }
+                lv_allsolo[lv] = all ? 1 : 0;
+            }
         // chain-group tables: for every BIG front the links of its group up to and including itself
         std::vector<GroupLink> gt;
         std::vector<int> gbase_of(Sy.num_sn, 0), gcols_of(Sy.num_sn, 0);
@@ -1612,7 +1685,11 @@ public:
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
             M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
             M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
-            M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.ttab = ttab_of[sn]; M.ttab2 = ttab2_of[sn]; M.pad_ = 0;
+            M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.ttab = ttab_of[sn]; M.ttab2 = ttab2_of[sn];
+            {   // 1: in-place chain link whose only child is the chain child, 2: no children at all => the fused forward kernel applies
+                const int nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
+                M.solo = (Sy.alias_child[sn] >= 0 && nch == 1) ? 1 : ((Sy.alias_child[sn] < 0 && nch == 0) ? 2 : 0);
+            }
             if (q < solve_entry.size() && solve_entry[q] && !Sy.solve_group) {     // per-link solves: every front is its own unit
                 M.gbase += M.gpos; M.gpos = 0; M.grem = 0; M.gcols = M.k;
             }
@@ -1639,7 +1716,7 @@ public:
         if (!dalloc(&V.arv, Sy.rslot_idx.size()) || !dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.scale2, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
-            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
+            !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 4)) return false;
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
@@ -1829,8 +1906,9 @@ public:
                     else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
                     else if (big_last1[lv] > big_last0[lv]) {
                            const int g0 = big_last0[lv], ng = big_last1[lv] - g0;
-                           LAUNCH(KK_FWD_BIG, k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, 0);
-                           LAUNCH(KK_FWD_BIG_UPD, k_fwd_grp_upd, dim3((big_maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); }
+                           if (lv_allsolo[lv]) LAUNCH(KK_FWD_BIG, k_fwd_solo, dim3((big_maxm[lv] + 63) / 64 + 1, ng), dim3(256), 0, stream, V, g0);
+                           else { LAUNCH(KK_FWD_BIG, k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, 0);
+                                  LAUNCH(KK_FWD_BIG_UPD, k_fwd_grp_upd, dim3((big_maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); } }
                 }
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
