@@ -1645,8 +1645,15 @@ public:
                 fprintf(stderr, "[mi355x_kkt] look-ahead: %d of %d group-end updates split (%lld part-2 tiles); not split: %d small, %d chain ends, %d impure next group\n",
                         nsplit, nfull, t2, nsmall, nend, nimpure);
             }
-            la_any = false;
-            for (int lv = 0; lv < Sy.num_levels; ++lv) if (la_tiles2[lv] > 0) la_any = true;
+            // look-ahead costs the graph replay (see factor()): only worth it when a good part of the flops is in split updates
+            long long la_total = 0;
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (split_of[sn]) {
+                const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+                const int nt = (mu + 127) / 128; la_total += (long long)(nt - 2) * (nt - 1) / 2;
+            }
+            if (la_total < 4000) { std::fill(split_of.begin(), split_of.end(), 0); std::fill(la_tiles2.begin(), la_tiles2.end(), 0);
+                for (int lv = 0; lv < Sy.num_levels; ++lv) la_tiles1[lv] = 0; }
+            la_any = la_total >= 4000;
             la_evA.assign(Sy.num_levels, nullptr); la_evB.assign(Sy.num_levels, nullptr);
             for (int lv = 0; lv < Sy.num_levels; ++lv) if (la_tiles2[lv] > 0) {
                 HIPCHK(hipEventCreateWithFlags(&la_evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&la_evB[lv], hipEventDisableTiming)); }
