@@ -266,7 +266,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
     // case -- 1x1 pivot on the first alive row -- is kept to ~100 instructions: unconditional wide LDS reads + bit-mask
     // selects, one ballot instead of a max-reduction for the Bunch-Kaufman acceptance test, reciprocal by v_rcp_f64 +
     // Newton, L column written by the 16 (8) threads that already hold it.
-    constexpr int G = (NT == 64) ? 8 : 16;
+    constexpr int G = (NT == 64) ? 8 : (NT == 1024 ? 32 : 16);
     constexpr int MAXM = G * TS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int ti = tid % G, tj = tid / G;
@@ -489,12 +489,14 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ldi] : (i == c ? 1.0 : 0.0); }
 }
 
-// pivot block of a BIG front on the register-tiled core: TS = 4 for k <= 64, TS = 8 (two-word alive mask) for k <= 128
-template <int TS>
-__global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
+// pivot block of a BIG front on the register-tiled core: 4x4 tiles on 16x16 threads for k <= 64, on 32x32 threads (two-word
+// alive mask) for the 128-column panels of the wide_panels option (19 ms against 28 ms with 8x8 tiles on 256 threads, but
+// still slower per column than two 64-column blocks: option off by default)
+template <int TS, int NT = 256>
+__global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int G = 16, MAXM = G * TS;
+    constexpr int G = (NT == 1024) ? 32 : 16, MAXM = G * TS;
     const int tid = threadIdx.x;
     const FrontMeta M = V.fmeta[list_off + blockIdx.x];
     const int s = M.s, c0 = M.c0, k = M.k;
@@ -516,22 +518,22 @@ __global__ __launch_bounds__(256) void k_big_diag_reg(DevView V, int list_off)
         }
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
     DBGSTAMP(0);
-    ldlt_reg<256, TS, (TS == 8)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
     __syncthreads();
     DBGSTAMP(1);
     // pivot-ordered unit-lower block -> panel (global), then back into the same LDS block for the inversion: the global
     // round trip (L2 hits, same workgroup) avoids a second k x k LDS buffer, which does not fit at k = 128
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; P[i + (size_t)c * ldp] = (i > c) ? Lb[ord[i] + c * ld] : 0.0; }
+    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; P[i + (size_t)c * ldp] = (i > c) ? Lb[ord[i] + c * ld] : 0.0; }
     __syncthreads();
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Lb[i + c * ld] = P[i + (size_t)c * ldp]; }
-    for (int j = tid; j < k; j += 256) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
+    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Lb[i + c * ld] = P[i + (size_t)c * ldp]; }
+    for (int j = tid; j < k; j += NT) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
     __syncthreads();
     DBGSTAMP(2);
-    invert_unit_lower<256>(Lb, ld, k);
+    invert_unit_lower<NT>(Lb, ld, k);
     DBGSTAMP(3);
     double* Mg = V.minv + M.minv_off;
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Lb[i + c * ld] : (i == c ? 1.0 : 0.0); }
+    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Lb[i + c * ld] : (i == c ? 1.0 : 0.0); }
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[15] = (unsigned long long)k;
 }
 
@@ -1732,7 +1734,7 @@ public:
         V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_big_diag_reg<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1805,7 +1807,7 @@ public:
         const int nball = b1 - b0;
         LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-        else          LAUNCH(KK_BIG_DIAG, k_big_diag_reg<8>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
         if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0);
         if (b1 == bs) return true;
