@@ -1653,9 +1653,10 @@ public:
                 const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
                 const int nt = (mu + 127) / 128; la_total += (long long)(nt - 2) * (nt - 1) / 2;
             }
-            if (la_total < 4000) { std::fill(split_of.begin(), split_of.end(), 0); std::fill(la_tiles2.begin(), la_tiles2.end(), 0);
+            const long long la_gate = getenv("MI355X_KKT_LA_MIN_TILES") ? atoll(getenv("MI355X_KKT_LA_MIN_TILES")) : 4000;     // (tests force 0)
+            if (la_total < la_gate || la_total == 0) { std::fill(split_of.begin(), split_of.end(), 0); std::fill(la_tiles2.begin(), la_tiles2.end(), 0);
                 for (int lv = 0; lv < Sy.num_levels; ++lv) la_tiles1[lv] = 0; }
-            la_any = la_total >= 4000;
+            la_any = la_total >= la_gate && la_total > 0;
             la_evA.assign(Sy.num_levels, nullptr); la_evB.assign(Sy.num_levels, nullptr);
             for (int lv = 0; lv < Sy.num_levels; ++lv) if (la_tiles2[lv] > 0) {
                 HIPCHK(hipEventCreateWithFlags(&la_evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&la_evB[lv], hipEventDisableTiming)); }

@@ -198,3 +198,21 @@ def test_optional_code_paths_stay_exact(opts):
     s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg, **opts)
     assert st == 0 and s.number_of_neg_evals() == neg
     assert sres(K, x, b) <= RES_TOL
+
+
+def test_lookahead_split_updates_are_exact_and_reproducible(monkeypatch):
+    """the two-stream look-ahead of the group-end trailing updates (normally only on very large fronts) forced onto a
+    mid-size system: same inertia, converged solve, bitwise identical to the single-stream factorisation"""
+    n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)        # fronts up to ~1 200 rows: several split updates
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    monkeypatch.setenv("MI355X_KKT_NO_LOOKAHEAD", "1")
+    s0, st0, x0 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+    monkeypatch.delenv("MI355X_KKT_NO_LOOKAHEAD")
+    monkeypatch.setenv("MI355X_KKT_LA_MIN_NT", "3"); monkeypatch.setenv("MI355X_KKT_LA_MIN_TILES", "0")
+    s1, st1, x1 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+    assert st0 == st1 == kkt.SUCCESS and s1.number_of_neg_evals() == neg
+    assert sres(K, x1, b) <= RES_TOL
+    assert np.array_equal(x0, x1)
+    x2 = b.copy(); s1.multi_solve(True, x2)
+    assert np.array_equal(x1, x2)
