@@ -1056,8 +1056,8 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     if (ibase >= m) return;
     const int kp = (k + 3) & ~3;                              // K padded to the MFMA depth
     double* As = reinterpret_cast<double*>(smem_raw);         // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
-    double* Ws = As + (size_t)65 * kp;                        // 64 x k : Ws[r + j*65]
-    double* Ds = Ws + (size_t)65 * k;                         // dinv[k], doff[k]
+    double* Ws = As;                                          // W overwrites A21 P in place (column tiles are processed last to first)
+    double* Ds = As + (size_t)65 * kp;                        // dinv[k], doff[k]
     int*    Ts = reinterpret_cast<int*>(Ds + 2 * k);          // ptype[k]
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
@@ -1071,7 +1071,9 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     __syncthreads();
     const int l15 = lane & 15, l4 = lane >> 4;
     const int r16 = wave * 16;
-    for (int c16 = 0; c16 < k; c16 += 16) {
+    // W(:, tile) needs A(:, 0 .. tile end) only (L11^{-1} is lower triangular): going from the last column tile to the first,
+    // a finished tile can be stored over the A columns that no later (lower) tile reads => half the LDS, twice the occupancy
+    for (int c16 = ((k - 1) >> 4) << 4; c16 >= 0; c16 -= 16) {
         const int col = c16 + l15;
         const int pend = min(kp, c16 + 16);                   // Minv(col,p) = 0 for p > col
         double mreg[32];                                      // Minv(col, p + l4), p = 0, 4, ..., pend-4
@@ -1809,7 +1811,7 @@ public:
         LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-        LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 65 * kk + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
+        LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
         if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0);
         if (b1 == bs) return true;
         const int nb = b1 - bs;
