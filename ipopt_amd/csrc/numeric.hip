@@ -53,7 +53,7 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
 struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt;
                    long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, solo; };
-struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase; };
+struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase, inv; };
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
 struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
 
@@ -67,6 +67,7 @@ struct DevView {
     const int* rslot_ptr; const int* rslot_idx; const int* rslot_col; int rslot_len;
     const int* level_sn;
     const FrontMeta* fmeta;   // parallel to level_sn
+    const int* relinv;        // per child of a BIG parent: parent front row -> index in the child's update rows, or -1 (ChildMeta::inv)
     const GroupLink* gtab;    // links of the chain groups (FrontMeta::gbase .. gbase + gpos)
     const int* tile_tab;      // XCD-aware tile orders of the large trailing updates ((ti << 16) | tc), see k_big_schur
     const ChildMeta* cmeta;   // parallel to child_idx
@@ -1024,9 +1025,8 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
         if (active && !Cm.aliased && !(skip_owned && Cm.owner >= 0)) {
             const int mc = Cm.mc;
             const int* relc = V.rel + Cm.relbase;
-            int lo = 0, hi = mc;                           // first b with relc[b] >= fc (relc is increasing)
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (relc[mid] < fc) lo = mid + 1; else hi = mid; }
-            if (lo < mc && relc[lo] == fc) {
+            const int lo = V.relinv[Cm.inv + fc];          // index of parent column fc among the child's update rows (one load, no search)
+            if (lo >= 0) {
                 const double* C = V.cb + Cm.cb_off + (size_t)lo * Cm.ldt;
                 int a = lo + lane;
                 for (; a + 192 < mc; a += 256) {             // 4 independent gather-add chains in flight per lane
@@ -1714,6 +1714,21 @@ public:
         }
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0)
             for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) if (Sy.child_idx[q] == Sy.alias_child[sn]) cm[q].aliased = 1;
+        // inverse relative indices for the children of BIG parents (k_big_assemble: one load instead of a binary search per column)
+        std::vector<int> relinv;
+        for (int sn = 0; sn < Sy.num_sn; ++sn) {
+            for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) cm[q].inv = 0;
+            if (Sy.sn_class[sn] != FC_BIG) continue;
+            const int mp = Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn];
+            for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) {
+                if (cm[q].aliased) continue;
+                cm[q].inv = (long long)relinv.size();
+                relinv.resize(relinv.size() + mp, -1);
+                int* inv = relinv.data() + cm[q].inv;
+                for (int a = 0; a < cm[q].mc; ++a) inv[Sy.rel[cm[q].relbase + a]] = a;
+            }
+        }
+        if (!upload(relinv, &V.relinv)) return false;
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
