@@ -1013,12 +1013,12 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
             for (int i = fc + lane; i < m; i += 64) col[i] = from_arena ? Ar[i] : 0.0;
         }
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // each wavefront owns its column: ordering of its own stores/loads is all that is needed
     if (active && fc < k) {
         const int q0 = V.acolptr[c0 + fc], q1 = V.acolptr[c0 + fc + 1];
         for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] += V.aval[q];
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // each wavefront owns its column: ordering of its own stores/loads is all that is needed
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
         const ChildMeta Cm = V.cmeta[cp];
         const int ch = Cm.ch; (void)ch;
@@ -1038,7 +1038,7 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
                 for (; a < mc; a += 64) col[relc[a]] += C[a];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // each wavefront owns its column: ordering of its own stores/loads is all that is needed
     }
 }
 
