@@ -1414,7 +1414,7 @@ public:
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
-    struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk, tiles, tiles64, last0, last1; };   // last0/1: per level, the group-last BIG fronts (solve units)
+    struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk, tiles, tiles64, last0, last1; std::vector<char> allsolo; };   // last0/1: per level, the group-last BIG fronts (solve units)
     Sched sch_local, sch_top;
     int top_list_base = 0, top_count = 0, top_maxm = 0;      // all replicated fronts (top-rhs assembly)
     int join_list_base = 0, join_count = 0, join_maxm = 0;   // replicated fronts with a rank-owned child (arena squares)
@@ -1512,6 +1512,16 @@ public:
                     for (int sn : bucket[(size_t)lv * FC_COUNT + FC_BIG]) if (Sy.grp_rem[sn] == 0 || !Sy.solve_group) { lvl_list.push_back(sn); solve_entry.resize(lvl_list.size(), 0); solve_entry.back() = 1; }
                     sc.last1[lv] = (int)lvl_list.size();
                 }
+                sc.allsolo.assign(Sy.num_levels, 0);
+                if (!Sy.solve_group)
+                    for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                        bool all = sc.last1[lv] > sc.last0[lv];
+                        for (int q = sc.last0[lv]; q < sc.last1[lv]; ++q) {
+                            const int sn = lvl_list[q], nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
+                            if (!((Sy.alias_child[sn] >= 0 && nch == 1) || (Sy.alias_child[sn] < 0 && nch == 0))) all = false;
+                        }
+                        sc.allsolo[lv] = all ? 1 : 0;
+                    }
             };
             build(sch_local, false); build(sch_top, true);
             // top-rhs accumulators for every replicated front; arena squares only for those that have a child owned by some
@@ -2010,8 +2020,9 @@ public:
                     else if (fc == FC_LDS128) hipLaunchKernelGGL((k_fwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, top_mode);
                     else if (sc.last1[lv] > sc.last0[lv]) {
                            const int g0 = sc.last0[lv], ng = sc.last1[lv] - g0;
-                           hipLaunchKernelGGL(k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, top_mode);
-                           hipLaunchKernelGGL(k_fwd_grp_upd, dim3((sc.maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); }
+                           if (!top_mode && sc.allsolo[lv]) hipLaunchKernelGGL(k_fwd_solo, dim3((sc.maxm[lv] + 63) / 64 + 1, ng), dim3(256), 0, stream, V, g0);
+                           else { hipLaunchKernelGGL(k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, top_mode);
+                                  hipLaunchKernelGGL(k_fwd_grp_upd, dim3((sc.maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); } }
                 } else {
                     if (fc == FC_WAVE)        hipLaunchKernelGGL((k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
                     else if (fc == FC_LDS64)  hipLaunchKernelGGL((k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
