@@ -310,16 +310,35 @@ public:
             }
             nlev = bfs_levels(root, cstamp, ++stamp, queue); cstamp = stamp;
             if (nlev < 3) { md.order(t.nodes, order.data() + t.start); return; }
-            vector<int> lsize(nlev, 0);
-            for (int v : queue) lsize[lev[v]]++;
             // choose the separator level: small and balanced
-            int bestl = -1; double bests = 1e300; int below = lsize[0];
-            for (int l = 1; l <= nlev - 2; ++l) {
-                int a = below, s = lsize[l], b = m - a - s; below += s;
-                if (a == 0 || b == 0) return;
-                double imb = std::fabs((double)a - b) / (double)(a + b);
-                double score = (double)s * (1.0 + 4.0 * imb * imb) + 0.05 * m * imb;
-                if (score < bests) { bests = score; bestl = l; }
+            auto best_level = [&](int nl, int& bestl, double& bests) {
+                vector<int> lsize(nl, 0);
+                for (int v : queue) lsize[lev[v]]++;
+                bestl = -1; bests = 1e300; int below = lsize[0];
+                for (int l = 1; l <= nl - 2; ++l) {
+                    int a = below, s = lsize[l], b = m - a - s; below += s;
+                    if (a == 0 || b == 0) break;
+                    double imb = std::fabs((double)a - b) / (double)(a + b);
+                    double score = (double)s * (1.0 + 4.0 * imb * imb) + 0.05 * m * imb;
+                    if (score < bests) { bests = score; bestl = l; }
+                }
+            };
+            int bestl = -1; double bests = 1e300;
+            best_level(nlev, bestl, bests);
+            // Second level structure, rooted at the whole LAST LEVEL of the first one.  On stencil-like graphs whose BFS balls
+            // are boxes (9-point / block couplings, i.e. every PDE-constrained KKT) the levels from a corner are L-shaped, but
+            // the last level is an entire side of the domain, and the levels grown from a side are straight lines: separators
+            // up to 2.7x smaller at the top of the tree.  Keep whichever structure has the better separator.
+            {
+                vector<int> src;
+                for (int q = (int)queue.size() - 1; q >= 0 && lev[queue[q]] == nlev - 1; --q) src.push_back(queue[q]);
+                vector<int> queue1 = queue, lev1(queue.size());
+                for (size_t q = 0; q < queue.size(); ++q) lev1[q] = lev[queue[q]];
+                const int nlev2 = bfs_levels_multi(src, cstamp, ++stamp, queue); cstamp = stamp;
+                int bestl2 = -1; double bests2 = 1e300;
+                if (nlev2 >= 3) best_level(nlev2, bestl2, bests2);
+                if (bestl2 >= 0 && bests2 < bests) { bestl = bestl2; bests = bests2; nlev = nlev2; }
+                else { queue = queue1; for (size_t q = 0; q < queue.size(); ++q) lev[queue[q]] = lev1[q]; }   // (tags are already the current stamp)
             }
             if (bestl < 0) { md.order(t.nodes, order.data() + t.start); return; }
             vector<int> A, B, S;
@@ -333,6 +352,7 @@ public:
                     if (touchesB) S.push_back(v); else A.push_back(v);
                 }
             }
+            if (getenv("MI355X_KKT_ND_DEBUG") && m > 20000) fprintf(stderr, "[nd] m=%d A=%zu B=%zu S=%zu nlev=%d level=%d\n", m, A.size(), B.size(), S.size(), nlev, bestl);
             if (A.empty() || B.empty() || (int)S.size() * 2 > m) { md.order(t.nodes, order.data() + t.start); return; }
             int sa = (int)A.size(), sb = (int)B.size();
             // separator last; inside S keep BFS order (dense clique anyway)
@@ -347,6 +367,14 @@ private:
     // BFS restricted to nodes with tag == in_stamp; re-tags visited with out_stamp; returns #levels
     int bfs_levels(int root, int in_stamp, int out_stamp, vector<int>& queue) {
         queue.clear(); queue.push_back(root); tag[root] = out_stamp; lev[root] = 0; int nl = 1;
+        for (size_t q = 0; q < queue.size(); ++q) { int v = queue[q];
+            for (int p = G.xadj[v]; p < G.xadj[v + 1]; ++p) { int u = G.adj[p];
+                if (tag[u] == in_stamp) { tag[u] = out_stamp; lev[u] = lev[v] + 1; nl = std::max(nl, lev[u] + 1); queue.push_back(u); } } }
+        return nl;
+    }
+    int bfs_levels_multi(const vector<int>& roots, int in_stamp, int out_stamp, vector<int>& queue) {
+        queue.clear(); int nl = 1;
+        for (int r : roots) if (tag[r] == in_stamp) { tag[r] = out_stamp; lev[r] = 0; queue.push_back(r); }
         for (size_t q = 0; q < queue.size(); ++q) { int v = queue[q];
             for (int p = G.xadj[v]; p < G.xadj[v + 1]; ++p) { int u = G.adj[p];
                 if (tag[u] == in_stamp) { tag[u] = out_stamp; lev[u] = lev[v] + 1; nl = std::max(nl, lev[u] + 1); queue.push_back(u); } } }
