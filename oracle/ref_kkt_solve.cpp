@@ -33,6 +33,7 @@ int main(int argc, char** argv)
 
    SmartPtr<IpoptApplication> app = IpoptApplicationFactory();
    app->Options()->SetIntegerValue("print_level", 0);
+   if( getenv("REF_PARDISO_MSGLVL") ) app->Options()->SetIntegerValue("pardisomkl_msglvl", atoi(getenv("REF_PARDISO_MSGLVL")));   // MKL's own statistics (nnz(L), flops)
    app->Initialize("");
    SmartPtr<PardisoMKLSolverInterface> iface = new PardisoMKLSolverInterface();
    if( !iface->ReducedInitialize(*app->Jnlst(), *app->Options(), "") ) { fprintf(stderr, "ReducedInitialize failed\n"); return 3; }
