@@ -603,7 +603,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     const int maxcols = std::max(2, opt.max_sn_cols);
     // fronts of order >= wide_from (the separator chains of the blocked path) get panels of 2*maxcols columns: half as many
     // tree levels and twice the arithmetic intensity of the Schur update (the pivot-block kernels handle <= 128 columns)
-    const int wide_from = opt.wide_panels > 0 ? 512 : (1 << 30);     // default off: measured slower (pivot block of 128 costs more than it saves)
+    const int wide_from = opt.wide_panels > 1 ? opt.wide_panels : (opt.wide_panels == 1 ? 512 : (1 << 30));     // > 1: the front order from which panels are wide     // default off: measured slower (pivot block of 128 costs more than it saves)
     // (a) whole small subtrees become one dense supernode: in the latency-bound regime (fronts of a few rows) dense
     //     arithmetic on <= leaf_cols columns is free, while every tree level costs a kernel launch and a dependent
     //     HBM round trip.  A subtree is a contiguous column range in the postorder.
