@@ -522,11 +522,16 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
     ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
     __syncthreads();
     DBGSTAMP(1);
-    // pivot-ordered unit-lower block -> panel (global), then back into the same LDS block for the inversion: the global
-    // round trip (L2 hits, same workgroup) avoids a second k x k LDS buffer, which does not fit at k = 128
-    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; P[i + (size_t)c * ldp] = (i > c) ? Lb[ord[i] + c * ld] : 0.0; }
-    __syncthreads();
-    for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Lb[i + c * ld] = P[i + (size_t)c * ldp]; }
+    // pivot-ordered unit-lower block: the row permutation is done IN PLACE in LDS through registers (each thread owns
+    // <= 16 entries: k*k <= 16*NT), the panel gets its copy on the way -- no second k x k buffer, no global round trip
+    {
+        double tmp[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const int idx = tid + e * NT; const int i = idx % k, c = idx / k; tmp[e] = (idx < k * k && i > c) ? Lb[ord[i] + c * ld] : 0.0; }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const int idx = tid + e * NT; const int i = idx % k, c = idx / k; if (idx < k * k) { Lb[i + c * ld] = tmp[e]; P[i + (size_t)c * ldp] = tmp[e]; } }
+    }
     for (int j = tid; j < k; j += NT) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
     __syncthreads();
