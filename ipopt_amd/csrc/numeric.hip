@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cmath>
+#include <chrono>
 #include <vector>
 #include <map>
 #include <string>
@@ -1473,6 +1474,9 @@ public:
 
     bool setup(const Symbolic& Sy, const NumericOptions& o) {
         release(); S = &Sy; opt = o;
+        auto now_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        double t_prev = now_();
+        auto lap = [&](const char* what) { if (opt.verbose >= 2) { const double t = now_(); fprintf(stderr, "[mi355x_kkt]   setup %-28s %.3f s\n", what, t - t_prev); t_prev = t; } };
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
             err_ = "no HIP device available: the MI355X KKT backend has no CPU fallback"; have_device = false; return false; }
@@ -1490,6 +1494,7 @@ public:
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
+        lap("device, streams, pinned buffer");
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
         std::vector<int> lvl_list(Sy.level_sn);
@@ -1744,6 +1749,7 @@ public:
             }
         }
         if (!upload(relinv, &V.relinv)) return false;
+        lap("host-side schedules and tables");
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
@@ -1752,6 +1758,7 @@ public:
             !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.rslot_ptr, &V.rslot_ptr) || !upload(Sy.rslot_idx, &V.rslot_idx) || !upload(Sy.rslot_col, &V.rslot_col) || !upload(lvl_list, &V.level_sn) ||
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
             !upload(Sy.perm, &V.perm)) return false;
+        lap("uploads");
         double* tv = nullptr;
         if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
         V.rslot_len = (int)Sy.rslot_idx.size();
