@@ -332,13 +332,38 @@ public:
             {
                 vector<int> src;
                 for (int q = (int)queue.size() - 1; q >= 0 && lev[queue[q]] == nlev - 1; --q) src.push_back(queue[q]);
-                vector<int> queue1 = queue, lev1(queue.size());
-                for (size_t q = 0; q < queue.size(); ++q) lev1[q] = lev[queue[q]];
-                const int nlev2 = bfs_levels_multi(src, cstamp, ++stamp, queue); cstamp = stamp;
-                int bestl2 = -1; double bests2 = 1e300;
-                if (nlev2 >= 3) best_level(nlev2, bestl2, bests2);
-                if (bestl2 >= 0 && bests2 < bests) { bestl = bestl2; bests = bests2; nlev = nlev2; }
-                else { queue = queue1; for (size_t q = 0; q < queue.size(); ++q) lev[queue[q]] = lev1[q]; }   // (tags are already the current stamp)
+                // second candidate source: HALF of that last level (on a square domain the last level is two sides meeting in
+                // the far corner, and only one side gives straight levels): the half reached first by a BFS inside the level
+                // from its lowest-degree vertex
+                vector<int> half;
+                if (src.size() >= 8) {
+                    const int mark = ++stamp;                          // temporary tag for "in src, not visited"
+                    int start = src[0], bd = 1 << 30;
+                    for (int v : src) { tag[v] = mark; const int d = G.xadj[v + 1] - G.xadj[v]; if (d < bd) { bd = d; start = v; } }
+                    half.push_back(start); tag[start] = cstamp;
+                    for (size_t q = 0; q < half.size() && half.size() < src.size() / 2; ++q) {
+                        const int v = half[q];
+                        for (int p = G.xadj[v]; p < G.xadj[v + 1] && half.size() < src.size() / 2; ++p) { const int u = G.adj[p]; if (tag[u] == mark) { tag[u] = cstamp; half.push_back(u); } }
+                    }
+                    for (int v : src) tag[v] = cstamp;                 // restore
+                    if (half.size() < src.size() / 4) half.clear();     // the level is not connected enough for this to mean anything
+                }
+                vector<int> queue0 = queue, lev0(queue.size());
+                for (size_t q = 0; q < queue.size(); ++q) lev0[q] = lev[queue[q]];
+                vector<int> queueb = queue0, levb = lev0;               // best structure so far
+                for (int cand = 0; cand < 2; ++cand) {
+                    const vector<int>& from = cand == 0 ? src : half;
+                    if (from.empty()) continue;
+                    const int nl2 = bfs_levels_multi(from, cstamp, ++stamp, queue); cstamp = stamp;
+                    int bl2 = -1; double bs2 = 1e300;
+                    if (nl2 >= 3 && (int)queue.size() == m) best_level(nl2, bl2, bs2);
+                    if (bl2 >= 0 && bs2 < bests) {
+                        bestl = bl2; bests = bs2; nlev = nl2; queueb = queue;
+                        levb.resize(queue.size()); for (size_t q = 0; q < queue.size(); ++q) levb[q] = lev[queue[q]];
+                    }
+                }
+                queue = queueb; for (size_t q = 0; q < queue.size(); ++q) lev[queue[q]] = levb[q];
+                for (int v : queue) tag[v] = cstamp;                    // (all tags of the component end on the current stamp)
             }
             if (bestl < 0) { md.order(t.nodes, order.data() + t.start); return; }
             vector<int> A, B, S;

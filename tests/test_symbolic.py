@@ -152,3 +152,14 @@ def test_chain_groups_are_consistent():
                 assert grem[cur] == grem[nxt[cur]] + k[nxt[cur]]
                 cur = nxt[cur]; cols += k[cur]; links += 1
             assert grem[cur] == 0 and links <= 4 and cols <= 256
+
+
+@pytest.mark.parametrize("nx,ny,limit", [(80, 50, 510), (64, 64, 540), (120, 40, 600)])
+def test_nested_dissection_finds_straight_separators_on_stencil_kkt(nx, ny, limit):
+    """ordering quality guard: on a 9-point-coupled grid KKT (5 unknowns per node) the separators must be straight grid lines
+    (level structures rooted at the last level, or at half of it on square domains, of a pseudo-peripheral BFS).  Largest
+    front with straight cuts: 460 / 490 / 545 rows; the L-shaped level sets of the plain BFS give 700-800."""
+    n, r, c, v, neg = kktgen.grid_kkt(nx, ny, dof=3, ncon=2, seed=7)
+    s = ipopt_amd.KKTSolver(device=-1)
+    s.initialize_structure(n, r, c, vals=v)
+    assert s.info().maxfront <= limit
