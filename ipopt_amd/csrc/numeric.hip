@@ -53,7 +53,7 @@ static constexpr double PIV_PERT = 1e-10;                // replacement magnitud
 // per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
 struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt;
-                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, solo; };
+                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, solo, selfasm, pad2_; };
 struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase, inv; };
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
 struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
@@ -509,6 +509,10 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
     int* ord = reinterpret_cast<int*>(doff_s + k); int* pt_s = ord + k;
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
+    if (M.selfasm) {            // pure in-place chain link (no assembly launch): the A entries of the pivot rows are added here
+        for (int q = M.aq0 + tid; q < M.aq1; q += NT) { const int pos = V.apos[q]; const int i = pos % M.m, c = pos / M.m; if (i < k) P[i + (size_t)c * ldp] += V.aval[q]; }
+        __syncthreads();
+    }
     const int ti = tid % G, tj = tid / G, row0 = ti * TS, col0 = tj * TS;
     double t[TS][TS];
 #pragma unroll
@@ -999,6 +1003,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, int top_mode)
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    if (M.selfasm && !top_mode) return;       // pure in-place chain link: its A entries are added by its own pivot-block / TRSM kernels
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     (void)0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1070,6 +1075,10 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
     double* W = V.wbuf + M.wb;
     const double* Mg = V.minv + M.minv_off;
     for (int j = tid; j < k; j += 256) { Ds[j] = V.dinv[c0 + j]; Ds[k + j] = V.doff[c0 + j]; Ts[j] = V.ptype[c0 + j]; }
+    if (M.selfasm) {            // ... and those of the rows below by the workgroup that owns the rows
+        for (int q = M.aq0 + tid; q < M.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
+        __syncthreads();
+    }
     for (int idx = tid; idx < 64 * kp; idx += 256) {
         const int r = idx & 63, p = idx >> 6;
         As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)V.lperm[c0 + p] * ldp] : 0.0;
@@ -1409,6 +1418,7 @@ public:
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
     std::vector<int> big_maxm, big_maxk, big_tiles, big_tiles64, big_last0, big_last1;
+    std::vector<char> lv_asm_skip;      // every big front of the level is a pure in-place chain link: no assembly launch at all
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
@@ -1708,6 +1718,17 @@ public:
             }
         }
         if (!upload(tile_tab, &V.tile_tab)) return false;
+        const bool selfasm_on = getenv("MI355X_KKT_NO_SELFASM") == nullptr;
+        lv_asm_skip.assign(Sy.num_levels, 0);
+        if (!multi && selfasm_on)
+            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                bool all = true; int cnt = 0;
+                for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1]; ++q) {
+                    const int sn = Sy.level_sn[q]; ++cnt;
+                    if (!(Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1)) all = false;
+                }
+                lv_asm_skip[lv] = (cnt > 0 && all) ? 1 : 0;
+            }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -1718,6 +1739,7 @@ public:
             M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
             M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
             M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.ttab = ttab_of[sn]; M.ttab2 = ttab2_of[sn];
+            M.selfasm = (!multi && selfasm_on && Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1) ? 1 : 0; M.pad2_ = 0;
             {   // 1: in-place chain link whose only child is the chain child, 2: no children at all => the fused forward kernel applies
                 const int nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
                 M.solo = (Sy.alias_child[sn] >= 0 && nch == 1) ? 1 : ((Sy.alias_child[sn] < 0 && nch == 0) ? 2 : 0);
@@ -1845,7 +1867,7 @@ public:
     // 128 x 128 tiles / 1024 threads on [bs, b1)
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
         const int nball = b1 - b0;
-        LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
+        if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
