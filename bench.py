@@ -82,38 +82,89 @@ def per_kind_work(solver):
     return out
 
 
-def cpu_baseline(n, r, c, v, b, x_gpu, nsolve):
+def source_hash():
+    """sha256 over the kernel + host sources: profiles/traffic_latest.json records the hash it was measured with, and
+    `roofline.traffic` is only emitted while it still matches (a cached PMC figure must not outlive the kernels)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ipopt_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_baseline(n, r, c, v, b, x_gpu, neg_gpu, nsolve):
     """the reference's own CPU path (TripletToCSRConverter + PardisoMKLSolverInterface, oneMKL PARDISO), prebuilt in
-    oracle/_ref by oracle/ref_build.mk, timed on this box's host cores; falls back to the C oracle port."""
+    oracle/_ref by oracle/ref_build.mk, timed on this box's host cores (several MKL thread counts in one process, one
+    symbolic analysis); its inertia and solution are compared with the GPU's.  Falls back to the C oracle port."""
     tool = os.path.join(ROOT, "oracle", "_ref", "ref_kkt_solve")
+    ncores = os.cpu_count() or 1
     if os.path.exists(tool):
-        with tempfile.NamedTemporaryFile(suffix=".kkt", delete=False) as f:
-            f.write(np.array([n, len(v)], dtype=np.int32).tobytes()); f.write(r.astype(np.int32).tobytes())
-            f.write(c.astype(np.int32).tobytes()); f.write(v.astype(np.float64).tobytes()); f.write(b.astype(np.float64).tobytes())
-            path = f.name
-        best = None
-        ncores = os.cpu_count() or 1
-        for threads in sorted({min(16, ncores)} if len(v) > 10_000_000 else {1, min(16, ncores)}):   # (1 thread on the 2e7-entry system alone would take minutes)
-            env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads), MKL_DYNAMIC="FALSE")
-            nfac = 4 if n <= 300_000 else (3 if len(v) <= 10_000_000 else 2)
+        with tempfile.TemporaryDirectory() as d:
+            path, xpath = os.path.join(d, "sys.kkt"), os.path.join(d, "x.bin")
+            with open(path, "wb") as f:
+                f.write(np.array([n, len(v)], dtype=np.int32).tobytes()); f.write(r.astype(np.int32).tobytes())
+                f.write(c.astype(np.int32).tobytes()); f.write(v.astype(np.float64).tobytes()); f.write(b.astype(np.float64).tobytes())
+            big = len(v) > 10_000_000        # (1 thread on the 2e7-entry system alone would take minutes)
+            legs = sorted({min(t, ncores) for t in ((16, 64) if big else (1, 16, 64))})
+            nfac = 3 if big else 4           # per leg: one warm-up + (nfac - 1) timed factor+solves
+            env = dict(os.environ, MKL_NUM_THREADS=str(legs[0]), OMP_NUM_THREADS=str(max(legs)), MKL_DYNAMIC="FALSE")
             try:
-                out = subprocess.run([tool, path, str(nfac), str(nsolve)], capture_output=True, text=True, env=env, timeout=900).stdout
+                out = subprocess.run([tool, path, str(nfac), str(nsolve), xpath, ",".join(map(str, legs))], capture_output=True, text=True, env=env, timeout=1500).stdout
                 j = json.loads(out.strip().splitlines()[-1])
+                xref = np.fromfile(xpath)
             except Exception:
-                continue
+                j = None
+        if j is not None and j.get("status") == 0:
             t = j["factor_plus_first_solve_s"] + j["extra_solves_s"]
-            if best is None or t < best[0]:
-                best = (t, threads, j, nfac)
-        os.unlink(path)
-        if best is not None:
-            t, threads, j, nfac = best
-            return dict(seconds_per_step=t, cores=threads, kind="reference", num_neg=j["num_neg"],
-                        sample=f"same KKT system, {nfac - 1} timed factor+{nsolve}-solve steps after one warm-up (symbolic excluded), "
-                               f"reference PardisoMKLSolverInterface on oneMKL PARDISO, best of MKL_NUM_THREADS in {{1,{min(16, ncores)}}} (16 only for the 2e7-entry system)")
-    # port: the C oracle (scalar, 1 core) on a bounded sample (leading principal sub-band of the workload if it is large)
+            rel = float(np.abs(x_gpu - xref).max() / np.abs(xref).max())
+            return dict(seconds_per_step=t, cores=j["best_threads"], kind="reference",
+                        legs={str(L["threads"]): 1e3 * (L["factor_plus_first_solve_s"] + L["extra_solves_s"]) for L in j["legs"]},
+                        parity=dict(num_neg_reference=j["num_neg"], num_neg_gpu=int(neg_gpu), inertia_equal=bool(j["num_neg"] == neg_gpu),
+                                    rel_diff_solution=rel, tolerance=1e-7),
+                        sample=f"same KKT system, {nfac - 1} timed factor+{nsolve}-solve steps per leg after a warm-up (symbolic excluded), reference "
+                               f"PardisoMKLSolverInterface on oneMKL PARDISO, MKL threads {legs} timed in turn, best reported")
+    # port: the C oracle (scalar, 1 core)
     from oracle import kkt_oracle as ko
-    t0 = time.perf_counter(); ko.factor_solve(n, r, c, v, np.stack([b] * nsolve), u=1e-8); t = time.perf_counter() - t0
-    return dict(seconds_per_step=t, cores=1, kind="port", num_neg=None, sample="same KKT system, one factor+solves with oracle/ldlt_oracle.c")
+    t0 = time.perf_counter(); xo, oneg, _, _ = ko.factor_solve(n, r, c, v, np.stack([b] * nsolve), u=1e-8); t = time.perf_counter() - t0
+    return dict(seconds_per_step=t, cores=1, kind="port", legs={"1": 1e3 * t},
+                parity=dict(num_neg_reference=int(oneg), num_neg_gpu=int(neg_gpu), inertia_equal=bool(oneg == neg_gpu),
+                            rel_diff_solution=float(np.abs(x_gpu - xo[0]).max() / np.abs(xo[0]).max()), tolerance=1e-7),
+                sample="same KKT system, one factor+solves with oracle/ldlt_oracle.c")
+
+
+def e2e_block():
+    """IpPDFullSpaceSolver::Solve wall clock (Ipopt's own PDSystemSolverTotal timer, IpTimingStatistics.hpp:123-170) on the
+    north-star instance LukVlE1 n = 10^6: the UNMODIFIED reference host with the MI355X backend against the same host with
+    its CPU linear solver (MKL PARDISO; MUMPS is not installable offline), same box, iteration counts side by side."""
+    drv = os.path.join(ROOT, "oracle", "_ref", "ipopt_mi355x_driver")
+    if not os.path.exists(drv):
+        return None
+
+    def run(solver, threads):
+        env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads), MKL_DYNAMIC="FALSE")
+        out = subprocess.run([drv, "LukVlE1", "1000000", "--solver", solver, "--quiet"], capture_output=True, text=True, timeout=900, cwd="/tmp", env=env).stdout
+        return json.loads(next(ln for ln in out.splitlines() if ln.startswith("DRIVER_SUMMARY"))[len("DRIVER_SUMMARY "):])
+
+    try:
+        run("mi355x", 1)                                   # warm-up (page-in, clocks)
+        g = run("mi355x", 1)                               # Ipopt's own BLAS-1 on one host thread
+        ncores = os.cpu_count() or 1
+        cpu = {t: run("pardisomkl", t) for t in sorted({1, min(16, ncores), min(64, ncores)})}
+        best_t = min(cpu, key=lambda t: cpu[t]["PDSystemSolverTotal"])
+        cb = cpu[best_t]
+        keys = ("PDSystemSolverTotal", "LinearSystemFactorization", "LinearSystemBackSolve", "LinearSystemSymbolicFactorization", "wall_total")
+        return {"problem": "ScalableProblems LukVlE1 n=1000000 (KKT dim 1999998)", "timer": "PDSystemSolverTotal = IpPDFullSpaceSolver::Solve wall seconds",
+                "mi355x": {k: g[k] for k in keys} | {"iterations": g["iterations"], "objective": g["objective"], "status": g["status"]},
+                "cpu_reference": {k: cb[k] for k in keys} | {"iterations": cb["iterations"], "objective": cb["objective"], "status": cb["status"],
+                                                             "solver": "pardisomkl (oneMKL PARDISO)", "mkl_threads": best_t},
+                "cpu_PDSystemSolverTotal_by_threads": {str(t): cpu[t]["PDSystemSolverTotal"] for t in cpu},
+                "iterations_equal": bool(g["iterations"] == cb["iterations"]),
+                "speedup_PDSystemSolverTotal": cb["PDSystemSolverTotal"] / g["PDSystemSolverTotal"],
+                "speedup_wall_total": cb["wall_total"] / g["wall_total"]}
+    except Exception as e:
+        return {"error": str(e)[:300]}
 
 
 def main():
@@ -124,6 +175,7 @@ def main():
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("MI355X_KKT_FORCE_MULTI"):
@@ -168,6 +220,19 @@ def main():
     flops_step = I.flops_factor + NSOLVE * I.flops_solve
     bytes_step = I.bytes_factor + NSOLVE * I.bytes_solve
     J = s.info()
+    # the same step through the reference's HOST-buffer contract (GetValuesArrayPtr + MultiSolve on host arrays,
+    # IpSparseSymLinearSolverInterface.hpp:155,190): values copied into the pinned staging buffer, right-hand sides pageable,
+    # PCIe both ways.  Reported next to `value`, never as `value`.
+    def host_step():
+        s.values()[:] = v
+        xh = b.copy(); s.multi_solve(True, xh, True, neg)
+        xh2 = b.copy(); s.multi_solve(False, xh2)
+    host_step()
+    hreps = max(3, min(args.steps, 10))
+    t0 = time.perf_counter()
+    for _ in range(hreps):
+        host_step()
+    dth = (time.perf_counter() - t0) / hreps
 
     # ---- roofline of the dominant kernel: hip events around every launch (eager), averaged over reps ----
     reps = 5
@@ -195,8 +260,10 @@ def main():
     if os.path.exists(tfile):
         try:
             tj = json.load(open(tfile))
-            if tj.get("workload") == wl and tj.get("kernel") == roof["kernel"]:
+            # a cached PMC figure (tools/prof.sh, separate --pmc passes): only valid for the sources it was measured with
+            if tj.get("workload") == wl and tj.get("kernel") == roof["kernel"] and tj.get("source_hash") == source_hash():
                 roof["traffic"] = tj["hbm_bytes_per_factorisation"] / max(dlaunch, 1)     # per launch, like `achieved`
+                roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources: hash %s)" % tj["source_hash"]
         except Exception:
             pass
     kernel_ms = {kname: round(ms * weight[kname], 4) for kname, (ms, _) in per_rep.items()}
@@ -210,6 +277,8 @@ def main():
                    "flops_per_solve": I.flops_solve, "solves_per_step": NSOLVE, "ordering": "nested dissection + minimum-degree leaves (own)",
                    "supernodes": I.num_sn, "tree_levels": I.num_levels, "maxfront": I.maxfront, "num_neg": nneg, "scaled_residual": res},
         "algorithmic_GBps": bytes_step / dt / 1e9,
+        "host_buffer_step": {"ms_per_step": dth * 1e3, "value": flops_step / dth / 1e9, "unit": "GFLOP/s",
+                             "what": "same step through the host-buffer boundary Ipopt uses: pinned values upload (8 nnz bytes) + 2 pageable rhs round trips over PCIe"},
         "device_ms": {"factor": J.time_factor_ms, "solve": J.time_solve_ms, "by_kernel_per_step": kernel_ms},
         "analyse_s": I.time_analyse,
         "roofline": roof,
@@ -246,9 +315,15 @@ def main():
                 also[w2] = {"error": str(e)[:200]}
         line["also"] = also
     if not args.no_cpu_baseline:
-        cb = cpu_baseline(n, r, c, v, b, x, NSOLVE)
+        cb = cpu_baseline(n, r, c, v, b, x, nneg, NSOLVE)
         line["cpu_baseline"] = {"value": flops_step / cb["seconds_per_step"] / 1e9, "unit": "GFLOP/s", "cores": cb["cores"], "kind": cb["kind"],
-                                "sample": cb["sample"], "ms_per_step": cb["seconds_per_step"] * 1e3, "host_cores_available": os.cpu_count()}
+                                "sample": cb["sample"], "ms_per_step": cb["seconds_per_step"] * 1e3, "ms_per_step_by_threads": cb["legs"],
+                                "parity_vs_gpu": cb["parity"], "host_cores_available": os.cpu_count()}
+        assert cb["parity"]["inertia_equal"], cb["parity"]
+    if args.workload == "auto" and not args.no_e2e:
+        e2e = e2e_block()
+        if e2e is not None:
+            line["e2e"] = e2e
     print(json.dumps(line))
 
 

@@ -15,7 +15,8 @@
  *                                       MUMPS job=2 (IpMumpsSolverInterface.cpp:448-541); returns inertia like INFOG(12)/info.num_neg
  *   mi355x_kkt_solve               <->  the back-solve half of MultiSolve: ma97_solve (IpMa97SolverInterface.cpp:790,805),
  *                                       MUMPS job=3 (IpMumpsSolverInterface.cpp:543-583)
- *   mi355x_kkt_set_pivtol          <->  IncreaseQuality (hpp:220; u <- u^0.75, IpMa97SolverInterface.cpp:822-854)
+ *   mi355x_kkt_increase_quality    <->  IncreaseQuality (hpp:220; u <- u^0.75, IpMa97SolverInterface.cpp:822-854)
+ *   mi355x_kkt_set_pivtol          <->  the ma97_u / ma27_pivtol option (IpMa97SolverInterface.cpp:93-106)
  *   mi355x_kkt_get_info            <->  struct ma97_info (hsl_ma97d.h:96-121) / MUMPS INFOG
  *
  * Conventions: plain pointers and sizes only, no C++ types, no exceptions cross this
@@ -99,13 +100,17 @@ typedef struct mi355x_kkt_info {
     int     num_neg;         /* negative eigenvalues of the last factorisation                          */
     int     num_zero;        /* zero pivots (=> singular) of the last factorisation                     */
     int     num_two;         /* 2x2 pivots of the last factorisation                                    */
-    int     num_small;       /* pivots that failed the relative threshold test u (static pivoting:      */
-                             /* accepted, counted; the analogue of info.num_delay)                      */
+    int     num_small;       /* FAILED pivots: no pivot of the front passed the threshold tests with u  */
+                             /* and the structure being static (no delay to the parent) the candidate   */
+                             /* was eliminated anyway; the analogue of info.num_delay (hsl_ma97d.h:103) */
     int     num_big_fronts;  /* fronts handled by the blocked (global-memory, MFMA) path                */
     double  time_analyse;    /* host seconds, last analyse                                              */
     double  time_factor_ms;  /* device ms (hip events on the solver's stream), last factor              */
     double  time_solve_ms;   /* device ms, last solve                                                   */
-    double  reserved[8];
+    double  pivtol;          /* the u the next factorisation will use                                   */
+    int     u_sensitive;     /* last factorisation: 1 if some pivot decision would differ at u=pivtolmax */
+    int     reserved_i;
+    double  reserved[6];
 } mi355x_kkt_info;
 
 /* fill opts with the defaults documented above */
@@ -144,6 +149,12 @@ int  mi355x_kkt_solve_device(mi355x_kkt_handle h, int nrhs, double* d_rhs_inout,
 int  mi355x_kkt_solve_device2(mi355x_kkt_handle h, int nrhs, const double* d_b, int ldb, double* d_x, int ldx);
 
 int  mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u);
+int  mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax);
+/* IncreaseQuality (IpSparseSymLinearSolverInterface.hpp:220): raises u <- min(pivtolmax, u^0.75) (the rule of
+ * IpMa97SolverInterface.cpp:822-854, IpMa27TSolverInterface.cpp:724-740) and returns 1 -- the caller then refactors,
+ * mi355x_kkt_refactor -- or returns 0 when u is at its maximum or when the last factorisation found that no pivot decision
+ * depends on u up to pivtolmax (nothing a refactorisation could improve).  *new_u (may be NULL) receives the new u. */
+int  mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u);
 int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
 const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
 

@@ -69,6 +69,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         h->num = new Numeric();
         NumericOptions no;
         no.device = h->opts.device; no.scaling = h->opts.scaling; no.pivtol = h->opts.pivtol; no.small = h->opts.small;
+        no.pivtolmax = h->opts.pivtolmax > h->opts.pivtol ? h->opts.pivtolmax : h->opts.pivtol;
         no.refine_steps = h->opts.refine_steps; no.use_graph = h->opts.use_graph; no.rank = h->opts.rank; no.nranks = so.nranks;
         no.verbose = h->opts.verbose;
         h->numeric_ready = h->num->setup(h->sym, no);
@@ -140,6 +141,35 @@ int mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u)
     return MI355X_KKT_SUCCESS;
 }
 
+int mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!(umax > 0.0) || umax > 0.5) { h->err = "set_pivtolmax: u must be in (0, 0.5]"; return MI355X_KKT_FATAL; }
+    h->opts.pivtolmax = umax;
+    if (h->num) h->num->set_pivtolmax(umax > h->opts.pivtol ? umax : h->opts.pivtol);
+    return MI355X_KKT_SUCCESS;
+}
+
+/* IncreaseQuality (IpSparseSymLinearSolverInterface.hpp:220).  u <- min(umax, u^0.75) as the MA27/MA97/SPRAL adapters do
+ * (IpMa97SolverInterface.cpp:822-854) -- but only when that can change the factorisation: the last factorisation recorded
+ * whether ANY pivot decision would come out differently at u = pivtolmax (a pivot that passes the threshold tests at umax
+ * passes them at every smaller u).  Returns 1 and stores the new u when the caller should refactor, 0 when the quality
+ * cannot be increased (u already at its maximum, or no decision depends on u: Ipopt then goes straight to its
+ * perturbation fallback instead of burning refactorisations, IpPDFullSpaceSolver.cpp:290-301). */
+int mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u)
+{
+    if (!h) return 0;
+    const double umax = h->opts.pivtolmax > h->opts.pivtol ? h->opts.pivtolmax : h->opts.pivtol;
+    if (h->opts.pivtol >= umax) return 0;
+    if (h->factored && !h->last.u_sensitive) return 0;
+    double u = std::pow(h->opts.pivtol, 0.75);
+    if (u > umax) u = umax;
+    h->opts.pivtol = u;
+    if (h->num) h->num->set_pivtol(u);
+    if (new_u) *new_u = u;
+    return 1;
+}
+
 int mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info)
 {
     if (!h || !info) return MI355X_KKT_FATAL;
@@ -153,6 +183,7 @@ int mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info)
     info->num_sn = S.num_sn; info->num_levels = S.num_levels; info->maxfront = S.maxfront; info->maxsupernode = S.maxsupernode;
     info->num_pairs = S.num_pairs; info->num_big_fronts = S.num_big;
     info->num_neg = h->last.num_neg; info->num_zero = h->last.num_zero; info->num_two = h->last.num_two; info->num_small = h->last.num_small;
+    info->u_sensitive = h->factored ? h->last.u_sensitive : 1; info->pivtol = h->opts.pivtol;
     info->time_analyse = S.time_analyse;
     if (h->num) { info->time_factor_ms = h->num->last_factor_ms(); info->time_solve_ms = h->num->last_solve_ms(); }
     return MI355X_KKT_SUCCESS;

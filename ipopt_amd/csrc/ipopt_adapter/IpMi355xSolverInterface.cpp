@@ -29,11 +29,11 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
 {
    roptions->SetRegisteringCategory("MI355X Linear Solver");
    roptions->AddBoundedNumberOption("mi355x_pivtol", "Pivot tolerance for the MI355X LDL^T solver.", 0., true, 0.5,
-                                    false, 1e-8, "Relative threshold u used inside the fully-summed block of a front.");
+                                    false, 1e-8, "Relative threshold u of the 1x1 / 2x2 pivot tests (MA27/MA57 tests against the whole front column).");
    roptions->AddBoundedNumberOption("mi355x_pivtolmax", "Maximum pivot tolerance for the MI355X LDL^T solver.", 0.,
                                     true, 0.5, false, 1e-4, "IncreaseQuality raises the tolerance u <- u^0.75 up to this value.");
    roptions->AddStringOption2("mi355x_scaling", "Symmetric equilibration of the KKT matrix on the device.", "ruiz", "none",
-                              "no scaling", "ruiz", "3 sweeps of inf-norm Ruiz equilibration");
+                              "no scaling", "ruiz", "4 sweeps of inf-norm Ruiz equilibration");
    roptions->AddStringOption3("mi355x_ordering", "Fill-reducing ordering.", "nd", "nd",
                               "nested dissection with minimum-degree leaves", "md", "minimum degree", "natural", "identity");
    roptions->AddStringOption2("mi355x_matching", "Pre-pair zero-diagonal rows into 2x2-capable supernodes.", "yes", "no", "",
@@ -133,6 +133,7 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
    else
    {
       mi355x_kkt_set_pivtol(handle_, pivtol_);
+      mi355x_kkt_set_pivtolmax(handle_, pivtolmax_);
    }
    pivtol_changed_ = false;
    negevals_ = -1;
@@ -270,16 +271,19 @@ Index Mi355xSolverInterface::NumberOfNegEVals() const
 bool Mi355xSolverInterface::IncreaseQuality()
 {
    // same escalation rule as the MA27 / MA97 / SPRAL adapters: u <- min(umax, u^0.75)
-   // (IpMa97SolverInterface.cpp:822-854, IpMa27TSolverInterface.cpp:724-740)
-   if( pivtol_ >= pivtolmax_ )
+   // (IpMa97SolverInterface.cpp:822-854, IpMa27TSolverInterface.cpp:724-740), applied by the library -- which also knows
+   // from the last factorisation whether ANY pivot decision depends on u: if none does, a refactorisation would reproduce
+   // the same factors, so the honest answer to PDFullSpaceSolver (IpPDFullSpaceSolver.cpp:290-301) is "no".
+   double unew = pivtol_;
+   if( !handle_ || mi355x_kkt_increase_quality(handle_, &unew) == 0 )
    {
+      Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA,
+                     "MI355X solver: pivot tolerance %7.2e cannot be increased usefully (maximum reached or no pivot depends on it).\n", pivtol_);
       return false;
    }
    pivtol_changed_ = true;
-   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Increasing pivot tolerance for MI355X solver from %7.2e ", pivtol_);
-   pivtol_ = Min(pivtolmax_, std::pow(pivtol_, Number(0.75)));
-   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "to %7.2e.\n", pivtol_);
-   mi355x_kkt_set_pivtol(handle_, pivtol_);
+   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Increasing pivot tolerance for MI355X solver from %7.2e to %7.2e.\n", pivtol_, unew);
+   pivtol_ = unew;
    return true;
 }
 

@@ -19,6 +19,7 @@ struct Keep {
     int n = 0, nnz = 0, base = 1;
     std::vector<int> ptr, row;
     bool analysed = false;
+    bool with_values = false;   // the analysis in place saw values (zero-diagonal 2x2 pre-pairing done)
     double u = -1.0;
 };
 
@@ -41,7 +42,7 @@ bool do_analyse(Keep* k, const mi355x_ma97_control* c, const double* val, mi355x
         if (mi355x_kkt_create(&k->h, &o) != 0) { info->flag = -1; info->stat = 1; return false; }
     }
     if (mi355x_kkt_analyse(k->h, k->n, k->nnz, k->ptr.data(), k->row.data(), MI355X_KKT_FMT_CSR_UPPER, val) != 0) { info->flag = -4; return false; }
-    k->analysed = true;
+    k->analysed = true; k->with_values = (val != nullptr);
     info->ordering = (c && (c->ordering == 1 || c->ordering == 2)) ? 1 : 3;
     fill_info(k, info);
     return true;
@@ -73,10 +74,12 @@ void ma97_analyse_d(int /*check*/, int n, const int ptr[], const int row[], doub
         k->ptr.assign(ptr, ptr + n + 1); k->row.assign(row, row + k->nnz);
         k->analysed = false;
         info->matrix_rank = n;
-        // Without values the zero-diagonal 2x2 pre-pairing cannot be done: defer the real analysis to
-        // the first factor call (akeep is opaque to the caller).  With values (the matching-based
-        // orderings 7/8 re-call analyse with values, IpMa97SolverInterface.cpp:654-674) analyse now.
-        if (val) { if (!do_analyse(k, control, val, info)) return; }
+        // The analysis runs NOW, also without values: errors (index out of range, out of memory) surface here and
+        // info.num_factor / num_flops / maxfront are the real predictions -- the adapter's `ma97_order best` compares
+        // info.num_flops of two analyses (IpMa97SolverInterface.cpp:567-600).  Without values the zero-diagonal 2x2
+        // pre-pairing cannot be done, so the first factor call redoes the analysis once with them (akeep is opaque to the
+        // caller).  With values (the matching-based orderings 7/8, IpMa97SolverInterface.cpp:654-674) this one is final.
+        if (!do_analyse(k, control, val, info)) return;
         if (order) { for (int i = 0; i < n; ++i) order[i] = i + k->base; }
         if (order && k->analysed) {
             std::vector<int> perm(n);
@@ -94,7 +97,7 @@ void ma97_factor_d(int /*matrix_type*/, const int /*ptr*/[], const int /*row*/[]
     if (!akeep || !*akeep || !val) { info->flag = -2; return; }
     try {
         Keep* k = static_cast<Keep*>(*akeep);
-        if (!k->analysed && !do_analyse(k, control, val, info)) return;
+        if ((!k->analysed || !k->with_values) && !do_analyse(k, control, val, info)) return;
         if (control && control->u > 0 && control->u != k->u) { mi355x_kkt_set_pivtol(k->h, control->u > 0.5 ? 0.5 : control->u); k->u = control->u; }
         double* buf = mi355x_kkt_values_buffer(k->h);
         if (!buf) { info->flag = -1; return; }

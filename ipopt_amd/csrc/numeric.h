@@ -11,6 +11,7 @@ struct NumericOptions {
     int    device = -1;
     int    scaling = 1;
     double pivtol = 1e-8;
+    double pivtolmax = 1e-4;   // the largest u IncreaseQuality can reach: the factorisation records whether any pivot decision would differ there
     double small = 1e-20;
     int    refine_steps = 0;
     int    use_graph = 1;
@@ -18,7 +19,9 @@ struct NumericOptions {
     int    verbose = 0;
 };
 
-struct FactorStats { int num_neg = 0, num_zero = 0, num_two = 0, num_small = 0; };
+// num_small = failed pivots (num_delay of MA97/SSIDS): eliminated although they failed the threshold test, because the static
+// structure cannot delay them to the parent front; u_sensitive != 0: some pivot decision would differ at u = pivtolmax
+struct FactorStats { int num_neg = 0, num_zero = 0, num_two = 0, num_small = 0, u_sensitive = 1; };
 
 class NumericImpl;
 
@@ -34,6 +37,7 @@ public:
     bool   solve_device(int nrhs, double* drhs, int ld);
     bool   solve_device2(int nrhs, const double* db, int ldb, double* dx, int ldx);   // out of place
     void   set_pivtol(double u);
+    void   set_pivtolmax(double u);
     double last_factor_ms() const;
     double last_solve_ms() const;
     const std::string& error() const;

@@ -46,6 +46,7 @@ enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_L
 
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
 static constexpr double PIV_PERT = 1e-10;                // replacement magnitude for a zero pivot
+static constexpr double ZERO_REL = 1e-14;                // zero-pivot test relative to the largest entry of the assembled front
 
 // ------------------------------------------------------------------------------------------------
 // device-side view of the symbolic structure + numeric storage (passed by value to kernels)
@@ -96,7 +97,9 @@ struct DevView {
     double* arena; const long long* arena_off;
     double* top_rhs; const long long* top_rhs_off;
     // parameters
-    double pivtol, small;
+    double pivtol, pivtol2, small;   // u, the largest u IncreaseQuality may reach (decision-change tracking), absolute zero threshold
+    int* colfail;           // per column of a BIG front: 1 once some multiplier of L21 exceeded 1/u (a posteriori test, k_big_trsm)
+    int* qstat;             // [0]: some pivot decision of this factorisation would differ at u = pivtol2
     int n, nnz_a, nsn, rank;
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
 };
@@ -259,17 +262,35 @@ __device__ __forceinline__ double fast_rcp(double d)
     return r;
 }
 
+// Threshold pivoting (what u = pivtol means here; DESIGN.md "pivoting"):
+//   * candidate order: the still-alive fully-summed rows in physical order; for the current candidate j the
+//     Bunch-Kaufman rule (alpha = 0.64, on the alive fully-summed part) PREFERS one of {1x1 at j, 1x1 at r, 2x2 (j,r)},
+//     r = the fully-summed row with the largest |a_rj|;
+//   * a pivot is ACCEPTED only if it passes the MA27/MA57 threshold tests against the WHOLE remaining front column --
+//     alive fully-summed rows AND update rows:   1x1: |a_pp| >= u max_{i != p} |a_ip|;
+//     2x2: |E^{-1}| (g_p, g_q)^T <= 1/u componentwise, g = column maxima outside the block (Duff & Reid 1983; MA57);
+//     if the preferred pivot fails, the other two are tried;
+//   * a candidate with no acceptable pivot is PASSED OVER (retried after the next elimination has updated it: the
+//     in-front part of MA27's delayed pivoting).  When every alive candidate has failed, the structure being static
+//     (no delay to the parent front), the first one is eliminated anyway by the plain Bunch-Kaufman choice and counted in
+//     `ndelay` (reported as num_delay; the reference adapters read the same counter from MA97/SPRAL);
+//   * zero test relative to the scale of the assembled front: a candidate whose whole remaining column is <= ztol
+//     (= max(small, 1e-14 max|front entry|)) is a zero pivot => SYMSOLVER_SINGULAR;
+//   * `chg` is set when some decision would come out differently at u2 (= pivtolmax): IncreaseQuality uses it to
+//     answer "can a larger u change the factorisation at all".
+// Big fronts: the pivot block only sees its k x k block here (ext rows are checked a posteriori in k_big_trsm).
 template <int NT, int TS, bool WIDE>
 __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const int k, double* Lbuf, const int ldL, double* colbuf,
-                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double small,
-                                         int& nneg, int& nzero, int& ntwo, int& nsmall)
+                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double u2, const double ztol,
+                                         int& nneg, int& nzero, int& ntwo, int& ndelay, int& chg)
 {
     // The per-pivot instruction stream IS the critical path (measured: ~5 cycles per wave instruction), so the common
     // case -- 1x1 pivot on the first alive row -- is kept to ~100 instructions: unconditional wide LDS reads + bit-mask
-    // selects, one ballot instead of a max-reduction for the Bunch-Kaufman acceptance test, reciprocal by v_rcp_f64 +
-    // Newton, L column written by the 16 (8) threads that already hold it.
+    // selects, ballots instead of max-reductions for the Bunch-Kaufman and threshold acceptance tests, reciprocal by
+    // v_rcp_f64 + Newton, L column written by the 16 (8) threads that already hold it.
     constexpr int G = (NT == 64) ? 8 : (NT == 1024 ? 32 : 16);
     constexpr int MAXM = G * TS;
+    constexpr bool TWO = MAXM > 64;              // each lane looks at rows `lane` and `lane + 64` of a published column
     const int tid = threadIdx.x, lane = tid & 63;
     const int ti = tid % G, tj = tid / G;
     const int row0 = ti * TS, col0 = tj * TS;
@@ -277,88 +298,128 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 #pragma unroll
     for (int x = 0; x < TS; ++x) if (row0 + x < m) rowvalid |= 1u << x;
     const unsigned long long lanebit = 1ull << lane;
+    const int lane1 = TWO ? min(lane + 64, MAXM - 1) : 0;
+    const bool up0 = lane >= k && lane < m;                   // update rows seen by this lane
+    const bool up1 = TWO && lane + 64 >= k && lane + 64 < m;
     // fully-summed rows not yet eliminated: rows 0..63 in alive, rows 64..127 in alive1 (WIDE: pivot blocks of <= 128 columns)
     unsigned long long alive = (k >= 64) ? ~0ull : ((1ull << k) - 1ull);
     unsigned long long alive1 = (WIDE && k > 64) ? ((k >= 128) ? ~0ull : ((1ull << (k - 64)) - 1ull)) : 0ull;
+    unsigned long long tryb = alive, tryb1 = alive1;          // candidates not yet passed over since the last elimination
+    bool force = false;
     auto clear_row = [&](int r) { if (!WIDE || r < 64) alive &= ~(1ull << r); else alive1 &= ~(1ull << (r - 64)); };
-    unsigned long long bigmask = 0ull;
     int step = 0, bufsel = 0;
     while ((alive | alive1) != 0ull) {
+        if ((tryb | tryb1) == 0ull) { force = true; tryb = alive; tryb1 = alive1; }     // every candidate failed: static pivoting
         double* colA = colbuf + bufsel * 2 * MAXM; bufsel ^= 1;
         double* colB = colA + MAXM;
-        const int j = __builtin_amdgcn_readfirstlane(alive != 0ull ? __ffsll((long long)alive) - 1 : 64 + __ffsll((long long)alive1) - 1);
+        const int j = __builtin_amdgcn_readfirstlane(tryb != 0ull ? __ffsll((long long)tryb) - 1 : 64 + __ffsll((long long)tryb1) - 1);
         if (tj == j / TS) publish_col<TS>(colA, t, row0, j % TS);
         __syncthreads();
         // every LDS read of the common case (1x1 pivot on row j) is issued here, in ONE round trip
         const double djj = colA[j];
         const double avr = colA[lane];
-        const double avr1 = WIDE ? colA[(lane + 64) & (MAXM - 1)] : 0.0;
+        const double avr1 = TWO ? colA[lane1] : 0.0;
         double rv[TS], cv[TS];
 #pragma unroll
         for (int x = 0; x < TS; ++x) { rv[x] = colA[row0 + x]; cv[x] = colA[col0 + x]; }
         const double ajj = fabs(djj);
+        const double f0 = fabs(avr), f1 = fabs(avr1);
         const bool cand = (alive & lanebit) != 0ull && lane != j;
         const bool cand1 = WIDE && (alive1 & lanebit) != 0ull && lane + 64 != j;
-        const double av0 = cand ? fabs(avr) : -1.0, av1 = cand1 ? fabs(avr1) : -1.0;
-        const double av = fmax(av0, av1);
+        const double av0 = cand ? f0 : -1.0, av1 = cand1 ? f1 : -1.0;
+        const double av = fmax(av0, av1);                      // alive fully-summed rows (the Bunch-Kaufman candidates)
+        const double ga = fmax(fmax(av, up0 ? f0 : 0.0), up1 ? f1 : 0.0);      // whole remaining column, diagonal excluded
         const int bi = (av1 > av0) ? lane + 64 : lane;       // this lane's best candidate row
         int p = j, q = -1;                 // 1x1 pivot p, or 2x2 pivot (p, q)
         double dpiv = djj;
-        if (__ballot(av * BK_ALPHA > ajj) != 0ull) {          // some |a_ij| > |a_jj| / alpha: run the full Bunch-Kaufman test
-            const double lam = wave_max_all(av);
-            const unsigned long long hit = __ballot(av == lam);
-            const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
-            const int r = __builtin_amdgcn_readlane(bi, src);
-            if (tj == r / TS) publish_col<TS>(colB, t, row0, r % TS);
-            __syncthreads();
-            const bool cs = (alive & lanebit) != 0ull && lane != r;
-            const bool cs1 = WIDE && (alive1 & lanebit) != 0ull && lane + 64 != r;
-            const double sig = wave_max_all(fmax(cs ? fabs(colB[lane]) : 0.0, cs1 ? fabs(colB[(lane + 64) & (MAXM - 1)]) : 0.0));
-            const double arr = fabs(colB[r]);
-            if (ajj * sig >= BK_ALPHA * lam * lam) { /* 1x1 at j */ }
-            else if (arr >= BK_ALPHA * sig) {
+        bool zero = false;
+        const bool bkneed = __ballot(av * BK_ALPHA > ajj) != 0ull;      // some |a_ij| > |a_jj| / alpha
+        const bool thfail = __ballot(ga * u > ajj) != 0ull;             // 1x1 at j fails the threshold test
+        if (!force && __ballot(ga * u2 > ajj) != 0ull) chg = 1;
+        if (bkneed || thfail || !(ajj > ztol)) {
+            const double uu = force ? 0.0 : u;
+            const double lam = wave_max_all(av);               // -1: no alive fully-summed partner
+            const double gj = wave_max_all(ga);
+            int sel = -1;                                      // 0: 1x1 at j, 1: 1x1 at r, 2: 2x2 (j, r)
+            int r = -1;
+            if (lam > 0.0) {
+                const unsigned long long hit = __ballot(av == lam);
+                const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
+                r = __builtin_amdgcn_readlane(bi, src);
+                if (tj == r / TS) publish_col<TS>(colB, t, row0, r % TS);
+                __syncthreads();
+                const double h0 = fabs(colB[lane]), h1 = TWO ? fabs(colB[lane1]) : 0.0;
+                const bool cs = (alive & lanebit) != 0ull && lane != r;
+                const bool cs1 = WIDE && (alive1 & lanebit) != 0ull && lane + 64 != r;
+                const double sfs = fmax(cs ? h0 : 0.0, cs1 ? h1 : 0.0);
+                const double sig = wave_max_all(sfs);                                            // Bunch-Kaufman sigma
+                const double gr = wave_max_all(fmax(fmax(sfs, up0 ? h0 : 0.0), up1 ? h1 : 0.0));  // whole column r
+                const bool nj0 = lane != j, nj1 = lane + 64 != j;
+                const double gj2 = wave_max_all(fmax(fmax((cand && lane != r) ? f0 : 0.0, (cand1 && lane + 64 != r) ? f1 : 0.0), fmax(up0 ? f0 : 0.0, up1 ? f1 : 0.0)));
+                const double gr2 = wave_max_all(fmax(fmax((cs && nj0) ? h0 : 0.0, (cs1 && nj1) ? h1 : 0.0), fmax(up0 ? h0 : 0.0, up1 ? h1 : 0.0)));
+                const double a = djj, b = colA[r], c = colB[r];
+                const double arr = fabs(c), ab = fabs(b);
+                const double det = a * c - b * b, adet = fabs(det);
+                const int pref = (ajj >= BK_ALPHA * lam || ajj * sig >= BK_ALPHA * lam * lam) ? 0 : ((arr >= BK_ALPHA * sig) ? 1 : 2);
+                const double t1 = arr * gj2 + ab * gr2, t2 = ab * gj2 + ajj * gr2;                // |E^{-1}| (gj2, gr2)^T |det|
+                const bool nz2 = adet > ztol * fmax(ab, fmax(ajj, arr));
+                const bool ok0 = ajj > ztol && ajj >= uu * gj;
+                const bool ok1 = arr > ztol && arr >= uu * gr;
+                const bool ok2 = nz2 && t1 * uu <= adet && t2 * uu <= adet;
+                if ((pref == 0 && ok0) || (pref == 1 && ok1) || (pref == 2 && ok2)) sel = pref;
+                else if (ok0) sel = 0; else if (ok2) sel = 2; else if (ok1) sel = 1;
+                if (sel >= 0) {
+                    const bool f_u  = (sel == 0) ? (ajj < u * gj)  : ((sel == 1) ? (arr < u * gr)  : (t1 * u > adet  || t2 * u > adet));
+                    const bool f_u2 = (sel == 0) ? (ajj < u2 * gj) : ((sel == 1) ? (arr < u2 * gr) : (t1 * u2 > adet || t2 * u2 > adet));
+                    if (f_u) ndelay += (sel == 2) ? 2 : 1;     // only possible when forced
+                    if (f_u2 && !force) chg = 1;               // (a forced pivot stays forced at any larger u)
+                }
+            } else {
+                if (ajj > ztol && ajj >= uu * gj) { sel = 0; if (ajj < u * gj) ndelay += 1; if (ajj < u2 * gj && !force) chg = 1; }
+                else if (!(ajj > ztol) && !(gj > ztol)) { sel = 0; zero = true; }          // the whole remaining column is zero
+            }
+            if (sel < 0) {
+                if (!force) {          // pass over: retried once another elimination has updated the column
+                    if (!WIDE || j < 64) tryb &= ~(1ull << j); else tryb1 &= ~(1ull << (j - 64));
+                    continue;
+                }
+                sel = 0; zero = true;  // forced and nothing usable: a (perturbed) zero pivot => singular
+            }
+            if (sel == 1) {
                 p = r; dpiv = colB[r];
 #pragma unroll
                 for (int x = 0; x < TS; ++x) { rv[x] = colB[row0 + x]; cv[x] = colB[col0 + x]; }
-            }
-            else { q = r; }
+            } else if (sel == 2) q = r;
         }
+        force = false;
         if (q >= 0) {
             const double a = colA[p], b = colA[q], c = colB[q];
             const double det = a * c - b * b;
-            if (fabs(det) <= small) q = -1;            // degenerate block: (perturbed) 1x1 at j instead
-            else {
-                const double idet = fast_rcp(det);
-                double l0[TS], l1[TS], w0[TS], w1[TS];
+            const double idet = fast_rcp(det);
+            double l0[TS], l1[TS], w0[TS], w1[TS];
 #pragma unroll
-                for (int x = 0; x < TS; ++x) {
-                    const double r0 = colA[row0 + x], r1 = colB[row0 + x];
-                    l0[x] = (c * r0 - b * r1) * idet; l1[x] = (a * r1 - b * r0) * idet;
-                    w0[x] = colA[col0 + x]; w1[x] = colB[col0 + x];
-                }
-#pragma unroll
-                for (int x = 0; x < TS; ++x)
-#pragma unroll
-                    for (int y = 0; y < TS; ++y) t[x][y] -= l0[x] * w0[y] + l1[x] * w1[y];
-                if (tj == 0) {
-#pragma unroll
-                    for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) {
-                        Lbuf[row0 + x + step * ldL] = l0[x]; Lbuf[row0 + x + (step + 1) * ldL] = l1[x];
-                        if (fmax(fabs(l0[x]), fabs(l1[x])) * u > 1.0) bigmask |= 1ull << (step < 63 ? step : 63);
-                    }
-                }
-                if (tid == 0) {
-                    ord[step] = p; ord[step + 1] = q; pt_s[step] = 2; pt_s[step + 1] = 3;
-                    dinv_s[step] = c * idet; dinv_s[step + 1] = a * idet; doff_s[step] = -b * idet; doff_s[step + 1] = 0.0;
-                }
-                if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
-                ntwo++; clear_row(p); clear_row(q); step += 2;
-                continue;
+            for (int x = 0; x < TS; ++x) {
+                const double r0 = colA[row0 + x], r1 = colB[row0 + x];
+                l0[x] = (c * r0 - b * r1) * idet; l1[x] = (a * r1 - b * r0) * idet;
+                w0[x] = colA[col0 + x]; w1[x] = colB[col0 + x];
             }
-        }
-        {   // 1x1 pivot on physical row p (pivot column already in rv / cv)
+#pragma unroll
+            for (int x = 0; x < TS; ++x)
+#pragma unroll
+                for (int y = 0; y < TS; ++y) t[x][y] -= l0[x] * w0[y] + l1[x] * w1[y];
+            if (tj == 0) {
+#pragma unroll
+                for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) { Lbuf[row0 + x + step * ldL] = l0[x]; Lbuf[row0 + x + (step + 1) * ldL] = l1[x]; }
+            }
+            if (tid == 0) {
+                ord[step] = p; ord[step + 1] = q; pt_s[step] = 2; pt_s[step + 1] = 3;
+                dinv_s[step] = c * idet; dinv_s[step + 1] = a * idet; doff_s[step] = -b * idet; doff_s[step + 1] = 0.0;
+            }
+            if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
+            ntwo++; clear_row(p); clear_row(q); step += 2;
+        } else {   // 1x1 pivot on physical row p (pivot column already in rv / cv)
             double d = dpiv;
-            if (fabs(d) <= small) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
+            if (zero) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
             const double di = fast_rcp(d);
             // No masking of dead rows / columns: the rank-1 update itself annihilates row and column p (l_p = 1 up to
             // rounding), padding rows are exact zeros, and whatever residue is left in dead positions is never read
@@ -373,28 +434,36 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                 for (int y = 0; y < TS; ++y) t[x][y] -= l0[x] * w0[y];
             if (tj == 0) {
 #pragma unroll
-                for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) {
-                    Lbuf[row0 + x + step * ldL] = l0[x];
-                    if (fabs(l0[x]) * u > 1.0) bigmask |= 1ull << (step < 63 ? step : 63);
-                }
+                for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) Lbuf[row0 + x + step * ldL] = l0[x];
             }
             if (tid == 0) { ord[step] = p; pt_s[step] = 1; dinv_s[step] = di; doff_s[step] = 0.0; }
             if (d < 0.0) nneg++;
             clear_row(p); step += 1;
         }
+        tryb = alive; tryb1 = alive1;
     }
-    bigmask = wave_or_all(bigmask);
     __syncthreads();
-    if (NT > 64) {
-        unsigned long long* red = reinterpret_cast<unsigned long long*>(colbuf);
-        if (lane == 0) red[tid >> 6] = bigmask;
-        __syncthreads();
-        bigmask = 0ull;
+}
+
+// scale of an assembled front held in register tiles (max |entry|) -> absolute zero-pivot tolerance
+template <int NT, int TS>
+__device__ __forceinline__ double front_ztol(const double (&t)[TS][TS], double* red, const double small)
+{
+    double mx = 0.0;
 #pragma unroll
-        for (int w = 0; w < NT / 64; ++w) bigmask |= red[w];
+    for (int x = 0; x < TS; ++x)
+#pragma unroll
+        for (int y = 0; y < TS; ++y) mx = fmax(mx, fabs(t[x][y]));
+    mx = wave_max_all(mx);
+    if (NT > 64) {
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+        __syncthreads();
+        mx = 0.0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, red[w]);
         __syncthreads();
     }
-    nsmall = __popcll(bigmask);
+    return fmax(small, ZERO_REL * mx);
 }
 
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
@@ -458,9 +527,11 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
         }
     __syncthreads();                                   // F is dead from here on: its storage becomes Lbuf
     // ---- (d) LDL^T ----
-    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(5);
-    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    const double ztol = front_ztol<NT, TS>(t, colbuf, V.small);
+    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, nneg, nzero, ntwo, nsmall, chg);
+    if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(6);
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[14] = (unsigned long long)k * 1000 + m;
@@ -522,9 +593,11 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
             const int i = row0 + x, c = col0 + y;
             t[x][y] = (i < k && c < k) ? ((i >= c) ? P[i + (size_t)c * ldp] : P[c + (size_t)i * ldp]) : 0.0;
         }
-    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0;
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(0);
-    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.small, nneg, nzero, ntwo, nsmall);
+    const double ztol = front_ztol<NT, TS>(t, colbuf, V.small);
+    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, nneg, nzero, ntwo, nsmall, chg);
+    if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(1);
     // pivot-ordered unit-lower block: the row permutation is done IN PLACE in LDS through registers (each thread owns
@@ -569,6 +642,7 @@ __global__ void k_reduce_stats(const int4* fstat, const int* owner, int nsn, int
     if (threadIdx.x < 4 && sh[threadIdx.x][0] != 0) atomicAdd(&out[threadIdx.x], sh[threadIdx.x][0]);
 }
 __global__ void k_zero_i32(int* p, int n) { if (threadIdx.x < n) p[threadIdx.x] = 0; }
+__global__ void k_fill_i32(int* p, int v, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v; }
 
 // ------------------------------------------------------------------------------------------------
 // solves
@@ -1101,7 +1175,8 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
         for (int g = 0; g < 4; ++g) { const int cc = c16 + l4 + 4 * g; if (cc < k) Ws[r16 + l15 + cc * 65] = acc[g]; }
     }
     __syncthreads();
-    double lmax = 0.0;
+    // a posteriori threshold test on the rows below the pivot block (the in-block test of ldlt_reg cannot see them): a column
+    // with a multiplier above 1/u is a FAILED pivot -- a delayed pivot in MA97/SSIDS, counted once per column here (num_delay)
     for (int idx = tid; idx < 64 * k; idx += 256) {
         const int r = idx & 63, j = idx >> 6;
         const int i = ibase + r;
@@ -1111,11 +1186,11 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
         if (pt == 1) l = wj * Ds[j];
         else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * Ws[r + (j + 1) * 65];
         else l = Ds[k + j - 1] * Ws[r + (j - 1) * 65] + Ds[j] * wj;
-        if (i < m) { W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l; lmax = fmax(lmax, fabs(l)); }
+        if (i < m) {
+            W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l;
+            if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
+        }
     }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) lmax = fmax(lmax, __shfl_xor(lmax, off));
-    if (lane == 0 && lmax * V.pivtol > 1.0) atomicMax(&V.fstat[s].w, 1);
 }
 
 // T(i,c) -= sum_p L21(i,p) W21(c,p),  i >= c, on 64x64 tiles; each of the 4 waves owns a 32x32 sub-tile made of
@@ -1400,9 +1475,18 @@ __global__ void k_store_sol_mg(DevView V, double* b)
 // ------------------------------------------------------------------------------------------------
 // host-side orchestration
 // ------------------------------------------------------------------------------------------------
+// every public entry point selects the handle's device and restores the caller's on exit: a host application (or another
+// handle on another GPU / thread) may have switched the current device since setup()
+struct DeviceGuard {
+    int prev = -1; bool sw = false;
+    explicit DeviceGuard(int dev) { if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) sw = (hipSetDevice(dev) == hipSuccess); }
+    ~DeviceGuard() { if (sw) (void)hipSetDevice(prev); }
+};
+
 class NumericImpl {
 public:
     std::string err_;
+    int dev = -1;            // HIP device ordinal of this handle
     const Symbolic* S = nullptr;
     NumericOptions opt;
     bool have_device = false, ready = false, have_values = false;
@@ -1454,6 +1538,7 @@ public:
     }
     ~NumericImpl() { release(); for (auto e : prof_ev) (void)hipEventDestroy(e); }
     void release() {
+        DeviceGuard guard(dev);
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
         for (void* p : allocs) (void)hipFree(p);
@@ -1490,7 +1575,8 @@ public:
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
             err_ = "no HIP device available: the MI355X KKT backend has no CPU fallback"; have_device = false; return false; }
-        if (opt.device >= 0) HIPCHK(hipSetDevice(opt.device));
+        if (opt.device >= 0) dev = opt.device; else HIPCHK(hipGetDevice(&dev));
+        DeviceGuard guard(dev);
         have_device = true;
         {   // the main stream carries the latency-bound pivot chains: highest priority; the look-ahead stream the lowest
             int plo = 0, phi = 0;
@@ -1503,7 +1589,7 @@ public:
         if (const char* e = getenv("MI355X_KKT_LA_MIN_NT")) la_min_nt = std::max(3, atoi(e));
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
         HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void**)&h_stats, 4 * sizeof(int), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void**)&h_stats, 8 * sizeof(int), hipHostMallocDefault));
         lap("device, streams, pinned buffer");
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
@@ -1788,12 +1874,13 @@ public:
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
-            !dalloc(&d_stats, 4)) return false;
+            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n)) return false;
+        V.qstat = d_stats + 4;
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
         if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 16)) return false; }
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
-        V.pivtol = opt.pivtol; V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
+        V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_big_diag_reg<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1892,6 +1979,8 @@ public:
     bool enqueue_factor() {
         const Symbolic& Sy = *S;
         const int n = Sy.n;
+        LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
+        LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         if (opt.scaling) {      // 4 sweeps, ping-pong between the two buffers, ending in V.scale
             LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
@@ -1916,9 +2005,10 @@ public:
     }
 
     bool factor(const double* dvals, bool reuse, FactorStats& st) {
+        DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "factor: solver not set up (no device?)"; return false; }
         const Symbolic& Sy = *S;
-        V.pivtol = opt.pivtol; V.small = opt.small;
+        V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
         if (!reuse) {
             if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -1929,7 +2019,7 @@ public:
         // replay on these ~10^3-launch sequences, whose kernels are long), because a two-stream hipGraph replays up to 1.5x
         // slower once another solver's graphs have been created and destroyed in the same process (ROCm 7.2).
         if (opt.use_graph && !la_any) {
-            if (!g_factor || graph_pivtol != V.pivtol) {
+            if (!g_factor || graph_pivtol != V.pivtol || graph_pivtol2 != V.pivtol2) {
                 if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -1939,7 +2029,7 @@ public:
                 if (e != hipSuccess) { err_ = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return false; }
                 HIPCHK(hipGraphInstantiate(&g_factor, g, nullptr, nullptr, 0));
                 (void)hipGraphDestroy(g);
-                graph_pivtol = V.pivtol;
+                graph_pivtol = V.pivtol; graph_pivtol2 = V.pivtol2;
                 // the events recorded before capture are still valid; re-record for timing accuracy
                 HIPCHK(hipEventRecord(ev0, stream));
             }
@@ -1948,18 +2038,26 @@ public:
             if (!enqueue_factor()) return false;
         }
         HIPCHK(hipEventRecord(ev1, stream));
-        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
-        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3];
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4];
         return true;
     }
-    double graph_pivtol = -1.0;
+    double graph_pivtol = -1.0, graph_pivtol2 = -1.0;
 
+    // The sweeps only touch the solver's own buffers, so ONE captured graph serves every right-hand side: the two kernels
+    // that see the caller's pointers (k_load_rhs / k_store_sol) are launched eagerly around the replay.
     bool enqueue_solve(const double* dsrc, double* drhs) {
+        LAUNCH(KK_SOLVE_PERM, k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, dsrc);
+        if (!enqueue_solve_core()) return false;
+        LAUNCH(KK_SOLVE_PERM, k_store_sol, dim3(grid1d(S->n)), dim3(256), 0, stream, V, drhs);
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+    bool enqueue_solve_core() {
         const Symbolic& Sy = *S;
         const int n = Sy.n;
-        LAUNCH(KK_SOLVE_PERM, k_load_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V, dsrc);
         const int nref = opt.refine_steps > 0 ? opt.refine_steps : 0;
         if (nref > 0) LAUNCH(KK_SOLVE_PERM, k_save_rhs, dim3(grid1d(n)), dim3(256), 0, stream, V);
         for (int pass = 0; pass <= nref; ++pass) {
@@ -1995,33 +2093,32 @@ public:
                 }
         }
         if (nref > 0) LAUNCH(KK_SOLVE_PERM, k_refine_finish, dim3(grid1d(n)), dim3(256), 0, stream, V);
-        LAUNCH(KK_SOLVE_PERM, k_store_sol, dim3(grid1d(n)), dim3(256), 0, stream, V, drhs);
         HIPCHK(hipGetLastError());
         return true;
     }
-    double* graph_rhs = nullptr; const double* graph_src = nullptr;
 
     bool solve_device(int nrhs, const double* dsrc, int lds_, double* drhs, int ld, bool timed) {
+        DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
         if (timed) HIPCHK(hipEventRecord(ev0, stream));
         for (int r = 0; r < nrhs; ++r) {
             double* col = drhs + (size_t)r * ld;
             const double* src = dsrc + (size_t)r * lds_;
             if (opt.use_graph) {
-                if (!g_solve || graph_rhs != col || graph_src != src) {
-                    if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
+                if (!g_solve) {
                     hipGraph_t g = nullptr;
                     HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                    bool ok = enqueue_solve(src, col);
+                    bool ok = enqueue_solve_core();
                     hipError_t e = hipStreamEndCapture(stream, &g);
                     if (!ok) return false;
                     if (e != hipSuccess) { err_ = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return false; }
                     HIPCHK(hipGraphInstantiate(&g_solve, g, nullptr, nullptr, 0));
                     (void)hipGraphDestroy(g);
-                    graph_rhs = col; graph_src = src;
                     if (timed && r == 0) HIPCHK(hipEventRecord(ev0, stream));
                 }
+                hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, src);
                 HIPCHK(hipGraphLaunch(g_solve, stream));
+                hipLaunchKernelGGL(k_store_sol, dim3(grid1d(S->n)), dim3(256), 0, stream, V, col);
             } else if (!enqueue_solve(src, col)) return false;
         }
         if (timed) { HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms; }
@@ -2072,13 +2169,16 @@ public:
         return true;
     }
     bool factor_local(const double* dvals) {
+        DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
         const Symbolic& Sy = *S; const int n = Sy.n;
-        V.pivtol = opt.pivtol; V.small = opt.small;
+        V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
         if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
         else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
         have_values = true;
         HIPCHK(hipEventRecord(ev0, stream));
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
+        hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         if (opt.scaling) {
             hipLaunchKernelGGL(k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
@@ -2098,15 +2198,16 @@ public:
         return true;
     }
     bool factor_top(FactorStats& st) {
+        DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "factor_top: not a multi-GPU handle"; return false; }
         HIPCHK(hipEventRecord(ev0, stream));
         if (!launch_fronts(sch_top, 1)) return false;
         // this rank reports its own subtrees; rank 0 also the replicated top => the sum over ranks is the inertia
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
         hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
-        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3];
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4];
         if (opt.rank == 0) {
             hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
             hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
@@ -2119,6 +2220,7 @@ public:
         return true;
     }
     bool solve_fwd_local(double* drhs) {
+        DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "solve_fwd_local: not a multi-GPU handle"; return false; }
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, (const double*)drhs);
@@ -2130,6 +2232,7 @@ public:
         return true;
     }
     bool solve_top_and_bwd(double* drhs) {
+        DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "solve_top_and_bwd: not a multi-GPU handle"; return false; }
         HIPCHK(hipEventRecord(ev0, stream));
         if (!launch_solve_sweep(sch_top, true, 1)) return false;
@@ -2143,11 +2246,13 @@ public:
     }
 
     bool debug_clocks(unsigned long long* out) {
+        DeviceGuard guard(dev);
         if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
         HIPCHK(hipMemcpy(out, V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost)); return true;
     }
     // eager (graph-less) factor + one solve with hip events around every launch; accumulates over `reps`
     bool profile(int reps, double* ms, int* launches) {
+        DeviceGuard guard(dev);
         if (!ready || !have_values) { err_ = "profile: factor() must have been called once"; return false; }
         for (int q = 0; q < KK_COUNT; ++q) { prof_ms[q] = 0; prof_launches[q] = 0; }
         if (d_rhs_cap < (size_t)S->n) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(S->n, 1) * sizeof(double))); d_rhs_cap = S->n; HIPCHK(hipMemset(d_rhs, 0, S->n * sizeof(double)));
@@ -2162,6 +2267,7 @@ public:
         return true;
     }
     bool solve_host(int nrhs, double* rhs, int ld) {
+        DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
         const size_t n = S->n;
         if (d_rhs_cap < n) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(n, 1) * sizeof(double))); d_rhs_cap = n;
@@ -2188,6 +2294,7 @@ bool Numeric::solve_host(int nrhs, double* rhs, int ld) { return p_->solve_host(
 bool Numeric::solve_device(int nrhs, double* drhs, int ld) { return p_->solve_device(nrhs, drhs, ld, drhs, ld, true); }
 bool Numeric::solve_device2(int nrhs, const double* db, int ldb, double* dx, int ldx) { return p_->solve_device(nrhs, db, ldb, dx, ldx, true); }
 void Numeric::set_pivtol(double u) { p_->opt.pivtol = u; }
+void Numeric::set_pivtolmax(double u) { p_->opt.pivtolmax = u; }
 double Numeric::last_factor_ms() const { return p_->factor_ms; }
 double Numeric::last_solve_ms() const { return p_->solve_ms; }
 const std::string& Numeric::error() const { return p_->err_; }

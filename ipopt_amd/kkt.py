@@ -39,7 +39,8 @@ class _Info(C.Structure):
                 ("num_sn", C.c_int), ("num_levels", C.c_int), ("maxfront", C.c_int), ("maxsupernode", C.c_int),
                 ("num_pairs", C.c_int), ("num_neg", C.c_int), ("num_zero", C.c_int), ("num_two", C.c_int),
                 ("num_small", C.c_int), ("num_big_fronts", C.c_int), ("time_analyse", C.c_double),
-                ("time_factor_ms", C.c_double), ("time_solve_ms", C.c_double), ("reserved", C.c_double * 8)]
+                ("time_factor_ms", C.c_double), ("time_solve_ms", C.c_double), ("pivtol", C.c_double), ("u_sensitive", C.c_int),
+                ("reserved_i", C.c_int), ("reserved", C.c_double * 6)]
 
 
 @dataclass
@@ -47,7 +48,7 @@ class KKTInfo:
     n: int; nnz_in: int; nnz_a: int; nnz_l: int; flops_factor: int; flops_solve: int; bytes_factor: int
     bytes_solve: int; sum_sn_rows: int; cb_doubles: int; num_sn: int; num_levels: int; maxfront: int
     maxsupernode: int; num_pairs: int; num_neg: int; num_zero: int; num_two: int; num_small: int
-    num_big_fronts: int; time_analyse: float; time_factor_ms: float; time_solve_ms: float
+    num_big_fronts: int; time_analyse: float; time_factor_ms: float; time_solve_ms: float; pivtol: float; u_sensitive: int
 
 
 def library_path() -> str:
@@ -60,7 +61,8 @@ _LIB = None
 ABI_SYMBOLS = [
     "mi355x_kkt_default_options", "mi355x_kkt_create", "mi355x_kkt_destroy", "mi355x_kkt_analyse",
     "mi355x_kkt_values_buffer", "mi355x_kkt_factor", "mi355x_kkt_refactor", "mi355x_kkt_solve",
-    "mi355x_kkt_solve_device", "mi355x_kkt_solve_device2", "mi355x_kkt_set_pivtol", "mi355x_kkt_get_info", "mi355x_kkt_last_error",
+    "mi355x_kkt_solve_device", "mi355x_kkt_solve_device2", "mi355x_kkt_set_pivtol", "mi355x_kkt_set_pivtolmax", "mi355x_kkt_increase_quality",
+    "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
 ]
@@ -94,6 +96,8 @@ def load_library():
     lib.mi355x_kkt_solve_device.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.mi355x_kkt_solve_device2.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
     lib.mi355x_kkt_set_pivtol.argtypes = [vp, C.c_double]
+    lib.mi355x_kkt_set_pivtolmax.argtypes = [vp, C.c_double]
+    lib.mi355x_kkt_increase_quality.argtypes = [vp, dp]
     lib.mi355x_kkt_get_info.argtypes = [vp, C.POINTER(_Info)]
     lib.mi355x_kkt_last_error.argtypes = [vp]
     lib.mi355x_kkt_last_error.restype = C.c_char_p
@@ -217,14 +221,20 @@ class KKTSolver:
     def number_of_neg_evals(self) -> int:
         return self._neg
 
-    # --- IncreaseQuality (hpp:220): u <- min(umax, u^0.75), as MA97/SPRAL/MA27 adapters do ---
+    # --- IncreaseQuality (hpp:220): u <- min(umax, u^0.75), as MA97/SPRAL/MA27 adapters do; False when u is at its
+    #     maximum OR the last factorisation found no pivot decision that depends on u (nothing a refactorisation could change) ---
     def increase_quality(self) -> bool:
-        if self.pivtol >= self.pivtolmax:
+        u = C.c_double(0.0)
+        if self.lib.mi355x_kkt_increase_quality(self._h, C.byref(u)) == 0:
             return False
-        self.pivtol = min(self.pivtolmax, self.pivtol ** 0.75)
-        self.lib.mi355x_kkt_set_pivtol(self._h, self.pivtol)
+        self.pivtol = u.value
         self._refactor = True
         return True
+
+    def set_pivtol(self, u: float):
+        if self.lib.mi355x_kkt_set_pivtol(self._h, float(u)) != 0:
+            raise KKTError("set_pivtol: " + self.last_error())
+        self.pivtol = float(u)
 
     @staticmethod
     def provides_inertia() -> bool:

@@ -37,7 +37,8 @@ OBJS := $(patsubst $(REF)/src/%.cpp,$(OUT)/obj/%.o,$(SRCS_CPP)) $(patsubst $(REF
 # MKL is isolated behind symlinks so that conda's older libstdc++ is never on the link path
 MKLLINK := -L$(OUT)/mkl -lmkl_rt -Wl,-rpath,'$$ORIGIN/mkl' -ldl -lm -lpthread
 
-all: $(OUT)/libipopt_ref.so $(OUT)/hs071_cpp $(OUT)/scalable.a $(OUT)/ref_driver $(OUT)/ref_kkt_solve $(OUT)/libmi355x_ipopt.so $(OUT)/ipopt_mi355x_driver
+all: $(OUT)/libipopt_ref.so $(OUT)/hs071_cpp $(OUT)/scalable.a $(OUT)/ref_driver $(OUT)/ref_kkt_solve $(OUT)/libmi355x_ipopt.so $(OUT)/ipopt_mi355x_driver \
+     $(OUT)/libipopt_ref_mi355x.so $(OUT)/ipopt_patched_driver
 
 $(OUT)/mkl/.stamp:
 	mkdir -p $(OUT)/mkl
@@ -95,6 +96,28 @@ $(OUT)/ref_kkt_solve: oracle/ref_kkt_solve.cpp $(OUT)/libipopt_ref.so
 $(OUT)/ipopt_mi355x_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/scalable.a $(OUT)/libmi355x_ipopt.so
 	$(CXX) -O2 -DHAVE_CONFIG_H -DWITH_MI355X -std=c++11 -w $(DRV_INCS) $< $(REF)/examples/hs071_cpp/hs071_nlp.cpp $(OUT)/scalable.a -o $@ \
 	  -L$(OUT) -lipopt_ref -lmi355x_ipopt -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib' $(MKLLINK)
+
+# --- route B1': the reference WITH the `linear_solver=mi355x` patch a maintainer would carry (oracle/patches/linear_solver_mi355x.patch:
+#     one factory arm in IpAlgBuilder.cpp:427-526, option registration in IpLinearSolversRegOp.cpp:84-90).  The two patched
+#     translation units are produced in the build directory, compiled and removed again; everything else is the unmodified objects. ---
+PATCH   := oracle/patches/linear_solver_mi355x.patch
+PSRC    := Algorithm/IpAlgBuilder.cpp Algorithm/LinearSolvers/IpLinearSolversRegOp.cpp
+POBJS   := $(OUT)/obj_patched/IpAlgBuilder.o $(OUT)/obj_patched/IpLinearSolversRegOp.o $(OUT)/obj_patched/IpMi355xSolverInterface.o
+$(OUT)/obj_patched/.stamp: $(PATCH) ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.hpp include/mi355x_kkt.h
+	rm -rf $(OUT)/obj_patched $(OUT)/patched_src; mkdir -p $(OUT)/obj_patched $(OUT)/patched_src/src/Algorithm/LinearSolvers
+	for f in $(PSRC); do cp $(REF)/src/$$f $(OUT)/patched_src/src/$$f; done
+	cd $(OUT)/patched_src && patch -p1 -s < $(CURDIR)/$(PATCH)
+	for f in $(PSRC); do $(CXX) $(CXXFLAGS_REF) -DIPOPT_HAS_MI355X $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c $(OUT)/patched_src/src/$$f -o $(OUT)/obj_patched/`basename $$f .cpp`.o || exit 1; done
+	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp -o $(OUT)/obj_patched/IpMi355xSolverInterface.o
+	rm -rf $(OUT)/patched_src
+	touch $@
+$(OUT)/libipopt_ref_mi355x.so: $(OBJS) $(OUT)/obj_patched/.stamp $(OUT)/mkl/.stamp
+	@$(CXX) -shared -o $@ $(filter-out %/Algorithm/IpAlgBuilder.o %/Algorithm/LinearSolvers/IpLinearSolversRegOp.o,$(OBJS)) $(POBJS) \
+	  -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib' $(MKLLINK)
+# the same driver against the patched library: `--solver stock --set linear_solver mi355x`
+$(OUT)/ipopt_patched_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref_mi355x.so $(OUT)/scalable.a
+	$(CXX) -O2 -DHAVE_CONFIG_H -std=c++11 -w $(DRV_INCS) $< $(REF)/examples/hs071_cpp/hs071_nlp.cpp $(OUT)/scalable.a -o $@ \
+	  -L$(OUT) -lipopt_ref_mi355x -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib' $(MKLLINK)
 
 clean:
 	rm -rf $(OUT)

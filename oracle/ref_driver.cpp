@@ -12,8 +12,13 @@
 // call crossing the boundary (structure, values, rhs, returned status / inertia / solution).  That
 // is how tests/golden/*.kktrec are produced from the reference itself (tests/golden/make_golden.sh).
 //
-// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x] [--record file] [--max-records K]
-//                   [--set name value]... [--quiet]
+// --solver stock leaves the choice to the reference's own AlgorithmBuilder, i.e. to the `linear_solver` option
+// (--set linear_solver ma97 --set hsllib .../libmi355x_kkt.so = route B2; --set linear_solver mi355x with the patched
+// library oracle/_ref/libipopt_ref_mi355x.so = route B1').
+//
+// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|stock] [--record file] [--max-records K]
+//                   [--set name value]... [--optfile ipopt.opt] [--reoptimize] [--quiet]
+//   --reoptimize: after the first solve, set warm_start_same_structure=yes and call ReOptimizeNLP (second DRIVER_SUMMARY line)
 #include "IpIpoptApplication.hpp"
 #include "IpTNLPAdapter.hpp"
 #include "IpAlgBuilder.hpp"
@@ -136,7 +141,8 @@ int main(int argc, char** argv)
    int N = atoi(argv[2]);
    std::string solver = "pardisomkl", record;
    int max_records = -1;
-   bool quiet = false;
+   bool quiet = false, reopt = false;
+   std::string optfile;
    std::vector<std::pair<std::string, std::string> > sets;
    for( int i = 3; i < argc; ++i )
    {
@@ -146,6 +152,8 @@ int main(int argc, char** argv)
       else if( a == "--max-records" && i + 1 < argc ) max_records = atoi(argv[++i]);
       else if( a == "--set" && i + 2 < argc ) { sets.push_back(std::make_pair(std::string(argv[i + 1]), std::string(argv[i + 2]))); i += 2; }
       else if( a == "--quiet" ) quiet = true;
+      else if( a == "--reoptimize" ) reopt = true;
+      else if( a == "--optfile" && i + 1 < argc ) optfile = argv[++i];
       else { fprintf(stderr, "bad argument %s\n", a.c_str()); return 2; }
    }
 
@@ -168,7 +176,7 @@ int main(int argc, char** argv)
 
    SmartPtr<IpoptApplication> app = IpoptApplicationFactory();
 #ifdef WITH_MI355X
-   Mi355xSolverInterface::RegisterOptions(app->RegOptions());
+   Mi355xSolverInterface::RegisterOptions(app->RegOptions());   // (the patched library registers them itself, IpLinearSolversRegOp.cpp)
 #endif
    app->Options()->SetStringValue("print_timing_statistics", "yes");
    if( problem == "hs071" )
@@ -188,14 +196,25 @@ int main(int argc, char** argv)
       if( !ok ) ok = app->Options()->SetStringValue(k, v, true, true);
       if( !ok ) { fprintf(stderr, "could not set option %s=%s\n", k.c_str(), v.c_str()); return 2; }
    }
-   if( app->Initialize("") != Solve_Succeeded ) { fprintf(stderr, "Initialize failed\n"); return 3; }
+   if( app->Initialize(optfile) != Solve_Succeeded ) { fprintf(stderr, "Initialize failed\n"); return 3; }
 
    SmartPtr<NLP> nlp = new TNLPAdapter(tnlp, app->Jnlst());
-   SmartPtr<AlgorithmBuilder> builder = new DriverAlgBuilder(solver, record, max_records);
+   SmartPtr<AlgorithmBuilder> builder;
+   if( solver == "stock" ) builder = new AlgorithmBuilder();     // the reference's own factory chain (IpAlgBuilder.cpp:427-526)
+   else builder = new DriverAlgBuilder(solver, record, max_records);
    auto t0 = std::chrono::steady_clock::now();
    ApplicationReturnStatus status = app->OptimizeNLP(nlp, builder);
    double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
+   for( int pass = 0; pass < (reopt ? 2 : 1); ++pass )
+   {
+   if( pass == 1 )
+   {  // same structure, same start: the backend must keep its symbolic analysis (IpMumpsSolverInterface.cpp:227-236 pattern)
+      app->Options()->SetStringValue("warm_start_same_structure", "yes");
+      t0 = std::chrono::steady_clock::now();
+      status = app->ReOptimizeNLP(nlp);
+      total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   }
    SmartPtr<SolveStatistics> stats = app->Statistics();
    int iters = IsValid(stats) ? stats->IterationCount() : -1;
    double obj = IsValid(stats) ? stats->FinalObjective() : 0.;
@@ -208,5 +227,6 @@ int main(int argc, char** argv)
           wall(ts.PDSystemSolverTotal()), wall(ts.PDSystemSolverSolveOnce()), wall(ts.LinearSystemFactorization()),
           wall(ts.LinearSystemBackSolve()), wall(ts.LinearSystemSymbolicFactorization()), wall(ts.LinearSystemStructureConverter()),
           wall(ts.StdAugSystemSolverMultiSolve()), wall(ts.OverallAlgorithm()), (double) ts.TotalFunctionEvaluationWallclockTime());
+   }
    return (status == Solve_Succeeded || status == Solved_To_Acceptable_Level) ? 0 : 1;
 }

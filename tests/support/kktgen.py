@@ -100,3 +100,38 @@ def to_scipy(n, row, col, val):
     L = sp.coo_matrix((val, (hi, lo)), shape=(n, n)).tocsr()
     D = sp.diags(L.diagonal())
     return (L + L.T - D).tocsr()
+
+
+# ---- known-answer systems for the pivot-threshold contract (u = pivtol) ----
+KAT_OPTS = dict(ordering=2, matching=0, scaling=0, nemin=1)     # natural order, no pre-pairing, no equilibration: the fronts are as written
+
+
+def threshold_kat(eps=1e-5):
+    """5 x 5 system whose first front has 3 fully-summed columns {1,2,3} and one update row {4} (natural order, KAT_OPTS).
+    Column 1: tiny diagonal eps, coupling 1 to the UPDATE row, 1e-3 to column 2; column 2 couples strongly (1) to column 3.
+    Bunch-Kaufman (which only sees the fully-summed block) prefers the 1x1 pivot eps.  With u = 1e-8 it passes the
+    threshold test (eps >= u * 1), with u = 1e-4 it fails and the 2x2 pivot (1,2) -- which passes the MA57 test -- is taken
+    instead: num_two differs, the inertia and the solution must not."""
+    ent = [(1, 1, eps), (2, 1, 1e-3), (3, 1, 0.0), (4, 1, 1.0),
+           (2, 2, 0.0), (3, 2, 1.0),
+           (3, 3, 2.0), (4, 3, 0.5),
+           (4, 4, -1.0), (5, 4, 1.0),
+           (5, 5, 3.0)]
+    r = np.array([e[0] for e in ent], dtype=np.int32); c = np.array([e[1] for e in ent], dtype=np.int32)
+    return 5, r, c, np.array([e[2] for e in ent], dtype=np.float64)
+
+
+def forced_pivot_kat(eps=1e-6):
+    """4 x 4 system: the leaf front of variable 2 has ONE fully-summed column with diagonal eps and an update-row entry 1.  u = 1e-8 accepts the pivot; at u = 1e-4 it fails the threshold test, nothing else in the
+    front can be pivoted on, and -- the structure being static -- it is eliminated anyway and reported: num_delay = 1."""
+    ent = [(1, 1, 2.0), (3, 1, 1.0), (2, 2, eps), (4, 2, 1.0), (3, 3, -1.0), (4, 3, 0.5), (4, 4, -1.0)]
+    r = np.array([e[0] for e in ent], dtype=np.int32); c = np.array([e[1] for e in ent], dtype=np.int32)
+    return 4, r, c, np.array([e[2] for e in ent], dtype=np.float64)
+
+
+def nearly_dependent_rows(delta=1e-15, nx=6):
+    """KKT with two constraint rows that differ by `delta` (relative): numerically rank deficient for delta ~ eps.  delta_c = 0."""
+    m = 3
+    H = (np.arange(nx), np.arange(nx), np.full(nx, 2.0))
+    ji = np.array([0, 0, 1, 1, 2, 2]); jj = np.array([0, 1, 0, 1, 3, 4]); jv = np.array([1.0, 2.0, 1.0, 2.0 * (1.0 + delta), 1.0, 1.0])
+    return kkt_from_blocks(H, np.zeros(nx), (ji, jj, jv), np.zeros(m), nx, m)

@@ -71,3 +71,215 @@ def factor_solve(sym, vals, rhs, only=None):
     out = np.zeros(n)
     out[sym["perm"]] = x
     return out, negs
+
+
+# ------------------------------------------------------------------------------------------------------
+# Executable SPECIFICATION of the pivoting rules of ipopt_amd/csrc/numeric.hip (ldlt_reg / k_big_trsm), in
+# plain numpy: same candidate order, same Bunch-Kaufman preference, same MA27/MA57 threshold tests against
+# the whole front column, same pass-over / forced-pivot / zero-pivot rules.  The CPU tests pin it against
+# the oracle (inertia, solution) at several u; the GPU tests compare the HIP kernels' pivot statistics
+# (num_two, num_delay, u_sensitive) with it.  TEST SUPPORT ONLY.
+# ------------------------------------------------------------------------------------------------------
+BK_ALPHA = 0.6403882032022076
+PIV_PERT = 1e-10
+ZERO_REL = 1e-14
+
+
+def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True):
+    """In-place LDL^T of the first k (fully-summed) rows/columns of the symmetric m x m front F.
+    Returns dict(ord, ptype, dinv, doff, L (m x k, physical rows, column = elimination step), nneg, nzero, ntwo, ndelay, chg)."""
+    m = F.shape[0]
+    ztol = max(small, ZERO_REL * (np.abs(F).max() if F.size else 0.0))
+    alive = list(range(k))
+    tryb = list(alive)
+    force = False
+    upd = list(range(k, m)) if see_update_rows else []
+    L = np.zeros((m, k)); order = []; ptype = []; dinv = []; doff = []
+    st = dict(nneg=0, nzero=0, ntwo=0, ndelay=0, chg=0)
+
+    def colmax(col, rows):
+        return max((abs(F[i, col]) for i in rows), default=0.0)
+
+    while alive:
+        if not tryb:
+            force = True; tryb = list(alive)
+        j = tryb[0]
+        ajj = abs(F[j, j])
+        fs = [i for i in alive if i != j]
+        gj = max(colmax(j, fs), colmax(j, upd))
+        lam = colmax(j, fs) if fs else -1.0
+        bkneed = lam * BK_ALPHA > ajj
+        thfail = gj * u > ajj
+        if not force and gj * u2 > ajj:
+            st["chg"] = 1
+        p, q, zero = j, -1, False
+        if bkneed or thfail or not (ajj > ztol):
+            uu = 0.0 if force else u
+            sel = -1
+            r = -1
+            if lam > 0.0:
+                r = next(i for i in fs if abs(F[i, j]) == lam)
+                fsr = [i for i in alive if i != r]
+                sig = colmax(r, fsr)
+                gr = max(sig, colmax(r, upd))
+                rest = [i for i in alive if i not in (j, r)] + upd
+                gj2, gr2 = colmax(j, rest), colmax(r, rest)
+                a, b, c = F[j, j], F[r, j], F[r, r]
+                arr, ab = abs(c), abs(b)
+                det = a * c - b * b; adet = abs(det)
+                pref = 0 if (ajj >= BK_ALPHA * lam or ajj * sig >= BK_ALPHA * lam * lam) else (1 if arr >= BK_ALPHA * sig else 2)
+                t1, t2 = arr * gj2 + ab * gr2, ab * gj2 + ajj * gr2
+                nz2 = adet > ztol * max(ab, ajj, arr)
+                ok = [ajj > ztol and ajj >= uu * gj, arr > ztol and arr >= uu * gr, nz2 and t1 * uu <= adet and t2 * uu <= adet]
+                if ok[pref]:
+                    sel = pref
+                elif ok[0]:
+                    sel = 0
+                elif ok[2]:
+                    sel = 2
+                elif ok[1]:
+                    sel = 1
+                if sel >= 0:
+                    fu = [ajj < u * gj, arr < u * gr, t1 * u > adet or t2 * u > adet][sel]
+                    fu2 = [ajj < u2 * gj, arr < u2 * gr, t1 * u2 > adet or t2 * u2 > adet][sel]
+                    if fu:
+                        st["ndelay"] += 2 if sel == 2 else 1
+                    if fu2 and not force:
+                        st["chg"] = 1
+            else:
+                if ajj > ztol and ajj >= uu * gj:
+                    sel = 0
+                    if ajj < u * gj:
+                        st["ndelay"] += 1
+                    if ajj < u2 * gj and not force:
+                        st["chg"] = 1
+                elif not (ajj > ztol) and not (gj > ztol):
+                    sel, zero = 0, True
+            if sel < 0:
+                if not force:
+                    tryb.remove(j)
+                    continue
+                sel, zero = 0, True
+            if sel == 1:
+                p = r
+            elif sel == 2:
+                q = r
+        force = False
+        s = len(order)
+        live = [i for i in alive if i not in (p, q)] + list(range(k, m))
+        if q >= 0:
+            a, b, c = F[p, p], F[q, p], F[q, q]
+            det = a * c - b * b
+            w0, w1 = F[:, p].copy(), F[:, q].copy()
+            l0, l1 = (c * w0 - b * w1) / det, (a * w1 - b * w0) / det
+            for i in live:
+                L[i, s], L[i, s + 1] = l0[i], l1[i]
+            idx = np.array(live, dtype=int)
+            F[np.ix_(idx, idx)] -= np.outer(l0[idx], w0[idx]) + np.outer(l1[idx], w1[idx])
+            order += [p, q]; ptype += [2, 3]; dinv += [c / det, a / det]; doff += [-b / det, 0.0]
+            st["nneg"] += 1 if det < 0 else (2 if a + c < 0 else 0)
+            st["ntwo"] += 1
+            alive.remove(p); alive.remove(q)
+        else:
+            d = F[p, p]
+            if zero:
+                st["nzero"] += 1
+                d = -PIV_PERT if d < 0 else PIV_PERT
+            w0 = F[:, p].copy()
+            l0 = w0 / d
+            for i in live:
+                L[i, s] = l0[i]
+            idx = np.array(live, dtype=int)
+            F[np.ix_(idx, idx)] -= np.outer(l0[idx], w0[idx])
+            order += [p]; ptype += [1]; dinv += [1.0 / d]; doff += [0.0]
+            if d < 0:
+                st["nneg"] += 1
+            alive.remove(p)
+        tryb = list(alive)
+    st.update(ord=np.array(order, dtype=int), ptype=ptype, dinv=np.array(dinv), doff=np.array(doff), L=L)
+    return st
+
+
+BIG_FRONT = 128      # fronts above this order take the blocked path: in-block test + a posteriori test on the rows below
+
+
+def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20):
+    """multifrontal LDL^T with the pivoting rules of the HIP kernels (no scaling: use scaling=0 on the GPU side).
+    Returns (x, dict(num_neg, num_zero, num_two, num_delay, u_sensitive))."""
+    I = sym["info"]
+    n, nsn = I.n, I.num_sn
+    aval = np.zeros(I.nnz_a)
+    np.add.at(aval, sym["t2s"], vals)
+    colptr, rowptr, rows, rel, parent = sym["colptr"], sym["rowptr"], sym["rows"], sym["rel"], sym["parent"]
+    children = [[] for _ in range(nsn)]
+    for s in range(nsn):
+        if parent[s] >= 0:
+            children[parent[s]].append(s)
+    fac, cbs, cvec = [None] * nsn, [None] * nsn, [None] * nsn
+    tot = dict(num_neg=0, num_zero=0, num_two=0, num_delay=0, u_sensitive=0)
+    b = rhs[sym["perm"]].astype(float).copy()
+    for s in range(nsn):
+        c0, c1 = colptr[s], colptr[s + 1]
+        k = c1 - c0
+        r = rows[rowptr[s]:rowptr[s + 1]]
+        m = r.shape[0]
+        F = np.zeros((m, m))
+        q0, q1 = sym["acolptr"][c0], sym["acolptr"][c1]
+        pos = sym["apos"][q0:q1]
+        li, lj = pos % m, pos // m
+        F[li, lj] += aval[q0:q1]
+        off = li != lj
+        F[lj[off], li[off]] += aval[q0:q1][off]
+        bs = np.zeros(m); bs[:k] = b[c0:c1]
+        for ch in children[s]:
+            kc = colptr[ch + 1] - colptr[ch]
+            rl = rel[rowptr[ch] + kc:rowptr[ch + 1]]
+            F[np.ix_(rl, rl)] += cbs[ch]
+            bs[rl] += cvec[ch]
+            cbs[ch] = None
+        if m <= BIG_FRONT:
+            st = ldlt_front(F, k, u, u2, small)
+            P = st["ord"]
+            L11 = np.tril(st["L"][P, :], -1) + np.eye(k)
+            L21 = st["L"][k:, :]
+            cb = F[k:, k:].copy()
+        else:
+            A11 = F[:k, :k].copy()
+            st = ldlt_front(A11, k, u, u2, small, see_update_rows=False)
+            P = st["ord"]
+            L11 = np.tril(st["L"][P, :], -1) + np.eye(k)
+            D = np.zeros((k, k))
+            Dinv = _dinv_matrix(st)
+            W = np.linalg.solve(L11, F[k:, :k][:, P].T).T            # W21 = A21 P L11^{-T}
+            L21 = W @ Dinv
+            st["ndelay"] += int((np.abs(L21).max(axis=0) * u > 1.0).sum()) if m > k else 0
+            cb = F[k:, k:] - L21 @ W.T
+        tot["num_neg"] += st["nneg"]; tot["num_zero"] += st["nzero"]; tot["num_two"] += st["ntwo"]; tot["num_delay"] += st["ndelay"]
+        tot["u_sensitive"] |= st["chg"]
+        Dinv = _dinv_matrix(st)
+        fac[s] = (P, L11, L21, Dinv)
+        cbs[s] = cb
+        y = np.linalg.solve(L11, bs[:k][P])
+        cvec[s] = bs[k:] - L21 @ y
+        b[c0:c1] = Dinv @ y                       # z, in pivot order
+    x = np.zeros(n)
+    for s in range(nsn - 1, -1, -1):
+        c0, c1 = colptr[s], colptr[s + 1]
+        k = c1 - c0
+        r = rows[rowptr[s]:rowptr[s + 1]]
+        P, L11, L21, _ = fac[s]
+        xp = np.linalg.solve(L11.T, b[c0:c1] - L21.T @ x[r[k:]])
+        x[c0 + P] = xp
+    out = np.zeros(n)
+    out[sym["perm"]] = x
+    return out, tot
+
+
+def _dinv_matrix(st):
+    k = len(st["ptype"])
+    Di = np.zeros((k, k))
+    for j, pt in enumerate(st["ptype"]):
+        Di[j, j] = st["dinv"][j]
+        if pt == 2:
+            Di[j, j + 1] = Di[j + 1, j] = st["doff"][j]
+    return Di

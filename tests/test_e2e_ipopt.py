@@ -27,7 +27,8 @@ def run_driver(problem, n, solver="mi355x"):
 
 @pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built (needs /root/reference at build time)")
 @pytest.mark.parametrize("name,problem,n", [("hs071", "hs071", 0), ("lukvle1_100", "LukVlE1", 100), ("mbndry1_8", "MBndryCntrl1", 8),
-                                            ("lukvle1_10000", "LukVlE1", 10000), ("mbndry1_100", "MBndryCntrl1", 100)])
+                                            ("lukvle1_10000", "LukVlE1", 10000), ("mbndry1_100", "MBndryCntrl1", 100),
+                                            ("lukvle1_1000000", "LukVlE1", 1000000)])     # the north-star target instance
 def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_dir):
     gold = open(os.path.join(golden_dir, name + ".iters")).read().splitlines()
     gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
@@ -66,3 +67,72 @@ def test_hsllib_route_stock_ipopt_loads_our_ma97_symbols(tmp_path, golden_dir):
         g = g.split()
         assert f[0] == g[0] and f[4] == g[4] and f[6] == g[5] and f[9] == g[6]      # iter, lg(mu), lg(rg), ls
         assert abs(float(f[1]) - float(g[1])) <= 1e-7 * max(1.0, abs(float(g[1])))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the other plug-in routes on real problems (SURVEY 8(b) B1' and B2) and warm_start_same_structure
+# ---------------------------------------------------------------------------------------------------------------
+PATCHED = os.path.join(ROOT, "oracle", "_ref", "ipopt_patched_driver")
+STOCK = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+
+
+def _run(binary, args, cwd):
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    out = subprocess.run([binary] + args, capture_output=True, text=True, timeout=900, cwd=str(cwd), env=env).stdout
+    iters = []
+    for ln in out.splitlines():
+        f = ln.split()
+        if len(f) >= 10 and f[0].rstrip("r").isdigit() and ln.startswith(" "):
+            iters.append(" ".join([f[0], f[1], f[2], f[3], f[4], f[6], f[9]]))
+    summ = [json.loads(ln[len("DRIVER_SUMMARY "):]) for ln in out.splitlines() if ln.startswith("DRIVER_SUMMARY")]
+    return iters, summ, out
+
+
+def _same_iterations(iters, gold):
+    assert len(iters) == len(gold)
+    for a, b in zip(iters, gold):
+        fa, fb = a.split(), b.split()
+        assert (fa[0], fa[4], fa[5], fa[6]) == (fb[0], fb[4], fb[5], fb[6]), f"{a}   |   {b}"
+        assert abs(float(fa[1]) - float(fb[1])) <= 1e-7 * max(1.0, abs(float(fb[1]))), f"{a}   |   {b}"
+
+
+@pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref not built")
+def test_registered_linear_solver_mi355x_from_ipopt_opt(tmp_path, golden_dir):
+    """Route B1': the reference built WITH oracle/patches/linear_solver_mi355x.patch (one factory arm in
+    IpAlgBuilder.cpp:427-526 + option registration, IpLinearSolversRegOp.cpp:84-90) selects the backend from ipopt.opt,
+    with the registered mi355x_* options, through the reference's OWN AlgorithmBuilder."""
+    (tmp_path / "ipopt.opt").write_text("linear_solver mi355x\nmi355x_pivtol 1e-8\nmi355x_ordering nd\n")
+    iters, summ, out = _run(PATCHED, ["LukVlE1", "10000", "--solver", "stock", "--optfile", "ipopt.opt"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    gsum = json.load(open(os.path.join(golden_dir, "lukvle1_10000.summary")))
+    assert summ[0]["iterations"] == gsum["iterations"]
+    _same_iterations(iters, open(os.path.join(golden_dir, "lukvle1_10000.iters")).read().splitlines())
+
+
+@pytest.mark.skipif(not os.path.exists(STOCK), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,problem,n", [("mbndry1_100", "MBndryCntrl1", 100), ("lukvle1_10000", "LukVlE1", 10000)])
+def test_hsllib_route_on_scalable_problems_with_default_dynamic_scaling(name, problem, n, tmp_path, golden_dir):
+    """Route B2 on real problems: the UNPATCHED reference, `linear_solver ma97` + `hsllib libmi355x_kkt.so`, the MA97 adapter's
+    DEFAULT `ma97_scaling dynamic` logic (IpMa97SolverInterface.cpp:725-771,824-840) driving our ma97_*_d symbols."""
+    import ipopt_amd
+    (tmp_path / "ipopt.opt").write_text(f"linear_solver ma97\nhsllib {ipopt_amd.library_path()}\n")
+    iters, summ, out = _run(STOCK, [problem, str(n), "--solver", "stock", "--optfile", "ipopt.opt"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
+    assert summ[0]["iterations"] == gsum["iterations"]
+    assert abs(summ[0]["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
+    _same_iterations(iters, open(os.path.join(golden_dir, name + ".iters")).read().splitlines())
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+def test_warm_start_same_structure_keeps_the_symbolic_analysis(tmp_path):
+    """InitializeImpl contract (IpSparseSymLinearSolverInterface.hpp:125; pattern IpMumpsSolverInterface.cpp:191-245): a second
+    Optimize with warm_start_same_structure=yes must reuse the analysis: same iterates, no symbolic phase."""
+    iters, summ, out = _run(DRIVER, ["MBndryCntrl1", "100", "--solver", "mi355x", "--reoptimize"], tmp_path)
+    assert len(summ) == 2 and summ[0]["status"] == 0 and summ[1]["status"] == 0
+    assert summ[0]["iterations"] == summ[1]["iterations"]
+    assert abs(summ[0]["objective"] - summ[1]["objective"]) <= 1e-12 * max(1.0, abs(summ[0]["objective"]))
+    assert summ[0]["LinearSystemSymbolicFactorization"] > 0.0
+    assert summ[1]["LinearSystemSymbolicFactorization"] == 0.0
+    half = len(iters) // 2
+    assert iters[:half] == iters[half:]

@@ -139,24 +139,6 @@ def test_edge_cases_tiny_empty_diagonal_multirhs():
     assert st == 0 and s.number_of_neg_evals() == 2 and np.allclose(x, [[1] * 5, [2] * 5, [-1] * 5], rtol=1e-15)
 
 
-def test_new_matrix_false_reuses_factor_and_increase_quality_refactors():
-    n, r, c, v, neg = kktgen.grid_kkt(12, 12, dof=2, ncon=1, seed=31)
-    K = kktgen.to_scipy(n, r, c, v)
-    s, st, x = gpu_factor_solve(n, r, c, v, K @ np.ones(n))
-    b2 = K @ np.arange(n, dtype=np.float64)
-    x2 = b2.copy(); assert s.multi_solve(False, x2) == 0
-    assert np.abs(x2 - np.arange(n)).max() <= 1e-8 * n
-    # IncreaseQuality then MultiSolve(new_matrix=false) must re-factor from the device copy (pitfall 7)
-    u0 = s.pivtol
-    assert s.increase_quality() and s.pivtol == pytest.approx(u0 ** 0.75)
-    s.values()[:] = 0.0       # the host staging buffer is NOT consulted on a refactor
-    x3 = b2.copy(); assert s.multi_solve(False, x3, True, neg) == 0
-    assert np.abs(x3 - np.arange(n)).max() <= 1e-8 * n
-    while s.increase_quality():
-        pass
-    assert s.pivtol == s.pivtolmax and not s.increase_quality()
-
-
 def test_full_size_properties_config_sized():
     """BASELINE.json sizes without the oracle: LukVlE1-shaped KKT with n = 10^6 variables (dim 1 999 998):
     by-construction inertia, residual, linearity of the solve, idempotence."""

@@ -1,0 +1,108 @@
+"""-m gpu: the HIP kernels against the pivoting specification (tests/support/mirror.py, pinned on CPU against the
+oracle by tests/test_pivoting_spec.py) and the IncreaseQuality contract of the plug-in interface
+(reference IpSparseSymLinearSolverInterface.hpp:220; consumer IpPDFullSpaceSolver.cpp:290-301)."""
+import numpy as np
+import pytest
+
+import ipopt_amd
+from ipopt_amd import kkt
+from oracle import kkt_oracle as ko
+from tests.support import kktgen, mirror
+
+pytestmark = pytest.mark.gpu
+
+
+def hip_run(n, r, c, v, b, u, **opts):
+    s = ipopt_amd.KKTSolver(pivtol=u, **opts)
+    s.initialize_structure(n, r, c, vals=v)
+    s.values()[:] = v
+    x = np.array(b, dtype=np.float64, copy=True)
+    st = s.multi_solve(True, x)
+    return s, st, x
+
+
+@pytest.mark.parametrize("kat,msc", [("threshold_kat", 3), ("forced_pivot_kat", 2)])
+def test_hip_pivot_statistics_equal_the_specification(kat, msc):
+    n, r, c, v = getattr(kktgen, kat)()
+    K = kktgen.to_scipy(n, r, c, v).toarray()
+    xt = np.arange(1.0, n + 1.0); b = K @ xt
+    seen = []
+    for u in (1e-8, 1e-4):
+        s, st, x = hip_run(n, r, c, v, b, u, max_sn_cols=msc, **kktgen.KAT_OPTS)
+        xs, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=1e-4)
+        I = s.info()
+        assert st == kkt.SUCCESS
+        assert (I.num_neg, I.num_zero, I.num_two, I.num_small, I.u_sensitive) == \
+               (spec["num_neg"], spec["num_zero"], spec["num_two"], spec["num_delay"], spec["u_sensitive"]), (u, I, spec)
+        xo, oneg, _, _ = ko.factor_solve(n, r, c, v, b, u=u)
+        assert I.num_neg == oneg                                       # oracle at the same u
+        assert np.abs(x - xo).max() <= 1e-9 and np.abs(x - xs).max() <= 1e-9
+        seen.append((I.num_two, I.num_small))
+    assert seen[0] != seen[1]                                          # u really changes the factorisation
+
+
+def test_increase_quality_changes_the_factors_or_says_no():
+    # (a) a system with a pivot between 1e-8 and 1e-4 of its column: IncreaseQuality -> true, refactorisation differs
+    n, r, c, v = kktgen.threshold_kat()
+    K = kktgen.to_scipy(n, r, c, v).toarray()
+    xt = np.arange(1.0, n + 1.0); b = K @ xt
+    s, st, x0 = hip_run(n, r, c, v, b, 1e-8, max_sn_cols=3, **kktgen.KAT_OPTS)
+    assert st == 0 and s.info().num_two == 0 and s.info().u_sensitive == 1
+    steps = 0
+    while s.increase_quality():
+        steps += 1
+        s.values()[:] = 0.0                       # the host staging buffer is NOT consulted on a refactor (pitfall 7)
+        x = b.copy(); assert s.multi_solve(False, x) == 0
+        assert np.abs(x - xt).max() <= 1e-9
+    assert steps == 3 and s.pivtol == pytest.approx(1e-4)              # 1e-8 -> 1e-6 -> 3.2e-5 -> 1e-4 (u^0.75, capped)
+    assert s.info().num_two == 1                                       # the last refactorisation took the 2x2 pivot
+    assert not s.increase_quality()                                    # at the maximum
+    # (b) a benign KKT system: no pivot decision depends on u => IncreaseQuality answers false at once, u untouched
+    n, r, c, v, neg = kktgen.grid_kkt(12, 12, dof=2, ncon=1, seed=31)
+    K = kktgen.to_scipy(n, r, c, v)
+    s, st, x = hip_run(n, r, c, v, K @ np.ones(n), 1e-8)
+    assert st == 0 and s.info().u_sensitive == 0 and s.info().num_small == 0
+    u0 = s.pivtol
+    assert not s.increase_quality() and s.pivtol == u0 and s.info().pivtol == pytest.approx(u0)
+
+
+def test_new_matrix_false_reuses_the_factorisation():
+    n, r, c, v, neg = kktgen.grid_kkt(12, 12, dof=2, ncon=1, seed=31)
+    K = kktgen.to_scipy(n, r, c, v)
+    s, st, x = hip_run(n, r, c, v, K @ np.ones(n), 1e-8)
+    b2 = K @ np.arange(n, dtype=np.float64)
+    x2 = b2.copy(); assert s.multi_solve(False, x2) == 0
+    assert np.abs(x2 - np.arange(n)).max() <= 1e-8 * n
+    # an explicit pivtol change + MultiSolve(new_matrix=false) refactors from the device copy of the values
+    s.set_pivtol(1e-2); s._refactor = True
+    s.values()[:] = 0.0
+    x3 = b2.copy(); assert s.multi_solve(False, x3, True, neg) == 0
+    assert np.abs(x3 - np.arange(n)).max() <= 1e-8 * n
+
+
+def test_nearly_dependent_constraint_rows_give_singular():
+    """ADVICE r1 (numeric.hip:361): relative zero-pivot test; Ipopt's cure (delta_c > 0) makes the system regular again."""
+    for delta, singular in ((0.0, True), (1e-15, True), (1e-4, False)):
+        n, r, c, v = kktgen.nearly_dependent_rows(delta)
+        for scaling in (0, 1):
+            s, st, x = hip_run(n, r, c, v, np.ones(n), 1e-8, scaling=scaling)
+            assert (st == kkt.SINGULAR) == singular, (delta, scaling, st)
+            if not singular:
+                assert st == kkt.SUCCESS and s.number_of_neg_evals() == 3
+
+
+@pytest.mark.parametrize("u", [1e-8, 1e-4, 0.01])
+def test_seeded_systems_at_several_u(u):
+    """the by-construction families at every threshold: inertia exact, converged solve, statistics equal to the specification
+    (no equilibration, so that the specification sees the same numbers)."""
+    for gen in (lambda: kktgen.lukvl_like(1000, seed=11), lambda: kktgen.grid_kkt(24, 24, dof=3, ncon=2, seed=15)):
+        n, r, c, v, neg = gen()
+        K = kktgen.to_scipy(n, r, c, v)
+        b = K @ np.ones(n)
+        s, st, x = hip_run(n, r, c, v, b, u, scaling=0)
+        _, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=1e-4)
+        I = s.info()
+        assert st == 0 and I.num_neg == neg == spec["num_neg"]
+        assert (I.num_two, I.num_small) == (spec["num_two"], spec["num_delay"])
+        res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+        assert res <= 1e-12

@@ -1,0 +1,109 @@
+"""-m 'not gpu': the pivot-threshold contract (u = pivtol) as an executable specification.
+
+tests/support/mirror.py restates the pivoting rules of the HIP kernels (ldlt_reg / k_big_trsm in
+ipopt_amd/csrc/numeric.hip) in numpy, walking the symbolic structures the C ABI exports.  Here that
+specification is pinned against the CPU oracle AT THE SAME u (inertia, solution) and against LAPACK on
+dense copies; tests/test_gpu_pivoting.py then holds the HIP kernels to the specification.
+
+What the reference expects of u (SURVEY 8(a) policy table): ma27_pivtol / ma57_pivtol / ma97_u = 1e-8,
+raised by IncreaseQuality as u <- u^0.75 up to 1e-4 (IpMa97SolverInterface.cpp:822-854,
+IpMa27TSolverInterface.cpp:724-740), consumed at IpPDFullSpaceSolver.cpp:290-301."""
+import numpy as np
+import pytest
+
+import ipopt_amd
+from oracle import kkt_oracle as ko
+from tests.support import kktgen, mirror
+
+
+def spec_run(n, r, c, v, b, u, u2=1e-4, **opts):
+    s = ipopt_amd.KKTSolver(**opts)
+    s.initialize_structure(n, r, c, vals=v)
+    sym = mirror.fetch(s)
+    x, st = mirror.factor_solve_pivoted(sym, v, b, u=u, u2=u2)
+    return sym, x, st
+
+
+def test_threshold_kat_u_changes_the_pivot_sequence_not_the_answer():
+    n, r, c, v = kktgen.threshold_kat()
+    K = kktgen.to_scipy(n, r, c, v).toarray()
+    true_neg = int((np.linalg.eigvalsh(K) < 0).sum())
+    xt = np.arange(1.0, n + 1.0); b = K @ xt
+    out = {}
+    for u in (1e-8, 1e-4):
+        sym, x, st = spec_run(n, r, c, v, b, u, max_sn_cols=3, **kktgen.KAT_OPTS)
+        assert list(sym["colptr"]) == [0, 3, 5] and list(sym["rowptr"]) == [0, 4, 6]      # front 0: 3 fully-summed columns + 1 update row
+        xo, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=u)
+        assert st["num_neg"] == oneg == true_neg and st["num_zero"] == ozero == 0           # inertia: exact, oracle at the same u
+        assert np.abs(x - xo).max() <= 1e-9 and np.abs(x - xt).max() <= 1e-9
+        out[u] = (st, np.abs(x - xt).max())
+    assert out[1e-8][0]["num_two"] == 0 and out[1e-4][0]["num_two"] == 1                    # u = 1e-4 rejects the tiny 1x1, takes the 2x2
+    assert out[1e-8][0]["u_sensitive"] == 1                                                 # ... and the u = 1e-8 run knows a larger u matters
+    assert out[1e-4][1] <= out[1e-8][1]                                                     # the stricter threshold is at least as accurate
+
+
+def test_forced_pivot_is_reported_as_num_delay():
+    n, r, c, v = kktgen.forced_pivot_kat()
+    K = kktgen.to_scipy(n, r, c, v).toarray()
+    b = K @ np.arange(1.0, n + 1.0)
+    res = {}
+    for u in (1e-8, 1e-4):
+        sym, x, st = spec_run(n, r, c, v, b, u, max_sn_cols=2, **kktgen.KAT_OPTS)
+        assert list(sym["colptr"]) == [0, 1, 3, 4]                   # the eps column is a front of its own with one update row
+        assert sym["perm"][0] == 1                                   # ... and it is variable 2 (0-based 1)
+        _, oneg, _, _ = ko.factor_solve(n, r, c, v, b, u=u)
+        assert st["num_neg"] == oneg == 2 and st["num_zero"] == 0
+        res[u] = st
+    assert res[1e-8]["num_delay"] == 0 and res[1e-4]["num_delay"] == 1
+    assert res[1e-8]["u_sensitive"] == 1
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_spec_inertia_and_solution_on_hostile_random_systems(seed):
+    """small dense-ish symmetric indefinite matrices with zero diagonal blocks and entries spread over 12 orders of
+    magnitude, no equilibration: inertia must equal LAPACK's at every u; the solve must be backward stable."""
+    rng = np.random.default_rng(seed)
+    n = 40
+    A = np.triu(rng.standard_normal((n, n)) * (rng.random((n, n)) < 0.15))
+    A = A + A.T
+    d = 10.0 ** rng.uniform(-6, 6, n) * rng.choice([-1, 1], n)
+    d[rng.random(n) < 0.3] = 0.0
+    A[np.arange(n), np.arange(n)] = d
+    A[0, :] += 1e-3; A[:, 0] += 1e-3                                   # keep it connected / nonsingular
+    r, c = np.nonzero(np.tril(A) != 0)
+    v = A[r, c]
+    r = (r + 1).astype(np.int32); c = (c + 1).astype(np.int32)
+    K = kktgen.to_scipy(n, r, c, v).toarray()
+    w = np.linalg.eigvalsh(K)
+    if np.abs(w).min() < 1e-9 * np.abs(w).max():
+        pytest.skip("numerically singular draw")
+    b = K @ np.ones(n)
+    for u in (1e-8, 1e-4, 0.01):
+        _, x, st = spec_run(n, r, c, v, b, u, scaling=0)
+        assert st["num_neg"] == int((w < 0).sum()) and st["num_zero"] == 0
+        res = np.abs(K @ x - b).max() / (np.abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+        assert res <= 1e-10 * max(1.0, 1e-8 / u)       # growth is bounded by 1/u: the weakest threshold gets the weakest bound
+
+
+def test_nearly_dependent_constraint_rows_are_singular_not_noise():
+    """a pivot that is pure cancellation noise must be reported as a zero pivot (=> SYMSOLVER_SINGULAR =>
+    delta_c path of PDPerturbationHandler), not counted into the inertia with a random sign."""
+    for delta, singular in ((0.0, True), (1e-15, True), (1e-4, False)):
+        n, r, c, v = kktgen.nearly_dependent_rows(delta)
+        _, x, st = spec_run(n, r, c, v, np.ones(n), 1e-8)
+        assert (st["num_zero"] > 0) == singular, (delta, st)
+        if not singular:
+            assert st["num_neg"] == 3
+        _, _, ozero, _ = ko.factor_solve(n, r, c, v, np.ones(n), small=1e-14 * np.abs(v).max())
+        assert (ozero > 0) == singular
+
+
+def test_benign_kkt_systems_do_not_depend_on_u():
+    """on the by-construction KKT families no pivot is anywhere near the threshold: u_sensitive = 0, i.e. IncreaseQuality
+    has nothing to offer and must say so (returns false) instead of triggering identical refactorisations."""
+    for gen in (lambda: kktgen.lukvl_like(300, seed=3), lambda: kktgen.grid_kkt(10, 9, dof=2, ncon=1, seed=14)):
+        n, r, c, v, neg = gen()
+        K = kktgen.to_scipy(n, r, c, v)
+        _, x, st = spec_run(n, r, c, v, K @ np.ones(n), 1e-8, scaling=0)
+        assert st["num_neg"] == neg and st["num_delay"] == 0 and st["u_sensitive"] == 0
+        assert np.abs(x - 1).max() <= 1e-8
