@@ -194,7 +194,26 @@ int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t ca
 #define MI355X_KKT_KERNEL_COUNT        18
 int  mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches, int capacity);
 
-/* ---- multi-GPU (one process per GPU; subtrees sharded, top of the tree replicated) ---- */
+/* ---- multi-GPU (one process per GPU; subtrees sharded, top of the tree replicated) ----
+ * Create every rank's handle with opts.nranks = P, opts.rank = r, analyse the SAME structure on every rank, then give the
+ * handle a communicator.  From then on the ordinary entry points (factor / refactor / solve / solve_device*) run the
+ * distributed sequence themselves, on the solver's stream, without host synchronisation between the phases:
+ *     factor:  own subtrees -> all-reduce(top arena, fp64 sum) -> replicated top -> all-reduce(inertia counters)
+ *     solve :  local forward -> all-reduce(top rhs) -> replicated top fwd/bwd -> local backward -> all-reduce(solution)
+ * Inputs (values, right-hand sides) are identical on every rank, outputs (inertia, status, solution) too -- which is what
+ * Ipopt needs when every rank runs the same (deterministic) algorithm around its share of the linear algebra; cf. the
+ * knobs the reference exposes for SPRAL's multi-GPU mode (IpSpralSolverInterface.cpp:55-67).
+ *   _comm_unique_id        rank 0: ncclGetUniqueId -> 128 bytes the launcher hands to every rank (file, MPI, torch store ...)
+ *   _set_comm_rccl         ncclCommInitRank(nranks, id, rank) on the handle's device: RCCL over xGMI.  librccl.so is
+ *                          dlopen()ed here; single-GPU users never load it
+ *   _set_comm_callbacks    a host that has its own communication layer supplies the one collective we need: in-place sum over
+ *                          the ranks of `count` elements of DEVICE memory (dtype 0 = fp64, 1 = int32), ordered after the work
+ *                          already enqueued on `hip_stream` and complete (or stream-ordered) when it returns; 0 = success */
+typedef int (*mi355x_kkt_allreduce_fn)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream);
+int  mi355x_kkt_comm_unique_id(void* out128);
+int  mi355x_kkt_set_comm_rccl(mi355x_kkt_handle h, const void* unique_id128);
+int  mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn fn, void* ctx);
+/* The phases are also exposed one by one (a caller that wants to overlap or replace the collectives): */
 /* The top-of-tree fronts live in one contiguous device buffer ("top arena").  After
  * factor_local() each rank holds its own subtrees' Schur contributions there; the caller
  * sums the arena over ranks (RCCL all-reduce) and calls factor_top().  See DESIGN.md (e). */

@@ -225,6 +225,23 @@ int mi355x_kkt_debug_clocks(mi355x_kkt_handle h, unsigned long long* out16)
 }
 
 // ---- multi-GPU ----
+int mi355x_kkt_comm_unique_id(void* out128)
+{
+    if (!out128) return MI355X_KKT_FATAL;
+    try { std::string err; return Numeric::rccl_unique_id(out128, err) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_set_comm_rccl(mi355x_kkt_handle h, const void* unique_id128)
+{
+    if (!h || !unique_id128) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready) { h->err = "set_comm_rccl: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    try { if (!h->num->set_comm_rccl(unique_id128)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn fn, void* ctx)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready) { h->err = "set_comm_callbacks: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    try { if (!h->num->set_comm_callback(fn, ctx)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
 #define MG_GUARD if (!h) return MI355X_KKT_FATAL; if (!h->numeric_ready) { h->err = "multi-GPU call without a device"; return MI355X_KKT_FATAL; }
 int mi355x_kkt_factor_local(mi355x_kkt_handle h, const double* dvals) { MG_GUARD try { if (!h->num->factor_local(dvals)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
 int mi355x_kkt_top_arena(mi355x_kkt_handle h, double** d, int64_t* nd) { MG_GUARD try { if (!h->num->top_arena(d, nd)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }

@@ -6,13 +6,16 @@
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
+#include <cstdio>
+#include <string>
+#include <unistd.h>
 
 namespace Ipopt
 {
 
 Mi355xSolverInterface::Mi355xSolverInterface()
    : handle_(NULL), dim_(0), nonzeros_(0), ia_(NULL), ja_(NULL), analysed_(false), pivtol_changed_(false),
-     warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1)
+     warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1), nranks_opt_(0), rank_opt_(-1), comm_ready_(false)
 {
    mi355x_kkt_default_options(&kopts_);
 }
@@ -43,6 +46,14 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
    roptions->AddLowerBoundedIntegerOption("mi355x_max_sn_cols", "Maximum columns per supernode.", 2, 64, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_device", "HIP device ordinal (-1: current).", -1, -1, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_verbose", "Verbosity of the MI355X backend.", 0, 0, "");
+   // multi-GPU: one Ipopt process per GPU, every process runs the same algorithm, the KKT factorisation is shared
+   // (elimination-tree subtrees per rank, RCCL all-reduce at the subtree joins); cf. the SPRAL knobs IpSpralSolverInterface.cpp:55-67
+   roptions->AddLowerBoundedIntegerOption("mi355x_nranks", "Number of processes (GPUs) sharing each KKT factorisation.", 0, 0,
+                                          "0: take WORLD_SIZE / OMPI_COMM_WORLD_SIZE from the environment (1 if unset).");
+   roptions->AddLowerBoundedIntegerOption("mi355x_rank", "Rank of this process among mi355x_nranks.", -1, -1,
+                                          "-1: take RANK / OMPI_COMM_WORLD_RANK from the environment.");
+   roptions->AddStringOption1("mi355x_comm_file", "File through which rank 0 hands the RCCL unique id to the other ranks.", "",
+                              "*", "any path on a file system all ranks see (default: $MI355X_KKT_COMM_FILE)");
 }
 
 bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std::string& prefix)
@@ -93,6 +104,18 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
       {
          kopts_.verbose = iv;
       }
+      if( options.GetIntegerValue("mi355x_nranks", iv, prefix) )
+      {
+         nranks_opt_ = iv;
+      }
+      if( options.GetIntegerValue("mi355x_rank", iv, prefix) )
+      {
+         rank_opt_ = iv;
+      }
+      if( options.GetStringValue("mi355x_comm_file", sv, prefix) )
+      {
+         comm_file_ = sv;
+      }
    }
    catch( ... )
    {
@@ -105,6 +128,30 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
    kopts_.pivtol = pivtol_;
    kopts_.pivtolmax = pivtolmax_;
    kopts_.index_base = 1;
+   {
+      // launcher conventions: torchrun (RANK / WORLD_SIZE / LOCAL_RANK), Open MPI (OMPI_COMM_WORLD_*)
+      const char* e;
+      int nranks = nranks_opt_, rank = rank_opt_;
+      if( nranks <= 0 )
+      {
+         nranks = (e = getenv("WORLD_SIZE")) ? atoi(e) : ((e = getenv("OMPI_COMM_WORLD_SIZE")) ? atoi(e) : 1);
+      }
+      if( rank < 0 )
+      {
+         rank = (e = getenv("RANK")) ? atoi(e) : ((e = getenv("OMPI_COMM_WORLD_RANK")) ? atoi(e) : 0);
+      }
+      kopts_.nranks = nranks > 0 ? nranks : 1;
+      kopts_.rank = rank;
+      if( kopts_.nranks > 1 && kopts_.device < 0 )
+      {
+         kopts_.device = (e = getenv("LOCAL_RANK")) ? atoi(e) : ((e = getenv("OMPI_COMM_WORLD_LOCAL_RANK")) ? atoi(e) : rank);
+      }
+      if( comm_file_.empty() && (e = getenv("MI355X_KKT_COMM_FILE")) )
+      {
+         comm_file_ = e;
+      }
+      comm_ready_ = false;
+   }
 
    bool ws = false;
    try
@@ -196,6 +243,13 @@ ESymSolverStatus Mi355xSolverInterface::MultiSolve(bool new_matrix, const Index*
       std::vector<Number>().swap(staging_);
       analysed_ = true;
       new_matrix = true;
+      if( (kopts_.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI")) && !comm_ready_ )
+      {
+         if( !SetupCommunicator() )
+         {
+            return SYMSOLVER_FATAL_ERROR;
+         }
+      }
       mi355x_kkt_info info;
       mi355x_kkt_get_info(handle_, &info);
       Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA,
@@ -261,6 +315,67 @@ ESymSolverStatus Mi355xSolverInterface::MultiSolve(bool new_matrix, const Index*
       return SYMSOLVER_FATAL_ERROR;
    }
    return SYMSOLVER_SUCCESS;
+}
+
+bool Mi355xSolverInterface::SetupCommunicator()
+{
+   // rank 0 creates the ncclUniqueId and publishes it through a file (write + rename = atomic); the others poll for it
+   unsigned char id[128];
+   const std::string path = comm_file_.empty() ? std::string("/tmp/mi355x_kkt_comm_id") : comm_file_;
+   if( kopts_.rank == 0 )
+   {
+      if( mi355x_kkt_comm_unique_id(id) != MI355X_KKT_SUCCESS )
+      {
+         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: could not create the RCCL unique id (librccl.so not loadable?)\n");
+         return false;
+      }
+      if( kopts_.nranks > 1 )
+      {
+         const std::string tmp = path + ".tmp";
+         FILE* f = fopen(tmp.c_str(), "wb");
+         if( !f || fwrite(id, 1, sizeof(id), f) != sizeof(id) )
+         {
+            Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: cannot write %s\n", tmp.c_str());
+            if( f ) fclose(f);
+            return false;
+         }
+         fclose(f);
+         if( rename(tmp.c_str(), path.c_str()) != 0 )
+         {
+            return false;
+         }
+      }
+   }
+   else
+   {
+      bool got = false;
+      for( int tries = 0; tries < 6000 && !got; ++tries )   // up to 10 minutes: rank 0 may still be in its (longer) start-up
+      {
+         FILE* f = fopen(path.c_str(), "rb");
+         if( f )
+         {
+            got = fread(id, 1, sizeof(id), f) == sizeof(id);
+            fclose(f);
+         }
+         if( !got )
+         {
+            usleep(100000);
+         }
+      }
+      if( !got )
+      {
+         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: rank %d never saw the communicator id file %s\n", kopts_.rank, path.c_str());
+         return false;
+      }
+   }
+   if( mi355x_kkt_set_comm_rccl(handle_, id) != MI355X_KKT_SUCCESS )
+   {
+      Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_set_comm_rccl failed: %s\n", mi355x_kkt_last_error(handle_));
+      return false;
+   }
+   comm_ready_ = true;
+   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X: rank %d of %d joined the RCCL communicator (device %d)\n", kopts_.rank, kopts_.nranks, kopts_.device);
+   return true;
 }
 
 Index Mi355xSolverInterface::NumberOfNegEVals() const

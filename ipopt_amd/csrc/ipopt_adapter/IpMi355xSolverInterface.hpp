@@ -16,6 +16,7 @@
 #include "IpRegOptions.hpp"
 #include "mi355x_kkt.h"
 #include <vector>
+#include <string>
 
 namespace Ipopt
 {
@@ -60,6 +61,11 @@ private:
    Number pivtol_, pivtolmax_;
    Index negevals_;
    std::vector<Number> staging_;   // values before the (lazy) analysis has produced the pinned buffer
+   // multi-GPU (options mi355x_nranks / mi355x_rank / mi355x_comm_file, or the launcher's environment)
+   Index nranks_opt_, rank_opt_;
+   std::string comm_file_;
+   bool comm_ready_;
+   bool SetupCommunicator();
 };
 
 /** AlgorithmBuilder that injects the MI355X backend through the reference's own virtual factory

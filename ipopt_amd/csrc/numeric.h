@@ -51,6 +51,10 @@ public:
     bool   solve_fwd_local(double* drhs);
     bool   top_rhs(double** dptr, int64_t* ndoubles);
     bool   solve_top_and_bwd(double* drhs);
+    // communicator of a multi-GPU handle: with one set, factor()/solve_*() run the whole distributed sequence themselves
+    bool   set_comm_rccl(const void* unique_id128);                                   // RCCL (dlopen'ed), ncclCommInitRank(nranks, id, rank)
+    bool   set_comm_callback(int (*allreduce)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream), void* ctx);
+    static bool rccl_unique_id(void* out128, std::string& err);                       // ncclGetUniqueId (rank 0 creates, the launcher distributes)
 private:
     NumericImpl* p_;
 };

@@ -23,6 +23,8 @@
 //   * larger fronts take the blocked global-memory path (panel kernels + v_mfma_f64_16x16x4
 //     trailing updates), see bigfront section.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types only: librccl.so is dlopen()ed when a communicator is requested (multi-GPU), never linked
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstring>
 #include <cmath>
@@ -306,10 +308,11 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
     unsigned long long alive1 = (WIDE && k > 64) ? ((k >= 128) ? ~0ull : ((1ull << (k - 64)) - 1ull)) : 0ull;
     unsigned long long tryb = alive, tryb1 = alive1;          // candidates not yet passed over since the last elimination
     bool force = false;
+    double u2e = u2;                                          // 0 while forced: a forced pivot stays forced at any larger u
+    unsigned long long chgm = 0ull;
     auto clear_row = [&](int r) { if (!WIDE || r < 64) alive &= ~(1ull << r); else alive1 &= ~(1ull << (r - 64)); };
     int step = 0, bufsel = 0;
     while ((alive | alive1) != 0ull) {
-        if ((tryb | tryb1) == 0ull) { force = true; tryb = alive; tryb1 = alive1; }     // every candidate failed: static pivoting
         double* colA = colbuf + bufsel * 2 * MAXM; bufsel ^= 1;
         double* colB = colA + MAXM;
         const int j = __builtin_amdgcn_readfirstlane(tryb != 0ull ? __ffsll((long long)tryb) - 1 : 64 + __ffsll((long long)tryb1) - 1);
@@ -329,19 +332,22 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
         const double av0 = cand ? f0 : -1.0, av1 = cand1 ? f1 : -1.0;
         const double av = fmax(av0, av1);                      // alive fully-summed rows (the Bunch-Kaufman candidates)
         const double ga = fmax(fmax(av, up0 ? f0 : 0.0), up1 ? f1 : 0.0);      // whole remaining column, diagonal excluded
-        const int bi = (av1 > av0) ? lane + 64 : lane;       // this lane's best candidate row
-        int p = j, q = -1;                 // 1x1 pivot p, or 2x2 pivot (p, q)
-        double dpiv = djj;
-        bool zero = false;
-        const bool bkneed = __ballot(av * BK_ALPHA > ajj) != 0ull;      // some |a_ij| > |a_jj| / alpha
-        const bool thfail = __ballot(ga * u > ajj) != 0ull;             // 1x1 at j fails the threshold test
-        if (!force && __ballot(ga * u2 > ajj) != 0ull) chg = 1;
-        if (bkneed || thfail || !(ajj > ztol)) {
+        // the common case must stay ONE straight instruction stream (every taken branch costs an instruction refetch on the
+        // serial pivot chain): three ballots OR-ed into one scalar test, statistics accumulated branch-free
+        const unsigned long long slowm = __ballot(av * BK_ALPHA > ajj)        // some |a_ij| > |a_jj| / alpha: full Bunch-Kaufman test
+                                       | __ballot(ga * u > ajj)               // 1x1 at j fails the threshold test
+                                       | __ballot(!(ajj > ztol));             // (numerically) zero diagonal
+        chgm |= __ballot(ga * u2e > ajj);
+        double d = djj;                    // 1x1 pivot value on physical row p (pivot column in rv / cv)
+        int p = j;
+        if (__builtin_expect(slowm != 0ull, 0)) {
+            const int bi = (av1 > av0) ? lane + 64 : lane;       // this lane's best candidate row
             const double uu = force ? 0.0 : u;
             const double lam = wave_max_all(av);               // -1: no alive fully-summed partner
             const double gj = wave_max_all(ga);
             int sel = -1;                                      // 0: 1x1 at j, 1: 1x1 at r, 2: 2x2 (j, r)
             int r = -1;
+            bool zero = false;
             if (lam > 0.0) {
                 const unsigned long long hit = __ballot(av == lam);
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
@@ -372,54 +378,58 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                     const bool f_u  = (sel == 0) ? (ajj < u * gj)  : ((sel == 1) ? (arr < u * gr)  : (t1 * u > adet  || t2 * u > adet));
                     const bool f_u2 = (sel == 0) ? (ajj < u2 * gj) : ((sel == 1) ? (arr < u2 * gr) : (t1 * u2 > adet || t2 * u2 > adet));
                     if (f_u) ndelay += (sel == 2) ? 2 : 1;     // only possible when forced
-                    if (f_u2 && !force) chg = 1;               // (a forced pivot stays forced at any larger u)
+                    if (f_u2 && !force) chgm |= 1ull;          // (a forced pivot stays forced at any larger u)
                 }
             } else {
-                if (ajj > ztol && ajj >= uu * gj) { sel = 0; if (ajj < u * gj) ndelay += 1; if (ajj < u2 * gj && !force) chg = 1; }
+                if (ajj > ztol && ajj >= uu * gj) { sel = 0; if (ajj < u * gj) ndelay += 1; }
                 else if (!(ajj > ztol) && !(gj > ztol)) { sel = 0; zero = true; }          // the whole remaining column is zero
             }
             if (sel < 0) {
                 if (!force) {          // pass over: retried once another elimination has updated the column
                     if (!WIDE || j < 64) tryb &= ~(1ull << j); else tryb1 &= ~(1ull << (j - 64));
+                    if ((tryb | tryb1) == 0ull) { force = true; u2e = 0.0; tryb = alive; tryb1 = alive1; }   // every candidate failed: static pivoting
                     continue;
                 }
                 sel = 0; zero = true;  // forced and nothing usable: a (perturbed) zero pivot => singular
             }
+            force = false; u2e = u2;
+            if (sel == 2) {
+                const int q = r;
+                const double a = colA[p], b = colA[q], c = colB[q];
+                const double det = a * c - b * b;
+                const double idet = fast_rcp(det);
+                double l0[TS], l1[TS], w0[TS], w1[TS];
+#pragma unroll
+                for (int x = 0; x < TS; ++x) {
+                    const double r0 = colA[row0 + x], r1 = colB[row0 + x];
+                    l0[x] = (c * r0 - b * r1) * idet; l1[x] = (a * r1 - b * r0) * idet;
+                    w0[x] = colA[col0 + x]; w1[x] = colB[col0 + x];
+                }
+#pragma unroll
+                for (int x = 0; x < TS; ++x)
+#pragma unroll
+                    for (int y = 0; y < TS; ++y) t[x][y] -= l0[x] * w0[y] + l1[x] * w1[y];
+                if (tj == 0) {
+#pragma unroll
+                    for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) { Lbuf[row0 + x + step * ldL] = l0[x]; Lbuf[row0 + x + (step + 1) * ldL] = l1[x]; }
+                }
+                if (tid == 0) {
+                    ord[step] = p; ord[step + 1] = q; pt_s[step] = 2; pt_s[step + 1] = 3;
+                    dinv_s[step] = c * idet; dinv_s[step + 1] = a * idet; doff_s[step] = -b * idet; doff_s[step + 1] = 0.0;
+                }
+                if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
+                ntwo++; clear_row(p); clear_row(q); step += 2;
+                tryb = alive; tryb1 = alive1;
+                continue;
+            }
             if (sel == 1) {
-                p = r; dpiv = colB[r];
+                p = r; d = colB[r];
 #pragma unroll
                 for (int x = 0; x < TS; ++x) { rv[x] = colB[row0 + x]; cv[x] = colB[col0 + x]; }
-            } else if (sel == 2) q = r;
-        }
-        force = false;
-        if (q >= 0) {
-            const double a = colA[p], b = colA[q], c = colB[q];
-            const double det = a * c - b * b;
-            const double idet = fast_rcp(det);
-            double l0[TS], l1[TS], w0[TS], w1[TS];
-#pragma unroll
-            for (int x = 0; x < TS; ++x) {
-                const double r0 = colA[row0 + x], r1 = colB[row0 + x];
-                l0[x] = (c * r0 - b * r1) * idet; l1[x] = (a * r1 - b * r0) * idet;
-                w0[x] = colA[col0 + x]; w1[x] = colB[col0 + x];
             }
-#pragma unroll
-            for (int x = 0; x < TS; ++x)
-#pragma unroll
-                for (int y = 0; y < TS; ++y) t[x][y] -= l0[x] * w0[y] + l1[x] * w1[y];
-            if (tj == 0) {
-#pragma unroll
-                for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) { Lbuf[row0 + x + step * ldL] = l0[x]; Lbuf[row0 + x + (step + 1) * ldL] = l1[x]; }
-            }
-            if (tid == 0) {
-                ord[step] = p; ord[step + 1] = q; pt_s[step] = 2; pt_s[step + 1] = 3;
-                dinv_s[step] = c * idet; dinv_s[step + 1] = a * idet; doff_s[step] = -b * idet; doff_s[step + 1] = 0.0;
-            }
-            if (det < 0.0) nneg += 1; else if (a + c < 0.0) nneg += 2;
-            ntwo++; clear_row(p); clear_row(q); step += 2;
-        } else {   // 1x1 pivot on physical row p (pivot column already in rv / cv)
-            double d = dpiv;
             if (zero) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
+        }
+        {   // 1x1 pivot on physical row p
             const double di = fast_rcp(d);
             // No masking of dead rows / columns: the rank-1 update itself annihilates row and column p (l_p = 1 up to
             // rounding), padding rows are exact zeros, and whatever residue is left in dead positions is never read
@@ -437,11 +447,12 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                 for (int x = 0; x < TS; ++x) if ((rowvalid >> x) & 1u) Lbuf[row0 + x + step * ldL] = l0[x];
             }
             if (tid == 0) { ord[step] = p; pt_s[step] = 1; dinv_s[step] = di; doff_s[step] = 0.0; }
-            if (d < 0.0) nneg++;
+            nneg += (d < 0.0) ? 1 : 0;
             clear_row(p); step += 1;
+            tryb = alive; tryb1 = alive1;
         }
-        tryb = alive; tryb1 = alive1;
     }
+    if (chgm != 0ull) chg = 1;
     __syncthreads();
 }
 
@@ -1521,6 +1532,66 @@ public:
     long long arena_doubles = 0, toprhs_doubles = 0;
     bool multi = false;
 
+    // ---- communicator of a multi-GPU handle: RCCL over xGMI created from an ncclUniqueId, or a caller-supplied
+    //      all-reduce (a host with its own communication layer; the single-GPU multi-rank tests).  All collectives are
+    //      enqueued on the solver's stream: no host synchronisation between factor_local -> all-reduce -> factor_top. ----
+    struct Rccl {
+        void* lib = nullptr; ncclComm_t comm = nullptr;
+        ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+        ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+        ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+        ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+        const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    } rccl;
+    int comm_kind = 0;                     // 0 none, 1 callback, 2 RCCL
+    int (*comm_fn)(void*, void*, int64_t, int, void*) = nullptr; void* comm_ctx = nullptr;
+    static bool rccl_load(Rccl& R, std::string& err) {
+        if (R.lib) return true;
+        // an RCCL instance the host process already loaded (e.g. the one bundled with PyTorch, soname librccl.so.1) is reused:
+        // one library, several communicators -- never two RCCL copies in one process
+        R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+        if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        if (!R.lib) R.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!R.lib) R.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!R.lib) { err = std::string("dlopen(librccl.so): ") + dlerror(); return false; }
+        R.GetUniqueId = (decltype(R.GetUniqueId))dlsym(R.lib, "ncclGetUniqueId");
+        R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.lib, "ncclCommInitRank");
+        R.AllReduce = (decltype(R.AllReduce))dlsym(R.lib, "ncclAllReduce");
+        R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
+        R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
+        if (!R.GetUniqueId || !R.CommInitRank || !R.AllReduce || !R.CommDestroy) { err = "librccl.so lacks the nccl* entry points"; return false; }
+        return true;
+    }
+    bool set_comm_rccl(const void* id128) {
+        DeviceGuard guard(dev);
+        if (!ready || !multi) { err_ = "set_comm_rccl: not a multi-GPU handle (nranks > 1 at create, analyse first)"; return false; }
+        if (!rccl_load(rccl, err_)) return false;
+        if (rccl.comm) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
+        ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
+        ncclResult_t r = rccl.CommInitRank(&rccl.comm, opt.nranks, id, opt.rank);
+        if (r != ncclSuccess) { err_ = std::string("ncclCommInitRank: ") + (rccl.GetErrorString ? rccl.GetErrorString(r) : "error"); rccl.comm = nullptr; return false; }
+        comm_kind = 2; return true;
+    }
+    bool set_comm_callback(int (*fn)(void*, void*, int64_t, int, void*), void* ctx) {
+        if (!ready || !multi) { err_ = "set_comm_callbacks: not a multi-GPU handle (nranks > 1 at create, analyse first)"; return false; }
+        comm_fn = fn; comm_ctx = ctx; comm_kind = fn ? 1 : 0; return true;
+    }
+    // in-place sum over the ranks of `count` elements of device memory (dtype 0: fp64, 1: int32), stream-ordered
+    bool allreduce(void* dptr, long long count, int dtype) {
+        if (count <= 0) return true;
+        if (comm_kind == 2) {
+            ncclResult_t r = rccl.AllReduce(dptr, dptr, (size_t)count, dtype == 0 ? ncclDouble : ncclInt32, ncclSum, rccl.comm, stream);
+            if (r != ncclSuccess) { err_ = std::string("ncclAllReduce: ") + (rccl.GetErrorString ? rccl.GetErrorString(r) : "error"); return false; }
+            return true;
+        }
+        if (comm_kind == 1) {
+            if (comm_fn(comm_ctx, dptr, (int64_t)count, dtype, (void*)stream) != 0) { err_ = "all-reduce callback failed"; return false; }
+            return true;
+        }
+        err_ = "multi-GPU handle without a communicator: call mi355x_kkt_set_comm_rccl / _set_comm_callbacks (or drive the phase entry points yourself)";
+        return false;
+    }
+
     // ---- per-kernel-kind timing (bench.py roofline): hip events around every launch, eager mode ----
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kind; size_t prof_used = 0;
@@ -1539,6 +1610,8 @@ public:
     ~NumericImpl() { release(); for (auto e : prof_ev) (void)hipEventDestroy(e); }
     void release() {
         DeviceGuard guard(dev);
+        if (rccl.comm && rccl.CommDestroy) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
+        comm_kind = 0;
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
         for (void* p : allocs) (void)hipFree(p);
@@ -2007,6 +2080,7 @@ public:
     bool factor(const double* dvals, bool reuse, FactorStats& st) {
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "factor: solver not set up (no device?)"; return false; }
+        if (multi) return factor_dist(dvals, reuse, st);          // needs a communicator (set_comm_*), fails loudly otherwise
         const Symbolic& Sy = *S;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
         if (!reuse) {
@@ -2100,6 +2174,7 @@ public:
     bool solve_device(int nrhs, const double* dsrc, int lds_, double* drhs, int ld, bool timed) {
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
+        if (multi) return solve_dist(nrhs, dsrc, lds_, drhs, ld);
         if (timed) HIPCHK(hipEventRecord(ev0, stream));
         for (int r = 0; r < nrhs; ++r) {
             double* col = drhs + (size_t)r * ld;
@@ -2170,12 +2245,22 @@ public:
     }
     bool factor_local(const double* dvals) {
         DeviceGuard guard(dev);
+        if (!enqueue_factor_local(dvals, false)) return false;
+        HIPCHK(hipEventRecord(ev1, stream));
+        HIPCHK(hipStreamSynchronize(stream));       // the caller's collective runs on another stream
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
+        return true;
+    }
+    // own subtrees + own contributions to the top arena, enqueued on the solver's stream (no host synchronisation)
+    bool enqueue_factor_local(const double* dvals, bool reuse) {
         if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
         const Symbolic& Sy = *S; const int n = Sy.n;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
-        if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
-        else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
-        have_values = true;
+        if (!reuse) {
+            if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
+            else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
+            have_values = true;
+        } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
         hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
@@ -2192,9 +2277,48 @@ public:
         HIPCHK(hipMemsetAsync(V.arena, 0, (size_t)arena_doubles * sizeof(double), stream));
         if (join_count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((join_maxm + 3) / 4, join_count), dim3(256), 0, stream, V, join_list_base);
         HIPCHK(hipGetLastError());
+        return true;
+    }
+    // The whole distributed factorisation behind the ordinary factor() entry point (a communicator has been set):
+    //   own subtrees -> all-reduce(top arena) -> replicated top -> all-reduce(inertia / pivot statistics),
+    // everything stream-ordered on the solver's stream, ONE host synchronisation at the end.
+    bool factor_dist(const double* dvals, bool reuse, FactorStats& st) {
+        if (!enqueue_factor_local(dvals, reuse)) return false;
+        if (!allreduce(V.arena, arena_doubles, 0)) return false;
+        if (!launch_fronts(sch_top, 1)) return false;
+        // this rank contributes its own subtrees; rank 0 also the replicated top => the sum over ranks is the inertia
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
+        if (opt.rank == 0) hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
+        HIPCHK(hipGetLastError());
+        if (!allreduce(d_stats, 8, 1)) return false;
         HIPCHK(hipEventRecord(ev1, stream));
-        HIPCHK(hipStreamSynchronize(stream));       // the caller's collective runs on another stream
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4] != 0;
+        return true;
+    }
+    // distributed solve of one right-hand side (identical on every rank), solution on every rank:
+    //   local forward -> all-reduce(top right-hand sides) -> replicated top forward + backward -> local backward ->
+    //   all-reduce of the solution pieces
+    bool solve_dist(int nrhs, const double* dsrc, int lds_, double* drhs, int ld) {
+        HIPCHK(hipEventRecord(ev0, stream));
+        for (int r = 0; r < nrhs; ++r) {
+            const double* src = dsrc + (size_t)r * lds_; double* col = drhs + (size_t)r * ld;
+            hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, src);
+            if (!launch_solve_sweep(sch_local, true, 0)) return false;
+            if (top_count > 0) hipLaunchKernelGGL(k_top_rhs_assemble, dim3(top_count), dim3(256), 0, stream, V, top_list_base);
+            if (!allreduce(V.top_rhs, toprhs_doubles, 0)) return false;
+            if (!launch_solve_sweep(sch_top, true, 1)) return false;
+            if (!launch_solve_sweep(sch_top, false, 1)) return false;
+            if (!launch_solve_sweep(sch_local, false, 0)) return false;
+            hipLaunchKernelGGL(k_store_sol_mg, dim3(grid1d(S->n)), dim3(256), 0, stream, V, col);
+            HIPCHK(hipGetLastError());
+            if (!allreduce(col, S->n, 0)) return false;
+        }
+        HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms;
         return true;
     }
     bool factor_top(FactorStats& st) {
@@ -2306,5 +2430,17 @@ bool Numeric::factor_top(FactorStats& st) { return p_->factor_top(st); }
 bool Numeric::solve_fwd_local(double* drhs) { return p_->solve_fwd_local(drhs); }
 bool Numeric::top_rhs(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_rhs: not a multi-GPU handle"; return false; } *d = p_->V.top_rhs; *nd = p_->toprhs_doubles; return true; }
 bool Numeric::solve_top_and_bwd(double* drhs) { return p_->solve_top_and_bwd(drhs); }
+bool Numeric::set_comm_rccl(const void* unique_id128) { return p_->set_comm_rccl(unique_id128); }
+bool Numeric::set_comm_callback(int (*fn)(void*, void*, int64_t, int, void*), void* ctx) { return p_->set_comm_callback(fn, ctx); }
+bool Numeric::rccl_unique_id(void* out128, std::string& err)
+{
+    NumericImpl::Rccl R;
+    if (!NumericImpl::rccl_load(R, err)) return false;
+    ncclUniqueId id;
+    ncclResult_t r = R.GetUniqueId(&id);
+    if (r != ncclSuccess) { err = std::string("ncclGetUniqueId: ") + (R.GetErrorString ? R.GetErrorString(r) : "error"); return false; }
+    std::memcpy(out128, &id, sizeof(id));
+    return true;
+}
 
 } // namespace mi355x

@@ -56,6 +56,8 @@ def library_path() -> str:
 
 
 _LIB = None
+# int (*)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream)  -- mi355x_kkt_allreduce_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 # every symbol include/mi355x_kkt.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -65,6 +67,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
+    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
                 "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big", "fwd_big_upd", "bwd_big_dot"]
@@ -109,6 +112,9 @@ def load_library():
     lib.mi355x_kkt_solve_fwd_local.argtypes = [vp, vp]
     lib.mi355x_kkt_top_rhs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.mi355x_kkt_solve_top_and_bwd.argtypes = [vp, vp]
+    lib.mi355x_kkt_comm_unique_id.argtypes = [vp]
+    lib.mi355x_kkt_set_comm_rccl.argtypes = [vp, vp]
+    lib.mi355x_kkt_set_comm_callbacks.argtypes = [vp, ALLREDUCE_FN, vp]
     _LIB = lib
     return lib
 
@@ -212,6 +218,33 @@ class KKTSolver:
         st = self.lib.mi355x_kkt_solve_device2(self._h, nrhs, C.c_void_p(db_ptr), self._n, C.c_void_p(dx_ptr), self._n)
         if st != 0:
             raise KKTError("solve_device2: " + self.last_error())
+
+    # --- multi-GPU communicator (include/mi355x_kkt.h): after one of these, multi_solve / factor_device / solve_device* of a
+    #     handle created with nranks > 1 run the distributed sequence inside the library ---
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        if load_library().mi355x_kkt_comm_unique_id(buf) != 0:
+            raise KKTError("comm_unique_id: librccl.so not loadable / ncclGetUniqueId failed")
+        return buf.raw
+
+    def set_comm_rccl(self, unique_id: bytes):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        if self.lib.mi355x_kkt_set_comm_rccl(self._h, buf) != 0:
+            raise KKTError("set_comm_rccl: " + self.last_error())
+
+    def set_comm_callback(self, fn):
+        """fn(dptr: int, count: int, dtype: int (0 fp64, 1 int32), hip_stream: int) -> None; must leave the buffer summed over the ranks"""
+        def _cb(ctx, dptr, count, dtype, stream):
+            try:
+                fn(int(dptr), int(count), int(dtype), int(stream or 0))
+                return 0
+            except Exception:          # never let an exception cross the C ABI
+                import traceback; traceback.print_exc()
+                return 1
+        self._comm_cb = ALLREDUCE_FN(_cb)       # keep the thunk alive as long as the handle
+        if self.lib.mi355x_kkt_set_comm_callbacks(self._h, self._comm_cb, None) != 0:
+            raise KKTError("set_comm_callbacks: " + self.last_error())
 
     _refactor = False
 

@@ -26,8 +26,8 @@ from . import kkt as _kkt
 class _DevArray:
     """zero-copy view of library-owned device memory for torch (CUDA array interface v2)."""
 
-    def __init__(self, ptr: int, n: int):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2, "strides": None}
+    def __init__(self, ptr: int, n: int, typestr: str = "<f8"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2, "strides": None}
 
 
 class HipEngine:
@@ -116,6 +116,34 @@ class DistributedKKT:
         return rhs
 
 
+def gloo_allreduce_callback(torch, dist):
+    """the ONE collective the C library needs (mi355x_kkt_allreduce_fn), supplied from Python over any process group --
+    used where RCCL cannot run: several ranks sharing one GPU (the single-GPU test box)."""
+    def fn(dptr, count, dtype, stream):
+        t = torch.as_tensor(_DevArray(dptr, count, "<f8" if dtype == 0 else "<i4"), device="cuda")
+        torch.cuda.synchronize()          # the library's stream has produced the buffer
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+    return fn
+
+
+class CommKKT:
+    """A multi-GPU handle whose collectives run INSIDE the C library (RCCL over xGMI, mi355x_kkt_set_comm_rccl):
+    after construction it is used exactly like a single-GPU KKTSolver (factor_device / solve_device2 / multi_solve).
+    torch.distributed is only the bootstrap that carries the 128-byte ncclUniqueId from rank 0 to the other ranks."""
+
+    def __init__(self, rank, nranks, device, n, row, col, vals, dist, use_rccl=True, **opts):
+        import torch
+        self.s = _kkt.KKTSolver(device=device, nranks=nranks, rank=rank, **opts)
+        self.s.initialize_structure(n, row, col, vals=vals)
+        if use_rccl:
+            box = [_kkt.KKTSolver.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.s.set_comm_rccl(box[0])
+        else:
+            self.s.set_comm_callback(gloo_allreduce_callback(torch, dist))
+
+
 def bench_main(args, rank, world, local):
     """bench.py --gpus N (N > 1): launched by torch.distributed.run, one rank per GPU."""
     import torch
@@ -129,22 +157,20 @@ def bench_main(args, rank, world, local):
     n, r, c, v, neg = B.make_workload(wl)
     K = kktgen.to_scipy(n, r, c, v)
     b = K @ np.ones(n)
-    eng = HipEngine(rank, world, local)
-    eng.analyse(n, r, c, v)
-    I = eng.s.info()
+    # the collectives (all-reduce of the top arena / top right-hand sides / solution, RCCL over xGMI) run inside the C library
+    ck = CommKKT(rank, world, local, n, r, c, v, dist, use_rccl=not os.environ.get("MI355X_KKT_BENCH_GLOO"))
+    s = ck.s
+    I = s.info()
     dv = torch.tensor(v, dtype=torch.float64, device="cuda")
     db = torch.tensor(b, dtype=torch.float64, device="cuda")
     dx = torch.empty_like(db)
     torch.cuda.synchronize()
-    D = DistributedKKT(eng, dist)
     NSOLVE = 2
 
     def step():
-        st, nneg = D.factor(dv)
+        st, nneg, _ = s.factor_device(dv.data_ptr())
         for _ in range(NSOLVE):
-            dx.copy_(db)
-            torch.cuda.synchronize()
-            D.solve(dx)
+            s.solve_device2(db.data_ptr(), dx.data_ptr())
         return st, nneg
 
     for _ in range(max(args.warmup, 1)):
@@ -161,7 +187,7 @@ def bench_main(args, rank, world, local):
     el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     dt = float(el[0]) / args.steps
-    own = eng.s.symbolic(11, I.num_sn)
+    own = s.symbolic(11, I.num_sn)
     flops_step = I.flops_factor + NSOLVE * I.flops_solve
     line = None
     if rank == 0:
@@ -198,8 +224,8 @@ def bench_main(args, rank, world, local):
             "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "kkt_dim": n, "triplet_nnz": int(len(v)), "nnz_L": I.nnz_l, "flops_per_factor": I.flops_factor,
                        "flops_per_solve": I.flops_solve, "solves_per_step": NSOLVE, "parallelism": f"etree subtrees over {world} ranks, replicated top, "
-                       "all-reduce of the top arena per factorisation", "supernodes": I.num_sn, "replicated_top_supernodes": int((own < 0).sum()),
-                       "arena_MB": float(eng.arena().numel() * 8 / 1e6), "num_neg": nneg, "scaled_residual": res},
+                       "RCCL all-reduce of the top arena per factorisation inside libmi355x_kkt (no Python collective on the data path)",
+                       "supernodes": I.num_sn, "replicated_top_supernodes": int((own < 0).sum()), "num_neg": nneg, "scaled_residual": res},
             "same_workload_1gpu": {"ms_per_step": dt1 * 1e3, "value": flops_step / dt1 / 1e9, "speedup": dt1 / dt},
             "roofline": roof,
         }

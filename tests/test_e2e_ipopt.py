@@ -136,3 +136,14 @@ def test_warm_start_same_structure_keeps_the_symbolic_analysis(tmp_path):
     assert summ[1]["LinearSystemSymbolicFactorization"] == 0.0
     half = len(iters) // 2
     assert iters[:half] == iters[half:]
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+def test_adapter_multigpu_path_with_rccl_world_of_one(tmp_path, golden_dir, monkeypatch):
+    """the adapter's multi-GPU plumbing (mi355x_nranks / rank options, unique-id bootstrap, mi355x_kkt_set_comm_rccl, the
+    distributed factor/solve behind MultiSolve) on the one-GPU box: an RCCL communicator of size 1"""
+    monkeypatch.setenv("MI355X_KKT_FORCE_MULTI", "1")
+    monkeypatch.setenv("MI355X_KKT_COMM_FILE", str(tmp_path / "comm_id"))
+    iters, summ, out = _run(DRIVER, ["LukVlE1", "10000", "--solver", "mi355x", "--set", "mi355x_nranks", "1", "--set", "mi355x_rank", "0"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    _same_iterations(iters, open(os.path.join(golden_dir, "lukvle1_10000.iters")).read().splitlines())

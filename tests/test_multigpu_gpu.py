@@ -76,3 +76,69 @@ def test_hip_multigpu_path_matches_single_gpu(world, case):
     for st, nneg, res, err in out:
         assert st == 0 and nneg == neg       # inertia: exact, summed over ranks
         assert res <= 1e-12                  # same tolerance as the single-GPU path
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# collectives INSIDE the C library (mi355x_kkt_set_comm_*): the ordinary entry points run the distributed sequence
+# ---------------------------------------------------------------------------------------------------------------
+def _worker_comm(rank, world, port, case, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ipopt_amd.multigpu import CommKKT
+    n, r, c, v, neg = case()
+    K = kktgen.to_scipy(n, r, c, v)
+    # RCCL refuses several ranks on one device, so the library gets the one collective it needs as a callback (gloo)
+    s = CommKKT(rank, world, 0, n, r, c, v, dist, use_rccl=False).s
+    out = []
+    for rep in range(2):
+        s.values()[:] = v
+        xt = np.random.default_rng(rep).standard_normal(n)
+        b = K @ xt
+        x = b.copy()
+        st = s.multi_solve(True, x, True, neg)             # the plug-in contract, unchanged: factor + inertia check + solve
+        x2 = (2.0 * b).copy(); st2 = s.multi_solve(False, x2)
+        res = float(np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max()))
+        out.append((st, st2, s.number_of_neg_evals(), res, float(np.abs(x2 - 2.0 * x).max()), s.info().num_two, s.info().num_small, x.copy()))
+    gathered = [None] * world
+    dist.all_gather_object(gathered, [o[-1] for o in out])
+    if rank == 0:
+        same = all(np.array_equal(gathered[0][k], g[k]) for g in gathered for k in range(2))     # every rank holds the same solution
+        ret.put(([o[:-1] for o in out], neg, same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_c_level_collectives_through_the_ordinary_entry_points(world):
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_comm, args=(rk, world, port, _case_grid, ret)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out, neg, same = ret.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same
+    for st, st2, nneg, res, lin, ntwo, nsmall in out:
+        assert st == 0 and st2 == 0 and nneg == neg and res <= 1e-12 and lin <= 1e-9
+
+
+def test_rccl_communicator_of_one_rank(monkeypatch):
+    """the real RCCL code path (dlopen librccl.so, ncclCommInitRank, stream-ordered ncclAllReduce of the arena, the
+    right-hand sides and the counters) with the only world size a one-GPU box allows"""
+    import ipopt_amd
+    monkeypatch.setenv("MI355X_KKT_FORCE_MULTI", "1")
+    n, r, c, v, neg = _case_grid()
+    K = kktgen.to_scipy(n, r, c, v)
+    s = ipopt_amd.KKTSolver(device=0, nranks=1, rank=0)
+    s.initialize_structure(n, r, c, vals=v)
+    with pytest.raises(ipopt_amd.kkt.KKTError):            # a multi-GPU handle without communicator must fail loudly
+        s.values()[:] = v; s.multi_solve(True, (K @ np.ones(n)).copy())
+    s.set_comm_rccl(ipopt_amd.KKTSolver.comm_unique_id())
+    s.values()[:] = v
+    b = K @ np.ones(n); x = b.copy()
+    assert s.multi_solve(True, x, True, neg) == 0
+    assert np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max()) <= 1e-12
