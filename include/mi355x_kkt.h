@@ -139,6 +139,21 @@ int  mi355x_kkt_factor(mi355x_kkt_handle h, const double* dvals, int* num_neg, i
  * adapters that refactor from their private val_ copy (IpMa97SolverInterface.cpp:623). */
 int  mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero);
 
+/* ---- device-side value assembly: the next row of the hot path --------------------------------------
+ * Replaces, for a host that keeps the pieces of the KKT matrix apart (Ipopt's AugSystemSolver contract,
+ * IpAugSystemSolver.hpp:40-120), TripletHelper::FillValues over the whole CompoundSymMatrix (IpTripletHelper.cpp:249-362,
+ * driven by IpTSymLinearSolver.cpp:453-533) and the per-factorisation 8 nnz-byte upload: the triplet value array is declared
+ * once as a sequence of SEGMENTS that tile [0, nnz) -- for Ipopt: W | D_x | D_s | J_c | D_c | J_d | -I | D_d in the order of
+ * IpStdAugSystemSolver.cpp:263-298 -- each with a device-resident source that is uploaded only when ITS content changed
+ * (_assembly_buffer: pinned staging, _assembly_upload: async copy).  _factor_assembled forms
+ *        values[offset_s + i] = scale_s * source_s[i] + shift_s          (scale_s = 0: the source is not read)
+ * on the device (W_factor; delta_x, delta_s, -delta_c, -delta_d as shifts; the (4,2) block as scale 0, shift -1) and factors.
+ * An inertia-correction retry (IpPDFullSpaceSolver.cpp:486-640: same matrices, new deltas) therefore uploads NOTHING. */
+int  mi355x_kkt_assembly_define(mi355x_kkt_handle h, int nseg, const int64_t* offset, const int64_t* length);   /* nseg <= 16 */
+double* mi355x_kkt_assembly_buffer(mi355x_kkt_handle h, int seg);
+int  mi355x_kkt_assembly_upload(mi355x_kkt_handle h, int seg);
+int  mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const double* shift, int* num_neg, int* num_zero);
+
 /* Solve A X = B in place for nrhs right-hand sides, rhs[irhs*ld + i], host memory. */
 int  mi355x_kkt_solve(mi355x_kkt_handle h, int nrhs, double* rhs_inout, int ld);
 /* Same with rhs/solution resident in device memory (nrhs columns, leading dimension ld). */

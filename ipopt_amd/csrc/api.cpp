@@ -105,6 +105,37 @@ static int do_factor(mi355x_kkt_handle h, const double* dvals, bool reuse, int* 
 int mi355x_kkt_factor(mi355x_kkt_handle h, const double* dvals, int* num_neg, int* num_zero) { return do_factor(h, dvals, false, num_neg, num_zero); }
 int mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero) { return do_factor(h, nullptr, true, num_neg, num_zero); }
 
+// ---- device-side value assembly ----
+int mi355x_kkt_assembly_define(mi355x_kkt_handle h, int nseg, const int64_t* offset, const int64_t* length)
+{
+    if (!h || !offset || !length) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready) { h->err = "assembly_define: analyse() first (and a usable HIP device; no CPU fallback)"; return MI355X_KKT_FATAL; }
+    try { if (!h->num->assembly_define(nseg, offset, length)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
+double* mi355x_kkt_assembly_buffer(mi355x_kkt_handle h, int seg)
+{
+    if (!h || !h->numeric_ready) return nullptr;
+    return h->num->assembly_buffer(seg);
+}
+int mi355x_kkt_assembly_upload(mi355x_kkt_handle h, int seg)
+{
+    if (!h || !h->numeric_ready) return MI355X_KKT_FATAL;
+    try { if (!h->num->assembly_upload(seg)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const double* shift, int* num_neg, int* num_zero)
+{
+    if (!h || !scale || !shift) return MI355X_KKT_FATAL;
+    if (!h->analysed || !h->numeric_ready) { h->err = "factor_assembled: analyse() + a usable HIP device needed (no CPU fallback)"; return MI355X_KKT_FATAL; }
+    try {
+        FactorStats st;
+        if (!h->num->factor_assembled(scale, shift, st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
+        h->last = st; h->factored = true;
+        if (num_neg) *num_neg = st.num_neg;
+        if (num_zero) *num_zero = st.num_zero;
+        return st.num_zero > 0 ? MI355X_KKT_SINGULAR : MI355X_KKT_SUCCESS;
+    } catch (...) { h->err = "factor_assembled: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
 int mi355x_kkt_solve(mi355x_kkt_handle h, int nrhs, double* rhs, int ld)
 {
     if (!h) return MI355X_KKT_FATAL;

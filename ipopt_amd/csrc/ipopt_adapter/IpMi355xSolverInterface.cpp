@@ -56,7 +56,8 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
                               "*", "any path on a file system all ranks see (default: $MI355X_KKT_COMM_FILE)");
 }
 
-bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std::string& prefix)
+void Mi355xSolverInterface::ReadNumericOptions(const OptionsList& options, const std::string& prefix, mi355x_kkt_options& kopts,
+      Number& pivtol, Number& pivtolmax)
 {
    // options are optional: a host that has not called RegisterOptions simply gets the defaults
    try
@@ -66,44 +67,65 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
       std::string sv;
       if( options.GetNumericValue("mi355x_pivtol", v, prefix) )
       {
-         pivtol_ = v;
+         pivtol = v;
       }
       if( options.GetNumericValue("mi355x_pivtolmax", v, prefix) )
       {
-         pivtolmax_ = v;
+         pivtolmax = v;
       }
       if( options.GetStringValue("mi355x_scaling", sv, prefix) )
       {
-         kopts_.scaling = (sv == "none") ? 0 : 1;
+         kopts.scaling = (sv == "none") ? 0 : 1;
       }
       if( options.GetStringValue("mi355x_ordering", sv, prefix) )
       {
-         kopts_.ordering = (sv == "md") ? 1 : (sv == "natural" ? 2 : 0);
+         kopts.ordering = (sv == "md") ? 1 : (sv == "natural" ? 2 : 0);
       }
       if( options.GetStringValue("mi355x_matching", sv, prefix) )
       {
-         kopts_.matching = (sv == "no") ? 0 : 1;
+         kopts.matching = (sv == "no") ? 0 : 1;
       }
       if( options.GetIntegerValue("mi355x_nemin", iv, prefix) )
       {
-         kopts_.nemin = iv;
+         kopts.nemin = iv;
       }
       if( options.GetIntegerValue("mi355x_nd_leaf", iv, prefix) )
       {
-         kopts_.nd_leaf = iv;
+         kopts.nd_leaf = iv;
       }
       if( options.GetIntegerValue("mi355x_max_sn_cols", iv, prefix) )
       {
-         kopts_.max_sn_cols = iv;
+         kopts.max_sn_cols = iv;
       }
       if( options.GetIntegerValue("mi355x_device", iv, prefix) )
       {
-         kopts_.device = iv;
+         kopts.device = iv;
       }
       if( options.GetIntegerValue("mi355x_verbose", iv, prefix) )
       {
-         kopts_.verbose = iv;
+         kopts.verbose = iv;
       }
+   }
+   catch( ... )
+   {
+      // unregistered options: keep defaults
+   }
+   if( pivtolmax < pivtol )
+   {
+      pivtolmax = pivtol;
+   }
+   kopts.pivtol = pivtol;
+   kopts.pivtolmax = pivtolmax;
+   kopts.index_base = 1;
+}
+
+bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std::string& prefix)
+{
+   ReadNumericOptions(options, prefix, kopts_, pivtol_, pivtolmax_);
+   try
+   {
+      Index iv;
+      std::string sv;
       if( options.GetIntegerValue("mi355x_nranks", iv, prefix) )
       {
          nranks_opt_ = iv;
@@ -119,7 +141,6 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
    }
    catch( ... )
    {
-      // unregistered options: keep defaults
    }
    if( pivtolmax_ < pivtol_ )
    {

@@ -45,6 +45,9 @@ public:
    }
 
    static void RegisterOptions(SmartPtr<RegisteredOptions> roptions);
+   /** the numeric mi355x_* options into a C-ABI option block (shared with Mi355xAugSystemSolver) */
+   static void ReadNumericOptions(const OptionsList& options, const std::string& prefix, mi355x_kkt_options& kopts, Number& pivtol,
+                                  Number& pivtolmax);
 
 private:
    Mi355xSolverInterface(const Mi355xSolverInterface&);

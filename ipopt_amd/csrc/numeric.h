@@ -51,6 +51,11 @@ public:
     bool   solve_fwd_local(double* drhs);
     bool   top_rhs(double** dptr, int64_t* ndoubles);
     bool   solve_top_and_bwd(double* drhs);
+    // device-side value assembly: triplet values = concatenated segments, each  scale * src + shift  from a device-resident source
+    bool   assembly_define(int nseg, const int64_t* off, const int64_t* len);
+    double* assembly_buffer(int seg);                      // pinned staging of the segment's source values
+    bool   assembly_upload(int seg);                       // async H2D on the solver's stream
+    bool   factor_assembled(const double* scale, const double* shift, FactorStats& st);
     // communicator of a multi-GPU handle: with one set, factor()/solve_*() run the whole distributed sequence themselves
     bool   set_comm_rccl(const void* unique_id128);                                   // RCCL (dlopen'ed), ncclCommInitRank(nranks, id, rank)
     bool   set_comm_callback(int (*allreduce)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream), void* ctx);

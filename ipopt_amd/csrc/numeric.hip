@@ -160,6 +160,24 @@ __global__ void k_gather_values(DevView V)
         V.aval[q] = s;
     }
 }
+// Device-side KKT value assembly (replaces TripletHelper::FillValues over the whole CompoundSymMatrix,
+// IpTripletHelper.cpp:249-362, and the 8 nnz-byte PCIe copy): the triplet value array is a concatenation of SEGMENTS, each
+//   tvals[off + i] = scale * src[i] + shift
+// with a device-resident source (W, J_c, J_d values; the Sigma / D diagonals) and two scalars per segment: W_factor,
+// delta_x/s, -delta_c/d, the -1 of the (4,2) identity block.  A retry that only changes the deltas uploads nothing.
+constexpr int ASM_MAXSEG = 16;
+struct AsmSegs { int nseg; long long off[ASM_MAXSEG], len[ASM_MAXSEG]; const double* src[ASM_MAXSEG]; double scale[ASM_MAXSEG], shift[ASM_MAXSEG]; };
+__global__ void k_assemble_segments(double* tvals, AsmSegs A)
+{
+    const int sgi = blockIdx.y;
+    if (sgi >= A.nseg) return;
+    const long long len = A.len[sgi];
+    const double sc = A.scale[sgi], sh = A.shift[sgi];
+    const double* src = A.src[sgi];
+    double* dst = tvals + A.off[sgi];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (long long)gridDim.x * blockDim.x)
+        dst[i] = (sc != 0.0 ? sc * src[i] : 0.0) + sh;
+}
 __global__ void k_fill(double* p, double v, long long n)
 {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
@@ -1532,6 +1550,46 @@ public:
     long long arena_doubles = 0, toprhs_doubles = 0;
     bool multi = false;
 
+    // ---- device-side value assembly: per segment a device source buffer + a pinned staging buffer of the same length ----
+    AsmSegs asm_{};
+    std::vector<double*> asm_host;        // pinned staging per segment
+    double* asm_pool = nullptr; double* asm_hpool = nullptr;
+    bool assembly_define(int nseg, const int64_t* off, const int64_t* len) {
+        DeviceGuard guard(dev);
+        if (!ready) { err_ = "assembly_define: analyse first (and a usable HIP device)"; return false; }
+        if (nseg < 1 || nseg > ASM_MAXSEG) { err_ = "assembly_define: 1..16 segments"; return false; }
+        long long total = 0;
+        for (int q = 0; q < nseg; ++q) { if (off[q] != total || len[q] < 0) { err_ = "assembly_define: segments must tile [0, nnz) in order"; return false; } total += len[q]; }
+        if (total != S->nnz_in) { err_ = "assembly_define: segments do not cover the nnz triplet values"; return false; }
+        if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
+        if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
+        HIPCHK(hipMalloc((void**)&asm_pool, std::max<long long>(total, 1) * sizeof(double)));
+        HIPCHK(hipMemset(asm_pool, 0, std::max<long long>(total, 1) * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&asm_hpool, std::max<long long>(total, 1) * sizeof(double), hipHostMallocDefault));
+        asm_.nseg = nseg; asm_host.assign(nseg, nullptr);
+        for (int q = 0; q < nseg; ++q) { asm_.off[q] = off[q]; asm_.len[q] = len[q]; asm_.src[q] = asm_pool + off[q]; asm_host[q] = asm_hpool + off[q]; asm_.scale[q] = 0.0; asm_.shift[q] = 0.0; }
+        return true;
+    }
+    double* assembly_buffer(int seg) { return (seg >= 0 && seg < asm_.nseg) ? asm_host[seg] : nullptr; }
+    bool assembly_upload(int seg) {
+        DeviceGuard guard(dev);
+        if (seg < 0 || seg >= asm_.nseg) { err_ = "assembly_upload: no such segment"; return false; }
+        if (asm_.len[seg] > 0) HIPCHK(hipMemcpyAsync((void*)asm_.src[seg], asm_host[seg], (size_t)asm_.len[seg] * sizeof(double), hipMemcpyHostToDevice, stream));
+        return true;
+    }
+    bool factor_assembled(const double* scale, const double* shift, FactorStats& st) {
+        {
+            DeviceGuard guard(dev);
+            if (!ready || asm_.nseg == 0) { err_ = "factor_assembled: assembly_define first"; return false; }
+            long long mx = 1;
+            for (int q = 0; q < asm_.nseg; ++q) { asm_.scale[q] = scale[q]; asm_.shift[q] = shift[q]; mx = std::max(mx, asm_.len[q]); }
+            hipLaunchKernelGGL(k_assemble_segments, dim3(grid1d(mx), asm_.nseg), dim3(256), 0, stream, (double*)V.tvals, asm_);
+            HIPCHK(hipGetLastError());
+            have_values = true;
+        }
+        return factor(nullptr, true, st);       // the values are on the device: the "refactor" path, no host buffer involved
+    }
+
     // ---- communicator of a multi-GPU handle: RCCL over xGMI created from an ncclUniqueId, or a caller-supplied
     //      all-reduce (a host with its own communication layer; the single-GPU multi-rank tests).  All collectives are
     //      enqueued on the solver's stream: no host synchronisation between factor_local -> all-reduce -> factor_top. ----
@@ -1617,6 +1675,9 @@ public:
         for (void* p : allocs) (void)hipFree(p);
         allocs.clear();
         if (d_rhs) { (void)hipFree(d_rhs); d_rhs = nullptr; d_rhs_cap = 0; }
+        if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
+        if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
+        asm_.nseg = 0;
         if (h_vals) { (void)hipHostFree(h_vals); h_vals = nullptr; }
         if (h_stats) { (void)hipHostFree(h_stats); h_stats = nullptr; }
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
@@ -2430,6 +2491,10 @@ bool Numeric::factor_top(FactorStats& st) { return p_->factor_top(st); }
 bool Numeric::solve_fwd_local(double* drhs) { return p_->solve_fwd_local(drhs); }
 bool Numeric::top_rhs(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_rhs: not a multi-GPU handle"; return false; } *d = p_->V.top_rhs; *nd = p_->toprhs_doubles; return true; }
 bool Numeric::solve_top_and_bwd(double* drhs) { return p_->solve_top_and_bwd(drhs); }
+bool Numeric::assembly_define(int nseg, const int64_t* off, const int64_t* len) { return p_->assembly_define(nseg, off, len); }
+double* Numeric::assembly_buffer(int seg) { return p_->assembly_buffer(seg); }
+bool Numeric::assembly_upload(int seg) { return p_->assembly_upload(seg); }
+bool Numeric::factor_assembled(const double* scale, const double* shift, FactorStats& st) { return p_->factor_assembled(scale, shift, st); }
 bool Numeric::set_comm_rccl(const void* unique_id128) { return p_->set_comm_rccl(unique_id128); }
 bool Numeric::set_comm_callback(int (*fn)(void*, void*, int64_t, int, void*), void* ctx) { return p_->set_comm_callback(fn, ctx); }
 bool Numeric::rccl_unique_id(void* out128, std::string& err)

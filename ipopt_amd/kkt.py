@@ -68,6 +68,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
     "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
+    "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
                 "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big", "fwd_big_upd", "bwd_big_dot"]
@@ -113,6 +114,11 @@ def load_library():
     lib.mi355x_kkt_top_rhs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.mi355x_kkt_solve_top_and_bwd.argtypes = [vp, vp]
     lib.mi355x_kkt_comm_unique_id.argtypes = [vp]
+    lib.mi355x_kkt_assembly_define.argtypes = [vp, C.c_int, vp, vp]
+    lib.mi355x_kkt_assembly_buffer.argtypes = [vp, C.c_int]
+    lib.mi355x_kkt_assembly_buffer.restype = dp
+    lib.mi355x_kkt_assembly_upload.argtypes = [vp, C.c_int]
+    lib.mi355x_kkt_factor_assembled.argtypes = [vp, vp, vp, ip, ip]
     lib.mi355x_kkt_set_comm_rccl.argtypes = [vp, vp]
     lib.mi355x_kkt_set_comm_callbacks.argtypes = [vp, ALLREDUCE_FN, vp]
     _LIB = lib
@@ -218,6 +224,31 @@ class KKTSolver:
         st = self.lib.mi355x_kkt_solve_device2(self._h, nrhs, C.c_void_p(db_ptr), self._n, C.c_void_p(dx_ptr), self._n)
         if st != 0:
             raise KKTError("solve_device2: " + self.last_error())
+
+    # --- device-side value assembly: segments  values[off + i] = scale * src[i] + shift ---
+    def assembly_define(self, lengths):
+        ln = np.asarray(lengths, dtype=np.int64)
+        off = np.concatenate([[0], np.cumsum(ln)[:-1]]).astype(np.int64)
+        if self.lib.mi355x_kkt_assembly_define(self._h, len(ln), off.ctypes.data, ln.ctypes.data) != 0:
+            raise KKTError("assembly_define: " + self.last_error())
+        self._seg_len = ln
+
+    def assembly_set(self, seg, values):
+        p = self.lib.mi355x_kkt_assembly_buffer(self._h, int(seg))
+        n = int(self._seg_len[seg])
+        if n:
+            np.ctypeslib.as_array(p, shape=(n,))[:] = values
+        if self.lib.mi355x_kkt_assembly_upload(self._h, int(seg)) != 0:
+            raise KKTError("assembly_upload: " + self.last_error())
+
+    def factor_assembled(self, scale, shift):
+        sc = np.ascontiguousarray(scale, dtype=np.float64); sh = np.ascontiguousarray(shift, dtype=np.float64)
+        neg, zero = C.c_int(0), C.c_int(0)
+        st = self.lib.mi355x_kkt_factor_assembled(self._h, sc.ctypes.data, sh.ctypes.data, C.byref(neg), C.byref(zero))
+        if st == FATAL:
+            raise KKTError("factor_assembled: " + self.last_error())
+        self._neg = neg.value
+        return st, neg.value, zero.value
 
     # --- multi-GPU communicator (include/mi355x_kkt.h): after one of these, multi_solve / factor_device / solve_device* of a
     #     handle created with nranks > 1 run the distributed sequence inside the library ---

@@ -80,8 +80,9 @@ $(OUT)/scalable.a: $(SCAL_OBJS)
 # --- the product's Ipopt adapter (B1), compiled against the reference headers where they lie.  The
 #     adapter SOURCE is product code (ipopt_amd/csrc/ipopt_adapter); only its build needs the reference. ---
 KKTLIB := ipopt_amd/lib
-$(OUT)/libmi355x_ipopt.so: ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.hpp $(OUT)/libipopt_ref.so
-	$(CXX) -O2 -fPIC -shared -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter $< -o $@ \
+ADAPTER_SRC := ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp
+$(OUT)/libmi355x_ipopt.so: $(ADAPTER_SRC) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h $(OUT)/libipopt_ref.so
+	$(CXX) -O2 -fPIC -shared -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter $(ADAPTER_SRC) -o $@ \
 	  -L$(OUT) -lipopt_ref -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib'
 
 DRV_INCS := $(INCS) -I$(REF)/examples/hs071_cpp -I$(REF)/examples/ScalableProblems -Iinclude -Iipopt_amd/csrc/ipopt_adapter

@@ -16,7 +16,7 @@
 // (--set linear_solver ma97 --set hsllib .../libmi355x_kkt.so = route B2; --set linear_solver mi355x with the patched
 // library oracle/_ref/libipopt_ref_mi355x.so = route B1').
 //
-// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|stock] [--record file] [--max-records K]
+// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|mi355x-aug|stock] [--record file] [--max-records K]
 //                   [--set name value]... [--optfile ipopt.opt] [--reoptimize] [--quiet]
 //   --reoptimize: after the first solve, set warm_start_same_structure=yes and call ReOptimizeNLP (second DRIVER_SUMMARY line)
 #include "IpIpoptApplication.hpp"
@@ -36,6 +36,7 @@
 #include "MittelmannDistCntrlDiri.hpp"
 #ifdef WITH_MI355X
 #include "IpMi355xSolverInterface.hpp"
+#include "IpMi355xAugSystemSolver.hpp"
 #endif
 #include <cstdio>
 #include <cstdlib>
@@ -200,7 +201,18 @@ int main(int argc, char** argv)
 
    SmartPtr<NLP> nlp = new TNLPAdapter(tnlp, app->Jnlst());
    SmartPtr<AlgorithmBuilder> builder;
+#ifdef WITH_MI355X
+   SmartPtr<Mi355xAugSystemSolver> aug;
+#endif
    if( solver == "stock" ) builder = new AlgorithmBuilder();     // the reference's own factory chain (IpAlgBuilder.cpp:427-526)
+#ifdef WITH_MI355X
+   else if( solver == "mi355x-aug" )
+   {  // route (ii): custom AugSystemSolver with device-side KKT assembly; needs linear_solver=custom (IpAlgBuilder.cpp:576-584)
+      app->Options()->SetStringValue("linear_solver", "custom");
+      aug = new Mi355xAugSystemSolver();
+      builder = new AlgorithmBuilder(GetRawPtr(aug), "mi355x-ldlt (device-side KKT assembly)");
+   }
+#endif
    else builder = new DriverAlgBuilder(solver, record, max_records);
    auto t0 = std::chrono::steady_clock::now();
    ApplicationReturnStatus status = app->OptimizeNLP(nlp, builder);
@@ -228,5 +240,9 @@ int main(int argc, char** argv)
           wall(ts.LinearSystemBackSolve()), wall(ts.LinearSystemSymbolicFactorization()), wall(ts.LinearSystemStructureConverter()),
           wall(ts.StdAugSystemSolverMultiSolve()), wall(ts.OverallAlgorithm()), (double) ts.TotalFunctionEvaluationWallclockTime());
    }
+#ifdef WITH_MI355X
+   if( IsValid(aug) )
+      printf("AUG_STATS {\"uploaded_value_bytes\": %lld, \"factorizations_without_upload\": %d}\n", aug->UploadedBytes(), (int) aug->FactorizationsWithoutUpload());
+#endif
    return (status == Solve_Succeeded || status == Solved_To_Acceptable_Level) ? 0 : 1;
 }

@@ -147,3 +147,21 @@ def test_adapter_multigpu_path_with_rccl_world_of_one(tmp_path, golden_dir, monk
     iters, summ, out = _run(DRIVER, ["LukVlE1", "10000", "--solver", "mi355x", "--set", "mi355x_nranks", "1", "--set", "mi355x_rank", "0"], tmp_path)
     assert "EXIT: Optimal Solution Found." in out, out[-1500:]
     _same_iterations(iters, open(os.path.join(golden_dir, "lukvle1_10000.iters")).read().splitlines())
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,problem,n", [("hs071", "hs071", 0), ("lukvle1_10000", "LukVlE1", 10000), ("mbndry1_100", "MBndryCntrl1", 100)])
+def test_custom_aug_system_solver_with_device_side_assembly(name, problem, n, tmp_path, golden_dir):
+    """Route (ii) + SURVEY 8(f)1: Mi355xAugSystemSolver (custom AugSystemSolver, IpAlgBuilder.cpp:82-88,576-584) uploads W / J /
+    Sigma pieces only when their tag changed and assembles the KKT values on the GPU.  Same iterates as the reference CPU run;
+    hs071's inertia-correction retries (5 trial factorisations in iteration 1) must upload nothing."""
+    iters, summ, out = _run(DRIVER, [problem, str(n), "--solver", "mi355x-aug", "--set", "print_level", "5"] +
+                            (["--set", "tol", "3.82e-6", "--set", "mu_strategy", "adaptive"] if problem == "hs071" else []), tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
+    assert summ[0]["iterations"] == gsum["iterations"]
+    assert abs(summ[0]["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
+    _same_iterations(iters, open(os.path.join(golden_dir, name + ".iters")).read().splitlines())
+    aug = json.loads(next(ln for ln in out.splitlines() if ln.startswith("AUG_STATS"))[len("AUG_STATS "):])
+    if problem == "hs071":
+        assert aug["factorizations_without_upload"] >= 4          # the delta_x escalation 1e-4 -> 1e-2 -> 1 -> 100 of iteration 1

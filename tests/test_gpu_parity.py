@@ -198,3 +198,37 @@ def test_lookahead_split_updates_are_exact_and_reproducible(monkeypatch):
     assert np.array_equal(x0, x1)
     x2 = b.copy(); s1.multi_solve(True, x2)
     assert np.array_equal(x1, x2)
+
+
+def test_device_side_assembly_equals_host_assembly_bitwise():
+    """mi355x_kkt_factor_assembled: values = scale * source + shift per segment, formed on the device, must
+    give the factorisation of the host-assembled values bit for bit; a delta-only refactorisation uploads nothing."""
+    rng = np.random.default_rng(5)
+    nx, m = 300, 120
+    # K = [[H + Sigma + dx I, J^T], [J, -dc I]] in Ipopt's segment order  W | D_x | J_c | D_c
+    hi = np.concatenate([np.arange(nx), np.arange(nx - 1)]); hj = np.concatenate([np.arange(nx), np.arange(1, nx)])
+    hv = np.concatenate([4.0 + rng.random(nx), rng.uniform(-1, 1, nx - 1)])
+    Sigma = 10.0 ** rng.uniform(-3, 3, nx)
+    ji = np.repeat(np.arange(m), 3); jj = (2 * np.arange(m)[:, None] + np.arange(3)[None, :]).ravel(); jv = rng.uniform(-1, 1, 3 * m); jv[1::3] += 2.0
+    r = np.concatenate([np.minimum(hi, hj), np.arange(nx), ji + nx, np.arange(m) + nx]).astype(np.int32) + 1
+    c = np.concatenate([np.maximum(hi, hj), np.arange(nx), jj, np.arange(m) + nx]).astype(np.int32) + 1
+    n = nx + m
+    lens = [len(hv), nx, len(jv), m]
+
+    def host_vals(dx, dc, wf=1.0):
+        return np.concatenate([wf * hv, Sigma + dx, jv, np.full(m, -dc)])
+
+    b = rng.standard_normal(n)
+    s = ipopt_amd.KKTSolver()
+    s.initialize_structure(n, r, c, vals=host_vals(0.0, 0.0))
+    s.assembly_define(lens)
+    s.assembly_set(0, hv); s.assembly_set(1, Sigma); s.assembly_set(2, jv)          # D_c has no source (NULL vector in Ipopt): scale 0
+    for dx, dc, wf in ((0.0, 0.0, 1.0), (1e-4, 0.0, 1.0), (1e-2, 1e-8, 1.0), (0.0, 1e-8, 0.0)):
+        st, neg, zero = s.factor_assembled([wf, 1.0, 1.0, 0.0], [0.0, dx, 0.0, -dc])     # nothing uploaded between the trials
+        x = b.copy(); s.multi_solve(False, x)
+        s2 = ipopt_amd.KKTSolver(); s2.initialize_structure(n, r, c, vals=host_vals(0.0, 0.0))
+        s2.values()[:] = host_vals(dx, dc, wf)
+        x2 = b.copy(); st2 = s2.multi_solve(True, x2)
+        assert st == st2 and neg == s2.number_of_neg_evals()
+        if st == 0:
+            assert np.array_equal(x, x2)
