@@ -171,6 +171,10 @@ int  mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax);
  * depends on u up to pivtolmax (nothing a refactorisation could improve).  *new_u (may be NULL) receives the new u. */
 int  mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u);
 int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
+/* The columns (caller's index base) whose pivot was numerically zero in the last factorisation, ascending; *count = how
+ * many there are (idx may be NULL / shorter).  This is what DetermineDependentRows needs
+ * (IpSparseSymLinearSolverInterface.hpp:240-255; MUMPS' PIVNUL_LIST, IpMumpsSolverInterface.cpp:617-709). */
+int  mi355x_kkt_zero_pivots(mi355x_kkt_handle h, int* idx, int capacity, int* count);
 const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
 
 /* ---- symbolic introspection (host logic tests, debugging; sizes via get_info) ---- */

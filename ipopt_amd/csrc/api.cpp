@@ -105,6 +105,21 @@ static int do_factor(mi355x_kkt_handle h, const double* dvals, bool reuse, int* 
 int mi355x_kkt_factor(mi355x_kkt_handle h, const double* dvals, int* num_neg, int* num_zero) { return do_factor(h, dvals, false, num_neg, num_zero); }
 int mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero) { return do_factor(h, nullptr, true, num_neg, num_zero); }
 
+/* DetermineDependentRows support (IpSparseSymLinearSolverInterface.hpp:240-255; MUMPS' null-pivot list,
+ * IpMumpsSolverInterface.cpp:617-709): the columns whose pivot was numerically zero in the last factorisation */
+int mi355x_kkt_zero_pivots(mi355x_kkt_handle h, int* idx, int capacity, int* count)
+{
+    if (!h || !count) return MI355X_KKT_FATAL;
+    if (!h->factored || !h->numeric_ready) { h->err = "zero_pivots: no factorisation available"; return MI355X_KKT_FATAL; }
+    try {
+        std::vector<int> z;
+        if (h->sym.n > 0 && !h->num->zero_pivots(z)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
+        *count = (int)z.size();
+        if (idx) for (int i = 0; i < (int)z.size() && i < capacity; ++i) idx[i] = z[i] + h->opts.index_base;
+        return MI355X_KKT_SUCCESS;
+    } catch (...) { h->err = "zero_pivots: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
 // ---- device-side value assembly ----
 int mi355x_kkt_assembly_define(mi355x_kkt_handle h, int nseg, const int64_t* offset, const int64_t* length)
 {

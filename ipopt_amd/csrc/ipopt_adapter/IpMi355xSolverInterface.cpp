@@ -338,6 +338,48 @@ ESymSolverStatus Mi355xSolverInterface::MultiSolve(bool new_matrix, const Index*
    return SYMSOLVER_SUCCESS;
 }
 
+ESymSolverStatus Mi355xSolverInterface::DetermineDependentRows(const Index* /*ia*/, const Index* /*ja*/, std::list<Index>& c_deps)
+{
+   // TSymLinearSolver::DetermineDependentRows (IpTSymLinearSolver.cpp:540-716) has called InitializeStructure for
+   // [[I, J^T], [J, 0]] (all diagonal entries present) and filled the values buffer; factor it and report the zero pivots
+   c_deps.clear();
+   if( !analysed_ )
+   {
+      if( mi355x_kkt_analyse(handle_, dim_, nonzeros_, ia_, ja_, MI355X_KKT_FMT_TRIPLET, &staging_[0]) != MI355X_KKT_SUCCESS )
+      {
+         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_analyse failed: %s\n", mi355x_kkt_last_error(handle_));
+         return SYMSOLVER_FATAL_ERROR;
+      }
+      Number* buf = mi355x_kkt_values_buffer(handle_);
+      if( !buf )
+      {
+         return SYMSOLVER_FATAL_ERROR;
+      }
+      std::memcpy(buf, &staging_[0], sizeof(Number) * (size_t) nonzeros_);
+      std::vector<Number>().swap(staging_);
+      analysed_ = true;
+   }
+   int nneg = 0, nzero = 0;
+   int st = mi355x_kkt_factor(handle_, NULL, &nneg, &nzero);
+   if( st == MI355X_KKT_FATAL )
+   {
+      Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_factor failed: %s\n", mi355x_kkt_last_error(handle_));
+      return SYMSOLVER_FATAL_ERROR;
+   }
+   negevals_ = nneg;
+   int count = 0;
+   std::vector<int> idx(nzero > 0 ? nzero : 1);
+   if( mi355x_kkt_zero_pivots(handle_, &idx[0], (int) idx.size(), &count) != MI355X_KKT_SUCCESS )
+   {
+      return SYMSOLVER_FATAL_ERROR;
+   }
+   for( int i = 0; i < count && i < (int) idx.size(); ++i )
+   {
+      c_deps.push_back(idx[i] - 1);      // 0-based, as MUMPS' pivnul_list - 1 (IpMumpsSolverInterface.cpp:703-706)
+   }
+   return SYMSOLVER_SUCCESS;
+}
+
 bool Mi355xSolverInterface::SetupCommunicator()
 {
    // rank 0 creates the ncclUniqueId and publishes it through a file (write + rename = atomic); the others poll for it

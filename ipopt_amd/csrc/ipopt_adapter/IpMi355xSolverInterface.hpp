@@ -16,6 +16,7 @@
 #include "IpRegOptions.hpp"
 #include "mi355x_kkt.h"
 #include <vector>
+#include <list>
 #include <string>
 
 namespace Ipopt
@@ -43,6 +44,14 @@ public:
    {
       return Triplet_Format;   // duplicates / mixed triangles are canonicalised by our own analysis
    }
+
+   /** degeneracy detection (IpSparseSymLinearSolverInterface.hpp:240-255): the zero pivots of the factorisation of
+    *  [[I, J^T], [J, 0]] are the linearly dependent rows of J (what the MUMPS adapter does, IpMumpsSolverInterface.cpp:617-709) */
+   bool ProvidesDegeneracyDetection() const
+   {
+      return true;
+   }
+   ESymSolverStatus DetermineDependentRows(const Index* ia, const Index* ja, std::list<Index>& c_deps);
 
    static void RegisterOptions(SmartPtr<RegisteredOptions> roptions);
    /** the numeric mi355x_* options into a C-ABI option block (shared with Mi355xAugSystemSolver) */

@@ -4,6 +4,7 @@
 #include "symbolic.h"
 #include <cstdint>
 #include <string>
+#include <vector>
 
 namespace mi355x {
 
@@ -51,6 +52,7 @@ public:
     bool   solve_fwd_local(double* drhs);
     bool   top_rhs(double** dptr, int64_t* ndoubles);
     bool   solve_top_and_bwd(double* drhs);
+    bool   zero_pivots(std::vector<int>& idx0);           // columns (original numbering, 0-based) with a zero pivot in the last factorisation
     // device-side value assembly: triplet values = concatenated segments, each  scale * src + shift  from a device-resident source
     bool   assembly_define(int nseg, const int64_t* off, const int64_t* len);
     double* assembly_buffer(int seg);                      // pinned staging of the segment's source values

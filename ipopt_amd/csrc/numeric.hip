@@ -102,6 +102,7 @@ struct DevView {
     double pivtol, pivtol2, small;   // u, the largest u IncreaseQuality may reach (decision-change tracking), absolute zero threshold
     int* colfail;           // per column of a BIG front: 1 once some multiplier of L21 exceeded 1/u (a posteriori test, k_big_trsm)
     int* qstat;             // [0]: some pivot decision of this factorisation would differ at u = pivtol2
+    int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
 };
@@ -301,7 +302,7 @@ __device__ __forceinline__ double fast_rcp(double d)
 // Big fronts: the pivot block only sees its k x k block here (ext rows are checked a posteriori in k_big_trsm).
 template <int NT, int TS, bool WIDE>
 __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const int k, double* Lbuf, const int ldL, double* colbuf,
-                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double u2, const double ztol,
+                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double u2, const double ztol, int* zp,
                                          int& nneg, int& nzero, int& ntwo, int& ndelay, int& chg)
 {
     // The per-pivot instruction stream IS the critical path (measured: ~5 cycles per wave instruction), so the common
@@ -445,7 +446,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 #pragma unroll
                 for (int x = 0; x < TS; ++x) { rv[x] = colB[row0 + x]; cv[x] = colB[col0 + x]; }
             }
-            if (zero) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; }
+            if (zero) { nzero++; d = (d < 0.0) ? -PIV_PERT : PIV_PERT; if (tid == 0) zp[p] = 1; }
         }
         {   // 1x1 pivot on physical row p
             const double di = fast_rcp(d);
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(5);
     const double ztol = front_ztol<NT, TS>(t, colbuf, V.small);
-    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, nneg, nzero, ntwo, nsmall, chg);
+    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(6);
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(0);
     const double ztol = front_ztol<NT, TS>(t, colbuf, V.small);
-    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, nneg, nzero, ntwo, nsmall, chg);
+    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(1);
@@ -2008,7 +2009,7 @@ public:
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
-            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n)) return false;
+            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n)) return false;
         V.qstat = d_stats + 4;
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
@@ -2115,6 +2116,7 @@ public:
         const int n = Sy.n;
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
         LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
+        LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         if (opt.scaling) {      // 4 sweeps, ping-pong between the two buffers, ending in V.scale
             LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
@@ -2325,6 +2327,7 @@ public:
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
         hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
+        hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         if (opt.scaling) {
             hipLaunchKernelGGL(k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
@@ -2430,6 +2433,17 @@ public:
         return true;
     }
 
+    // indices (original numbering, 0-based) of the columns whose pivot was (numerically) zero in the last factorisation
+    bool zero_pivots(std::vector<int>& out) {
+        DeviceGuard guard(dev);
+        out.clear();
+        if (!ready) { err_ = "zero_pivots: solver not set up"; return false; }
+        std::vector<int> z(S->n);
+        if (S->n > 0) HIPCHK(hipMemcpy(z.data(), V.zpiv, (size_t)S->n * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < S->n; ++i) if (z[i]) out.push_back(S->perm[i]);
+        std::sort(out.begin(), out.end());
+        return true;
+    }
     bool debug_clocks(unsigned long long* out) {
         DeviceGuard guard(dev);
         if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
@@ -2491,6 +2505,7 @@ bool Numeric::factor_top(FactorStats& st) { return p_->factor_top(st); }
 bool Numeric::solve_fwd_local(double* drhs) { return p_->solve_fwd_local(drhs); }
 bool Numeric::top_rhs(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_rhs: not a multi-GPU handle"; return false; } *d = p_->V.top_rhs; *nd = p_->toprhs_doubles; return true; }
 bool Numeric::solve_top_and_bwd(double* drhs) { return p_->solve_top_and_bwd(drhs); }
+bool Numeric::zero_pivots(std::vector<int>& out) { return p_->zero_pivots(out); }
 bool Numeric::assembly_define(int nseg, const int64_t* off, const int64_t* len) { return p_->assembly_define(nseg, off, len); }
 double* Numeric::assembly_buffer(int seg) { return p_->assembly_buffer(seg); }
 bool Numeric::assembly_upload(int seg) { return p_->assembly_upload(seg); }

@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
     "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
-    "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
+    "mi355x_kkt_zero_pivots", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
                 "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big", "fwd_big_upd", "bwd_big_dot"]
@@ -114,6 +114,7 @@ def load_library():
     lib.mi355x_kkt_top_rhs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.mi355x_kkt_solve_top_and_bwd.argtypes = [vp, vp]
     lib.mi355x_kkt_comm_unique_id.argtypes = [vp]
+    lib.mi355x_kkt_zero_pivots.argtypes = [vp, vp, C.c_int, ip]
     lib.mi355x_kkt_assembly_define.argtypes = [vp, C.c_int, vp, vp]
     lib.mi355x_kkt_assembly_buffer.argtypes = [vp, C.c_int]
     lib.mi355x_kkt_assembly_buffer.restype = dp
@@ -303,6 +304,15 @@ class KKTSolver:
     @staticmethod
     def provides_inertia() -> bool:
         return True
+
+    # --- DetermineDependentRows support (hpp:240-255): columns with a zero pivot in the last factorisation (caller's index base) ---
+    def zero_pivots(self) -> np.ndarray:
+        cnt = C.c_int(0)
+        if self.lib.mi355x_kkt_zero_pivots(self._h, None, 0, C.byref(cnt)) != 0:
+            raise KKTError("zero_pivots: " + self.last_error())
+        out = np.zeros(max(cnt.value, 1), dtype=np.int32)
+        self.lib.mi355x_kkt_zero_pivots(self._h, out.ctypes.data, cnt.value, C.byref(cnt))
+        return out[:cnt.value]
 
     def info(self) -> KKTInfo:
         i = _Info()

@@ -102,18 +102,20 @@ $(OUT)/ipopt_mi355x_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/
 #     one factory arm in IpAlgBuilder.cpp:427-526, option registration in IpLinearSolversRegOp.cpp:84-90).  The two patched
 #     translation units are produced in the build directory, compiled and removed again; everything else is the unmodified objects. ---
 PATCH   := oracle/patches/linear_solver_mi355x.patch
-PSRC    := Algorithm/IpAlgBuilder.cpp Algorithm/LinearSolvers/IpLinearSolversRegOp.cpp
-POBJS   := $(OUT)/obj_patched/IpAlgBuilder.o $(OUT)/obj_patched/IpLinearSolversRegOp.o $(OUT)/obj_patched/IpMi355xSolverInterface.o
-$(OUT)/obj_patched/.stamp: $(PATCH) ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.hpp include/mi355x_kkt.h
-	rm -rf $(OUT)/obj_patched $(OUT)/patched_src; mkdir -p $(OUT)/obj_patched $(OUT)/patched_src/src/Algorithm/LinearSolvers
+PSRC    := Algorithm/IpAlgBuilder.cpp Algorithm/LinearSolvers/IpLinearSolversRegOp.cpp Interfaces/IpTNLPAdapter.cpp
+POBJS   := $(OUT)/obj_patched/IpAlgBuilder.o $(OUT)/obj_patched/IpLinearSolversRegOp.o $(OUT)/obj_patched/IpTNLPAdapter.o \
+           $(OUT)/obj_patched/IpMi355xSolverInterface.o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o
+$(OUT)/obj_patched/.stamp: $(PATCH) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.cpp) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h
+	rm -rf $(OUT)/obj_patched $(OUT)/patched_src; mkdir -p $(OUT)/obj_patched $(OUT)/patched_src/src/Algorithm/LinearSolvers $(OUT)/patched_src/src/Interfaces
 	for f in $(PSRC); do cp $(REF)/src/$$f $(OUT)/patched_src/src/$$f; done
 	cd $(OUT)/patched_src && patch -p1 -s < $(CURDIR)/$(PATCH)
 	for f in $(PSRC); do $(CXX) $(CXXFLAGS_REF) -DIPOPT_HAS_MI355X $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c $(OUT)/patched_src/src/$$f -o $(OUT)/obj_patched/`basename $$f .cpp`.o || exit 1; done
 	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp -o $(OUT)/obj_patched/IpMi355xSolverInterface.o
+	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp -o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o
 	rm -rf $(OUT)/patched_src
 	touch $@
 $(OUT)/libipopt_ref_mi355x.so: $(OBJS) $(OUT)/obj_patched/.stamp $(OUT)/mkl/.stamp
-	@$(CXX) -shared -o $@ $(filter-out %/Algorithm/IpAlgBuilder.o %/Algorithm/LinearSolvers/IpLinearSolversRegOp.o,$(OBJS)) $(POBJS) \
+	@$(CXX) -shared -o $@ $(filter-out %/Algorithm/IpAlgBuilder.o %/Algorithm/LinearSolvers/IpLinearSolversRegOp.o %/Interfaces/IpTNLPAdapter.o,$(OBJS)) $(POBJS) \
 	  -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib' $(MKLLINK)
 # the same driver against the patched library: `--solver stock --set linear_solver mi355x`
 $(OUT)/ipopt_patched_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref_mi355x.so $(OUT)/scalable.a

@@ -47,6 +47,42 @@
 
 using namespace Ipopt;
 
+// A 6-variable test NLP of this harness (not from the reference): min sum (x_i - i)^2  s.t. three equality constraints of which
+// the third is the sum of the first two -- exercises dependency_detector (TNLPAdapter::DetermineDependentConstraints,
+// IpTNLPAdapter.cpp:636-700 -> TSymDependencyDetector -> SparseSymLinearSolverInterface::DetermineDependentRows).
+class DepTestNLP: public TNLP
+{
+public:
+   bool get_nlp_info(Index& n, Index& m, Index& nnz_jac_g, Index& nnz_h_lag, IndexStyleEnum& index_style)
+   { n = 6; m = 3; nnz_jac_g = 8; nnz_h_lag = 6; index_style = C_STYLE; return true; }
+   bool get_bounds_info(Index n, Number* x_l, Number* x_u, Index m, Number* g_l, Number* g_u)
+   { for( Index i = 0; i < n; ++i ) { x_l[i] = -1e19; x_u[i] = 1e19; } g_l[0] = g_u[0] = 1.; g_l[1] = g_u[1] = 2.; g_l[2] = g_u[2] = 3.; return true; }
+   bool get_starting_point(Index n, bool, Number* x, bool, Number*, Number*, Index, bool, Number*)
+   { for( Index i = 0; i < n; ++i ) x[i] = 0.; return true; }
+   bool eval_f(Index n, const Number* x, bool, Number& f)
+   { f = 0.; for( Index i = 0; i < n; ++i ) f += (x[i] - (i + 1)) * (x[i] - (i + 1)); return true; }
+   bool eval_grad_f(Index n, const Number* x, bool, Number* g)
+   { for( Index i = 0; i < n; ++i ) g[i] = 2. * (x[i] - (i + 1)); return true; }
+   bool eval_g(Index, const Number* x, bool, Index, Number* g)
+   { g[0] = x[0] + x[1]; g[1] = x[2] + x[3]; g[2] = x[0] + x[1] + x[2] + x[3]; return true; }
+   bool eval_jac_g(Index, const Number*, bool, Index, Index, Index* iRow, Index* jCol, Number* v)
+   {
+      static const Index r[8] = {0, 0, 1, 1, 2, 2, 2, 2}, c[8] = {0, 1, 2, 3, 0, 1, 2, 3};
+      if( !v ) for( int k = 0; k < 8; ++k ) { iRow[k] = r[k]; jCol[k] = c[k]; }
+      else for( int k = 0; k < 8; ++k ) v[k] = 1.;
+      return true;
+   }
+   bool eval_h(Index n, const Number*, bool, Number obj_factor, Index, const Number*, bool, Index, Index* iRow, Index* jCol, Number* v)
+   {
+      if( !v ) for( Index i = 0; i < n; ++i ) { iRow[i] = jCol[i] = i; }
+      else for( Index i = 0; i < n; ++i ) v[i] = 2. * obj_factor;
+      return true;
+   }
+   void finalize_solution(SolverReturn, Index, const Number*, const Number*, const Number*, Index, const Number*, const Number*, Number,
+                          const IpoptData*, IpoptCalculatedQuantities*)
+   { }
+};
+
 // ------------------------------------------------------------------------------------------
 // recording decorator
 // ------------------------------------------------------------------------------------------
@@ -160,6 +196,7 @@ int main(int argc, char** argv)
 
    SmartPtr<TNLP> tnlp;
    if( problem == "hs071" ) tnlp = new HS071_NLP();
+   else if( problem == "deptest" ) tnlp = new DepTestNLP();
    else
    {
       SmartPtr<RegisteredTNLP> r;

@@ -165,3 +165,15 @@ def test_custom_aug_system_solver_with_device_side_assembly(name, problem, n, tm
     aug = json.loads(next(ln for ln in out.splitlines() if ln.startswith("AUG_STATS"))[len("AUG_STATS "):])
     if problem == "hs071":
         assert aug["factorizations_without_upload"] >= 4          # the delta_x escalation 1e-4 -> 1e-2 -> 1 -> 100 of iteration 1
+
+
+@pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref not built")
+def test_dependency_detector_mi355x_removes_the_dependent_constraint(tmp_path):
+    """ProvidesDegeneracyDetection / DetermineDependentRows (IpSparseSymLinearSolverInterface.hpp:240-255) through
+    the reference's TSymDependencyDetector: on a 6-variable NLP whose third equality constraint is the sum of the first two,
+    `dependency_detector mi355x` (patched TNLPAdapter arm) must find exactly one dependent row and Ipopt must then converge."""
+    iters, summ, out = _run(PATCHED, ["deptest", "0", "--solver", "stock", "--set", "linear_solver", "mi355x", "--set", "dependency_detector", "mi355x"], tmp_path)
+    assert "Detected 1 linearly dependent equality constraints; taking those out." in out, out[-2000:]
+    assert "EXIT: Optimal Solution Found." in out
+    # min sum (x_i - i)^2 s.t. x1 + x2 = 1, x3 + x4 = 2:  x = (0, 1, 0.5, 1.5, 5, 6), f = 2 + 12.5
+    assert abs(summ[0]["objective"] - 14.5) <= 1e-8

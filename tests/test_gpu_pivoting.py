@@ -106,3 +106,27 @@ def test_seeded_systems_at_several_u(u):
         assert (I.num_two, I.num_small) == (spec["num_two"], spec["num_delay"])
         res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
         assert res <= 1e-12
+
+
+def test_zero_pivot_list_names_the_dependent_rows():
+    """mi355x_kkt_zero_pivots on [[I, J^T], [J, 0]] (the matrix TSymLinearSolver::DetermineDependentRows builds,
+    IpTSymLinearSolver.cpp:540-716): rows of J that are combinations of earlier ones come back, nothing else."""
+    rng = np.random.default_rng(3)
+    ncol, nrow = 30, 12
+    J = rng.standard_normal((nrow, ncol)) * (rng.random((nrow, ncol)) < 0.3)
+    J[np.arange(nrow), np.arange(nrow)] += 2.0
+    J[7] = J[2] - 3.0 * J[5]           # dependent
+    J[11] = 2.0 * J[0]                 # dependent
+    jr, jc = np.nonzero(J)
+    n = ncol + nrow
+    r = np.concatenate([jr + ncol, np.arange(n)]).astype(np.int32) + 1
+    c = np.concatenate([jc, np.arange(n)]).astype(np.int32) + 1
+    v = np.concatenate([J[jr, jc], np.ones(ncol), np.zeros(nrow)])
+    s = ipopt_amd.KKTSolver()
+    s.initialize_structure(n, r, c, vals=v)
+    s.values()[:] = v
+    st = s.multi_solve(True, None)
+    z = s.zero_pivots() - 1 - ncol                     # row indices of J
+    assert st == kkt.SINGULAR and len(z) == 2
+    keep = [i for i in range(nrow) if i not in set(z.tolist())]
+    assert np.linalg.matrix_rank(J[keep]) == nrow - 2 == np.linalg.matrix_rank(J)      # what is left has full row rank
