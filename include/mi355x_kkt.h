@@ -171,6 +171,16 @@ int  mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax);
  * depends on u up to pivtolmax (nothing a refactorisation could improve).  *new_u (may be NULL) receives the new u. */
 int  mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u);
 int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
+/* Symmetric scaling at run time (the option `scaling` only sets the initial mode): 0 none, 1 Ruiz inf-norm equilibration
+ * on the device, 2 the caller's factors (n doubles, caller's numbering; copied).  _get_scaling returns the factors the last
+ * factorisation used.  Together they give the MA97 call protocol its meaning: control.scaling > 0 => compute and hand back in
+ * scale[], control.scaling == 0 with scale != NULL => reuse the caller-held factors, else none (IpMa97SolverInterface.cpp:641-678). */
+int  mi355x_kkt_set_scaling(mi355x_kkt_handle h, int mode, const double* user_factors);
+int  mi355x_kkt_get_scaling(mi355x_kkt_handle h, double* factors_out);
+/* Stand-alone (no handle): Ruiz factors of a triplet matrix computed on the device -- the hook for a host that scales outside
+ * the solver, i.e. Ipopt's TSymScalingMethod (IpTSymLinearSolver.cpp:429-441,511-514; cf. IpMc19TSymScalingMethod.cpp:100-204). */
+int  mi355x_kkt_ruiz_scaling(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int index_base,
+                             int sweeps, double* factors_out);
 /* The columns (caller's index base) whose pivot was numerically zero in the last factorisation, ascending; *count = how
  * many there are (idx may be NULL / shorter).  This is what DetermineDependentRows needs
  * (IpSparseSymLinearSolverInterface.hpp:240-255; MUMPS' PIVNUL_LIST, IpMumpsSolverInterface.cpp:617-709). */

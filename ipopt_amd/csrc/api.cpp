@@ -105,6 +105,27 @@ static int do_factor(mi355x_kkt_handle h, const double* dvals, bool reuse, int* 
 int mi355x_kkt_factor(mi355x_kkt_handle h, const double* dvals, int* num_neg, int* num_zero) { return do_factor(h, dvals, false, num_neg, num_zero); }
 int mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero) { return do_factor(h, nullptr, true, num_neg, num_zero); }
 
+/* symmetric scaling at run time: what the MA97 call protocol needs (control.scaling / scale[], IpMa97SolverInterface.cpp:641-678) */
+int mi355x_kkt_set_scaling(mi355x_kkt_handle h, int mode, const double* user_factors)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready) { h->opts.scaling = mode == 2 ? 1 : mode; h->err = "set_scaling: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    try { if (!h->num->set_scaling(mode, user_factors)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } h->opts.scaling = mode; return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_get_scaling(mi355x_kkt_handle h, double* out)
+{
+    if (!h || !out) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready || !h->factored) { h->err = "get_scaling: no factorisation available"; return MI355X_KKT_FATAL; }
+    try { if (!h->num->get_scaling(out)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
+/* stand-alone: symmetric Ruiz inf-norm equilibration factors of a triplet matrix, computed on the device (no handle needed) */
+int mi355x_kkt_ruiz_scaling(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int index_base, int sweeps, double* factors)
+{
+    if (n < 0 || nnz < 0 || !factors || (nnz > 0 && (!irn || !jcn || !a))) return MI355X_KKT_FATAL;
+    try { std::string err; return Numeric::ruiz_triplet(device, n, nnz, irn, jcn, a, index_base, sweeps > 0 ? sweeps : 4, factors, err) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL; }
+    catch (...) { return MI355X_KKT_FATAL; }
+}
+
 /* DetermineDependentRows support (IpSparseSymLinearSolverInterface.hpp:240-255; MUMPS' null-pivot list,
  * IpMumpsSolverInterface.cpp:617-709): the columns whose pivot was numerically zero in the last factorisation */
 int mi355x_kkt_zero_pivots(mi355x_kkt_handle h, int* idx, int capacity, int* count)

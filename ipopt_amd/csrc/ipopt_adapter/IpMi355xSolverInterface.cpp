@@ -1,5 +1,6 @@
 // IpMi355xSolverInterface.cpp -- see the header.  Status protocol as in IpSymLinearSolver.hpp:19-33.
 #include "IpMi355xSolverInterface.hpp"
+#include "IpMi355xTSymScalingMethod.hpp"
 #include "IpTSymLinearSolver.hpp"
 #include "IpIpoptData.hpp"
 #include "IpTimingStatistics.hpp"
@@ -41,6 +42,9 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
                               "nested dissection with minimum-degree leaves", "md", "minimum degree", "natural", "identity");
    roptions->AddStringOption2("mi355x_matching", "Pre-pair zero-diagonal rows into 2x2-capable supernodes.", "yes", "no", "",
                               "yes", "");
+   roptions->AddStringOption2("mi355x_outer_scaling", "Equilibrate through Ipopt's TSymScalingMethod hook instead of inside the backend.", "no",
+                              "no", "the backend equilibrates internally (mi355x_scaling)", "yes",
+                              "Ruiz factors computed on the device are applied by TSymLinearSolver, subject to linear_scaling_on_demand");
    roptions->AddLowerBoundedIntegerOption("mi355x_nemin", "Supernode amalgamation parameter.", 1, 8, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_nd_leaf", "Nested dissection leaf size.", 8, 32, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_max_sn_cols", "Maximum columns per supernode.", 2, 64, "");
@@ -466,11 +470,26 @@ bool Mi355xSolverInterface::IncreaseQuality()
 }
 
 SmartPtr<SymLinearSolver> Mi355xAlgorithmBuilder::SymLinearSolverFactory(const Journalist& /*jnlst*/,
-      const OptionsList& /*options*/, const std::string& /*prefix*/)
+      const OptionsList& options, const std::string& prefix)
 {
    SmartPtr<SparseSymLinearSolverInterface> iface = new Mi355xSolverInterface();
-   SmartPtr<TSymScalingMethod> noscaling;
-   return new TSymLinearSolver(iface, noscaling);
+   SmartPtr<TSymScalingMethod> scaling;
+   // `mi355x_outer_scaling yes`: equilibration as a TSymScalingMethod OUTSIDE the backend (computed on the device), under the
+   // reference's own control -- with the default linear_scaling_on_demand=yes it only switches on once Ipopt asks for better
+   // quality (IpTSymLinearSolver.cpp:429-441), exactly like mc19 does when HSL is linked (IpAlgBuilder.cpp:530-537)
+   std::string sv;
+   bool outer = false;
+   try
+   {
+      outer = options.GetStringValue("mi355x_outer_scaling", sv, prefix) && sv == "yes";
+   }
+   catch( ... )
+   { }
+   if( outer )
+   {
+      scaling = new Mi355xTSymScalingMethod();
+   }
+   return new TSymLinearSolver(iface, scaling);
 }
 
 } // namespace Ipopt

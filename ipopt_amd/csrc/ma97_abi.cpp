@@ -99,6 +99,13 @@ void ma97_factor_d(int /*matrix_type*/, const int /*ptr*/[], const int /*row*/[]
         Keep* k = static_cast<Keep*>(*akeep);
         if ((!k->analysed || !k->with_values) && !do_analyse(k, control, val, info)) return;
         if (control && control->u > 0 && control->u != k->u) { mi355x_kkt_set_pivtol(k->h, control->u > 0.5 ? 0.5 : control->u); k->u = control->u; }
+        // scaling semantics of the MA97 call protocol (IpMa97SolverInterface.cpp:641-652,707):
+        //   control.scaling  > 0               compute factors (HSL would run MC64 / MC77 / MC30; here: Ruiz equilibration on the
+        //                                      device) and WRITE them to scale[n]
+        //   control.scaling == 0, scale given  apply the caller-held factors ("reuse")
+        //   control.scaling == 0, scale NULL   no scaling
+        const int mode = (control && control->scaling > 0) ? 1 : (scale ? 2 : 0);
+        if (mi355x_kkt_set_scaling(k->h, mode, scale) != 0) { info->flag = -1; return; }
         double* buf = mi355x_kkt_values_buffer(k->h);
         if (!buf) { info->flag = -1; return; }
         std::memcpy(buf, val, sizeof(double) * (size_t)k->nnz);
@@ -106,8 +113,8 @@ void ma97_factor_d(int /*matrix_type*/, const int /*ptr*/[], const int /*row*/[]
         int st = mi355x_kkt_factor(k->h, nullptr, &nneg, &nzero);
         if (fkeep) *fkeep = k;
         fill_info(k, info);
-        if (scale && control && control->scaling > 0) for (int i = 0; i < k->n; ++i) scale[i] = 1.0;   // our equilibration is internal
         if (st == MI355X_KKT_FATAL) { info->flag = -1; return; }
+        if (scale && mode == 1 && mi355x_kkt_get_scaling(k->h, scale) != 0) { info->flag = -1; return; }   // hand the factors back for reuse
         if (st == MI355X_KKT_SINGULAR) info->flag = (control && control->action) ? 7 : -7;
         else info->flag = 0;
     } catch (...) { info->flag = -1; }

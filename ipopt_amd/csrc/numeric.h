@@ -52,6 +52,9 @@ public:
     bool   solve_fwd_local(double* drhs);
     bool   top_rhs(double** dptr, int64_t* ndoubles);
     bool   solve_top_and_bwd(double* drhs);
+    bool   set_scaling(int mode, const double* user_factors_orig_numbering);   // 0 none, 1 Ruiz (device), 2 the caller's factors
+    bool   get_scaling(double* out_orig_numbering);                             // factors of the last factorisation
+    static bool ruiz_triplet(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int base, int sweeps, double* out, std::string& err);
     bool   zero_pivots(std::vector<int>& idx0);           // columns (original numbering, 0-based) with a zero pivot in the last factorisation
     // device-side value assembly: triplet values = concatenated segments, each  scale * src + shift  from a device-resident source
     bool   assembly_define(int nseg, const int64_t* off, const int64_t* len);

@@ -208,6 +208,32 @@ __global__ void k_ruiz_sweep(DevView V, const double* sin, double* sout)
         if (i < V.n && sub == 0) { const double si = sin ? sin[i] : 1.0; mx *= si; sout[i] = mx > 0.0 ? si / sqrt(mx) : si; }
     }
 }
+// user-supplied symmetric scaling (original numbering) -> permuted numbering (the MA97 "reuse the caller-held factors" mode)
+__global__ void k_user_scale(DevView V, const double* s_orig)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) V.scale[i] = s_orig[V.perm[i]];
+}
+// stand-alone symmetric Ruiz equilibration of a TRIPLET matrix (for hosts that scale outside the solver: Ipopt's
+// TSymScalingMethod hook, IpTSymLinearSolver.cpp:429-441,511-514).  Row maxima by atomicMax on the bit pattern of the
+// non-negative doubles (max is order independent => deterministic).
+__global__ void k_trip_rowmax(int nnz, const int* irn, const int* jcn, const double* a, const double* s, unsigned long long* rowmax, int base)
+{
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < nnz; q += gridDim.x * blockDim.x) {
+        const int i = irn[q] - base, j = jcn[q] - base;
+        const double v = fabs(a[q]) * s[i] * s[j];
+        const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+        atomicMax(&rowmax[i], b);
+        if (j != i) atomicMax(&rowmax[j], b);
+    }
+}
+__global__ void k_trip_rescale(int n, double* s, unsigned long long* rowmax)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const double mx = __longlong_as_double((long long)rowmax[i]);
+        if (mx > 0.0) s[i] /= sqrt(mx);
+        rowmax[i] = 0ull;
+    }
+}
 __global__ void k_apply_scale(DevView V)
 {
     for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < V.nnz_a; q += gridDim.x * blockDim.x)
@@ -1531,6 +1557,30 @@ public:
     double* d_rhs = nullptr; size_t d_rhs_cap = 0;
     hipGraphExec_t g_factor = nullptr, g_solve = nullptr;
     bool scale_identity = true;
+    double* d_user_scale = nullptr;      // caller-supplied scaling factors, original numbering (scaling mode 2)
+    // scaling mode at run time: 0 none, 1 Ruiz on device, 2 the caller's factors (MA97 semantics, IpMa97SolverInterface.cpp:641-678)
+    bool set_scaling(int mode, const double* user) {
+        DeviceGuard guard(dev);
+        if (!ready) { err_ = "set_scaling: solver not set up"; return false; }
+        if (mode < 0 || mode > 2 || (mode == 2 && !user)) { err_ = "set_scaling: mode 0 (none), 1 (ruiz) or 2 (user factors, non-null)"; return false; }
+        if (mode == 2) {
+            if (!d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
+            HIPCHK(hipMemcpyAsync(d_user_scale, user, (size_t)S->n * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));      // `user` is the caller's pageable memory
+        }
+        if (mode != opt.scaling && g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }     // the captured sequence differs
+        opt.scaling = mode;
+        return true;
+    }
+    // the symmetric scaling of the last factorisation, original numbering (what MA97 writes into scale[])
+    bool get_scaling(double* out) {
+        DeviceGuard guard(dev);
+        if (!ready) { err_ = "get_scaling: solver not set up"; return false; }
+        std::vector<double> sp(S->n);
+        if (S->n > 0) HIPCHK(hipMemcpy(sp.data(), V.scale, (size_t)S->n * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < S->n; ++i) out[S->perm[i]] = sp[i];
+        return true;
+    }
     std::vector<int> big_maxm, big_maxk, big_tiles, big_tiles64, big_last0, big_last1;
     std::vector<char> lv_asm_skip;      // every big front of the level is a pure in-place chain link: no assembly launch at all
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
@@ -2118,7 +2168,10 @@ public:
         LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
         LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        if (opt.scaling) {      // 4 sweeps, ping-pong between the two buffers, ending in V.scale
+        if (opt.scaling == 2) {     // factors supplied by the caller (set_scaling)
+            LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);
+            LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        } else if (opt.scaling) {      // 4 sweeps, ping-pong between the two buffers, ending in V.scale
             LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
             LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
             LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
@@ -2329,7 +2382,10 @@ public:
         hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
         hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        if (opt.scaling) {
+        if (opt.scaling == 2) {
+            hipLaunchKernelGGL(k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);
+            hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        } else if (opt.scaling) {
             hipLaunchKernelGGL(k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
             hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
             hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
@@ -2505,11 +2561,42 @@ bool Numeric::factor_top(FactorStats& st) { return p_->factor_top(st); }
 bool Numeric::solve_fwd_local(double* drhs) { return p_->solve_fwd_local(drhs); }
 bool Numeric::top_rhs(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_rhs: not a multi-GPU handle"; return false; } *d = p_->V.top_rhs; *nd = p_->toprhs_doubles; return true; }
 bool Numeric::solve_top_and_bwd(double* drhs) { return p_->solve_top_and_bwd(drhs); }
+bool Numeric::set_scaling(int mode, const double* user) { return p_->set_scaling(mode, user); }
+bool Numeric::get_scaling(double* out) { return p_->get_scaling(out); }
 bool Numeric::zero_pivots(std::vector<int>& out) { return p_->zero_pivots(out); }
 bool Numeric::assembly_define(int nseg, const int64_t* off, const int64_t* len) { return p_->assembly_define(nseg, off, len); }
 double* Numeric::assembly_buffer(int seg) { return p_->assembly_buffer(seg); }
 bool Numeric::assembly_upload(int seg) { return p_->assembly_upload(seg); }
 bool Numeric::factor_assembled(const double* scale, const double* shift, FactorStats& st) { return p_->factor_assembled(scale, shift, st); }
+bool Numeric::ruiz_triplet(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int base, int sweeps, double* out, std::string& err)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { err = "no HIP device available (no CPU fallback)"; return false; }
+    int dev = device; if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    DeviceGuard guard(dev);
+#define RCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); ok = false; break; } } while (0)
+    int *di = nullptr, *dj = nullptr; double *da = nullptr, *ds = nullptr; unsigned long long* dm = nullptr;
+    bool ok = true;
+    do {
+        RCHK(hipMalloc((void**)&di, std::max(nnz, 1) * sizeof(int))); RCHK(hipMalloc((void**)&dj, std::max(nnz, 1) * sizeof(int)));
+        RCHK(hipMalloc((void**)&da, std::max(nnz, 1) * sizeof(double))); RCHK(hipMalloc((void**)&ds, std::max(n, 1) * sizeof(double)));
+        RCHK(hipMalloc((void**)&dm, std::max(n, 1) * sizeof(unsigned long long)));
+        RCHK(hipMemcpy(di, irn, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice)); RCHK(hipMemcpy(dj, jcn, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice));
+        RCHK(hipMemcpy(da, a, (size_t)nnz * sizeof(double), hipMemcpyHostToDevice));
+        RCHK(hipMemset(dm, 0, std::max(n, 1) * sizeof(unsigned long long)));
+        const int g1 = std::max(1, std::min(2048, (n + 255) / 256)), g2 = std::max(1, std::min(2048, (nnz + 255) / 256));
+        hipLaunchKernelGGL(k_fill, dim3(g1), dim3(256), 0, 0, ds, 1.0, (long long)n);
+        for (int it = 0; it < sweeps; ++it) {
+            hipLaunchKernelGGL(k_trip_rowmax, dim3(g2), dim3(256), 0, 0, nnz, (const int*)di, (const int*)dj, (const double*)da, (const double*)ds, dm, base);
+            hipLaunchKernelGGL(k_trip_rescale, dim3(g1), dim3(256), 0, 0, n, ds, dm);
+        }
+        RCHK(hipGetLastError());
+        RCHK(hipMemcpy(out, ds, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    } while (false);
+#undef RCHK
+    (void)hipFree(di); (void)hipFree(dj); (void)hipFree(da); (void)hipFree(ds); (void)hipFree(dm);
+    return ok;
+}
 bool Numeric::set_comm_rccl(const void* unique_id128) { return p_->set_comm_rccl(unique_id128); }
 bool Numeric::set_comm_callback(int (*fn)(void*, void*, int64_t, int, void*), void* ctx) { return p_->set_comm_callback(fn, ctx); }
 bool Numeric::rccl_unique_id(void* out128, std::string& err)

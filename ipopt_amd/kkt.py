@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
     "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
-    "mi355x_kkt_zero_pivots", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
+    "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
                 "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big", "fwd_big_upd", "bwd_big_dot"]
@@ -114,6 +114,9 @@ def load_library():
     lib.mi355x_kkt_top_rhs.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int64)]
     lib.mi355x_kkt_solve_top_and_bwd.argtypes = [vp, vp]
     lib.mi355x_kkt_comm_unique_id.argtypes = [vp]
+    lib.mi355x_kkt_set_scaling.argtypes = [vp, C.c_int, vp]
+    lib.mi355x_kkt_get_scaling.argtypes = [vp, vp]
+    lib.mi355x_kkt_ruiz_scaling.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.mi355x_kkt_zero_pivots.argtypes = [vp, vp, C.c_int, ip]
     lib.mi355x_kkt_assembly_define.argtypes = [vp, C.c_int, vp, vp]
     lib.mi355x_kkt_assembly_buffer.argtypes = [vp, C.c_int]
@@ -304,6 +307,17 @@ class KKTSolver:
     @staticmethod
     def provides_inertia() -> bool:
         return True
+
+    def set_scaling(self, mode: int, factors=None):
+        f = None if factors is None else np.ascontiguousarray(factors, dtype=np.float64)
+        if self.lib.mi355x_kkt_set_scaling(self._h, int(mode), f.ctypes.data if f is not None else None) != 0:
+            raise KKTError("set_scaling: " + self.last_error())
+
+    def get_scaling(self) -> np.ndarray:
+        out = np.zeros(max(self._n, 1))
+        if self.lib.mi355x_kkt_get_scaling(self._h, out.ctypes.data) != 0:
+            raise KKTError("get_scaling: " + self.last_error())
+        return out[: self._n]
 
     # --- DetermineDependentRows support (hpp:240-255): columns with a zero pivot in the last factorisation (caller's index base) ---
     def zero_pivots(self) -> np.ndarray:

@@ -177,3 +177,17 @@ def test_dependency_detector_mi355x_removes_the_dependent_constraint(tmp_path):
     assert "EXIT: Optimal Solution Found." in out
     # min sum (x_i - i)^2 s.t. x1 + x2 = 1, x3 + x4 = 2:  x = (0, 1, 0.5, 1.5, 5, 6), f = 2 + 12.5
     assert abs(summ[0]["objective"] - 14.5) <= 1e-8
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+@pytest.mark.parametrize("on_demand", ["yes", "no"])
+def test_outer_scaling_through_the_reference_scaling_hook(on_demand, tmp_path, golden_dir):
+    """Mi355xTSymScalingMethod (device Ruiz) plugged into the reference's TSymLinearSolver; with
+    linear_scaling_on_demand=yes (default) it stays off unless Ipopt asks for more quality (IpTSymLinearSolver.cpp:429-441),
+    with =no every matrix is scaled outside the backend.  The internal equilibration is switched off in both runs."""
+    iters, summ, out = _run(DRIVER, ["MBndryCntrl1", "100", "--solver", "mi355x", "--set", "mi355x_outer_scaling", "yes", "--set", "mi355x_scaling", "none",
+                                     "--set", "linear_scaling_on_demand", on_demand], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    gsum = json.load(open(os.path.join(golden_dir, "mbndry1_100.summary")))
+    assert summ[0]["iterations"] == gsum["iterations"]
+    assert abs(summ[0]["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))

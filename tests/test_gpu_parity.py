@@ -232,3 +232,37 @@ def test_device_side_assembly_equals_host_assembly_bitwise():
         assert st == st2 and neg == s2.number_of_neg_evals()
         if st == 0:
             assert np.array_equal(x, x2)
+
+
+def test_scaling_modes_and_factor_exchange():
+    """run-time scaling modes (none / Ruiz on device / caller's factors) and the exchange of the factors -- the meaning of
+    control.scaling and scale[] in the MA97 call protocol (IpMa97SolverInterface.cpp:641-678)"""
+    n, r, c, v, neg = kktgen.grid_kkt(20, 18, dof=2, ncon=1, seed=41, sigma_exp=6.0)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    s1, st1, x1 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)           # Ruiz (default)
+    f = s1.get_scaling()
+    assert st1 == 0 and f.shape == (n,) and np.all(f > 0)
+    Ks = abs(K).multiply(f[:, None]).multiply(f[None, :]).tocsr()
+    assert 0.2 <= Ks.max(axis=1).toarray().min() and Ks.max() <= 1.0 + 1e-12           # equilibrated: row maxima within [0.2, 1]
+    s2 = ipopt_amd.KKTSolver(); s2.initialize_structure(n, r, c, vals=v); s2.set_scaling(2, f); s2.values()[:] = v
+    x2 = b.copy(); assert s2.multi_solve(True, x2, True, neg) == 0
+    assert np.array_equal(x1, x2)                                                        # the caller-held factors reproduce the run bit for bit
+    s0 = ipopt_amd.KKTSolver(); s0.initialize_structure(n, r, c, vals=v); s0.set_scaling(0); s0.values()[:] = v
+    x0 = b.copy(); assert s0.multi_solve(True, x0, True, neg) == 0
+    assert np.all(s0.get_scaling() == 1.0) and sres(K, x0, b) <= 1e-11
+
+
+def test_standalone_ruiz_scaling_of_a_triplet_matrix():
+    """mi355x_kkt_ruiz_scaling (the TSymScalingMethod hook): same sweeps in numpy"""
+    import ctypes as C
+    n, r, c, v, neg = kktgen.lukvl_like(500, seed=9)
+    out = np.zeros(n)
+    lib = kkt.load_library()
+    assert lib.mi355x_kkt_ruiz_scaling(0, n, len(v), r.ctypes.data, c.ctypes.data, v.ctypes.data, 1, 4, out.ctypes.data) == 0
+    s = np.ones(n)
+    for _ in range(4):
+        w = np.abs(v) * s[r - 1] * s[c - 1]
+        mx = np.zeros(n); np.maximum.at(mx, r - 1, w); np.maximum.at(mx, c - 1, w)
+        s = np.where(mx > 0, s / np.sqrt(np.where(mx > 0, mx, 1.0)), s)
+    assert np.allclose(out, s, rtol=1e-14, atol=0)
