@@ -48,7 +48,7 @@ enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_L
 
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
 static constexpr double PIV_PERT = 1e-10;                // replacement magnitude for a zero pivot
-static constexpr double ZERO_REL = 1e-14;                // zero-pivot test relative to the largest entry of the assembled front
+static constexpr double ZERO_REL = 1e-14;                // zero-pivot test relative to the largest entry assembled into the pivot's column
 
 // ------------------------------------------------------------------------------------------------
 // device-side view of the symbolic structure + numeric storage (passed by value to kernels)
@@ -321,14 +321,14 @@ __device__ __forceinline__ double fast_rcp(double d)
 //     in-front part of MA27's delayed pivoting).  When every alive candidate has failed, the structure being static
 //     (no delay to the parent front), the first one is eliminated anyway by the plain Bunch-Kaufman choice and counted in
 //     `ndelay` (reported as num_delay; the reference adapters read the same counter from MA97/SPRAL);
-//   * zero test relative to the scale of the assembled front: a candidate whose whole remaining column is <= ztol
-//     (= max(small, 1e-14 max|front entry|)) is a zero pivot => SYMSOLVER_SINGULAR;
+//   * zero test relative to what was assembled into the candidate's own column: a candidate whose whole remaining column is
+//     <= max(small, 1e-14 max_i |F(i,j)| at assembly) is a zero pivot => SYMSOLVER_SINGULAR;
 //   * `chg` is set when some decision would come out differently at u2 (= pivtolmax): IncreaseQuality uses it to
 //     answer "can a larger u change the factorisation at all".
 // Big fronts: the pivot block only sees its k x k block here (ext rows are checked a posteriori in k_big_trsm).
 template <int NT, int TS, bool WIDE>
 __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const int k, double* Lbuf, const int ldL, double* colbuf,
-                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double u2, const double ztol, int* zp,
+                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double u2, const double small, const double* cm0, int* zp,
                                          int& nneg, int& nzero, int& ntwo, int& ndelay, int& chg)
 {
     // The per-pivot instruction stream IS the critical path (measured: ~5 cycles per wave instruction), so the common
@@ -365,6 +365,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
         __syncthreads();
         // every LDS read of the common case (1x1 pivot on row j) is issued here, in ONE round trip
         const double djj = colA[j];
+        const double ztol = fmax(small, ZERO_REL * cm0[j]);     // zero threshold of candidate j
         const double avr = colA[lane];
         const double avr1 = TWO ? colA[lane1] : 0.0;
         double rv[TS], cv[TS];
@@ -413,9 +414,10 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                 const double det = a * c - b * b, adet = fabs(det);
                 const int pref = (ajj >= BK_ALPHA * lam || ajj * sig >= BK_ALPHA * lam * lam) ? 0 : ((arr >= BK_ALPHA * sig) ? 1 : 2);
                 const double t1 = arr * gj2 + ab * gr2, t2 = ab * gj2 + ajj * gr2;                // |E^{-1}| (gj2, gr2)^T |det|
-                const bool nz2 = adet > ztol * fmax(ab, fmax(ajj, arr));
+                const double ztr = fmax(small, ZERO_REL * cm0[r]);
+                const bool nz2 = adet > fmax(small, ZERO_REL * fmax(ajj * arr, ab * ab));     // the block itself is not (numerically) singular
                 const bool ok0 = ajj > ztol && ajj >= uu * gj;
-                const bool ok1 = arr > ztol && arr >= uu * gr;
+                const bool ok1 = arr > ztr && arr >= uu * gr;
                 const bool ok2 = nz2 && t1 * uu <= adet && t2 * uu <= adet;
                 if ((pref == 0 && ok0) || (pref == 1 && ok1) || (pref == 2 && ok2)) sel = pref;
                 else if (ok0) sel = 0; else if (ok2) sel = 2; else if (ok1) sel = 1;
@@ -501,25 +503,28 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
     __syncthreads();
 }
 
-// scale of an assembled front held in register tiles (max |entry|) -> absolute zero-pivot tolerance
+// zero-pivot scale: max |entry| of every fully-summed COLUMN of the assembled front (register tiles) -> cm0[0..k).  A pivot
+// is numerically zero relative to what was assembled into ITS column -- a huge Sigma entry elsewhere in the front (late
+// barrier iterations, no equilibration) must not make healthy small pivots look like zeros.
 template <int NT, int TS>
-__device__ __forceinline__ double front_ztol(const double (&t)[TS][TS], double* red, const double small)
+__device__ __forceinline__ void front_colmax(const double (&t)[TS][TS], double* cm0, const int k)
 {
-    double mx = 0.0;
+    constexpr int G = (NT == 64) ? 8 : (NT == 1024 ? 32 : 16);
+    const int tid = threadIdx.x, ti = tid % G, tj = tid / G;
 #pragma unroll
-    for (int x = 0; x < TS; ++x)
+    for (int y = 0; y < TS; ++y) {
+        double mx = 0.0;
 #pragma unroll
-        for (int y = 0; y < TS; ++y) mx = fmax(mx, fabs(t[x][y]));
-    mx = wave_max_all(mx);
-    if (NT > 64) {
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-        __syncthreads();
-        mx = 0.0;
-#pragma unroll
-        for (int w = 0; w < NT / 64; ++w) mx = fmax(mx, red[w]);
-        __syncthreads();
+        for (int x = 0; x < TS; ++x) mx = fmax(mx, fabs(t[x][y]));
+        // the G threads that share tile column tj are G consecutive lanes (tid = ti + G tj): butterfly inside the group
+        mx = fmax(mx, dpp_f64<0xB1>(mx));
+        mx = fmax(mx, dpp_f64<0x4E>(mx));
+        mx = fmax(mx, dpp_f64<0x141>(mx));           // 8 lanes
+        if (G >= 16) mx = fmax(mx, dpp_f64<0x140>(mx));   // 16 lanes
+        if (G == 32) mx = fmax(mx, __shfl_xor(mx, 16));
+        if (ti == 0 && tj * TS + y < k) cm0[tj * TS + y] = mx;
     }
-    return fmax(small, ZERO_REL * mx);
+    __syncthreads();
 }
 
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
@@ -541,7 +546,8 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     double* colbuf = F + fdoubles;               // 4 * MAXM
     double* dinv_s = colbuf + 4 * MAXM;          // k
     double* doff_s = dinv_s + k;                 // k
-    int*    ord    = reinterpret_cast<int*>(doff_s + k);   // k
+    double* cm0    = doff_s + k;                 // k   max |entry| of each fully-summed column of the assembled front
+    int*    ord    = reinterpret_cast<int*>(cm0 + k);      // k
     int*    pt_s   = ord + k;                    // k
 
     // ---- (a)-(c) assembly in LDS (lower storage) ----
@@ -585,8 +591,8 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     // ---- (d) LDL^T ----
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(5);
-    const double ztol = front_ztol<NT, TS>(t, colbuf, V.small);
-    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
+    front_colmax<NT, TS>(t, cm0, k);
+    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(6);
@@ -632,8 +638,8 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
     const int ld = k | 1;
     double* Lb     = reinterpret_cast<double*>(smem_raw);   // k x k L columns (physical rows); later the pivot-ordered block / its inverse
     double* colbuf = Lb + (size_t)ld * k;
-    double* dinv_s = colbuf + 4 * MAXM; double* doff_s = dinv_s + k;
-    int* ord = reinterpret_cast<int*>(doff_s + k); int* pt_s = ord + k;
+    double* dinv_s = colbuf + 4 * MAXM; double* doff_s = dinv_s + k; double* cm0 = doff_s + k;
+    int* ord = reinterpret_cast<int*>(cm0 + k); int* pt_s = ord + k;
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
     if (M.selfasm) {            // pure in-place chain link (no assembly launch): the A entries of the pivot rows are added here
@@ -651,8 +657,8 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
         }
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(0);
-    const double ztol = front_ztol<NT, TS>(t, colbuf, V.small);
-    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, ztol, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
+    front_colmax<NT, TS>(t, cm0, k);
+    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(1);
@@ -1855,7 +1861,7 @@ public:
             while (q < b1 && order_of(lvl_list[q]) <= 96) {
                 const int sn = lvl_list[q];
                 const size_t m = order_of(sn), k = Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn], ld = m | 1, ldi = k | 1;
-                mid_lds[lv] = std::max(mid_lds[lv], (std::max(ld * m, k * ld + k * ldi) + 4 * 96 + 2 * k) * sizeof(double) + 2 * k * sizeof(int) + 64);
+                mid_lds[lv] = std::max(mid_lds[lv], (std::max(ld * m, k * ld + k * ldi) + 4 * 96 + 3 * k) * sizeof(double) + 2 * k * sizeof(int) + 64);
                 ++q;
             }
             mid_split[lv] = (q - b0 >= 256) ? q - b0 : 0;
@@ -2080,7 +2086,7 @@ public:
             const size_t m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s], k = Sy.sn_colptr[s + 1] - Sy.sn_colptr[s];
             const size_t ld = m | 1, ldi = k | 1;
             const size_t maxm = Sy.sn_class[s] == FC_WAVE ? 32 : (Sy.sn_class[s] == FC_LDS64 ? 64 : 128);
-            const size_t need = (std::max(ld * m, k * ld + k * ldi) + 4 * maxm + 2 * k) * sizeof(double) + 2 * k * sizeof(int) + 64;
+            const size_t need = (std::max(ld * m, k * ld + k * ldi) + 4 * maxm + 3 * k) * sizeof(double) + 2 * k * sizeof(int) + 64;
             size_t& r = reg_lds[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]];
             r = std::max(r, need);
         }
@@ -2140,8 +2146,8 @@ public:
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
-        if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-        else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 2 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
         if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0);
         if (b1 == bs) return true;

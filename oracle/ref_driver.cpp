@@ -152,8 +152,12 @@ class DriverAlgBuilder: public AlgorithmBuilder
 public:
    DriverAlgBuilder(const std::string& solver, const std::string& record, int max_records)
       : solver_(solver), record_(record), max_records_(max_records) { }
-   virtual SmartPtr<SymLinearSolver> SymLinearSolverFactory(const Journalist&, const OptionsList&, const std::string&)
+   virtual SmartPtr<SymLinearSolver> SymLinearSolverFactory(const Journalist& jnlst, const OptionsList& options, const std::string& prefix)
    {
+#ifdef WITH_MI355X
+      // the product's own builder (honours mi355x_outer_scaling) unless the boundary is being recorded
+      if( solver_ == "mi355x" && record_.empty() ) return Mi355xAlgorithmBuilder().SymLinearSolverFactory(jnlst, options, prefix);
+#endif
       SmartPtr<SparseSymLinearSolverInterface> iface;
       if( solver_ == "pardisomkl" ) iface = new PardisoMKLSolverInterface();
 #ifdef WITH_MI355X

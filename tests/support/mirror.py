@@ -89,7 +89,7 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True):
     """In-place LDL^T of the first k (fully-summed) rows/columns of the symmetric m x m front F.
     Returns dict(ord, ptype, dinv, doff, L (m x k, physical rows, column = elimination step), nneg, nzero, ntwo, ndelay, chg)."""
     m = F.shape[0]
-    ztol = max(small, ZERO_REL * (np.abs(F).max() if F.size else 0.0))
+    cm0 = np.abs(F[:, :k]).max(axis=0) if (k and F.size) else np.zeros(k)      # scale of each fully-summed column as assembled
     alive = list(range(k))
     tryb = list(alive)
     force = False
@@ -104,6 +104,7 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True):
         if not tryb:
             force = True; tryb = list(alive)
         j = tryb[0]
+        ztol = max(small, ZERO_REL * cm0[j])
         ajj = abs(F[j, j])
         fs = [i for i in alive if i != j]
         gj = max(colmax(j, fs), colmax(j, upd))
@@ -129,8 +130,9 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True):
                 det = a * c - b * b; adet = abs(det)
                 pref = 0 if (ajj >= BK_ALPHA * lam or ajj * sig >= BK_ALPHA * lam * lam) else (1 if arr >= BK_ALPHA * sig else 2)
                 t1, t2 = arr * gj2 + ab * gr2, ab * gj2 + ajj * gr2
-                nz2 = adet > ztol * max(ab, ajj, arr)
-                ok = [ajj > ztol and ajj >= uu * gj, arr > ztol and arr >= uu * gr, nz2 and t1 * uu <= adet and t2 * uu <= adet]
+                ztr = max(small, ZERO_REL * cm0[r])
+                nz2 = adet > max(small, ZERO_REL * max(ajj * arr, ab * ab))
+                ok = [ajj > ztol and ajj >= uu * gj, arr > ztr and arr >= uu * gr, nz2 and t1 * uu <= adet and t2 * uu <= adet]
                 if ok[pref]:
                     sel = pref
                 elif ok[0]:
