@@ -364,7 +364,11 @@ ESymSolverStatus Mi355xSolverInterface::DetermineDependentRows(const Index* /*ia
       analysed_ = true;
    }
    int nneg = 0, nzero = 0;
+   // (no equilibration here: exact cancellations between dependent rows should stay exact; the MUMPS adapter likewise
+   //  switches its permuting scaling off for this call, IpMumpsSolverInterface.cpp:632-641)
+   mi355x_kkt_set_scaling(handle_, 0, NULL);
    int st = mi355x_kkt_factor(handle_, NULL, &nneg, &nzero);
+   mi355x_kkt_set_scaling(handle_, kopts_.scaling, NULL);
    if( st == MI355X_KKT_FATAL )
    {
       Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_factor failed: %s\n", mi355x_kkt_last_error(handle_));

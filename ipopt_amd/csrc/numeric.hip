@@ -102,6 +102,7 @@ struct DevView {
     double pivtol, pivtol2, small;   // u, the largest u IncreaseQuality may reach (decision-change tracking), absolute zero threshold
     int* colfail;           // per column of a BIG front: 1 once some multiplier of L21 exceeded 1/u (a posteriori test, k_big_trsm)
     int* qstat;             // [0]: some pivot decision of this factorisation would differ at u = pivtol2
+    double* cnorm;          // inf-norm of every column of the (scaled) INPUT matrix, permuted numbering: scale of the zero-pivot test
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
@@ -232,6 +233,20 @@ __global__ void k_trip_rescale(int n, double* s, unsigned long long* rowmax)
         const double mx = __longlong_as_double((long long)rowmax[i]);
         if (mx > 0.0) s[i] /= sqrt(mx);
         rowmax[i] = 0ull;
+    }
+}
+// inf-norm of every row (= column) of the scaled input matrix over the symmetric row view: cnorm(i) = s(i) max_p arv(p) s(col(p))
+__global__ void k_colnorm(DevView V, int scaled)
+{
+    const int sub = threadIdx.x & 7;
+    for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < ((V.n + 7) & ~7); i += (gridDim.x * blockDim.x) >> 3) {
+        double mx = 0.0;
+        if (i < V.n) {
+            const int p1 = V.rslot_ptr[i + 1];
+            for (int p = V.rslot_ptr[i] + sub; p < p1; p += 8) mx = fmax(mx, V.arv[p] * (scaled ? V.scale[V.rslot_col[p]] : 1.0));
+        }
+        mx = fmax(mx, __shfl_xor(mx, 1)); mx = fmax(mx, __shfl_xor(mx, 2)); mx = fmax(mx, __shfl_xor(mx, 4));
+        if (i < V.n && sub == 0) V.cnorm[i] = mx * (scaled ? V.scale[i] : 1.0);
     }
 }
 __global__ void k_apply_scale(DevView V)
@@ -503,11 +518,12 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
     __syncthreads();
 }
 
-// zero-pivot scale: max |entry| of every fully-summed COLUMN of the assembled front (register tiles) -> cm0[0..k).  A pivot
-// is numerically zero relative to what was assembled into ITS column -- a huge Sigma entry elsewhere in the front (late
-// barrier iterations, no equilibration) must not make healthy small pivots look like zeros.
+// zero-pivot scale of every fully-summed COLUMN -> cm0[0..k): the larger of the column's inf-norm in the (scaled) input matrix
+// and of what was assembled into it in this front.  A pivot is numerically zero relative to ITS column -- a huge Sigma entry
+// elsewhere in the front (late barrier iterations, no equilibration) must not make healthy small pivots look like zeros, and a
+// column whose entries already cancelled in the children (dependent constraint rows) must still be measured against what it was.
 template <int NT, int TS>
-__device__ __forceinline__ void front_colmax(const double (&t)[TS][TS], double* cm0, const int k)
+__device__ __forceinline__ void front_colmax(const double (&t)[TS][TS], double* cm0, const int k, const double* cnorm)
 {
     constexpr int G = (NT == 64) ? 8 : (NT == 1024 ? 32 : 16);
     const int tid = threadIdx.x, ti = tid % G, tj = tid / G;
@@ -522,7 +538,7 @@ __device__ __forceinline__ void front_colmax(const double (&t)[TS][TS], double* 
         mx = fmax(mx, dpp_f64<0x141>(mx));           // 8 lanes
         if (G >= 16) mx = fmax(mx, dpp_f64<0x140>(mx));   // 16 lanes
         if (G == 32) mx = fmax(mx, __shfl_xor(mx, 16));
-        if (ti == 0 && tj * TS + y < k) cm0[tj * TS + y] = mx;
+        if (ti == 0 && tj * TS + y < k) cm0[tj * TS + y] = fmax(mx, cnorm[tj * TS + y]);
     }
     __syncthreads();
 }
@@ -591,7 +607,7 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     // ---- (d) LDL^T ----
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(5);
-    front_colmax<NT, TS>(t, cm0, k);
+    front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
     ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
@@ -657,7 +673,7 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
         }
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(0);
-    front_colmax<NT, TS>(t, cm0, k);
+    front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
     ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
@@ -2065,7 +2081,7 @@ public:
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
-            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n)) return false;
+            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n)) return false;
         V.qstat = d_stats + 4;
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
@@ -2167,6 +2183,21 @@ public:
         return true;
     }
 
+    // symmetric scaling of the gathered values (mode 0 none / 1 Ruiz, 4 Jacobi-style sweeps ping-ponging between two buffers /
+    // 2 the caller's factors) and the column norms of the scaled matrix that anchor the zero-pivot test
+    void enqueue_scaling() {
+        const Symbolic& Sy = *S; const int n = Sy.n;
+        LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
+        if (opt.scaling == 2) LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);
+        else if (opt.scaling) {
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+        } else LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
+        LAUNCH(KK_GATHER_SCALE, k_colnorm, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, opt.scaling ? 1 : 0);
+        if (opt.scaling) LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+    }
     bool enqueue_factor() {
         const Symbolic& Sy = *S;
         const int n = Sy.n;
@@ -2174,17 +2205,7 @@ public:
         LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
         LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        if (opt.scaling == 2) {     // factors supplied by the caller (set_scaling)
-            LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);
-            LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        } else if (opt.scaling) {      // 4 sweeps, ping-pong between the two buffers, ending in V.scale
-            LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
-            LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        } else LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
+        enqueue_scaling();
         for (int lv = 0; lv < Sy.num_levels; ++lv) {
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
@@ -2388,17 +2409,7 @@ public:
         hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
         hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        if (opt.scaling == 2) {
-            hipLaunchKernelGGL(k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);
-            hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        } else if (opt.scaling) {
-            hipLaunchKernelGGL(k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
-            hipLaunchKernelGGL(k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
-            hipLaunchKernelGGL(k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
-        } else hipLaunchKernelGGL(k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
+        enqueue_scaling();
         if (!launch_fronts(sch_local, 0)) return false;
         HIPCHK(hipMemsetAsync(V.arena, 0, (size_t)arena_doubles * sizeof(double), stream));
         if (join_count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((join_maxm + 3) / 4, join_count), dim3(256), 0, stream, V, join_list_base);

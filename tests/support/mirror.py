@@ -85,11 +85,13 @@ PIV_PERT = 1e-10
 ZERO_REL = 1e-14
 
 
-def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True):
+def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True, cnorm=None):
     """In-place LDL^T of the first k (fully-summed) rows/columns of the symmetric m x m front F.
     Returns dict(ord, ptype, dinv, doff, L (m x k, physical rows, column = elimination step), nneg, nzero, ntwo, ndelay, chg)."""
     m = F.shape[0]
-    cm0 = np.abs(F[:, :k]).max(axis=0) if (k and F.size) else np.zeros(k)      # scale of each fully-summed column as assembled
+    cm0 = np.abs(F[:, :k]).max(axis=0) if (k and F.size) else np.zeros(k)      # scale of each fully-summed column as assembled ...
+    if cnorm is not None:
+        cm0 = np.maximum(cm0, cnorm)                                           # ... or in the input matrix, whichever is larger
     alive = list(range(k))
     tryb = list(alive)
     force = False
@@ -220,6 +222,10 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20):
     fac, cbs, cvec = [None] * nsn, [None] * nsn, [None] * nsn
     tot = dict(num_neg=0, num_zero=0, num_two=0, num_delay=0, u_sensitive=0)
     b = rhs[sym["perm"]].astype(float).copy()
+    # inf-norm of every column of the (symmetric) input matrix, permuted numbering
+    cn = np.zeros(n)
+    col_of = np.repeat(np.arange(n), np.diff(sym["acolptr"]))
+    np.maximum.at(cn, col_of, np.abs(aval)); np.maximum.at(cn, sym["arow"], np.abs(aval))
     for s in range(nsn):
         c0, c1 = colptr[s], colptr[s + 1]
         k = c1 - c0
@@ -240,14 +246,14 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20):
             bs[rl] += cvec[ch]
             cbs[ch] = None
         if m <= BIG_FRONT:
-            st = ldlt_front(F, k, u, u2, small)
+            st = ldlt_front(F, k, u, u2, small, cnorm=cn[c0:c1])
             P = st["ord"]
             L11 = np.tril(st["L"][P, :], -1) + np.eye(k)
             L21 = st["L"][k:, :]
             cb = F[k:, k:].copy()
         else:
             A11 = F[:k, :k].copy()
-            st = ldlt_front(A11, k, u, u2, small, see_update_rows=False)
+            st = ldlt_front(A11, k, u, u2, small, see_update_rows=False, cnorm=cn[c0:c1])
             P = st["ord"]
             L11 = np.tril(st["L"][P, :], -1) + np.eye(k)
             D = np.zeros((k, k))

@@ -122,10 +122,12 @@ def test_zero_pivot_list_names_the_dependent_rows():
     r = np.concatenate([jr + ncol, np.arange(n)]).astype(np.int32) + 1
     c = np.concatenate([jc, np.arange(n)]).astype(np.int32) + 1
     v = np.concatenate([J[jr, jc], np.ones(ncol), np.zeros(nrow)])
-    s = ipopt_amd.KKTSolver()
+    s = ipopt_amd.KKTSolver(scaling=0)                 # as the adapter's DetermineDependentRows does
     s.initialize_structure(n, r, c, vals=v)
     s.values()[:] = v
     st = s.multi_solve(True, None)
+    _, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, np.ones(n))
+    assert s.info().num_zero == spec["num_zero"]
     z = s.zero_pivots() - 1 - ncol                     # row indices of J
     assert st == kkt.SINGULAR and len(z) == 2
     keep = [i for i in range(nrow) if i not in set(z.tolist())]
