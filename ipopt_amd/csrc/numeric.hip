@@ -405,7 +405,6 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             const int bi = (av1 > av0) ? lane + 64 : lane;       // this lane's best candidate row
             const double uu = force ? 0.0 : u;
             const double lam = wave_max_all(av);               // -1: no alive fully-summed partner
-            const double gj = wave_max_all(ga);
             int sel = -1;                                      // 0: 1x1 at j, 1: 1x1 at r, 2: 2x2 (j, r)
             int r = -1;
             bool zero = false;
@@ -420,29 +419,42 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                 const bool cs1 = WIDE && (alive1 & lanebit) != 0ull && lane + 64 != r;
                 const double sfs = fmax(cs ? h0 : 0.0, cs1 ? h1 : 0.0);
                 const double sig = wave_max_all(sfs);                                            // Bunch-Kaufman sigma
-                const double gr = wave_max_all(fmax(fmax(sfs, up0 ? h0 : 0.0), up1 ? h1 : 0.0));  // whole column r
-                const bool nj0 = lane != j, nj1 = lane + 64 != j;
-                const double gj2 = wave_max_all(fmax(fmax((cand && lane != r) ? f0 : 0.0, (cand1 && lane + 64 != r) ? f1 : 0.0), fmax(up0 ? f0 : 0.0, up1 ? f1 : 0.0)));
-                const double gr2 = wave_max_all(fmax(fmax((cs && nj0) ? h0 : 0.0, (cs1 && nj1) ? h1 : 0.0), fmax(up0 ? h0 : 0.0, up1 ? h1 : 0.0)));
+                const double hall = fmax(fmax(sfs, up0 ? h0 : 0.0), up1 ? h1 : 0.0);             // whole column r, diagonal excluded
                 const double a = djj, b = colA[r], c = colB[r];
                 const double arr = fabs(c), ab = fabs(b);
                 const double det = a * c - b * b, adet = fabs(det);
-                const int pref = (ajj >= BK_ALPHA * lam || ajj * sig >= BK_ALPHA * lam * lam) ? 0 : ((arr >= BK_ALPHA * sig) ? 1 : 2);
-                const double t1 = arr * gj2 + ab * gr2, t2 = ab * gj2 + ajj * gr2;                // |E^{-1}| (gj2, gr2)^T |det|
                 const double ztr = fmax(small, ZERO_REL * cm0[r]);
                 const bool nz2 = adet > fmax(small, ZERO_REL * fmax(ajj * arr, ab * ab));     // the block itself is not (numerically) singular
-                const bool ok0 = ajj > ztol && ajj >= uu * gj;
-                const bool ok1 = arr > ztr && arr >= uu * gr;
-                const bool ok2 = nz2 && t1 * uu <= adet && t2 * uu <= adet;
-                if ((pref == 0 && ok0) || (pref == 1 && ok1) || (pref == 2 && ok2)) sel = pref;
-                else if (ok0) sel = 0; else if (ok2) sel = 2; else if (ok1) sel = 1;
-                if (sel >= 0) {
-                    const bool f_u  = (sel == 0) ? (ajj < u * gj)  : ((sel == 1) ? (arr < u * gr)  : (t1 * u > adet  || t2 * u > adet));
-                    const bool f_u2 = (sel == 0) ? (ajj < u2 * gj) : ((sel == 1) ? (arr < u2 * gr) : (t1 * u2 > adet || t2 * u2 > adet));
-                    if (f_u) ndelay += (sel == 2) ? 2 : 1;     // only possible when forced
-                    if (f_u2 && !force) chgm |= 1ull;          // (a forced pivot stays forced at any larger u)
+                const int pref = (ajj >= BK_ALPHA * lam || ajj * sig >= BK_ALPHA * lam * lam) ? 0 : ((arr >= BK_ALPHA * sig) ? 1 : 2);
+                // ONE reduction bounds every column maximum the threshold tests need (G >= gj, gr, gj2, gr2): when the
+                // preferred pivot passes them with G -- at u and at u2, the usual case -- it passes the exact tests too
+                const double G = wave_max_all(fmax(ga, hall));
+                const double um = fmax(uu, u2e);
+                const bool quick = !force && ((pref == 0) ? (ajj > ztol && ajj >= um * G)
+                                            : (pref == 1) ? (arr > ztr && arr >= um * G)
+                                                          : (nz2 && (arr + ab) * G * um <= adet && (ab + ajj) * G * um <= adet));   // (forced pivots are counted exactly)
+                if (quick) sel = pref;
+                else {
+                    const double gj = wave_max_all(ga);
+                    const double gr = wave_max_all(hall);
+                    const bool nj0 = lane != j, nj1 = lane + 64 != j;
+                    const double gj2 = wave_max_all(fmax(fmax((cand && lane != r) ? f0 : 0.0, (cand1 && lane + 64 != r) ? f1 : 0.0), fmax(up0 ? f0 : 0.0, up1 ? f1 : 0.0)));
+                    const double gr2 = wave_max_all(fmax(fmax((cs && nj0) ? h0 : 0.0, (cs1 && nj1) ? h1 : 0.0), fmax(up0 ? h0 : 0.0, up1 ? h1 : 0.0)));
+                    const double t1 = arr * gj2 + ab * gr2, t2 = ab * gj2 + ajj * gr2;                // |E^{-1}| (gj2, gr2)^T |det|
+                    const bool ok0 = ajj > ztol && ajj >= uu * gj;
+                    const bool ok1 = arr > ztr && arr >= uu * gr;
+                    const bool ok2 = nz2 && t1 * uu <= adet && t2 * uu <= adet;
+                    if ((pref == 0 && ok0) || (pref == 1 && ok1) || (pref == 2 && ok2)) sel = pref;
+                    else if (ok0) sel = 0; else if (ok2) sel = 2; else if (ok1) sel = 1;
+                    if (sel >= 0) {
+                        const bool f_u  = (sel == 0) ? (ajj < u * gj)  : ((sel == 1) ? (arr < u * gr)  : (t1 * u > adet  || t2 * u > adet));
+                        const bool f_u2 = (sel == 0) ? (ajj < u2 * gj) : ((sel == 1) ? (arr < u2 * gr) : (t1 * u2 > adet || t2 * u2 > adet));
+                        if (f_u) ndelay += (sel == 2) ? 2 : 1;     // only possible when forced
+                        if (f_u2 && !force) chgm |= 1ull;          // (a forced pivot stays forced at any larger u)
+                    }
                 }
             } else {
+                const double gj = wave_max_all(ga);
                 if (ajj > ztol && ajj >= uu * gj) { sel = 0; if (ajj < u * gj) ndelay += 1; }
                 else if (!(ajj > ztol) && !(gj > ztol)) { sel = 0; zero = true; }          // the whole remaining column is zero
             }
