@@ -1221,13 +1221,13 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
 // then L21 = W21 D^{-1}.  64 rows per workgroup, 16 rows per wavefront; A21 P is staged in LDS, the rows of L11^{-1} needed
 // by a 16-column tile are pulled straight into registers (<= 32 values per lane, L2 resident); the product is formed
 // transposed (A operand = rows of L11^{-1}, B operand = rows of A21 P) so that lanes hold consecutive rows.  k <= 128.
-__global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
+__global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off, int rb0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
     const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
-    const int ibase = k + blockIdx.x * 64;
+    const int ibase = k + ((int)blockIdx.x + rb0) * 64;       // rb0: first row block of this launch (chain look-ahead: block 0 alone, then the rest)
     if (ibase >= m) return;
     const int kp = (k + 3) & ~3;                              // K padded to the MFMA depth
     double* As = reinterpret_cast<double*>(smem_raw);         // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
@@ -1294,7 +1294,7 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off)
 // tile columns (all that the next group's panels, pivot blocks and narrow updates touch) stays on the main stream, part 2 =
 // the rest runs on a second stream, overlapped with the latency-bound pivot chains of the next group.  part 0 = everything.
 constexpr int SCHUR_KC = 16, SCHUR_LD = 132;
-__device__ __forceinline__ void schur_tile(const DevView& V, const FrontMeta& M, const int t, const int part,
+__device__ __forceinline__ void schur_tile(const DevView& V, const FrontMeta& M, const int t, const int part, const int skip00,
                                            double (&As)[2][SCHUR_KC][SCHUR_LD], double (&Bs)[2][SCHUR_KC][SCHUR_LD])
 {
     // 128 x 128 tile per workgroup of 16 wavefronts (32 x 32 each = 2 x 2 accumulators of v_mfma_f64_16x16x4_f64).  The
@@ -1343,7 +1343,8 @@ __device__ __forceinline__ void schur_tile(const DevView& V, const FrontMeta& M,
     const int l15 = lane & 15, l4 = lane >> 4;
     const int wr = (wave >> 2) * 32, wc = (wave & 3) * 32;             // this wavefront's 32 x 32 block inside the tile
     const int i0 = ti * 128, cc0 = tc * 128;
-    const bool work = (i0 + wr + 31 >= cc0 + wc) && (cc0 + wc < climit) && (i0 + wr < mu);
+    // skip00: the leading 64 x 64 block of the trailing matrix (the NEXT link's pivot block) was already updated by the look-ahead launch
+    const bool work = (i0 + wr + 31 >= cc0 + wc) && (cc0 + wc < climit) && (i0 + wr < mu) && !(skip00 && i0 + wr < 64 && cc0 + wc < 64);
     v4f64 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -1420,27 +1421,28 @@ __device__ __forceinline__ void schur_tile(const DevView& V, const FrontMeta& M,
 }
 // part 0 / 1: one tile per workgroup.  part 2 (look-ahead, second stream) strides over the tiles, normally also one per
 // workgroup (a persistent grid smaller than the chip was measured: one 16-wave workgroup per CU reaches half the MFMA rate).
-__global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off, int part, int ntiles)
+__global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off, int part, int ntiles, int skip00)
 {
     __shared__ double As[2][SCHUR_KC][SCHUR_LD];      // W rows (-> T columns) of the tile
     __shared__ double Bs[2][SCHUR_KC][SCHUR_LD];      // L rows (-> T rows)
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
-    if (part != 2) { schur_tile(V, M, blockIdx.x, part, As, Bs); return; }
+    if (part != 2) { schur_tile(V, M, blockIdx.x, part, skip00, As, Bs); return; }
     if (!M.split) return;
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) { schur_tile(V, M, t, part, As, Bs); __syncthreads(); }
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) { schur_tile(V, M, t, part, 0, As, Bs); __syncthreads(); }
 }
 
 
 // Small-front variant of the trailing update (levels whose largest front has <= 640 rows: thousands of fronts, a handful
 // of tiles each): 64 x 64 tile per 256-thread workgroup, 32 x 32 per wavefront, operands straight from L2.  The 128 x 128
 // LDS-staged kernel above leaves most of its 16 wavefronts idle on such fronts (PMC: 7.6 % MFMA utilisation).
-__global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off)
+__global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off, int mode)      // mode 0: every tile, 1: tile (0,0) only (look-ahead), 2: all but it
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
     const int k = M.k, m = M.m;
     const int mu = m - k;
     const int nt = (mu + 63) >> 6;
     const int t = blockIdx.x;
+    if ((mode == 2 && t == 0) || (mode == 1 && t != 0)) return;
     int ti, tc, climit, j0;
     if (M.grem > 0) {
         const int ntc = (M.grem + 63) >> 6;
@@ -1622,6 +1624,15 @@ public:
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
     std::vector<int> la_tiles1, la_tiles2; std::vector<char> la_full;     // la_full: the level has a full (group-last) update
     std::vector<hipEvent_t> la_evA, la_evB;
+    // chain look-ahead (single-GPU schedule, levels whose fronts are all pure in-place chain links): the critical path
+    //   pivot block (k_big_diag_reg) -> first row block of the panel (k_big_trsm, 1 workgroup) -> the NEXT link's 64 x 64 pivot
+    //   block (k_big_schur64, tile (0,0))
+    // stays on the main stream; the bulk of the panel solve and of the trailing update trails on `stream3` (the far part of
+    // a split group-end update on `stream2`), overlapped with the next link's latency-bound pivot block
+    hipStream_t stream3 = nullptr;
+    std::vector<char> lv_chain; bool chain_la = true; int chain_maxf = 64;
+    std::vector<hipEvent_t> chD, chLA, chN, chG1, chFar;
+    hipEvent_t ch_bulk_last = nullptr, ch_far_last = nullptr; bool ch_bulk_pending = false, ch_far_pending = false;
     hipStream_t stream2 = nullptr; bool la_pending = false; hipEvent_t la_last = nullptr; bool lookahead = true, la_any = false; int la_wgs = 1 << 20, la_min_nt = 12;
     std::vector<size_t> reg_lds;
     std::vector<int> mid_split; std::vector<size_t> mid_lds;   // per level: leading FC_LDS128 fronts of order <= 96 (6x6-tile kernel, 2 workgroups per CU) and their LDS need
@@ -1770,6 +1781,8 @@ public:
         for (auto e : la_evA) if (e) (void)hipEventDestroy(e);
         for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
         la_evA.clear(); la_evB.clear();
+        for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
+        if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
         if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         ready = false;
@@ -1802,8 +1815,11 @@ public:
             (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
             HIPCHK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
             HIPCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
+            HIPCHK(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, (plo + phi) / 2));
         }
         lookahead = getenv("MI355X_KKT_NO_LOOKAHEAD") == nullptr;
+        chain_la = getenv("MI355X_KKT_NO_CHAIN_LA") == nullptr;
+        if (const char* e = getenv("MI355X_KKT_CHAIN_LA_MAXF")) chain_maxf = std::max(1, atoi(e));
         if (const char* e = getenv("MI355X_KKT_LA_WGS")) la_wgs = std::max(1, atoi(e));          // development knobs
         if (const char* e = getenv("MI355X_KKT_LA_MIN_NT")) la_min_nt = std::max(3, atoi(e));
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
@@ -2034,6 +2050,25 @@ public:
                 }
                 lv_asm_skip[lv] = (cnt > 0 && all) ? 1 : 0;
             }
+        lv_chain.assign(Sy.num_levels, 0);
+        if (!multi && selfasm_on && chain_la)
+            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                const int nbig = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1] - Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG];
+                const int nall = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)lv * FC_COUNT];
+                int kmax = 0;
+                for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1]; ++q) kmax = std::max(kmax, Sy.sn_colptr[Sy.level_sn[q] + 1] - Sy.sn_colptr[Sy.level_sn[q]]);
+                lv_chain[lv] = (lv_asm_skip[lv] && nbig == nall && nbig <= chain_maxf && kmax <= 64) ? 1 : 0;
+            }
+        {
+            int nchain = 0;
+            for (int lv = 0; lv < Sy.num_levels; ++lv) nchain += lv_chain[lv];
+            if (nchain < 8) std::fill(lv_chain.begin(), lv_chain.end(), 0);      // not worth leaving the graph replay for
+            else la_any = true;                                                  // multi-stream schedule => eager launches (see factor())
+            chD.assign(Sy.num_levels, nullptr); chLA.assign(Sy.num_levels, nullptr); chN.assign(Sy.num_levels, nullptr); chG1.assign(Sy.num_levels, nullptr); chFar.assign(Sy.num_levels, nullptr);
+            for (int lv = 0; lv < Sy.num_levels; ++lv) if (lv_chain[lv])
+                for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) HIPCHK(hipEventCreateWithFlags(&(*v)[lv], hipEventDisableTiming));
+            if (opt.verbose) fprintf(stderr, "[mi355x_kkt] chain look-ahead on %d of %d levels\n", nchain >= 8 ? nchain : 0, Sy.num_levels);
+        }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -2144,12 +2179,14 @@ public:
         const int nt = (mu + 127) / 128;
         return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 127) / 128) : tri_tiles(nt);
     }
+    static size_t trsm_lds(int kk) { return (size_t)(65 * ((kk + 3) & ~3) + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16; }
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
 
     // one (level, class) bucket of fronts
     bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk, int tiles, int tiles64) {
         const int nb = b1 - b0;
+        if (fc != FC_BIG && !drain_chain()) return false;        // (a level with small fronts is never a chain level)
         const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
         if (fc == FC_WAVE) {
             const int nt = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_WAVE]) ? tiny_split[lv] : 0;     // single-GPU schedule only
@@ -2171,13 +2208,53 @@ public:
     // the big-front launches of one level: assembly, pivot blocks and TRSM over the whole list [b0, b1); the trailing update with
     // 64 x 64 tiles / 256 threads on the fronts [b0, bs) of order <= 1024 (a handful of tiles, K = 16..64 each) and with
     // 128 x 128 tiles / 1024 threads on [bs, b1)
+    bool drain_chain() {
+        if (ch_bulk_pending) { HIPCHK(hipStreamWaitEvent(stream, ch_bulk_last, 0)); ch_bulk_pending = false; }
+        if (ch_far_pending) { HIPCHK(hipStreamWaitEvent(stream, ch_far_last, 0)); ch_far_pending = false; }
+        return true;
+    }
+    // one level of pure chain links with look-ahead (see the member comment): [b0, bs) fronts of order <= 1024, [bs, b1) larger
+    bool launch_big_chain(int lv, int b0, int bs, int b1, int mm, int kk, int tiles_small, int tiles) {
+        const int nball = b1 - b0, nrb = (mm + 63) / 64;
+        if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
+        // ---- critical path (main stream) ----
+        hipLaunchKernelGGL(k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        HIPCHK(hipEventRecord(chD[lv], stream));
+        if (ch_bulk_pending) HIPCHK(hipStreamWaitEvent(stream, ch_bulk_last, 0));      // this panel's first row block was finalised by the previous level's bulk update
+        hipLaunchKernelGGL(k_big_trsm, dim3(1, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
+        hipLaunchKernelGGL(k_big_schur64, dim3(1, nball), dim3(256), 0, stream, V, b0, 1);
+        HIPCHK(hipEventRecord(chLA[lv], stream));
+        // ---- bulk (stream3): the rest of the panel solve, then the trailing update minus the block done above ----
+        HIPCHK(hipStreamWaitEvent(stream3, chD[lv], 0));
+        if (nrb > 1) hipLaunchKernelGGL(k_big_trsm, dim3(nrb - 1, nball), dim3(256), trsm_lds(kk), stream3, V, b0, 1);
+        HIPCHK(hipStreamWaitEvent(stream3, chLA[lv], 0));
+        if (bs > b0 && tiles_small > 0) hipLaunchKernelGGL(k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream3, V, b0, 2);
+        if (b1 > bs) {
+            const int nb = b1 - bs;
+            if (la_full[lv] && ch_far_pending) { HIPCHK(hipStreamWaitEvent(stream3, ch_far_last, 0)); ch_far_pending = false; }   // a full update touches what the previous far part writes
+            if (la_tiles2[lv] > 0) {
+                hipLaunchKernelGGL(k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream3, V, bs, 1, 0, 1);
+                HIPCHK(hipEventRecord(chG1[lv], stream3));
+                HIPCHK(hipStreamWaitEvent(stream2, chG1[lv], 0));
+                hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, bs, 2, la_tiles2[lv], 0);
+                HIPCHK(hipEventRecord(chFar[lv], stream2));
+                ch_far_last = chFar[lv]; ch_far_pending = true;
+            } else if (tiles > 0) hipLaunchKernelGGL(k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream3, V, bs, 0, 0, 1);
+        }
+        HIPCHK(hipEventRecord(chN[lv], stream3));
+        ch_bulk_last = chN[lv]; ch_bulk_pending = true;
+        HIPCHK(hipGetLastError());
+        return true;
+    }
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
+        if (single && lv_chain[lv] && !prof_on && !top_mode) return launch_big_chain(lv, b0, bs, b1, mm, kk, tiles_small, tiles);
+        if (!drain_chain()) return false;
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-        LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), (size_t)(65 * ((kk + 3) & ~3) + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16, stream, V, b0);
-        if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0);
+        LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
+        if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0, 0);
         if (b1 == bs) return true;
         const int nb = b1 - bs;
         b0 = bs;
@@ -2185,13 +2262,13 @@ public:
             HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false;
         }
         if (single && la_tiles2[lv] > 0 && !prof_on) {
-            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream, V, b0, 1, 0);
+            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream, V, b0, 1, 0, 0);
             HIPCHK(hipEventRecord(la_evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, la_evA[lv], 0));
-            hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, b0, 2, la_tiles2[lv]);
+            hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, b0, 2, la_tiles2[lv], 0);
             HIPCHK(hipEventRecord(la_evB[lv], stream2));
             la_last = la_evB[lv]; la_pending = true;
-        } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0, 0, 0);
+        } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0, 0, 0, 0);
         return true;
     }
 
@@ -2226,6 +2303,7 @@ public:
             }
         }
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
+        if (!drain_chain()) return false;
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
         LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());

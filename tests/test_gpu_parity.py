@@ -266,3 +266,21 @@ def test_standalone_ruiz_scaling_of_a_triplet_matrix():
         mx = np.zeros(n); np.maximum.at(mx, r - 1, w); np.maximum.at(mx, c - 1, w)
         s = np.where(mx > 0, s / np.sqrt(np.where(mx > 0, mx, 1.0)), s)
     assert np.allclose(out, s, rtol=1e-14, atol=0)
+
+
+def test_chain_lookahead_schedule_is_bitwise_identical(monkeypatch):
+    """the three-stream look-ahead along the separator chains (pivot block / first panel rows / next pivot block on the
+    critical stream, bulk panel solve and trailing update trailing behind) must not change a single bit"""
+    n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    monkeypatch.setenv("MI355X_KKT_NO_CHAIN_LA", "1")
+    s0, st0, x0 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+    monkeypatch.delenv("MI355X_KKT_NO_CHAIN_LA")
+    s1, st1, x1 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+    assert st0 == st1 == kkt.SUCCESS and s1.number_of_neg_evals() == neg
+    assert sres(K, x1, b) <= RES_TOL
+    assert np.array_equal(x0, x1)
+    for _ in range(3):                                   # repeated factorisations: no race between the streams
+        x2 = b.copy(); s1.multi_solve(True, x2)
+        assert np.array_equal(x1, x2)
