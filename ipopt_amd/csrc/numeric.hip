@@ -1818,7 +1818,7 @@ public:
             HIPCHK(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, (plo + phi) / 2));
         }
         lookahead = getenv("MI355X_KKT_NO_LOOKAHEAD") == nullptr;
-        chain_la = getenv("MI355X_KKT_NO_CHAIN_LA") == nullptr;
+        chain_la = getenv("MI355X_KKT_CHAIN_LA") != nullptr;      // default OFF: measured slower (DESIGN.md "measured design decisions")
         if (const char* e = getenv("MI355X_KKT_CHAIN_LA_MAXF")) chain_maxf = std::max(1, atoi(e));
         if (const char* e = getenv("MI355X_KKT_LA_WGS")) la_wgs = std::max(1, atoi(e));          // development knobs
         if (const char* e = getenv("MI355X_KKT_LA_MIN_NT")) la_min_nt = std::max(3, atoi(e));
