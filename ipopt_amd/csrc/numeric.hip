@@ -260,6 +260,7 @@ __global__ void k_apply_scale(DevView V)
 // Each stage is two fully parallel small products (T = B A^{-1} parked in the unused mirror position above the
 // diagonal, then B <- -C^{-1} T): log2(k) stages of 2 barriers instead of a k-step substitution chain.  Every solve
 // then multiplies by L11^{-1}.
+typedef double v4f64_ __attribute__((ext_vector_type(4)));
 template <int NT>
 __device__ __forceinline__ void invert_unit_lower(double* F, const int ld, const int k)
 {
@@ -267,6 +268,48 @@ __device__ __forceinline__ void invert_unit_lower(double* F, const int ld, const
     for (int sh = 0; (1 << sh) < k; ++sh) {
         const int h = 1 << sh;
         const int npair = (k + 2 * h - 1) >> (sh + 1);
+        if (h >= 16) {
+            // the last stages carry ~90 % of the n^3/3 flops: 16 x 16 output tiles on v_mfma_f64_16x16x4_f64 (one wavefront per
+            // tile, operands straight from LDS with the triangular / unit-diagonal masks applied on the fly).
+            //   D[l4 + 4g][l15] = sum_k A[l15][k = l4] B[k = l4][l15]
+            const int lane = tid & 63, wave = tid >> 6, l15 = lane & 15, l4 = lane >> 4;
+            const int tpp = (h >> 4) * (h >> 4), ntile = npair * tpp;
+            for (int tile = wave; tile < ntile; tile += NT / 64) {          // phase 1: T = B A^{-1}  -> mirror position
+                const int pr = tile / tpp, rem = tile - pr * tpp, ib = rem / (h >> 4), cb = rem - ib * (h >> 4);
+                const int o = pr << (sh + 1);
+                if (o + h >= k) continue;                                   // no B block in this pair
+                const int gi = o + h + ib * 16 + l15;                       // A operand row (a row of B)
+                const int c = cb * 16 + l15;                                // B operand column (a column of A^{-1})
+                v4f64_ acc = (v4f64_){0.0, 0.0, 0.0, 0.0};
+                for (int p0 = cb * 16; p0 < h; p0 += 4) {
+                    const int pp = p0 + l4;
+                    const double av = (gi < k) ? F[gi + (o + pp) * ld] : 0.0;
+                    const double bv = (pp > c) ? F[o + pp + (o + c) * ld] : (pp == c ? 1.0 : 0.0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const int ri = o + h + ib * 16 + l4 + 4 * g; if (ri < k) F[(o + c) + ri * ld] = acc[g]; }
+            }
+            __syncthreads();
+            for (int tile = wave; tile < ntile; tile += NT / 64) {          // phase 2: B <- -C^{-1} T
+                const int pr = tile / tpp, rem = tile - pr * tpp, ib = rem / (h >> 4), cb = rem - ib * (h >> 4);
+                const int o = pr << (sh + 1);
+                if (o + h >= k) continue;
+                const int i = ib * 16 + l15;                                // A operand row (a row of C^{-1})
+                const int c = cb * 16 + l15;                                // B operand column (a column of T)
+                v4f64_ acc = (v4f64_){0.0, 0.0, 0.0, 0.0};
+                for (int p0 = 0; p0 < (ib + 1) * 16; p0 += 4) {
+                    const int pp = p0 + l4;
+                    const double av = (i > pp) ? ((o + h + i < k) ? F[o + h + i + (o + h + pp) * ld] : 0.0) : (i == pp ? 1.0 : 0.0);
+                    const double bv = (o + h + pp < k) ? F[(o + c) + (o + h + pp) * ld] : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const int ri = o + h + ib * 16 + l4 + 4 * g; if (ri < k) F[ri + (o + c) * ld] = -acc[g]; }
+            }
+            __syncthreads();
+            continue;
+        }
         const int total = npair << (2 * sh);
         for (int e = tid; e < total; e += NT) {
             const int pr = e >> (2 * sh), rem = e & ((1 << (2 * sh)) - 1);
@@ -343,7 +386,7 @@ __device__ __forceinline__ double fast_rcp(double d)
 // Big fronts: the pivot block only sees its k x k block here (ext rows are checked a posteriori in k_big_trsm).
 template <int NT, int TS, bool WIDE>
 __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const int k, double* Lbuf, const int ldL, double* colbuf,
-                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double u2, const double small, const double* cm0, int* zp,
+                                         double* dinv_s, double* doff_s, int* pt_s, int* ord, const double u, const double u2, const double small, const double* cm0, const double cmx, int* zp,
                                          int& nneg, int& nzero, int& ntwo, int& ndelay, int& chg)
 {
     // The per-pivot instruction stream IS the critical path (measured: ~5 cycles per wave instruction), so the common
@@ -370,6 +413,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
     bool force = false;
     double u2e = u2;                                          // 0 while forced: a forced pivot stays forced at any larger u
     unsigned long long chgm = 0ull;
+    const double zmax = fmax(small, ZERO_REL * cmx);
     auto clear_row = [&](int r) { if (!WIDE || r < 64) alive &= ~(1ull << r); else alive1 &= ~(1ull << (r - 64)); };
     int step = 0, bufsel = 0;
     while ((alive | alive1) != 0ull) {
@@ -380,7 +424,6 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
         __syncthreads();
         // every LDS read of the common case (1x1 pivot on row j) is issued here, in ONE round trip
         const double djj = colA[j];
-        const double ztol = fmax(small, ZERO_REL * cm0[j]);     // zero threshold of candidate j
         const double avr = colA[lane];
         const double avr1 = TWO ? colA[lane1] : 0.0;
         double rv[TS], cv[TS];
@@ -397,12 +440,13 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
         // serial pivot chain): three ballots OR-ed into one scalar test, statistics accumulated branch-free
         const unsigned long long slowm = __ballot(av * BK_ALPHA > ajj)        // some |a_ij| > |a_jj| / alpha: full Bunch-Kaufman test
                                        | __ballot(ga * u > ajj)               // 1x1 at j fails the threshold test
-                                       | __ballot(!(ajj > ztol));             // (numerically) zero diagonal
+                                       | __ballot(!(ajj > zmax));             // possibly a (numerically) zero diagonal: exact test below
         chgm |= __ballot(ga * u2e > ajj);
         double d = djj;                    // 1x1 pivot value on physical row p (pivot column in rv / cv)
         int p = j;
         if (__builtin_expect(slowm != 0ull, 0)) {
             const int bi = (av1 > av0) ? lane + 64 : lane;       // this lane's best candidate row
+            const double ztol = fmax(small, ZERO_REL * cm0[j]);     // zero threshold of candidate j
             const double uu = force ? 0.0 : u;
             const double lam = wave_max_all(av);               // -1: no alive fully-summed partner
             int sel = -1;                                      // 0: 1x1 at j, 1: 1x1 at r, 2: 2x2 (j, r)
@@ -535,7 +579,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 // elsewhere in the front (late barrier iterations, no equilibration) must not make healthy small pivots look like zeros, and a
 // column whose entries already cancelled in the children (dependent constraint rows) must still be measured against what it was.
 template <int NT, int TS>
-__device__ __forceinline__ void front_colmax(const double (&t)[TS][TS], double* cm0, const int k, const double* cnorm)
+__device__ __forceinline__ double front_colmax(const double (&t)[TS][TS], double* cm0, const int k, const double* cnorm)
 {
     constexpr int G = (NT == 64) ? 8 : (NT == 1024 ? 32 : 16);
     const int tid = threadIdx.x, ti = tid % G, tj = tid / G;
@@ -553,6 +597,10 @@ __device__ __forceinline__ void front_colmax(const double (&t)[TS][TS], double* 
         if (ti == 0 && tj * TS + y < k) cm0[tj * TS + y] = fmax(mx, cnorm[tj * TS + y]);
     }
     __syncthreads();
+    // the largest of them: lets the per-pivot fast path test |a_jj| against ONE register value (a pivot that clears the largest
+    // threshold clears its own); only candidates below it look their own threshold up (slow path)
+    const int lane = tid & 63;
+    return wave_max_all(fmax(lane < k ? cm0[lane] : 0.0, lane + 64 < k ? cm0[lane + 64] : 0.0));
 }
 
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
@@ -619,8 +667,8 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     // ---- (d) LDL^T ----
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(5);
-    front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
-    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
+    const double cmx = front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
+    ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, cmx, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(6);
@@ -685,8 +733,8 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
         }
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(0);
-    front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
-    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
+    const double cmx = front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
+    ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, cmx, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(1);
