@@ -58,7 +58,8 @@ typedef struct mi355x_kkt_options {
                             /* 2 = natural (identity)                                                   */
     int    matching;        /* 1 (default) = pre-pair zero-diagonal rows with a partner column so that  */
                             /* the pair is one 2x2-capable supernode; 0 = off                           */
-    int    scaling;         /* 0 none, 1 (default) = symmetric Ruiz inf-norm equilibration on device    */
+    int    scaling;         /* 0 none, 1 (default) = symmetric Ruiz inf-norm equilibration on device,   */
+                            /* 3 = maximum-product matching scaling (MC64-style; host, per factorisation) */
     int    nd_leaf;         /* ND stops splitting below this many (compressed) nodes; default 32        */
     int    nemin;           /* relaxed-supernode amalgamation: always merge below this #cols; default 8 */
     int    max_sn_cols;     /* cap on columns of an amalgamated supernode; default (and max) 64                */
@@ -172,7 +173,8 @@ int  mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax);
 int  mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u);
 int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
 /* Symmetric scaling at run time (the option `scaling` only sets the initial mode): 0 none, 1 Ruiz inf-norm equilibration
- * on the device, 2 the caller's factors (n doubles, caller's numbering; copied).  _get_scaling returns the factors the last
+ * on the device (the algorithm of MC77), 2 the caller's factors (n doubles, caller's numbering; copied), 3 maximum-product
+ * matching scaling (the job of MC64: Duff & Koster 2001; host algorithm, recomputed at every factorisation while selected).  _get_scaling returns the factors the last
  * factorisation used.  Together they give the MA97 call protocol its meaning: control.scaling > 0 => compute and hand back in
  * scale[], control.scaling == 0 with scale != NULL => reuse the caller-held factors, else none (IpMa97SolverInterface.cpp:641-678). */
 int  mi355x_kkt_set_scaling(mi355x_kkt_handle h, int mode, const double* user_factors);
@@ -181,6 +183,11 @@ int  mi355x_kkt_get_scaling(mi355x_kkt_handle h, double* factors_out);
  * the solver, i.e. Ipopt's TSymScalingMethod (IpTSymLinearSolver.cpp:429-441,511-514; cf. IpMc19TSymScalingMethod.cpp:100-204). */
 int  mi355x_kkt_ruiz_scaling(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int index_base,
                              int sweeps, double* factors_out);
+/* Stand-alone, HOST (no GPU needed): symmetric maximum-product matching scaling of a triplet matrix -- what HSL's MC64 provides
+ * to MA97 / SPRAL (`ma97_scaling mc64`, `spral_scaling matching`): |s_i a_ij s_j| <= 1 with equality on a maximum transversal.
+ * *num_unmatched (may be NULL) = structural rank deficiency. */
+int  mi355x_kkt_matching_scaling(int n, int nnz, const int* irn, const int* jcn, const double* a, int index_base,
+                                 double* factors_out, int* num_unmatched);
 /* The columns (caller's index base) whose pivot was numerically zero in the last factorisation, ascending; *count = how
  * many there are (idx may be NULL / shorter).  This is what DetermineDependentRows needs
  * (IpSparseSymLinearSolverInterface.hpp:240-255; MUMPS' PIVNUL_LIST, IpMumpsSolverInterface.cpp:617-709). */

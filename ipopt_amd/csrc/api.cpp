@@ -3,6 +3,8 @@
 #include "../../include/mi355x_kkt.h"
 #include "symbolic.h"
 #include "numeric.h"
+#include "matching_scaling.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -124,6 +126,38 @@ int mi355x_kkt_ruiz_scaling(int device, int n, int nnz, const int* irn, const in
     if (n < 0 || nnz < 0 || !factors || (nnz > 0 && (!irn || !jcn || !a))) return MI355X_KKT_FATAL;
     try { std::string err; return Numeric::ruiz_triplet(device, n, nnz, irn, jcn, a, index_base, sweeps > 0 ? sweeps : 4, factors, err) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL; }
     catch (...) { return MI355X_KKT_FATAL; }
+}
+
+/* stand-alone, HOST: maximum-product matching scaling (the job of MC64) of a symmetric triplet matrix; duplicates are summed,
+ * either triangle accepted.  Works without a GPU (it is an analysis-type algorithm like the ordering). */
+int mi355x_kkt_matching_scaling(int n, int nnz, const int* irn, const int* jcn, const double* a, int index_base, double* factors, int* num_unmatched)
+{
+    if (n < 0 || nnz < 0 || !factors || (nnz > 0 && (!irn || !jcn || !a))) return MI355X_KKT_FATAL;
+    try {
+        // canonical lower entries, duplicates summed, then the full symmetric pattern by columns
+        std::vector<std::pair<long long, double>> e; e.reserve(nnz);
+        for (int t = 0; t < nnz; ++t) {
+            int i = irn[t] - index_base, j = jcn[t] - index_base;
+            if (i < 0 || j < 0 || i >= n || j >= n) return MI355X_KKT_FATAL;
+            if (i < j) std::swap(i, j);
+            e.emplace_back((long long)j * n + i, a[t]);
+        }
+        std::sort(e.begin(), e.end(), [](const std::pair<long long, double>& x, const std::pair<long long, double>& y) { return x.first < y.first; });
+        std::vector<int> li, lj; std::vector<double> lv;
+        for (size_t q = 0; q < e.size(); ++q) {
+            if (!li.empty() && (long long)lj.back() * n + li.back() == e[q].first) lv.back() += e[q].second;
+            else { lj.push_back((int)(e[q].first / n)); li.push_back((int)(e[q].first % n)); lv.push_back(e[q].second); }
+        }
+        std::vector<int> ptr(n + 1, 0);
+        for (size_t q = 0; q < li.size(); ++q) { ptr[lj[q] + 1]++; if (li[q] != lj[q]) ptr[li[q] + 1]++; }
+        for (int j = 0; j < n; ++j) ptr[j + 1] += ptr[j];
+        std::vector<int> idx(ptr[n]), fill(ptr.begin(), ptr.end() - 1); std::vector<double> av(ptr[n]);
+        for (size_t q = 0; q < li.size(); ++q) {
+            idx[fill[lj[q]]] = li[q]; av[fill[lj[q]]++] = std::fabs(lv[q]);
+            if (li[q] != lj[q]) { idx[fill[li[q]]] = lj[q]; av[fill[li[q]]++] = std::fabs(lv[q]); }
+        }
+        return matching_scaling(n, ptr.data(), idx.data(), av.data(), factors, num_unmatched) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL;
+    } catch (...) { return MI355X_KKT_FATAL; }
 }
 
 /* DetermineDependentRows support (IpSparseSymLinearSolverInterface.hpp:240-255; MUMPS' null-pivot list,

@@ -36,15 +36,17 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
                                     false, 1e-8, "Relative threshold u of the 1x1 / 2x2 pivot tests (MA27/MA57 tests against the whole front column).");
    roptions->AddBoundedNumberOption("mi355x_pivtolmax", "Maximum pivot tolerance for the MI355X LDL^T solver.", 0.,
                                     true, 0.5, false, 1e-4, "IncreaseQuality raises the tolerance u <- u^0.75 up to this value.");
-   roptions->AddStringOption2("mi355x_scaling", "Symmetric equilibration of the KKT matrix on the device.", "ruiz", "none",
-                              "no scaling", "ruiz", "4 sweeps of inf-norm Ruiz equilibration");
+   roptions->AddStringOption3("mi355x_scaling", "Symmetric scaling of the KKT matrix inside the backend.", "ruiz", "none",
+                              "no scaling", "ruiz", "4 sweeps of inf-norm Ruiz equilibration on the device (the algorithm of MC77)", "matching",
+                              "maximum-product matching scaling (the job of MC64), recomputed on the host at every factorisation");
    roptions->AddStringOption3("mi355x_ordering", "Fill-reducing ordering.", "nd", "nd",
                               "nested dissection with minimum-degree leaves", "md", "minimum degree", "natural", "identity");
    roptions->AddStringOption2("mi355x_matching", "Pre-pair zero-diagonal rows into 2x2-capable supernodes.", "yes", "no", "",
                               "yes", "");
-   roptions->AddStringOption2("mi355x_outer_scaling", "Equilibrate through Ipopt's TSymScalingMethod hook instead of inside the backend.", "no",
-                              "no", "the backend equilibrates internally (mi355x_scaling)", "yes",
-                              "Ruiz factors computed on the device are applied by TSymLinearSolver, subject to linear_scaling_on_demand");
+   roptions->AddStringOption3("mi355x_outer_scaling", "Scale through Ipopt's TSymScalingMethod hook instead of inside the backend.", "no",
+                              "no", "the backend scales internally (mi355x_scaling)", "yes",
+                              "Ruiz factors computed on the device are applied by TSymLinearSolver, subject to linear_scaling_on_demand", "matching",
+                              "same with maximum-product matching (MC64-style) factors");
    roptions->AddLowerBoundedIntegerOption("mi355x_nemin", "Supernode amalgamation parameter.", 1, 8, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_nd_leaf", "Nested dissection leaf size.", 8, 32, "");
    roptions->AddLowerBoundedIntegerOption("mi355x_max_sn_cols", "Maximum columns per supernode.", 2, 64, "");
@@ -79,7 +81,7 @@ void Mi355xSolverInterface::ReadNumericOptions(const OptionsList& options, const
       }
       if( options.GetStringValue("mi355x_scaling", sv, prefix) )
       {
-         kopts.scaling = (sv == "none") ? 0 : 1;
+         kopts.scaling = (sv == "none") ? 0 : (sv == "matching" ? 3 : 1);
       }
       if( options.GetStringValue("mi355x_ordering", sv, prefix) )
       {
@@ -482,16 +484,20 @@ SmartPtr<SymLinearSolver> Mi355xAlgorithmBuilder::SymLinearSolverFactory(const J
    // reference's own control -- with the default linear_scaling_on_demand=yes it only switches on once Ipopt asks for better
    // quality (IpTSymLinearSolver.cpp:429-441), exactly like mc19 does when HSL is linked (IpAlgBuilder.cpp:530-537)
    std::string sv;
-   bool outer = false;
+   bool outer = false, matching = false;
    try
    {
-      outer = options.GetStringValue("mi355x_outer_scaling", sv, prefix) && sv == "yes";
+      if( options.GetStringValue("mi355x_outer_scaling", sv, prefix) )
+      {
+         outer = sv != "no";
+         matching = sv == "matching";
+      }
    }
    catch( ... )
    { }
    if( outer )
    {
-      scaling = new Mi355xTSymScalingMethod();
+      scaling = new Mi355xTSymScalingMethod(matching);
    }
    return new TSymLinearSolver(iface, scaling);
 }

@@ -16,8 +16,9 @@ namespace Ipopt
 class Mi355xTSymScalingMethod: public TSymScalingMethod
 {
 public:
-   Mi355xTSymScalingMethod(int device = -1, int sweeps = 4)
-      : device_(device), sweeps_(sweeps)
+   /** matching = false: Ruiz equilibration on the device; true: maximum-product matching scaling (MC64-style, host) */
+   Mi355xTSymScalingMethod(bool matching = false, int device = -1, int sweeps = 4)
+      : matching_(matching), device_(device), sweeps_(sweeps)
    { }
    virtual ~Mi355xTSymScalingMethod()
    { }
@@ -28,11 +29,16 @@ public:
    virtual bool ComputeSymTScalingFactors(Index n, Index nnz, const Index* airn, const Index* ajcn, const Number* a,
                                           Number* scaling_factors)
    {
+      if( matching_ )
+      {
+         return mi355x_kkt_matching_scaling(n, nnz, airn, ajcn, a, 1, scaling_factors, NULL) == MI355X_KKT_SUCCESS;
+      }
       return mi355x_kkt_ruiz_scaling(device_, n, nnz, airn, ajcn, a, 1, sweeps_, scaling_factors) == MI355X_KKT_SUCCESS;
    }
 private:
    Mi355xTSymScalingMethod(const Mi355xTSymScalingMethod&);
    void operator=(const Mi355xTSymScalingMethod&);
+   bool matching_;
    int device_, sweeps_;
 };
 

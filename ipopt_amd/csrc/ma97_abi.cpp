@@ -100,11 +100,13 @@ void ma97_factor_d(int /*matrix_type*/, const int /*ptr*/[], const int /*row*/[]
         if ((!k->analysed || !k->with_values) && !do_analyse(k, control, val, info)) return;
         if (control && control->u > 0 && control->u != k->u) { mi355x_kkt_set_pivtol(k->h, control->u > 0.5 ? 0.5 : control->u); k->u = control->u; }
         // scaling semantics of the MA97 call protocol (IpMa97SolverInterface.cpp:641-652,707):
-        //   control.scaling  > 0               compute factors (HSL would run MC64 / MC77 / MC30; here: Ruiz equilibration on the
-        //                                      device) and WRITE them to scale[n]
+        //   control.scaling  > 0               compute factors (matching scaling for MC64, Ruiz equilibration on the device for
+        //                                      MC77 / MC30) and WRITE them to scale[n]
         //   control.scaling == 0, scale given  apply the caller-held factors ("reuse")
         //   control.scaling == 0, scale NULL   no scaling
-        const int mode = (control && control->scaling > 0) ? 1 : (scale ? 2 : 0);
+        // HSL's choices map onto ours: 1 (MC64) and 3 (MC64 from the matching ordering) -> matching scaling; 2 (MC77) and 4 (MC30) ->
+        // Ruiz equilibration (MC77 IS Ruiz's algorithm)
+        const int mode = (control && control->scaling > 0) ? ((control->scaling == 1 || control->scaling == 3) ? 3 : 1) : (scale ? 2 : 0);
         if (mi355x_kkt_set_scaling(k->h, mode, scale) != 0) { info->flag = -1; return; }
         double* buf = mi355x_kkt_values_buffer(k->h);
         if (!buf) { info->flag = -1; return; }
@@ -114,7 +116,7 @@ void ma97_factor_d(int /*matrix_type*/, const int /*ptr*/[], const int /*row*/[]
         if (fkeep) *fkeep = k;
         fill_info(k, info);
         if (st == MI355X_KKT_FATAL) { info->flag = -1; return; }
-        if (scale && mode == 1 && mi355x_kkt_get_scaling(k->h, scale) != 0) { info->flag = -1; return; }   // hand the factors back for reuse
+        if (scale && (mode == 1 || mode == 3) && mi355x_kkt_get_scaling(k->h, scale) != 0) { info->flag = -1; return; }   // hand the factors back for reuse
         if (st == MI355X_KKT_SINGULAR) info->flag = (control && control->action) ? 7 : -7;
         else info->flag = 0;
     } catch (...) { info->flag = -1; }

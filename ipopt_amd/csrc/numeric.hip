@@ -34,6 +34,7 @@
 #include <string>
 #include <algorithm>
 #include "numeric.h"
+#include "matching_scaling.h"
 
 namespace mi355x {
 
@@ -1646,14 +1647,34 @@ public:
     bool set_scaling(int mode, const double* user) {
         DeviceGuard guard(dev);
         if (!ready) { err_ = "set_scaling: solver not set up"; return false; }
-        if (mode < 0 || mode > 2 || (mode == 2 && !user)) { err_ = "set_scaling: mode 0 (none), 1 (ruiz) or 2 (user factors, non-null)"; return false; }
+        if (mode < 0 || mode > 3 || (mode == 2 && !user)) { err_ = "set_scaling: mode 0 (none), 1 (ruiz), 2 (user factors, non-null) or 3 (matching)"; return false; }
         if (mode == 2) {
             if (!d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
             HIPCHK(hipMemcpyAsync(d_user_scale, user, (size_t)S->n * sizeof(double), hipMemcpyHostToDevice, stream));
             HIPCHK(hipStreamSynchronize(stream));      // `user` is the caller's pageable memory
         }
+        if (mode == 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         if (mode != opt.scaling && g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }     // the captured sequence differs
         opt.scaling = mode;
+        return true;
+    }
+    // scaling mode 3: maximum-product matching scaling (MC64-style, matching_scaling.cpp) of the values now in V.tvals.  Host
+    // algorithm, like the analysis: gather on the device, one D2H of the nnz(A) summed values, the matching, one H2D of n
+    // factors -- which the factorisation then applies exactly like caller-supplied ones.
+    bool compute_matching_scaling() {
+        const Symbolic& Sy = *S;
+        hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        std::vector<double> av(std::max(Sy.nnz_a, 1));
+        HIPCHK(hipMemcpyAsync(av.data(), V.aval, (size_t)Sy.nnz_a * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<double> absval(Sy.rslot_idx.size()), sp(std::max(Sy.n, 1)), so(std::max(Sy.n, 1));
+        for (size_t p = 0; p < absval.size(); ++p) absval[p] = std::fabs(av[Sy.rslot_idx[p]]);
+        int unmatched = 0;
+        if (!matching_scaling(Sy.n, Sy.rslot_ptr.data(), Sy.rslot_col.data(), absval.data(), sp.data(), &unmatched)) { err_ = "matching scaling failed"; return false; }
+        for (int i = 0; i < Sy.n; ++i) so[Sy.perm[i]] = sp[i];
+        if (opt.verbose) fprintf(stderr, "[mi355x_kkt] matching scaling: %d unmatched columns\n", unmatched);
+        HIPCHK(hipMemcpyAsync(d_user_scale, so.data(), (size_t)Sy.n * sizeof(double), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));          // `so` is about to go out of scope
         return true;
     }
     // the symmetric scaling of the last factorisation, original numbering (what MA97 writes into scale[])
@@ -2178,6 +2199,8 @@ public:
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n)) return false;
         V.qstat = d_stats + 4;
+        if (opt.scaling == 3) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
+        else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
         if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 16)) return false; }
@@ -2325,7 +2348,7 @@ public:
     void enqueue_scaling() {
         const Symbolic& Sy = *S; const int n = Sy.n;
         LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
-        if (opt.scaling == 2) LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);
+        if (opt.scaling >= 2) LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);     // 2: the caller's factors, 3: matching (computed just before)
         else if (opt.scaling) {
             LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
             LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
@@ -2369,6 +2392,7 @@ public:
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
             have_values = true;
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
+        if (opt.scaling == 3 && Sy.n > 0 && !compute_matching_scaling()) return false;
         HIPCHK(hipEventRecord(ev0, stream));
         // A factorisation with look-ahead forks onto the second stream: it is launched eagerly (measured equal to the graph
         // replay on these ~10^3-launch sequences, whose kernels are long), because a two-stream hipGraph replays up to 1.5x
@@ -2542,6 +2566,7 @@ public:
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
             have_values = true;
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
+        if (opt.scaling == 3 && n > 0 && !compute_matching_scaling()) return false;
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
         hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);

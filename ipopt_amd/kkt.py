@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
     "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
-    "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
+    "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
                 "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big", "fwd_big_upd", "bwd_big_dot"]
@@ -117,6 +117,7 @@ def load_library():
     lib.mi355x_kkt_set_scaling.argtypes = [vp, C.c_int, vp]
     lib.mi355x_kkt_get_scaling.argtypes = [vp, vp]
     lib.mi355x_kkt_ruiz_scaling.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.mi355x_kkt_matching_scaling.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, ip]
     lib.mi355x_kkt_zero_pivots.argtypes = [vp, vp, C.c_int, ip]
     lib.mi355x_kkt_assembly_define.argtypes = [vp, C.c_int, vp, vp]
     lib.mi355x_kkt_assembly_buffer.argtypes = [vp, C.c_int]

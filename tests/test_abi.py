@@ -62,3 +62,21 @@ def test_no_cpu_fallback_factor_fails_loudly():
     s.values()[:] = v
     with pytest.raises(ipopt_amd.KKTError, match="no HIP device|no CPU fallback|no usable HIP"):
         s.multi_solve(True, np.ones(2))
+
+
+def test_matching_scaling_is_a_maximum_product_scaling():
+    """mi355x_kkt_matching_scaling (host, the job of MC64: Duff & Koster 2001): |s_i a_ij s_j| <= 1 everywhere, = 1 on a
+    transversal (so every row and column of the scaled matrix has inf-norm exactly 1), also with zero diagonals and entries
+    spread over 16 orders of magnitude -- the KKT shape MA97/SPRAL use it for."""
+    import numpy as np
+    from ipopt_amd import kkt
+    from tests.support import kktgen
+    lib = kkt.load_library()
+    for gen in (lambda: kktgen.lukvl_like(400, seed=2, sigma_scale=1e3), lambda: kktgen.grid_kkt(9, 8, dof=2, ncon=2, seed=4, sigma_exp=8.0)):
+        n, r, c, v, _ = gen()
+        s = np.zeros(n); un = kkt.C.c_int(-1)
+        assert lib.mi355x_kkt_matching_scaling(n, len(v), r.ctypes.data, c.ctypes.data, v.ctypes.data, 1, s.ctypes.data, kkt.C.byref(un)) == 0
+        K = abs(kktgen.to_scipy(n, r, c, v)).multiply(s[:, None]).multiply(s[None, :]).tocsr()
+        assert un.value == 0 and np.all(s > 0)
+        assert K.max() <= 1.0 + 1e-10
+        assert np.allclose(K.max(axis=1).toarray().ravel(), 1.0, rtol=1e-10)

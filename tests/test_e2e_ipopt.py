@@ -191,3 +191,17 @@ def test_outer_scaling_through_the_reference_scaling_hook(on_demand, tmp_path, g
     gsum = json.load(open(os.path.join(golden_dir, "mbndry1_100.summary")))
     assert summ[0]["iterations"] == gsum["iterations"]
     assert abs(summ[0]["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
+
+
+@pytest.mark.skipif(not os.path.exists(STOCK), reason="oracle/_ref not built")
+@pytest.mark.parametrize("scaling", ["mc64", "mc77"])
+def test_hsllib_route_with_explicit_ma97_scaling(scaling, tmp_path, golden_dir):
+    """Route B2 with the scaling the MA97 adapter can request explicitly: `ma97_scaling mc64` (control.scaling = 1 -> our
+    maximum-product matching scaling, factors written to scale[]) and `mc77` (= Ruiz equilibration on the device)."""
+    import ipopt_amd
+    (tmp_path / "ipopt.opt").write_text(f"linear_solver ma97\nhsllib {ipopt_amd.library_path()}\nma97_scaling {scaling}\n")
+    iters, summ, out = _run(STOCK, ["MBndryCntrl1", "100", "--solver", "stock", "--optfile", "ipopt.opt"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    gsum = json.load(open(os.path.join(golden_dir, "mbndry1_100.summary")))
+    assert summ[0]["iterations"] == gsum["iterations"]
+    assert abs(summ[0]["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))

@@ -283,3 +283,19 @@ def test_chain_lookahead_schedule_is_bitwise_identical(monkeypatch):
     for _ in range(3):                                   # repeated factorisations: no race between the streams
         x2 = b.copy(); s1.multi_solve(True, x2)
         assert np.array_equal(x1, x2)
+
+
+def test_matching_scaling_mode():
+    """scaling mode 3: maximum-product matching scaling (MC64-style, host) computed from the values of each factorisation and
+    applied on the device like caller-supplied factors; the factors handed back equal the stand-alone routine's"""
+    n, r, c, v, neg = kktgen.grid_kkt(20, 18, dof=2, ncon=1, seed=41, sigma_exp=8.0)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg, scaling=3)
+    assert st == 0 and sres(K, x, b) <= RES_TOL
+    f = s.get_scaling()
+    ref = np.zeros(n)
+    assert kkt.load_library().mi355x_kkt_matching_scaling(n, len(v), r.ctypes.data, c.ctypes.data, v.ctypes.data, 1, ref.ctypes.data, None) == 0
+    assert np.allclose(f, ref, rtol=1e-12)
+    Ks = abs(K).multiply(f[:, None]).multiply(f[None, :]).tocsr()
+    assert Ks.max() <= 1.0 + 1e-10 and np.allclose(Ks.max(axis=1).toarray().ravel(), 1.0, rtol=1e-10)
