@@ -25,4 +25,11 @@ run mbndry1_8 MBndryCntrl1 8 rec
 run lukvle1_10000 LukVlE1 10000 norec
 run mbndry1_100 MBndryCntrl1 100 norec
 run lukvle1_1000000 LukVlE1 1000000 norec
+# more problem classes of examples/ScalableProblems (inequalities, other PDE controls, 3-D): iteration tables only
+run lukvli1_10000 LukVlI1 10000 norec
+run lukvle5_10000 LukVlE5 10000 norec
+run mbndry2_100 MBndryCntrl2 100 norec
+run mdist1_100 MDistCntrl1 100 norec
+run mbndry3d_12 MBndryCntrl_3D 12 norec
+run mbndry1_300 MBndryCntrl1 300 norec
 ls -la

@@ -28,7 +28,9 @@ def run_driver(problem, n, solver="mi355x"):
 @pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built (needs /root/reference at build time)")
 @pytest.mark.parametrize("name,problem,n", [("hs071", "hs071", 0), ("lukvle1_100", "LukVlE1", 100), ("mbndry1_8", "MBndryCntrl1", 8),
                                             ("lukvle1_10000", "LukVlE1", 10000), ("mbndry1_100", "MBndryCntrl1", 100),
-                                            ("lukvle1_1000000", "LukVlE1", 1000000)])     # the north-star target instance
+                                            ("lukvle1_1000000", "LukVlE1", 1000000),     # the north-star target instance
+                                            ("lukvli1_10000", "LukVlI1", 10000), ("lukvle5_10000", "LukVlE5", 10000), ("mbndry2_100", "MBndryCntrl2", 100),
+                                            ("mdist1_100", "MDistCntrl1", 100), ("mbndry3d_12", "MBndryCntrl_3D", 12), ("mbndry1_300", "MBndryCntrl1", 300)])
 def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_dir):
     gold = open(os.path.join(golden_dir, name + ".iters")).read().splitlines()
     gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
