@@ -62,6 +62,14 @@ struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliase
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
 struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
 
+// Sync-free triangular solves along pure in-place separator chains (a run of consecutive tree levels whose fronts are all chain
+// links): ONE launch per sweep for the whole run instead of 1 (forward) / 2 (backward) launches per level.  One workgroup per link
+// (+ one per 64 rows beyond the chain in the forward sweep); a link's workgroup waits on a flag for each earlier (forward) / later
+// (backward) link, applies that link's 64 x 64 block of the panel to its own rows, then solves with its pivot block and raises its
+// own flag -- the point-to-point pipeline of a "synchronisation-free" sparse triangular solve (Liu et al., Euro-Par 2016).
+struct ChainLink { long long panel_off, minv_off; int c0, k, ldp, s, r0, koff, pad0, pad1; };      // links of all chains, chain by chain, bottom link first
+struct ChainDesc { long long cvb; int link0, nlinks, tail, ktot, wg0f, wg0b, pad0, pad1; };         // cvb: chain vector base, ktot: columns of the chain
+
 struct DevView {
     // symbolic
     const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
@@ -104,6 +112,8 @@ struct DevView {
     int* colfail;           // per column of a BIG front: 1 once some multiplier of L21 exceeded 1/u (a posteriori test, k_big_trsm)
     int* qstat;             // [0]: some pivot decision of this factorisation would differ at u = pivtol2
     double* cnorm;          // inf-norm of every column of the (scaled) INPUT matrix, permuted numbering: scale of the zero-pivot test
+    const ChainLink* chlink; const ChainDesc* chdesc;     // chain solve tables
+    int* sflag_f; int* sflag_b; int* sepoch;              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
@@ -1203,6 +1213,148 @@ __global__ __launch_bounds__(256) void k_bwd_grp(DevView V, int list_off)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// sync-free chain sweeps (see ChainLink / ChainDesc)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bump_epoch(int* e) { if (threadIdx.x == 0 && blockIdx.x == 0) *e += 1; }
+__device__ __forceinline__ void chain_wait(const int* flag, const int epoch, int* err)
+{
+    if (threadIdx.x == 0) {
+        // bounded: a producer that never shows up (it cannot, all workgroups of the launch are resident) must not hang the GPU
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > (1 << 24)) { *err = 1; break; }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void chain_signal(int* flag, const int epoch)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // every wavefront publishes its own stores
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int desc0, int ndesc)
+{
+    __shared__ double acc[64], ys[64], bp[64], part[4][64];
+    const int tid = threadIdx.x;
+    ChainDesc C = V.chdesc[desc0];
+    for (int q = 1; q < ndesc; ++q) { const ChainDesc Cn = V.chdesc[desc0 + q]; if ((int)blockIdx.x >= Cn.wg0f) C = Cn; }
+    const int w = (int)blockIdx.x - C.wg0f;
+    const int epoch = *V.sepoch;
+    const bool is_link = w < C.nlinks;
+    const ChainLink Me = V.chlink[C.link0 + (is_link ? w : C.nlinks - 1)];
+    const int roff = is_link ? Me.koff : C.ktot + 64 * (w - C.nlinks);       // my rows inside the chain vector
+    const int rows = is_link ? Me.k : min(64, C.tail - 64 * (w - C.nlinks));
+    double* cvp = V.cvec + C.cvb;
+    if (tid < 64) acc[tid] = (tid < rows) ? cvp[roff + tid] + (is_link ? V.xw[Me.c0 + tid] : 0.0) : 0.0;
+    __syncthreads();
+    const int nprev = is_link ? w : C.nlinks;
+    const int p = tid & 63, qq = tid >> 6;
+    for (int i = 0; i < nprev; ++i) {
+        const ChainLink Li = V.chlink[C.link0 + i];
+        chain_wait(&V.sflag_f[Li.s], epoch, V.sepoch + 1);
+        if (tid < 64) ys[tid] = (tid < Li.k) ? V.ybuf[Li.c0 + tid] : 0.0;
+        __syncthreads();
+        const double* Lb = V.L + Li.panel_off + (roff - Li.koff) + p;          // my rows of panel i
+        double a0 = 0.0, a1 = 0.0;
+        if (p < rows) {
+            int q = qq;
+            for (; q + 4 < Li.k; q += 8) { a0 += Lb[(size_t)q * Li.ldp] * ys[q]; a1 += Lb[(size_t)(q + 4) * Li.ldp] * ys[q + 4]; }
+            if (q < Li.k) a0 += Lb[(size_t)q * Li.ldp] * ys[q];
+        }
+        part[qq][p] = a0 + a1;
+        __syncthreads();
+        if (tid < 64) acc[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
+        __syncthreads();
+    }
+    if (!is_link) { if (tid < rows) cvp[roff + tid] = acc[tid]; return; }
+    const int k = Me.k, c0 = Me.c0;
+    if (tid < k) bp[tid] = acc[V.lperm[c0 + tid]];
+    __syncthreads();
+    const double* Mg = V.minv + Me.minv_off;
+    {   // y = Minv (P b): 4 threads per row
+        const int part4 = tid & 3;
+        for (int q = tid >> 2; q < k; q += 64) {
+            double a = 0.0;
+            for (int pp = part4; pp <= q; pp += 4) a += Mg[q + (size_t)pp * k] * bp[pp];
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+            if (part4 == 0) ys[q] = a;
+        }
+    }
+    __syncthreads();
+    if (tid < k) {
+        const int pt = V.ptype[c0 + tid];
+        double z;
+        if (pt == 1) z = ys[tid] * V.dinv[c0 + tid];
+        else if (pt == 2) z = V.dinv[c0 + tid] * ys[tid] + V.doff[c0 + tid] * ys[tid + 1];
+        else z = V.doff[c0 + tid - 1] * ys[tid - 1] + V.dinv[c0 + tid] * ys[tid];
+        V.zb[c0 + tid] = z;
+        V.ybuf[c0 + tid] = ys[tid];
+    }
+    chain_signal(&V.sflag_f[Me.s], epoch);
+}
+__global__ __launch_bounds__(256) void k_bwd_chain(DevView V, int desc0, int ndesc)
+{
+    __shared__ double ws[64], xs[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ChainDesc C = V.chdesc[desc0];
+    for (int q = 1; q < ndesc; ++q) { const ChainDesc Cn = V.chdesc[desc0 + q]; if ((int)blockIdx.x >= Cn.wg0b) C = Cn; }
+    // the TOP link gets the first workgroup of its chain: it is the head of the dependency chain
+    const int j = C.nlinks - 1 - ((int)blockIdx.x - C.wg0b);
+    const int epoch = *V.sepoch;
+    const ChainLink Me = V.chlink[C.link0 + j];
+    const int k = Me.k, c0 = Me.c0;
+    if (tid < 64) ws[tid] = (tid < k) ? V.zb[c0 + tid] : 0.0;
+    __syncthreads();
+    // rows beyond the chain: their solution is known since the levels above
+    const int toff = C.ktot - Me.koff;
+    const double* Lt = V.L + Me.panel_off + toff;
+    for (int base = 0; base < C.tail; base += 256) {
+        const int nrow = min(256, C.tail - base);
+        xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[Me.r0 + toff + base + tid]] : 0.0;
+        __syncthreads();
+        for (int pb = wave * 4; pb < k; pb += 16) {           // 4 columns per pass: their loads are all in flight together
+            double t[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int i = lane; i < nrow; i += 64) {
+                const double x = xs[i];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (pb + u < k) t[u] += Lt[base + i + (size_t)(pb + u) * Me.ldp] * x;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { t[u] = wave_sum(t[u]); if (lane == 0 && pb + u < k) ws[pb + u] -= t[u]; }
+        }
+        __syncthreads();
+    }
+    for (int r = C.nlinks - 1; r > j; --r) {                  // later links of the chain, top first
+        const ChainLink Lr = V.chlink[C.link0 + r];
+        chain_wait(&V.sflag_b[Lr.s], epoch, V.sepoch + 1);
+        if (tid < 64) xs[tid] = (tid < Lr.k) ? V.xw[Lr.c0 + tid] : 0.0;
+        __syncthreads();
+        const double* Lb = V.L + Me.panel_off + (Lr.koff - Me.koff) + lane;
+        const double xv = xs[lane];
+        for (int q = wave; q < k; q += 4) {
+            double v = (lane < Lr.k) ? Lb[(size_t)q * Me.ldp] * xv : 0.0;
+            v = wave_sum(v);
+            if (lane == 0) ws[q] -= v;
+        }
+        __syncthreads();
+    }
+    const double* Mg = V.minv + Me.minv_off;
+    {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column
+        const int part4 = tid & 3;
+        for (int pp = tid >> 2; pp < k; pp += 64) {
+            double a = 0.0;
+            for (int q = pp + part4; q < k; q += 4) a += Mg[q + (size_t)pp * k] * ws[q];
+            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+            if (part4 == 0) V.xw[c0 + V.lperm[c0 + pp]] = a;
+        }
+    }
+    chain_signal(&V.sflag_b[Me.s], epoch);
+}
+
 // ================================================================================================
 // BIG fronts (order > 128): the front stays in HBM/L2 -- panel (m x k, k <= 66) in the L storage, the
 // (m-k)^2 contribution block in the cb arena -- and is processed by four launches per tree level:
@@ -1688,6 +1840,10 @@ public:
     }
     std::vector<int> big_maxm, big_maxk, big_tiles, big_tiles64, big_last0, big_last1;
     std::vector<char> lv_asm_skip;      // every big front of the level is a pure in-place chain link: no assembly launch at all
+    // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
+    struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b; };
+    std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
+    bool chain_solve = true;
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
@@ -2015,6 +2171,57 @@ public:
                 }
                 lv_allsolo[lv] = all ? 1 : 0;
             }
+        // ---- sync-free chain sweeps: segments of >= 4 consecutive levels whose fronts are all pure in-place chain links ----
+        std::vector<ChainLink> chl; std::vector<ChainDesc> chd;
+        chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
+        chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
+        if (!multi && !Sy.solve_group && chain_solve) {
+            auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
+            auto Mr = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
+            auto pure = [&](int sn) { return Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1 && Kc(sn) <= 64; };
+            std::vector<char> lvok(Sy.num_levels, 0);
+            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                const int a = Sy.level_ptr[(size_t)lv * FC_COUNT], b = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT];
+                bool ok = b > a;
+                for (int q = a; q < b && ok; ++q) { const int sn = Sy.level_sn[q]; ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1; }
+                lvok[lv] = ok ? 1 : 0;
+            }
+            std::vector<int> alias_parent(Sy.num_sn, -1);
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0) alias_parent[Sy.alias_child[sn]] = sn;
+            for (int lv = 0; lv < Sy.num_levels; ) {
+                if (!lvok[lv]) { ++lv; continue; }
+                int e = lv;
+                auto cnt = [&](int l) { return Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)l * FC_COUNT]; };
+                while (e + 1 < Sy.num_levels && lvok[e + 1] && cnt(e + 1) == cnt(lv)) ++e;
+                if (e - lv + 1 >= 4) {
+                    ChainSeg sg{lv, e, (int)chd.size(), 0, 0, 0};
+                    bool good = true;
+                    const size_t chl0 = chl.size(), chd0 = chd.size();
+                    for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT] && good; ++q) {
+                        ChainDesc D{}; D.link0 = (int)chl.size(); D.cvb = Sy.cv_off[Sy.level_sn[q]]; D.wg0f = sg.nwg_f; D.wg0b = sg.nwg_b;
+                        int koff = 0, sn = Sy.level_sn[q], last = sn;
+                        for (int l = lv; l <= e && sn >= 0; ++l, sn = alias_parent[sn]) {
+                            if (Sy.sn_level[sn] != l || Sy.cv_off[sn] != D.cvb + koff) { good = false; break; }
+                            ChainLink L{}; L.panel_off = Sy.panel_off[sn]; L.minv_off = Sy.minv_off[sn]; L.c0 = Sy.sn_colptr[sn]; L.k = Kc(sn); L.ldp = Sy.sn_ldp[sn];
+                            L.s = sn; L.r0 = Sy.sn_rowptr[sn]; L.koff = koff;
+                            chl.push_back(L); koff += L.k; last = sn; D.nlinks++;
+                        }
+                        if (D.nlinks != e - lv + 1) good = false;
+                        D.ktot = koff; D.tail = Mr(last) - Kc(last);
+                        // in-place construction: every link's rows = its columns + the later links' columns + the common tail
+                        for (int t = 0; t < D.nlinks && good; ++t) { const ChainLink& L = chl[D.link0 + t]; if (Mr(L.s) != D.ktot - L.koff + D.tail) good = false; }
+                        sg.nwg_f += D.nlinks + (D.tail + 63) / 64; sg.nwg_b += D.nlinks;
+                        chd.push_back(D);
+                    }
+                    sg.ndesc = (int)chd.size() - sg.desc0;
+                    if (good && sg.nwg_f <= 1024) { seg_at_lv0[lv] = seg_at_lv1[e] = (int)chain_segs.size(); chain_segs.push_back(sg); }
+                    else { chl.resize(chl0); chd.resize(chd0); }
+                }
+                lv = e + 1;
+            }
+            if (opt.verbose) { int nl = 0; for (auto& sg : chain_segs) nl += sg.lv1 - sg.lv0 + 1; fprintf(stderr, "[mi355x_kkt] sync-free chain sweeps: %d segments covering %d of %d levels\n", (int)chain_segs.size(), nl, Sy.num_levels); }
+        }
+        if (!upload(chl, &V.chlink) || !upload(chd, &V.chdesc)) return false;
         // chain-group tables: for every BIG front the links of its group up to and including itself
         std::vector<GroupLink> gt;
         std::vector<int> gbase_of(Sy.num_sn, 0), gcols_of(Sy.num_sn, 0);
@@ -2197,7 +2404,8 @@ public:
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
-            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n)) return false;
+            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
+            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         if (opt.scaling == 3) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
@@ -2445,7 +2653,13 @@ public:
                 LAUNCH(KK_SOLVE_PERM, k_refine_spmv, dim3(grid1d(n)), dim3(256), 0, stream, V);
             }
             auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
-            for (int lv = 0; lv < Sy.num_levels; ++lv)
+            if (!chain_segs.empty()) LAUNCH(KK_SOLVE_PERM, k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
+            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                if (seg_at_lv0[lv] >= 0) {      // a run of pure chain levels: one sync-free launch for all of them
+                    const ChainSeg& sg = chain_segs[seg_at_lv0[lv]];
+                    LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(256), 0, stream, V, sg.desc0, sg.ndesc);
+                    lv = sg.lv1; continue;
+                }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
@@ -2458,7 +2672,13 @@ public:
                            else { LAUNCH(KK_FWD_BIG, k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, 0);
                                   LAUNCH(KK_FWD_BIG_UPD, k_fwd_grp_upd, dim3((big_maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); } }
                 }
-            for (int lv = Sy.num_levels - 1; lv >= 0; --lv)
+            }
+            for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
+                if (seg_at_lv1[lv] >= 0) {
+                    const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
+                    LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(256), 0, stream, V, sg.desc0, sg.ndesc);
+                    lv = sg.lv0; continue;
+                }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
@@ -2470,6 +2690,7 @@ public:
                            LAUNCH(KK_BWD_BIG_DOT, k_bwd_grp_dot, dim3((big_maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
                            LAUNCH(KK_BWD_BIG, k_bwd_grp, dim3(ng), dim3(256), 0, stream, V, g0); }
                 }
+            }
         }
         if (nref > 0) LAUNCH(KK_SOLVE_PERM, k_refine_finish, dim3(grid1d(n)), dim3(256), 0, stream, V);
         HIPCHK(hipGetLastError());
@@ -2501,7 +2722,13 @@ public:
                 hipLaunchKernelGGL(k_store_sol, dim3(grid1d(S->n)), dim3(256), 0, stream, V, col);
             } else if (!enqueue_solve(src, col)) return false;
         }
-        if (timed) { HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream)); float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms; }
+        if (timed) {
+            HIPCHK(hipEventRecord(ev1, stream));
+            if (!chain_segs.empty()) HIPCHK(hipMemcpyAsync(h_stats + 6, V.sepoch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms;
+            if (!chain_segs.empty() && h_stats[6] != 0) { err_ = "solve: a chain sweep timed out waiting for its predecessor (workgroups not co-resident?)"; return false; }
+        }
         return true;
     }
 

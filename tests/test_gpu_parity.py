@@ -299,3 +299,26 @@ def test_matching_scaling_mode():
     assert np.allclose(f, ref, rtol=1e-12)
     Ks = abs(K).multiply(f[:, None]).multiply(f[None, :]).tocsr()
     assert Ks.max() <= 1.0 + 1e-10 and np.allclose(Ks.max(axis=1).toarray().ravel(), 1.0, rtol=1e-10)
+
+
+def test_sync_free_chain_sweeps_match_the_level_by_level_solves(monkeypatch):
+    """the flag-synchronised chain sweeps (one launch per run of pure chain levels) against the launch-per-level solves:
+    same solution to rounding (the summation order along the chain differs), deterministic across repetitions"""
+    n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)
+    K = kktgen.to_scipy(n, r, c, v)
+    rng = np.random.default_rng(4)
+    B = [K @ np.ones(n), rng.standard_normal(n), K @ rng.standard_normal(n)]
+    monkeypatch.setenv("MI355X_KKT_NO_CHAIN_SOLVE", "1")
+    s0, st0, _ = gpu_factor_solve(n, r, c, v, B[0], check=True, required=neg)
+    X0 = []
+    for b in B:
+        x = b.copy(); s0.multi_solve(False, x); X0.append(x)
+    monkeypatch.delenv("MI355X_KKT_NO_CHAIN_SOLVE")
+    s1, st1, _ = gpu_factor_solve(n, r, c, v, B[0], check=True, required=neg)
+    assert st0 == st1 == kkt.SUCCESS
+    for b, x0 in zip(B, X0):
+        x = b.copy(); s1.multi_solve(False, x)
+        assert sres(K, x, b) <= RES_TOL
+        assert np.abs(x - x0).max() <= 1e-11 * max(1.0, np.abs(x0).max())
+        x2 = b.copy(); s1.multi_solve(False, x2)
+        assert np.array_equal(x, x2)
