@@ -155,6 +155,15 @@ __device__ __forceinline__ unsigned long long wave_or_all(unsigned long long v)
     const unsigned int h = (unsigned)(__builtin_amdgcn_readlane(hi, 0) | __builtin_amdgcn_readlane(hi, 16) | __builtin_amdgcn_readlane(hi, 32) | __builtin_amdgcn_readlane(hi, 48));
     return ((unsigned long long)h << 32) | l;
 }
+// sum over the 64 lanes on the DPP path (row-local butterflies + 4 readlanes), wave-uniform result
+__device__ __forceinline__ double wave_sum_dpp(double x)
+{
+    x += dpp_f64<0xB1>(x);
+    x += dpp_f64<0x4E>(x);
+    x += dpp_f64<0x141>(x);
+    x += dpp_f64<0x140>(x);
+    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
 __device__ __forceinline__ double wave_sum(double x)
 {
 #pragma unroll
@@ -1236,9 +1245,15 @@ __device__ __forceinline__ void chain_signal(int* flag, const int epoch)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// One hop of the pipeline costs a flag round trip through memory plus every DEPENDENT global access behind it (~1.5-2 us each
+// on this part): so everything that does not depend on the incoming vector -- the link's inverse, pivot order and D, and the panel
+// block of the NEXT predecessor -- is fetched BEFORE the wait (measured: 13 us per hop without).
 __global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int desc0, int ndesc)
 {
-    __shared__ double acc[64], ys[64], bp[64], part[4][64];
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* Ms = reinterpret_cast<double*>(smem_raw);           // 64 x 65: the link's stored inverse
+    __shared__ double acc[64], ys[64], bp[64], part[4][64], dv[64], dof[64];
+    __shared__ int lp[64], pts[64];
     const int tid = threadIdx.x;
     ChainDesc C = V.chdesc[desc0];
     for (int q = 1; q < ndesc; ++q) { const ChainDesc Cn = V.chdesc[desc0 + q]; if ((int)blockIdx.x >= Cn.wg0f) C = Cn; }
@@ -1250,55 +1265,67 @@ __global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int desc0, int nde
     const int rows = is_link ? Me.k : min(64, C.tail - 64 * (w - C.nlinks));
     double* cvp = V.cvec + C.cvb;
     if (tid < 64) acc[tid] = (tid < rows) ? cvp[roff + tid] + (is_link ? V.xw[Me.c0 + tid] : 0.0) : 0.0;
-    __syncthreads();
+    if (is_link) {
+        const int k = Me.k, c0 = Me.c0;
+        const double* Mg = V.minv + Me.minv_off;
+        for (int idx = tid; idx < k * k; idx += 256) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
+        if (tid < k) { lp[tid] = V.lperm[c0 + tid]; pts[tid] = V.ptype[c0 + tid]; dv[tid] = V.dinv[c0 + tid]; dof[tid] = V.doff[c0 + tid]; }
+    }
     const int nprev = is_link ? w : C.nlinks;
     const int p = tid & 63, qq = tid >> 6;
+    double lreg[16];
+    ChainLink Li = V.chlink[C.link0];
+    auto fetch_block = [&](const ChainLink& L) {
+        const double* Lb = V.L + L.panel_off + (roff - L.koff) + p;              // my rows of that link's panel
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int q = qq + 4 * u; lreg[u] = (p < rows && q < L.k) ? Lb[(size_t)q * L.ldp] : 0.0; }
+    };
+    if (nprev > 0) fetch_block(Li);
+    __syncthreads();
     for (int i = 0; i < nprev; ++i) {
-        const ChainLink Li = V.chlink[C.link0 + i];
         chain_wait(&V.sflag_f[Li.s], epoch, V.sepoch + 1);
         if (tid < 64) ys[tid] = (tid < Li.k) ? V.ybuf[Li.c0 + tid] : 0.0;
         __syncthreads();
-        const double* Lb = V.L + Li.panel_off + (roff - Li.koff) + p;          // my rows of panel i
         double a0 = 0.0, a1 = 0.0;
-        if (p < rows) {
-            int q = qq;
-            for (; q + 4 < Li.k; q += 8) { a0 += Lb[(size_t)q * Li.ldp] * ys[q]; a1 += Lb[(size_t)(q + 4) * Li.ldp] * ys[q + 4]; }
-            if (q < Li.k) a0 += Lb[(size_t)q * Li.ldp] * ys[q];
-        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) { a0 += lreg[u] * ys[qq + 4 * u]; a1 += lreg[u + 1] * ys[qq + 4 * u + 4]; }
         part[qq][p] = a0 + a1;
+        if (i + 1 < nprev) { Li = V.chlink[C.link0 + i + 1]; fetch_block(Li); }        // in flight while the next flag is awaited
         __syncthreads();
         if (tid < 64) acc[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
         __syncthreads();
     }
     if (!is_link) { if (tid < rows) cvp[roff + tid] = acc[tid]; return; }
     const int k = Me.k, c0 = Me.c0;
-    if (tid < k) bp[tid] = acc[V.lperm[c0 + tid]];
+    if (tid < k) bp[tid] = acc[lp[tid]];
     __syncthreads();
-    const double* Mg = V.minv + Me.minv_off;
-    {   // y = Minv (P b): 4 threads per row
+    {   // y = Minv (P b): 4 threads per row, inverse from LDS
         const int part4 = tid & 3;
         for (int q = tid >> 2; q < k; q += 64) {
             double a = 0.0;
-            for (int pp = part4; pp <= q; pp += 4) a += Mg[q + (size_t)pp * k] * bp[pp];
+            for (int pp = part4; pp <= q; pp += 4) a += Ms[q + pp * 65] * bp[pp];
             a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
             if (part4 == 0) ys[q] = a;
         }
     }
     __syncthreads();
     if (tid < k) {
-        const int pt = V.ptype[c0 + tid];
+        const int pt = pts[tid];
         double z;
-        if (pt == 1) z = ys[tid] * V.dinv[c0 + tid];
-        else if (pt == 2) z = V.dinv[c0 + tid] * ys[tid] + V.doff[c0 + tid] * ys[tid + 1];
-        else z = V.doff[c0 + tid - 1] * ys[tid - 1] + V.dinv[c0 + tid] * ys[tid];
-        V.zb[c0 + tid] = z;
+        if (pt == 1) z = ys[tid] * dv[tid];
+        else if (pt == 2) z = dv[tid] * ys[tid] + dof[tid] * ys[tid + 1];
+        else z = dof[tid - 1] * ys[tid - 1] + dv[tid] * ys[tid];
         V.ybuf[c0 + tid] = ys[tid];
+        V.zb[c0 + tid] = z;
     }
     chain_signal(&V.sflag_f[Me.s], epoch);
 }
 __global__ __launch_bounds__(256) void k_bwd_chain(DevView V, int desc0, int ndesc)
 {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* Ms = reinterpret_cast<double*>(smem_raw);           // 64 x 65: the link's stored inverse
     __shared__ double ws[64], xs[256];
+    __shared__ int lp[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ChainDesc C = V.chdesc[desc0];
     for (int q = 1; q < ndesc; ++q) { const ChainDesc Cn = V.chdesc[desc0 + q]; if ((int)blockIdx.x >= Cn.wg0b) C = Cn; }
@@ -1308,6 +1335,11 @@ __global__ __launch_bounds__(256) void k_bwd_chain(DevView V, int desc0, int nde
     const ChainLink Me = V.chlink[C.link0 + j];
     const int k = Me.k, c0 = Me.c0;
     if (tid < 64) ws[tid] = (tid < k) ? V.zb[c0 + tid] : 0.0;
+    {
+        const double* Mg = V.minv + Me.minv_off;
+        for (int idx = tid; idx < k * k; idx += 256) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
+        if (tid < k) lp[tid] = V.lperm[c0 + tid];
+    }
     __syncthreads();
     // rows beyond the chain: their solution is known since the levels above
     const int toff = C.ktot - Me.koff;
@@ -1328,28 +1360,33 @@ __global__ __launch_bounds__(256) void k_bwd_chain(DevView V, int desc0, int nde
         }
         __syncthreads();
     }
-    for (int r = C.nlinks - 1; r > j; --r) {                  // later links of the chain, top first
-        const ChainLink Lr = V.chlink[C.link0 + r];
+    // later links of the chain, top first; the block of my panel that meets link r's rows is fetched before r's flag is awaited
+    double lreg[16];                                           // lane = row t of the block, columns wave, wave + 4, ...
+    ChainLink Lr = V.chlink[C.link0 + C.nlinks - 1];
+    auto fetch_block = [&](const ChainLink& L) {
+        const double* Lb = V.L + Me.panel_off + (L.koff - Me.koff) + lane;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int q = wave + 4 * u; lreg[u] = (lane < L.k && q < k) ? Lb[(size_t)q * Me.ldp] : 0.0; }
+    };
+    if (j < C.nlinks - 1) fetch_block(Lr);
+    for (int r = C.nlinks - 1; r > j; --r) {
         chain_wait(&V.sflag_b[Lr.s], epoch, V.sepoch + 1);
-        if (tid < 64) xs[tid] = (tid < Lr.k) ? V.xw[Lr.c0 + tid] : 0.0;
-        __syncthreads();
-        const double* Lb = V.L + Me.panel_off + (Lr.koff - Me.koff) + lane;
-        const double xv = xs[lane];
-        for (int q = wave; q < k; q += 4) {
-            double v = (lane < Lr.k) ? Lb[(size_t)q * Me.ldp] * xv : 0.0;
-            v = wave_sum(v);
-            if (lane == 0) ws[q] -= v;
-        }
+        const double xv = (lane < Lr.k) ? V.xw[Lr.c0 + lane] : 0.0;
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = lreg[u] * xv;
+        if (r - 1 > j) { Lr = V.chlink[C.link0 + r - 1]; fetch_block(Lr); }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const double sv = wave_sum_dpp(v[u]); if (lane == 0 && wave + 4 * u < k) ws[wave + 4 * u] -= sv; }
         __syncthreads();
     }
-    const double* Mg = V.minv + Me.minv_off;
-    {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column
+    {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column, inverse from LDS
         const int part4 = tid & 3;
         for (int pp = tid >> 2; pp < k; pp += 64) {
             double a = 0.0;
-            for (int q = pp + part4; q < k; q += 4) a += Mg[q + (size_t)pp * k] * ws[q];
+            for (int q = pp + part4; q < k; q += 4) a += Ms[q + pp * 65] * ws[q];
             a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
-            if (part4 == 0) V.xw[c0 + V.lperm[c0 + pp]] = a;
+            if (part4 == 0) V.xw[c0 + lp[pp]] = a;
         }
     }
     chain_signal(&V.sflag_b[Me.s], epoch);
@@ -1843,7 +1880,7 @@ public:
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
-    bool chain_solve = true;
+    bool chain_solve = true; int chain_maxc = 8;       // only where few chains run side by side (the latency-bound top of the tree)
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
@@ -2175,6 +2212,7 @@ public:
         std::vector<ChainLink> chl; std::vector<ChainDesc> chd;
         chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
+        if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
         if (!multi && !Sy.solve_group && chain_solve) {
             auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
             auto Mr = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
@@ -2193,7 +2231,7 @@ public:
                 int e = lv;
                 auto cnt = [&](int l) { return Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)l * FC_COUNT]; };
                 while (e + 1 < Sy.num_levels && lvok[e + 1] && cnt(e + 1) == cnt(lv)) ++e;
-                if (e - lv + 1 >= 4) {
+                if (e - lv + 1 >= 4 && cnt(lv) <= chain_maxc) {
                     ChainSeg sg{lv, e, (int)chd.size(), 0, 0, 0};
                     bool good = true;
                     const size_t chl0 = chl.size(), chd0 = chd.size();
@@ -2657,7 +2695,7 @@ public:
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
                 if (seg_at_lv0[lv] >= 0) {      // a run of pure chain levels: one sync-free launch for all of them
                     const ChainSeg& sg = chain_segs[seg_at_lv0[lv]];
-                    LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(256), 0, stream, V, sg.desc0, sg.ndesc);
+                    LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
                     lv = sg.lv1; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -2676,7 +2714,7 @@ public:
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
-                    LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(256), 0, stream, V, sg.desc0, sg.ndesc);
+                    LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
                     lv = sg.lv0; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
