@@ -1320,11 +1320,13 @@ __global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int desc0, int nde
     }
     chain_signal(&V.sflag_f[Me.s], epoch);
 }
-__global__ __launch_bounds__(256) void k_bwd_chain(DevView V, int desc0, int ndesc)
+__global__ __launch_bounds__(1024) void k_bwd_chain(DevView V, int desc0, int ndesc)
 {
+    // 16 wavefronts: the part of the panel that meets the rows BEYOND the chain (up to a few thousand rows x 64 columns) is streamed
+    // by this one workgroup, so it needs memory-level parallelism: 4 columns per wavefront, 4 row strips of 64 in flight per lane
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* Ms = reinterpret_cast<double*>(smem_raw);           // 64 x 65: the link's stored inverse
-    __shared__ double ws[64], xs[256];
+    __shared__ double ws[64], xs[1024];
     __shared__ int lp[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ChainDesc C = V.chdesc[desc0];
@@ -1337,50 +1339,64 @@ __global__ __launch_bounds__(256) void k_bwd_chain(DevView V, int desc0, int nde
     if (tid < 64) ws[tid] = (tid < k) ? V.zb[c0 + tid] : 0.0;
     {
         const double* Mg = V.minv + Me.minv_off;
-        for (int idx = tid; idx < k * k; idx += 256) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
+        for (int idx = tid; idx < k * k; idx += 1024) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
         if (tid < k) lp[tid] = V.lperm[c0 + tid];
     }
-    __syncthreads();
-    // rows beyond the chain: their solution is known since the levels above
-    const int toff = C.ktot - Me.koff;
-    const double* Lt = V.L + Me.panel_off + toff;
-    for (int base = 0; base < C.tail; base += 256) {
-        const int nrow = min(256, C.tail - base);
-        xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[Me.r0 + toff + base + tid]] : 0.0;
-        __syncthreads();
-        for (int pb = wave * 4; pb < k; pb += 16) {           // 4 columns per pass: their loads are all in flight together
-            double t[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int i = lane; i < nrow; i += 64) {
-                const double x = xs[i];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) if (pb + u < k) t[u] += Lt[base + i + (size_t)(pb + u) * Me.ldp] * x;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { t[u] = wave_sum(t[u]); if (lane == 0 && pb + u < k) ws[pb + u] -= t[u]; }
-        }
-        __syncthreads();
-    }
-    // later links of the chain, top first; the block of my panel that meets link r's rows is fetched before r's flag is awaited
-    double lreg[16];                                           // lane = row t of the block, columns wave, wave + 4, ...
+    // later links of the chain, top first: the block of my panel that meets link r's rows is fetched before r's flag is awaited
+    double lreg[4];                                            // lane = row t of the block, columns wave, wave + 16, ...
     ChainLink Lr = V.chlink[C.link0 + C.nlinks - 1];
     auto fetch_block = [&](const ChainLink& L) {
         const double* Lb = V.L + Me.panel_off + (L.koff - Me.koff) + lane;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int q = wave + 4 * u; lreg[u] = (lane < L.k && q < k) ? Lb[(size_t)q * Me.ldp] : 0.0; }
+        for (int u = 0; u < 4; ++u) { const int q = wave + 16 * u; lreg[u] = (lane < L.k && q < k) ? Lb[(size_t)q * Me.ldp] : 0.0; }
     };
     if (j < C.nlinks - 1) fetch_block(Lr);
+    __syncthreads();
+    // rows beyond the chain: their solution is known since the levels above
+    const int toff = C.ktot - Me.koff;
+    const double* Lt = V.L + Me.panel_off + toff;
+    double t[4] = {0.0, 0.0, 0.0, 0.0};                        // columns 4 wave .. 4 wave + 3
+    for (int base = 0; base < C.tail; base += 1024) {
+        const int nrow = min(1024, C.tail - base);
+        xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[Me.r0 + toff + base + tid]] : 0.0;
+        __syncthreads();
+        if (4 * wave < k) {
+            for (int i0 = 0; i0 < nrow; i0 += 256) {
+                double lv[4][4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int i = i0 + 64 * a + lane, q = 4 * wave + u;
+                        lv[a][u] = (i < nrow && q < k) ? Lt[base + i + (size_t)q * Me.ldp] : 0.0;
+                    }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const double x = xs[min(i0 + 64 * a + lane, 1023)];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] += lv[a][u] * x;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (C.tail > 0 && 4 * wave < k) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const double sv = wave_sum_dpp(t[u]); if (lane == 0 && 4 * wave + u < k) ws[4 * wave + u] -= sv; }
+    }
+    __syncthreads();
     for (int r = C.nlinks - 1; r > j; --r) {
         chain_wait(&V.sflag_b[Lr.s], epoch, V.sepoch + 1);
         const double xv = (lane < Lr.k) ? V.xw[Lr.c0 + lane] : 0.0;
-        double v[16];
+        double v[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = lreg[u] * xv;
+        for (int u = 0; u < 4; ++u) v[u] = lreg[u] * xv;
         if (r - 1 > j) { Lr = V.chlink[C.link0 + r - 1]; fetch_block(Lr); }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const double sv = wave_sum_dpp(v[u]); if (lane == 0 && wave + 4 * u < k) ws[wave + 4 * u] -= sv; }
+        for (int u = 0; u < 4; ++u) { const double sv = wave_sum_dpp(v[u]); if (lane == 0 && wave + 16 * u < k) ws[wave + 16 * u] -= sv; }
         __syncthreads();
     }
-    {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column, inverse from LDS
+    if (tid < 256) {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column, inverse from LDS
         const int part4 = tid & 3;
         for (int pp = tid >> 2; pp < k; pp += 64) {
             double a = 0.0;
@@ -2714,7 +2730,7 @@ public:
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
-                    LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
                     lv = sg.lv0; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
