@@ -1320,13 +1320,16 @@ __global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int desc0, int nde
     }
     chain_signal(&V.sflag_f[Me.s], epoch);
 }
-__global__ __launch_bounds__(1024) void k_bwd_chain(DevView V, int desc0, int ndesc)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_bwd_chain(DevView V, int desc0, int ndesc)
 {
-    // 16 wavefronts: the part of the panel that meets the rows BEYOND the chain (up to a few thousand rows x 64 columns) is streamed
-    // by this one workgroup, so it needs memory-level parallelism: 4 columns per wavefront, 4 row strips of 64 in flight per lane
+    constexpr int NW = NT / 64, CPW = 64 / NW;                 // wavefronts, columns per wavefront
+    // NT = 1024 where rows BEYOND the chain exist: that part of the panel (up to a few thousand rows x 64 columns) is streamed by this
+    // one workgroup, so it needs memory-level parallelism (4 columns per wavefront, 4 row strips of 64 in flight per lane);
+    // NT = 256 for a chain that ends at a root (no such rows): cheaper barriers on the flag pipeline
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* Ms = reinterpret_cast<double*>(smem_raw);           // 64 x 65: the link's stored inverse
-    __shared__ double ws[64], xs[1024];
+    __shared__ double ws[64], xs[NT];
     __shared__ int lp[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     ChainDesc C = V.chdesc[desc0];
@@ -1339,25 +1342,25 @@ __global__ __launch_bounds__(1024) void k_bwd_chain(DevView V, int desc0, int nd
     if (tid < 64) ws[tid] = (tid < k) ? V.zb[c0 + tid] : 0.0;
     {
         const double* Mg = V.minv + Me.minv_off;
-        for (int idx = tid; idx < k * k; idx += 1024) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
+        for (int idx = tid; idx < k * k; idx += NT) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
         if (tid < k) lp[tid] = V.lperm[c0 + tid];
     }
     // later links of the chain, top first: the block of my panel that meets link r's rows is fetched before r's flag is awaited
-    double lreg[4];                                            // lane = row t of the block, columns wave, wave + 16, ...
+    double lreg[CPW];                                          // lane = row t of the block, columns wave, wave + NW, ...
     ChainLink Lr = V.chlink[C.link0 + C.nlinks - 1];
     auto fetch_block = [&](const ChainLink& L) {
         const double* Lb = V.L + Me.panel_off + (L.koff - Me.koff) + lane;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const int q = wave + 16 * u; lreg[u] = (lane < L.k && q < k) ? Lb[(size_t)q * Me.ldp] : 0.0; }
+        for (int u = 0; u < CPW; ++u) { const int q = wave + NW * u; lreg[u] = (lane < L.k && q < k) ? Lb[(size_t)q * Me.ldp] : 0.0; }
     };
     if (j < C.nlinks - 1) fetch_block(Lr);
     __syncthreads();
     // rows beyond the chain: their solution is known since the levels above
     const int toff = C.ktot - Me.koff;
     const double* Lt = V.L + Me.panel_off + toff;
-    double t[4] = {0.0, 0.0, 0.0, 0.0};                        // columns 4 wave .. 4 wave + 3
-    for (int base = 0; base < C.tail; base += 1024) {
-        const int nrow = min(1024, C.tail - base);
+    double t[4] = {0.0, 0.0, 0.0, 0.0};                        // columns 4 wave .. 4 wave + 3 (NT = 1024; a chain with such rows always gets NT = 1024)
+    for (int base = 0; base < C.tail; base += NT) {
+        const int nrow = min(NT, C.tail - base);
         xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[Me.r0 + toff + base + tid]] : 0.0;
         __syncthreads();
         if (4 * wave < k) {
@@ -1372,7 +1375,7 @@ __global__ __launch_bounds__(1024) void k_bwd_chain(DevView V, int desc0, int nd
                     }
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const double x = xs[min(i0 + 64 * a + lane, 1023)];
+                    const double x = xs[min(i0 + 64 * a + lane, NT - 1)];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) t[u] += lv[a][u] * x;
                 }
@@ -1388,12 +1391,12 @@ __global__ __launch_bounds__(1024) void k_bwd_chain(DevView V, int desc0, int nd
     for (int r = C.nlinks - 1; r > j; --r) {
         chain_wait(&V.sflag_b[Lr.s], epoch, V.sepoch + 1);
         const double xv = (lane < Lr.k) ? V.xw[Lr.c0 + lane] : 0.0;
-        double v[4];
+        double v[CPW];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = lreg[u] * xv;
+        for (int u = 0; u < CPW; ++u) v[u] = lreg[u] * xv;
         if (r - 1 > j) { Lr = V.chlink[C.link0 + r - 1]; fetch_block(Lr); }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const double sv = wave_sum_dpp(v[u]); if (lane == 0 && wave + 16 * u < k) ws[wave + 16 * u] -= sv; }
+        for (int u = 0; u < CPW; ++u) { const double sv = wave_sum_dpp(v[u]); if (lane == 0 && wave + NW * u < k) ws[wave + NW * u] -= sv; }
         __syncthreads();
     }
     if (tid < 256) {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column, inverse from LDS
@@ -1894,7 +1897,7 @@ public:
     std::vector<int> big_maxm, big_maxk, big_tiles, big_tiles64, big_last0, big_last1;
     std::vector<char> lv_asm_skip;      // every big front of the level is a pure in-place chain link: no assembly launch at all
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
-    struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b; };
+    struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
     bool chain_solve = true; int chain_maxc = 8;       // only where few chains run side by side (the latency-bound top of the tree)
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
@@ -2248,7 +2251,7 @@ public:
                 auto cnt = [&](int l) { return Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)l * FC_COUNT]; };
                 while (e + 1 < Sy.num_levels && lvok[e + 1] && cnt(e + 1) == cnt(lv)) ++e;
                 if (e - lv + 1 >= 4 && cnt(lv) <= chain_maxc) {
-                    ChainSeg sg{lv, e, (int)chd.size(), 0, 0, 0};
+                    ChainSeg sg{lv, e, (int)chd.size(), 0, 0, 0, 0};
                     bool good = true;
                     const size_t chl0 = chl.size(), chd0 = chd.size();
                     for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT] && good; ++q) {
@@ -2264,7 +2267,7 @@ public:
                         D.ktot = koff; D.tail = Mr(last) - Kc(last);
                         // in-place construction: every link's rows = its columns + the later links' columns + the common tail
                         for (int t = 0; t < D.nlinks && good; ++t) { const ChainLink& L = chl[D.link0 + t]; if (Mr(L.s) != D.ktot - L.koff + D.tail) good = false; }
-                        sg.nwg_f += D.nlinks + (D.tail + 63) / 64; sg.nwg_b += D.nlinks;
+                        sg.nwg_f += D.nlinks + (D.tail + 63) / 64; sg.nwg_b += D.nlinks; sg.maxtail = std::max(sg.maxtail, D.tail);
                         chd.push_back(D);
                     }
                     sg.ndesc = (int)chd.size() - sg.desc0;
@@ -2730,7 +2733,8 @@ public:
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
-                    LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    if (sg.maxtail > 0) LAUNCH(KK_BWD_BIG, (k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    else                LAUNCH(KK_BWD_BIG, (k_bwd_chain<256>),  dim3(sg.nwg_b), dim3(256),  64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
                     lv = sg.lv0; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
