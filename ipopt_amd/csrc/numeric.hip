@@ -1087,6 +1087,67 @@ __global__ __launch_bounds__(256) void k_fwd_solo(DevView V, int list_off)
     }
 }
 
+// k <= 64 variant of k_fwd_solo with every load that only depends on the front record issued up front (the pivot order, the
+// inverse and the panel entries do not depend on the right-hand side): one dependent round trip instead of four.  On this part a
+// dependent global access costs 1.5-2 us, which is what a launch of these latency-bound kernels is made of.
+__global__ __launch_bounds__(256) void k_fwd_solo64(DevView V, int list_off)
+{
+    __shared__ double bp[64], ys[64];
+    __shared__ double red[4][64];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int k = M.k, m = M.m, c0 = M.c0;
+    const int rb = (int)blockIdx.x - 1;                       // -1: pivot part
+    if (rb >= 0 && k + rb * 64 >= m) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double* cv = V.cvec + M.cv;
+    // ---- everything that depends on M only ----
+    const int lpv = (tid < k) ? V.lperm[c0 + tid] : 0;
+    const double* Mg = V.minv + M.minv_off;
+    const int q = tid >> 2, part = tid & 3;
+    double mreg[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int p = part + 4 * u; mreg[u] = (q < k && p <= q) ? Mg[q + (size_t)p * k] : 0.0; }
+    const int i = k + rb * 64 + lane;
+    const bool ok = rb >= 0 && i < m;
+    const double* Lg = V.L + M.panel_off + (ok ? i : k);
+    double lreg[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int p = wave * 8 + (u & 7) + 32 * (u >> 3); lreg[u] = (ok && p < k) ? Lg[(size_t)p * M.ldp] : 0.0; }
+    const double cvi = (ok && wave == 0 && M.solo == 1) ? cv[i] : 0.0;
+    int pt = 1; double dq = 0.0, oq = 0.0, oq1 = 0.0;
+    if (rb < 0 && tid < k) { pt = V.ptype[c0 + tid]; dq = V.dinv[c0 + tid]; oq = V.doff[c0 + tid]; oq1 = tid > 0 ? V.doff[c0 + tid - 1] : 0.0; }
+    // ---- dependent on the pivot order ----
+    if (tid < k) bp[tid] = V.xw[c0 + lpv] + (M.solo == 1 ? cv[lpv] : 0.0);
+    __syncthreads();
+    {
+        double a = 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a += mreg[u] * bp[(part + 4 * u) & 63];
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+        if (part == 0 && q < k) ys[q] = a;
+    }
+    __syncthreads();
+    if (rb < 0) {
+        if (tid < k) {
+            double z;
+            if (pt == 1) z = ys[tid] * dq;
+            else if (pt == 2) z = dq * ys[tid] + oq * ys[tid + 1];
+            else z = oq1 * ys[tid - 1] + dq * ys[tid];
+            V.zb[c0 + tid] = z;
+        }
+        return;
+    }
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) {
+        const int p = wave * 8 + (u & 7) + 32 * (u >> 3);
+        t0 += lreg[u] * ((p < k) ? ys[p] : 0.0); t1 += lreg[u + 1] * ((p + 1 < k) ? ys[p + 1] : 0.0);
+    }
+    red[wave][lane] = t0 + t1;
+    __syncthreads();
+    if (wave == 0 && ok) cv[i] = cvi - ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
+}
+
 __global__ __launch_bounds__(256) void k_fwd_grp_upd(DevView V, int list_off)
 {
     // 64 rows per workgroup (one per lane); the group's columns are dealt to the 4 wavefronts in blocks of 8 (8 coalesced
@@ -1163,6 +1224,76 @@ __global__ __launch_bounds__(256) void k_bwd_grp_dot(DevView V, int list_off)
         }
         cb += k;
     }
+}
+
+// per-link (one link per solve unit), k <= 64 variants of k_bwd_grp_dot / k_bwd_grp with the loads that only depend on the front
+// record hoisted to the top (same arithmetic, same order of summation)
+__global__ __launch_bounds__(256) void k_bwd_dot64(DevView V, int list_off)
+{
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ibase = M.k + blockIdx.x * 256;
+    if (ibase >= M.m) return;
+    const int nrow = min(256, M.m - ibase), k = M.k;
+    const bool v0 = lane < nrow, v1 = lane + 64 < nrow, v2 = lane + 128 < nrow, v3 = lane + 192 < nrow;
+    // the panel entries first (they depend on the front record only) ...
+    const double* Lg = V.L + M.panel_off + ibase + lane;
+    double lv[4][4][4];                                      // [pass][column of the pass][row strip]
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int col = wave * 4 + 16 * ps + u;
+            const bool cv = col < k;
+            const double* c = Lg + (size_t)col * M.ldp;
+            lv[ps][u][0] = (cv && v0) ? c[0] : 0.0; lv[ps][u][1] = (cv && v1) ? c[64] : 0.0;
+            lv[ps][u][2] = (cv && v2) ? c[128] : 0.0; lv[ps][u][3] = (cv && v3) ? c[192] : 0.0;
+        }
+    // ... then the two dependent hops to the solution entries of the rows
+    const int r0i = M.r0 + ibase;
+    const double x0 = v0 ? V.xw[V.sn_rows[r0i + lane]] : 0.0, x1 = v1 ? V.xw[V.sn_rows[r0i + lane + 64]] : 0.0;
+    const double x2 = v2 ? V.xw[V.sn_rows[r0i + lane + 128]] : 0.0, x3 = v3 ? V.xw[V.sn_rows[r0i + lane + 192]] : 0.0;
+    double* part = V.gpart + M.gpart + (size_t)blockIdx.x * M.gcols;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int col = wave * 4 + 16 * ps + u;
+            double t = (lv[ps][u][0] * x0 + lv[ps][u][1] * x1) + (lv[ps][u][2] * x2 + lv[ps][u][3] * x3);
+            t = wave_sum(t);
+            if (lane == 0 && col < k) part[col] = t;
+        }
+}
+__global__ __launch_bounds__(256) void k_bwd_fin64(DevView V, int list_off)
+{
+    __shared__ double ws[64];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    const int tid = threadIdx.x;
+    const int k = M.k, c0 = M.c0;
+    const int nch = (M.m - M.k + 255) / 256;
+    const double* part = V.gpart + M.gpart;
+    const double* Mg = V.minv + M.minv_off;
+    const int pcol = tid >> 2, part4 = tid & 3;
+    double mreg[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int q = pcol + part4 + 4 * u; mreg[u] = (pcol < k && q < k) ? Mg[q + (size_t)pcol * k] : 0.0; }
+    const int lpv = (part4 == 0 && pcol < k) ? V.lperm[c0 + pcol] : 0;
+    if (tid < 64) ws[tid] = 0.0;
+    __syncthreads();
+    if (tid < k) {
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        int c = 0;
+        for (; c + 3 < nch; c += 4) { t0 += part[(size_t)c * M.gcols + tid]; t1 += part[(size_t)(c + 1) * M.gcols + tid];
+                                      t2 += part[(size_t)(c + 2) * M.gcols + tid]; t3 += part[(size_t)(c + 3) * M.gcols + tid]; }
+        for (; c < nch; ++c) t0 += part[(size_t)c * M.gcols + tid];
+        ws[tid] = V.zb[c0 + tid] - ((t0 + t1) + (t2 + t3));
+    }
+    __syncthreads();
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a += mreg[u] * ws[(pcol + part4 + 4 * u) & 63];       // (entries beyond k are zero in mreg)
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+    if (part4 == 0 && pcol < k) V.xw[c0 + lpv] = a;
 }
 
 __global__ __launch_bounds__(256) void k_bwd_grp(DevView V, int list_off)
@@ -2725,7 +2856,8 @@ public:
                     else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
                     else if (big_last1[lv] > big_last0[lv]) {
                            const int g0 = big_last0[lv], ng = big_last1[lv] - g0;
-                           if (lv_allsolo[lv]) LAUNCH(KK_FWD_BIG, k_fwd_solo, dim3((big_maxm[lv] + 63) / 64 + 1, ng), dim3(256), 0, stream, V, g0);
+                           if (lv_allsolo[lv] && big_maxk[lv] <= 64) LAUNCH(KK_FWD_BIG, k_fwd_solo64, dim3((big_maxm[lv] + 63) / 64 + 1, ng), dim3(256), 0, stream, V, g0);
+                           else if (lv_allsolo[lv]) LAUNCH(KK_FWD_BIG, k_fwd_solo, dim3((big_maxm[lv] + 63) / 64 + 1, ng), dim3(256), 0, stream, V, g0);
                            else { LAUNCH(KK_FWD_BIG, k_fwd_grp, dim3(ng), dim3(256), 0, stream, V, g0, 0);
                                   LAUNCH(KK_FWD_BIG_UPD, k_fwd_grp_upd, dim3((big_maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); } }
                 }
@@ -2745,8 +2877,12 @@ public:
                     else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
                     else if (big_last1[lv] > big_last0[lv]) {
                            const int g0 = big_last0[lv], ng = big_last1[lv] - g0;
-                           LAUNCH(KK_BWD_BIG_DOT, k_bwd_grp_dot, dim3((big_maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
-                           LAUNCH(KK_BWD_BIG, k_bwd_grp, dim3(ng), dim3(256), 0, stream, V, g0); }
+                           if (!Sy.solve_group && big_maxk[lv] <= 64) {      // one link per unit: load-hoisted kernels
+                               LAUNCH(KK_BWD_BIG_DOT, k_bwd_dot64, dim3((big_maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
+                               LAUNCH(KK_BWD_BIG, k_bwd_fin64, dim3(ng), dim3(256), 0, stream, V, g0);
+                           } else {
+                               LAUNCH(KK_BWD_BIG_DOT, k_bwd_grp_dot, dim3((big_maxm[lv] + 255) / 256, ng), dim3(256), 0, stream, V, g0);
+                               LAUNCH(KK_BWD_BIG, k_bwd_grp, dim3(ng), dim3(256), 0, stream, V, g0); } }
                 }
             }
         }
