@@ -1455,9 +1455,9 @@ template <int NT>
 __global__ __launch_bounds__(NT) void k_bwd_chain(DevView V, int desc0, int ndesc)
 {
     constexpr int NW = NT / 64, CPW = 64 / NW;                 // wavefronts, columns per wavefront
-    // NT = 1024 where rows BEYOND the chain exist: that part of the panel (up to a few thousand rows x 64 columns) is streamed by this
+    // NT = 1024 where many rows BEYOND the chain exist: that part of the panel (up to a few thousand rows x 64 columns) is streamed by this
     // one workgroup, so it needs memory-level parallelism (4 columns per wavefront, 4 row strips of 64 in flight per lane);
-    // NT = 256 for a chain that ends at a root (no such rows): cheaper barriers on the flag pipeline
+    // NT = 256 for a chain that ends (almost) at a root: cheaper barriers on the flag pipeline
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     double* Ms = reinterpret_cast<double*>(smem_raw);           // 64 x 65: the link's stored inverse
     __shared__ double ws[64], xs[NT];
@@ -1489,34 +1489,37 @@ __global__ __launch_bounds__(NT) void k_bwd_chain(DevView V, int desc0, int ndes
     // rows beyond the chain: their solution is known since the levels above
     const int toff = C.ktot - Me.koff;
     const double* Lt = V.L + Me.panel_off + toff;
-    double t[4] = {0.0, 0.0, 0.0, 0.0};                        // columns 4 wave .. 4 wave + 3 (NT = 1024; a chain with such rows always gets NT = 1024)
+    double t[CPW];                                             // columns CPW wave .. CPW wave + CPW - 1
+#pragma unroll
+    for (int u = 0; u < CPW; ++u) t[u] = 0.0;
     for (int base = 0; base < C.tail; base += NT) {
         const int nrow = min(NT, C.tail - base);
         xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[Me.r0 + toff + base + tid]] : 0.0;
         __syncthreads();
-        if (4 * wave < k) {
-            for (int i0 = 0; i0 < nrow; i0 += 256) {
-                double lv[4][4];
+        if (CPW * wave < k) {
+            constexpr int RS = (CPW <= 4) ? 4 : 1;               // row strips of 64 in flight per lane (16 loads per lane either way)
+            for (int i0 = 0; i0 < nrow; i0 += 64 * RS) {
+                double lv[RS][CPW];
 #pragma unroll
-                for (int a = 0; a < 4; ++a)
+                for (int a = 0; a < RS; ++a)
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int i = i0 + 64 * a + lane, q = 4 * wave + u;
+                    for (int u = 0; u < CPW; ++u) {
+                        const int i = i0 + 64 * a + lane, q = CPW * wave + u;
                         lv[a][u] = (i < nrow && q < k) ? Lt[base + i + (size_t)q * Me.ldp] : 0.0;
                     }
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
+                for (int a = 0; a < RS; ++a) {
                     const double x = xs[min(i0 + 64 * a + lane, NT - 1)];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) t[u] += lv[a][u] * x;
+                    for (int u = 0; u < CPW; ++u) t[u] += lv[a][u] * x;
                 }
             }
         }
         __syncthreads();
     }
-    if (C.tail > 0 && 4 * wave < k) {
+    if (C.tail > 0 && CPW * wave < k) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const double sv = wave_sum_dpp(t[u]); if (lane == 0 && 4 * wave + u < k) ws[4 * wave + u] -= sv; }
+        for (int u = 0; u < CPW; ++u) { const double sv = wave_sum_dpp(t[u]); if (lane == 0 && CPW * wave + u < k) ws[CPW * wave + u] -= sv; }
     }
     __syncthreads();
     for (int r = C.nlinks - 1; r > j; --r) {
@@ -2865,7 +2868,7 @@ public:
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
-                    if (sg.maxtail > 0) LAUNCH(KK_BWD_BIG, (k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    if (sg.maxtail > 256) LAUNCH(KK_BWD_BIG, (k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
                     else                LAUNCH(KK_BWD_BIG, (k_bwd_chain<256>),  dim3(sg.nwg_b), dim3(256),  64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
                     lv = sg.lv0; continue;
                 }
