@@ -113,7 +113,7 @@ struct DevView {
     int* qstat;             // [0]: some pivot decision of this factorisation would differ at u = pivtol2
     double* cnorm;          // inf-norm of every column of the (scaled) INPUT matrix, permuted numbering: scale of the zero-pivot test
     const ChainLink* chlink; const ChainDesc* chdesc;     // chain solve tables
-    int* sflag_f; int* sflag_b; int* sepoch;              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
+    int* sflag_f; int* sflag_b; int* sflag_d; int* sepoch;     // (sflag_d / sepoch[2]: pivot block done, fused pivot-block + panel-solve launch)              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
@@ -723,13 +723,11 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
 // pivot block of a BIG front on the register-tiled core: 4x4 tiles on 16x16 threads for k <= 64, on 32x32 threads (two-word
 // alive mask) for the 128-column panels of the wide_panels option (19 ms against 28 ms with 8x8 tiles on 256 threads, but
 // still slower per column than two 64-column blocks: option off by default)
-template <int TS, int NT = 256>
-__global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
+template <int TS, int NT>
+__device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta& M, char* smem_raw)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = (NT == 1024) ? 32 : 16, MAXM = G * TS;
     const int tid = threadIdx.x;
-    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
     const int s = M.s, c0 = M.c0, k = M.k;
     const int ld = k | 1;
     double* Lb     = reinterpret_cast<double*>(smem_raw);   // k x k L columns (physical rows); later the pivot-ordered block / its inverse
@@ -777,6 +775,14 @@ __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
     double* Mg = V.minv + M.minv_off;
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Lb[i + c * ld] : (i == c ? 1.0 : 0.0); }
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[15] = (unsigned long long)k;
+}
+
+template <int TS, int NT = 256>
+__global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    big_diag_body<TS, NT>(V, M, smem_raw);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1674,6 +1680,72 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off, int r
     }
 }
 
+// Pivot block AND panel solve of a front in ONE launch (the top of the tree, where a level has a handful of fronts and both
+// kernels are a chain of dependent round trips rather than work): workgroup 0 of a front is the pivot-block kernel and raises the
+// front's flag; workgroups 1.. each own 64 panel rows, add their A entries and stage their rows in LDS BEFORE they wait, then
+// permute / solve / scale.  Same arithmetic as k_big_diag_reg + k_big_trsm, bit for bit.
+__global__ __launch_bounds__(256) void k_big_diag_trsm(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int epoch = V.sepoch[2];
+    if (blockIdx.x == 0) { big_diag_body<4, 256>(V, M, smem_raw); chain_signal(&V.sflag_d[M.s], epoch); return; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
+    const int ibase = k + ((int)blockIdx.x - 1) * 64;
+    if (ibase >= m) return;
+    const int kp = (k + 3) & ~3;
+    double* As = reinterpret_cast<double*>(smem_raw);         // 64 x kp: (A21 P), later W
+    double* Ws = As;
+    double* Ds = As + (size_t)65 * kp;                        // dinv[k], doff[k]
+    int*    Ts = reinterpret_cast<int*>(Ds + 2 * k);          // ptype[k], then lperm[k]
+    int*    Lp = Ts + k;
+    double* Au = reinterpret_cast<double*>(Lp + k);           // 64 x k: my rows as they lie in the panel (unpermuted); (2k ints: 8-byte aligned)
+    double* P = V.L + M.panel_off;
+    const size_t ldp = (size_t)M.ldp;
+    double* W = V.wbuf + M.wb;
+    const double* Mg = V.minv + M.minv_off;
+    if (M.selfasm) {
+        for (int q = M.aq0 + tid; q < M.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < 64 * k; idx += 256) { const int r = idx & 63, c = idx >> 6; Au[r + c * 65] = (ibase + r < m) ? P[ibase + r + (size_t)c * ldp] : 0.0; }
+    chain_wait(&V.sflag_d[s], epoch, V.qstat + 1);            // the pivot block of this front is done
+    for (int j = tid; j < k; j += 256) { Ds[j] = V.dinv[c0 + j]; Ds[k + j] = V.doff[c0 + j]; Ts[j] = V.ptype[c0 + j]; Lp[j] = V.lperm[c0 + j]; }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * kp; idx += 256) { const int r = idx & 63, p = idx >> 6; As[r + p * 65] = (p < k) ? Au[r + Lp[p] * 65] : 0.0; }
+    __syncthreads();
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int r16 = wave * 16;
+    for (int c16 = ((k - 1) >> 4) << 4; c16 >= 0; c16 -= 16) {
+        const int col = c16 + l15;
+        const int pend = min(kp, c16 + 16);
+        double mreg[32];
+#pragma unroll
+        for (int u = 0; u < 32; ++u) { const int p = 4 * u + l4; mreg[u] = (4 * u < pend && col < k && p < k) ? Mg[col + (size_t)p * k] : 0.0; }
+        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 32; ++u) if (4 * u < pend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[u], As[r16 + l15 + (4 * u + l4) * 65], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const int cc = c16 + l4 + 4 * g; if (cc < k) Ws[r16 + l15 + cc * 65] = acc[g]; }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * k; idx += 256) {
+        const int r = idx & 63, j = idx >> 6;
+        const int i = ibase + r;
+        const int pt = Ts[j];
+        const double wj = Ws[r + j * 65];
+        double l;
+        if (pt == 1) l = wj * Ds[j];
+        else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * Ws[r + (j + 1) * 65];
+        else l = Ds[k + j - 1] * Ws[r + (j - 1) * 65] + Ds[j] * wj;
+        if (i < m) {
+            W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l;
+            if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
+        }
+    }
+}
+
 // T(i,c) -= sum_p L21(i,p) W21(c,p),  i >= c, on 64x64 tiles; each of the 4 waves owns a 32x32 sub-tile made of
 // 2x2 v_mfma_f64_16x16x4_f64 accumulators.  The product is formed TRANSPOSED (A operand = W rows, B operand = L rows)
 // so that the 16 lanes sharing an accumulator register hold 16 consecutive ROWS of the column-major T => 128-byte
@@ -2033,6 +2105,7 @@ public:
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
+    bool fuse_dt = true;                               // pivot block + panel solve in one launch where a level has few fronts
     bool chain_solve = true; int chain_maxc = 8;       // only where few chains run side by side (the latency-bound top of the tree)
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
@@ -2365,6 +2438,7 @@ public:
         std::vector<ChainLink> chl; std::vector<ChainDesc> chd;
         chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
+        fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
         if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
         if (!multi && !Sy.solve_group && chain_solve) {
             auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
@@ -2596,7 +2670,7 @@ public:
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
-            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
+            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         if (opt.scaling == 3) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
@@ -2624,6 +2698,7 @@ public:
             r = std::max(r, need);
         }
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
@@ -2721,9 +2796,18 @@ public:
         if (!drain_chain()) return false;
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
+        const int nrb = (mm + 63) / 64;
+        if (fuse_dt && single && !top_mode && kk <= 64 && nball * (1 + nrb) <= 448) {
+            // few fronts on the level: pivot block + panel solve in one flag-synchronised launch (k_big_diag_trsm)
+            const size_t lds = std::max((size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64,
+                                        trsm_lds(kk) + (size_t)(kk + 2) * sizeof(int) + (size_t)65 * kk * sizeof(double) + 16);
+            LAUNCH(KK_BIG_DIAG, k_big_diag_trsm, dim3(1 + nrb, nball), dim3(256), lds, stream, V, b0);
+            goto updates;
+        }
         if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
+      updates:
         if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0, 0);
         if (b1 == bs) return true;
         const int nb = b1 - bs;
@@ -2761,6 +2845,7 @@ public:
         const Symbolic& Sy = *S;
         const int n = Sy.n;
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
+        LAUNCH(KK_STATS, k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch + 2);
         LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
         LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
@@ -2820,6 +2905,7 @@ public:
         HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
         st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4];
+        if (h_stats[5] != 0) { err_ = "factor: a panel workgroup timed out waiting for its pivot block"; return false; }
         return true;
     }
     double graph_pivtol = -1.0, graph_pivtol2 = -1.0;

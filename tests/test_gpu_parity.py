@@ -322,3 +322,20 @@ def test_sync_free_chain_sweeps_match_the_level_by_level_solves(monkeypatch):
         assert np.abs(x - x0).max() <= 1e-11 * max(1.0, np.abs(x0).max())
         x2 = b.copy(); s1.multi_solve(False, x2)
         assert np.array_equal(x, x2)
+
+
+def test_fused_pivot_block_and_panel_solve_is_bitwise_identical(monkeypatch):
+    """k_big_diag_trsm (pivot block + panel solve of a front in one flag-synchronised launch, used where a level has few
+    fronts) against the two separate launches: the same arithmetic, so the same bits"""
+    n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    monkeypatch.setenv("MI355X_KKT_NO_FUSE_DT", "1")
+    s0, st0, x0 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+    monkeypatch.delenv("MI355X_KKT_NO_FUSE_DT")
+    s1, st1, x1 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+    assert st0 == st1 == kkt.SUCCESS and s0.info().num_two == s1.info().num_two
+    assert np.array_equal(x0, x1)
+    for _ in range(3):
+        x2 = b.copy(); s1.multi_solve(True, x2)
+        assert np.array_equal(x1, x2)
