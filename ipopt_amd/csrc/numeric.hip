@@ -2797,7 +2797,7 @@ public:
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         const int nrb = (mm + 63) / 64;
-        if (fuse_dt && single && !top_mode && kk <= 64 && nball * (1 + nrb) <= 448) {
+        if (fuse_dt && single && !top_mode && !prof_on && kk <= 64 && nball * (1 + nrb) <= 448) {      // (the per-kernel profile keeps the two kernels apart)
             // few fronts on the level: pivot block + panel solve in one flag-synchronised launch (k_big_diag_trsm)
             const size_t lds = std::max((size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64,
                                         trsm_lds(kk) + (size_t)(kk + 2) * sizeof(int) + (size_t)65 * kk * sizeof(double) + 16);
