@@ -944,6 +944,118 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
 
 
 
+// ------------------------------------------------------------------------------------------------
+// Fronts of order <= 32 (the LukVl regime: 10^5..10^6 of them per sweep): TWO fronts per wavefront (one per half: a front of
+// order <= 32 leaves half a wavefront idle) and three dependent memory phases instead of seven -- everything that only depends on
+// the front record (pivot order, D, the row of L11^{-1} and the panel row / column a lane owns) is loaded up front into registers,
+// then the children's contributions (forward) or the ancestors' solution entries (backward), then arithmetic.  The sweeps are
+// bound by (dependent round trips) x (fronts / resident wavefronts), not by bytes.  KP = compile-time bound on the pivot count.
+// ------------------------------------------------------------------------------------------------
+template <int KP>
+__global__ __launch_bounds__(64) void k_fwd_pair(DevView V, int list_off, int nfronts)
+{
+    __shared__ double xs[2][32], bp[2][32], ys[2][33];
+    const int lane = threadIdx.x, h = lane >> 5, li = lane & 31;
+    const int f = 2 * (int)blockIdx.x + h;
+    const bool act = f < nfronts;
+    const FrontMeta* Mp = V.fmeta + list_off + (act ? f : 0);
+    const int c0 = Mp->c0, k = act ? Mp->k : 0, m = act ? Mp->m : 0, ch0 = Mp->ch0, ch1 = act ? Mp->ch1 : Mp->ch0, ldp = Mp->ldp;
+    const long long cvo = Mp->cv;
+    // ---- phase 1: depends on the front record only ----
+    const bool piv = li < k, upd = li >= k && li < m;
+    const double xwv = piv ? V.xw[c0 + li] : 0.0;
+    const int lpv = piv ? V.lperm[c0 + li] : 0;
+    int pt = 1; double dq = 0.0, oq = 0.0, oq1 = 0.0;
+    if (piv) { pt = V.ptype[c0 + li]; dq = V.dinv[c0 + li]; oq = V.doff[c0 + li]; oq1 = li > 0 ? V.doff[c0 + li - 1] : 0.0; }
+    const double* Mg = V.minv + Mp->minv_off;
+    const double* Lg = V.L + Mp->panel_off;
+    double mrow[KP], lrow[KP];
+#pragma unroll
+    for (int p = 0; p < KP; ++p) {
+        mrow[p] = (piv && p <= li) ? Mg[li + (size_t)p * k] : 0.0;
+        lrow[p] = (upd && p < k) ? Lg[li + (size_t)p * ldp] : 0.0;
+    }
+    int cmc[4], crel[4]; long long ccv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const bool has = ch0 + c < ch1;
+        const ChildMeta* Cp = V.cmeta + ch0 + (has ? c : 0);
+        cmc[c] = has ? Cp->mc : 0; crel[c] = Cp->relbase; ccv[c] = Cp->cvbase;
+    }
+    // ---- phase 2: the children's contribution vectors ----
+    int tg[4]; double cv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { const bool on = li < cmc[c]; tg[c] = on ? V.rel[crel[c] + li] : -1; cv[c] = on ? V.cvec[ccv[c] + li] : 0.0; }
+    // ---- phase 3: arithmetic ----
+    xs[h][li] = xwv;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { if (tg[c] >= 0) xs[h][tg[c]] += cv[c]; __syncthreads(); }
+    for (int cp = ch0 + 4; cp < ch1; ++cp) {                 // (more than four children: rare)
+        const int mc = V.cmeta[cp].mc;
+        if (li < mc) xs[h][V.rel[V.cmeta[cp].relbase + li]] += V.cvec[V.cmeta[cp].cvbase + li];
+        __syncthreads();
+    }
+    bp[h][li] = piv ? xs[h][lpv] : 0.0;
+    __syncthreads();
+    double y = 0.0;
+#pragma unroll
+    for (int p = 0; p < KP; ++p) y += mrow[p] * bp[h][p];
+    ys[h][li] = piv ? y : 0.0;
+    if (li == 0) ys[h][32] = 0.0;
+    __syncthreads();
+    if (upd) {
+        double t = 0.0;
+#pragma unroll
+        for (int p = 0; p < KP; ++p) t += lrow[p] * ys[h][p];
+        V.cvec[cvo + li] = xs[h][li] - t;
+    }
+    if (piv) {
+        double z;
+        if (pt == 1) z = y * dq;
+        else if (pt == 2) z = dq * y + oq * ys[h][li + 1];
+        else z = oq1 * ys[h][li - 1] + dq * y;
+        V.zb[c0 + li] = z;
+    }
+}
+template <int KP>
+__global__ __launch_bounds__(64) void k_bwd_pair(DevView V, int list_off, int nfronts)
+{
+    __shared__ double xus[2][32], w[2][32];
+    const int lane = threadIdx.x, h = lane >> 5, li = lane & 31;
+    const int f = 2 * (int)blockIdx.x + h;
+    const bool act = f < nfronts;
+    const FrontMeta* Mp = V.fmeta + list_off + (act ? f : 0);
+    const int c0 = Mp->c0, k = act ? Mp->k : 0, m = act ? Mp->m : 0, r0 = Mp->r0, ldp = Mp->ldp;
+    const bool piv = li < k, upd = li >= k && li < m;
+    // ---- phase 1 ----
+    const double zbv = piv ? V.zb[c0 + li] : 0.0;
+    const int lpv = piv ? V.lperm[c0 + li] : 0;
+    const int ridx = upd ? V.sn_rows[r0 + li] : 0;
+    const double* Mg = V.minv + Mp->minv_off;
+    const double* Lg = V.L + Mp->panel_off;
+    double mcol[KP], lcol[32];
+#pragma unroll
+    for (int q = 0; q < KP; ++q) mcol[q] = (piv && li + q < k) ? Mg[li + q + (size_t)li * k] : 0.0;      // Minv(li + q, li)
+#pragma unroll
+    for (int i = 0; i < 32; ++i) lcol[i] = (piv && k + i < m) ? Lg[k + i + (size_t)li * ldp] : 0.0;        // L(k + i, li)
+    // ---- phase 2: the ancestors' solution entries ----
+    xus[h][li] = upd ? V.xw[ridx] : 0.0;
+    __syncthreads();
+    // ---- phase 3 ----
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t += lcol[i] * xus[h][(k + i) & 31];
+    w[h][li] = piv ? zbv - t : 0.0;
+    __syncthreads();
+    if (piv) {
+        double a = 0.0;
+#pragma unroll
+        for (int q = 0; q < KP; ++q) a += mcol[q] * w[h][(li + q) & 31];
+        V.xw[c0 + lpv] = a;
+    }
+}
+
 // ================================================================================================
 // BIG fronts in the triangular solves: a CHAIN GROUP (<= 4 links of an in-place separator chain, <= 256 columns) is one
 // unit, handled at its LAST link (FrontMeta::grem == 0; the other links return at once).  All links of a chain share one
@@ -2105,6 +2217,7 @@ public:
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
+    bool pair_solve = true; std::vector<int> wave_kmax;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
     bool fuse_dt = true;                               // pivot block + panel solve in one launch where a level has few fronts
     bool chain_solve = true; int chain_maxc = 8;       // only where few chains run side by side (the latency-bound top of the tree)
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
@@ -2439,6 +2552,9 @@ public:
         chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
+        pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
+        wave_kmax.assign(Sy.num_levels, 0);
+        for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
         if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
         if (!multi && !Sy.solve_group && chain_solve) {
             auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
@@ -2940,7 +3056,9 @@ public:
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
-                    if (fc == FC_WAVE)        LAUNCH(KK_FWD_WAVE, (k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
+                    if (fc == FC_WAVE && pair_solve && wave_kmax[lv] <= 16) LAUNCH(KK_FWD_WAVE, (k_fwd_pair<16>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
+                    else if (fc == FC_WAVE && pair_solve)                   LAUNCH(KK_FWD_WAVE, (k_fwd_pair<32>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
+                    else if (fc == FC_WAVE)   LAUNCH(KK_FWD_WAVE, (k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
                     else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
                     else if (fc == FC_LDS128) LAUNCH(KK_FWD_LDS,  (k_fwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0, 0);
                     else if (big_last1[lv] > big_last0[lv]) {
@@ -2961,7 +3079,9 @@ public:
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
-                    if (fc == FC_WAVE)        LAUNCH(KK_BWD_WAVE, (k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
+                    if (fc == FC_WAVE && pair_solve && wave_kmax[lv] <= 16) LAUNCH(KK_BWD_WAVE, (k_bwd_pair<16>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
+                    else if (fc == FC_WAVE && pair_solve)                   LAUNCH(KK_BWD_WAVE, (k_bwd_pair<32>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
+                    else if (fc == FC_WAVE)   LAUNCH(KK_BWD_WAVE, (k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
                     else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
                     else if (fc == FC_LDS128) LAUNCH(KK_BWD_LDS,  (k_bwd<256>), dim3(b1 - b0), dim3(256), lds_solve(128, 128), stream, V, b0);
                     else if (big_last1[lv] > big_last0[lv]) {
