@@ -661,6 +661,33 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
         for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] += V.aval[q]; }
     }
     __syncthreads();
+    if (NT == 64 && MAXM <= 32) {
+        // one-wavefront fronts of order <= 32 (the LukVl regime): a child's whole contribution block (<= 32 x 32) is fetched in ONE
+        // batch of independent loads -- 16 per lane -- instead of a dependent round trip per column; the extend-add then runs out of
+        // registers.  (On this part a dependent global access costs 1.5-2 us: the assembly of such a front is made of round trips.)
+        int* relS = reinterpret_cast<int*>(colbuf);              // the child's relative indices (colbuf is free until the LDL^T)
+        for (int cp = M.ch0; cp < M.ch1; ++cp) {
+            const ChildMeta* Cp = V.cmeta + cp;
+            if (skip_owned && Cp->owner >= 0) continue;
+            const int mc = Cp->mc, ldt = Cp->ldt;
+            const double* C = V.cb + Cp->cb_off;
+            const int rl = (lane < mc) ? V.rel[Cp->relbase + lane] : 0;
+            const unsigned inv = 65536u / (unsigned)max(mc, 1) + 1u;     // exact floor(e / mc) for e < 2048, mc <= 32
+            double cvv[16]; int ea[16], eb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int e = lane + 64 * u;
+                const int b = (int)(((unsigned)e * inv) >> 16), a = e - b * mc;
+                ea[u] = a; eb[u] = (b < mc && a >= b) ? b : -1;
+                cvv[u] = (eb[u] >= 0) ? C[a + (size_t)b * ldt] : 0.0;
+            }
+            if (lane < 32) relS[lane] = rl;
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (eb[u] >= 0) F[relS[ea[u]] + relS[eb[u]] * ld] += cvv[u];
+            __syncthreads();
+        }
+    } else
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
         const ChildMeta Cm = V.cmeta[cp];
         if (skip_owned && Cm.owner >= 0) continue;
