@@ -216,7 +216,7 @@ __global__ void k_abs_rowview(DevView V)
     const int total = V.rslot_len;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < total; p += gridDim.x * blockDim.x) V.arv[p] = fabs(V.aval[V.rslot_idx[p]]);
 }
-__global__ void k_ruiz_sweep(DevView V, const double* sin, double* sout)
+__global__ void k_ruiz_sweep(DevView V, const double* sin, double* sout, double* cnorm_out)
 {
     const int sub = threadIdx.x & 7;
     for (int i = (blockIdx.x * blockDim.x + threadIdx.x) >> 3; i < ((V.n + 7) & ~7) + 0; i += (gridDim.x * blockDim.x) >> 3) {
@@ -226,7 +226,10 @@ __global__ void k_ruiz_sweep(DevView V, const double* sin, double* sout)
             for (int p = V.rslot_ptr[i] + sub; p < p1; p += 8) mx = fmax(mx, V.arv[p] * (sin ? sin[V.rslot_col[p]] : 1.0));
         }
         mx = fmax(mx, __shfl_xor(mx, 1)); mx = fmax(mx, __shfl_xor(mx, 2)); mx = fmax(mx, __shfl_xor(mx, 4));
-        if (i < V.n && sub == 0) { const double si = sin ? sin[i] : 1.0; mx *= si; sout[i] = mx > 0.0 ? si / sqrt(mx) : si; }
+        if (i < V.n && sub == 0) {
+            const double si = sin ? sin[i] : 1.0; mx *= si; sout[i] = mx > 0.0 ? si / sqrt(mx) : si;
+            if (cnorm_out) cnorm_out[i] = 1.0;        // after the last sweep every row / column of the scaled matrix has inf-norm ~ 1: the scale of the zero-pivot test
+        }
     }
 }
 // user-supplied symmetric scaling (original numbering) -> permuted numbering (the MA97 "reuse the caller-held factors" mode)
@@ -833,6 +836,14 @@ __global__ void k_reduce_stats(const int4* fstat, const int* owner, int nsn, int
     if (threadIdx.x < 4 && sh[threadIdx.x][0] != 0) atomicAdd(&out[threadIdx.x], sh[threadIdx.x][0]);
 }
 __global__ void k_zero_i32(int* p, int n) { if (threadIdx.x < n) p[threadIdx.x] = 0; }
+// start of a factorisation in one launch: per-column flags cleared, quality flags cleared, the epoch of the flag-synchronised
+// launches advanced
+__global__ void k_factor_prologue(DevView V)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) { V.colfail[i] = 0; V.zpiv[i] = 0; }
+    if (blockIdx.x == 0 && threadIdx.x < 4) V.qstat[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) V.sepoch[2] += 1;
+}
 __global__ void k_fill_i32(int* p, int v, int n) { for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v; }
 
 // ------------------------------------------------------------------------------------------------
@@ -2976,21 +2987,18 @@ public:
         LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
         if (opt.scaling >= 2) LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);     // 2: the caller's factors, 3: matching (computed just before)
         else if (opt.scaling) {
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2, (double*)nullptr);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, (double*)nullptr);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2, (double*)nullptr);
+            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, V.cnorm);
         } else LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
-        LAUNCH(KK_GATHER_SCALE, k_colnorm, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, opt.scaling ? 1 : 0);
+        if (opt.scaling != 1) LAUNCH(KK_GATHER_SCALE, k_colnorm, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, opt.scaling ? 1 : 0);      // (Ruiz: ~1 by construction, written by the last sweep)
         if (opt.scaling) LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
     }
     bool enqueue_factor() {
         const Symbolic& Sy = *S;
         const int n = Sy.n;
-        LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
-        LAUNCH(KK_STATS, k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch + 2);
-        LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
-        LAUNCH(KK_STATS, k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
+        LAUNCH(KK_STATS, k_factor_prologue, dim3(grid1d(n)), dim3(256), 0, stream, V);
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         enqueue_scaling();
         for (int lv = 0; lv < Sy.num_levels; ++lv) {
@@ -3225,9 +3233,7 @@ public:
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
         if (opt.scaling == 3 && n > 0 && !compute_matching_scaling()) return false;
         HIPCHK(hipEventRecord(ev0, stream));
-        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, V.qstat, 4);
-        hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.colfail, 0, n);
-        hipLaunchKernelGGL(k_fill_i32, dim3(grid1d(n)), dim3(256), 0, stream, V.zpiv, 0, n);
+        hipLaunchKernelGGL(k_factor_prologue, dim3(grid1d(n)), dim3(256), 0, stream, V);
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         enqueue_scaling();
         if (!launch_fronts(sch_local, 0)) return false;
