@@ -193,6 +193,7 @@ def bench_main(args, rank, world, local):
     if rank == 0:
         # the same workload on ONE GPU of this node, so that the line carries its own strong-scaling reference
         import ipopt_amd
+        os.environ.pop("MI355X_KKT_FORCE_MULTI", None)      # (the 1-rank smoke run of this path forces it; the comparison handle is a plain single-GPU one)
         s1 = ipopt_amd.KKTSolver(device=local)
         s1.initialize_structure(n, r, c, vals=v)
         for _ in range(2):
