@@ -48,6 +48,7 @@ enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_L
 #define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); } while (0)
 
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
+static constexpr double BK_ALPHA0 = 0.1;                 // a diagonal within this factor of its whole remaining column is taken as it comes (no partner search)
 static constexpr double PIV_PERT = 1e-10;                // replacement magnitude for a zero pivot
 static constexpr double ZERO_REL = 1e-14;                // zero-pivot test relative to the largest entry assembled into the pivot's column
 
@@ -382,6 +383,17 @@ __device__ __forceinline__ void publish_col(double* buf, const double (&t)[TS][T
         }
 }
 
+#ifdef MI355X_PIVSTAT
+__device__ unsigned long long g_pivstat[16];      // development build only: [0] pivots steps, [1] slow-path entries, [2] quick accepts, [3] exact path, [4] pass-overs, [5] 2x2, [6] no-partner
+#ifdef MI355X_PIVSTAT_COUNT
+#define PIVSTAT(i) do { if (threadIdx.x == 0) atomicAdd(&g_pivstat[i], 1ull); } while (0)
+#else
+#define PIVSTAT(i) do { } while (0)
+#endif
+#else
+#define PIVSTAT(i) do { } while (0)
+#endif
+
 __device__ __forceinline__ double fast_rcp(double d)
 {
     double r = __builtin_amdgcn_rcp(d);          // v_rcp_f64 + two Newton steps: full fp64 accuracy without the division macro
@@ -391,9 +403,11 @@ __device__ __forceinline__ double fast_rcp(double d)
 }
 
 // Threshold pivoting (what u = pivtol means here; DESIGN.md "pivoting"):
-//   * candidate order: the still-alive fully-summed rows in physical order; for the current candidate j the
-//     Bunch-Kaufman rule (alpha = 0.64, on the alive fully-summed part) PREFERS one of {1x1 at j, 1x1 at r, 2x2 (j,r)},
-//     r = the fully-summed row with the largest |a_rj|;
+//   * candidate order: the still-alive fully-summed rows in physical order; a candidate j whose diagonal is within
+//     alpha0 = 0.1 of its whole remaining column (|a_jj| >= alpha0 max_{i != j} |a_ij|: the threshold test of UMFPACK / MA48
+//     at their default u, seven orders of magnitude tighter than Ipopt's 1e-8) is eliminated as a 1x1 without looking
+//     further; otherwise the Bunch-Kaufman rule (alpha = 0.64, on the alive fully-summed part) PREFERS one of
+//     {1x1 at j, 1x1 at r, 2x2 (j,r)}, r = the fully-summed row with the largest |a_rj|;
 //   * a pivot is ACCEPTED only if it passes the MA27/MA57 threshold tests against the WHOLE remaining front column --
 //     alive fully-summed rows AND update rows:   1x1: |a_pp| >= u max_{i != p} |a_ip|;
 //     2x2: |E^{-1}| (g_p, g_q)^T <= 1/u componentwise, g = column maxima outside the block (Duff & Reid 1983; MA57);
@@ -439,7 +453,13 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
     const double zmax = fmax(small, ZERO_REL * cmx);
     auto clear_row = [&](int r) { if (!WIDE || r < 64) alive &= ~(1ull << r); else alive1 &= ~(1ull << (r - 64)); };
     int step = 0, bufsel = 0;
+#ifdef MI355X_PIVSTAT
+    long long tprev = clock64(); bool was_slow = false; int first = 1; unsigned long long acc_f = 0, acc_s = 0, n_f = 0, n_s = 0;
+#endif
     while ((alive | alive1) != 0ull) {
+#ifdef MI355X_PIVSTAT
+        if (NT == 256 && TS == 4 && tid == 0 && gridDim.y == 1 && blockIdx.x == 0) { const long long tn = clock64(); if (!first) { if (was_slow) { acc_s += tn - tprev; n_s++; } else { acc_f += tn - tprev; n_f++; } } tprev = tn; first = 0; was_slow = false; }
+#endif
         double* colA = colbuf + bufsel * 2 * MAXM; bufsel ^= 1;
         double* colB = colA + MAXM;
         const int j = __builtin_amdgcn_readfirstlane(tryb != 0ull ? __ffsll((long long)tryb) - 1 : 64 + __ffsll((long long)tryb1) - 1);
@@ -461,13 +481,18 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
         const double ga = fmax(fmax(av, up0 ? f0 : 0.0), up1 ? f1 : 0.0);      // whole remaining column, diagonal excluded
         // the common case must stay ONE straight instruction stream (every taken branch costs an instruction refetch on the
         // serial pivot chain): three ballots OR-ed into one scalar test, statistics accumulated branch-free
-        const unsigned long long slowm = __ballot(av * BK_ALPHA > ajj)        // some |a_ij| > |a_jj| / alpha: full Bunch-Kaufman test
+        const unsigned long long slowm = __ballot(ga * BK_ALPHA0 > ajj)       // some |a_ij| > |a_jj| / alpha0: full Bunch-Kaufman test
                                        | __ballot(ga * u > ajj)               // 1x1 at j fails the threshold test
                                        | __ballot(!(ajj > zmax));             // possibly a (numerically) zero diagonal: exact test below
         chgm |= __ballot(ga * u2e > ajj);
         double d = djj;                    // 1x1 pivot value on physical row p (pivot column in rv / cv)
         int p = j;
+        PIVSTAT(0);
         if (__builtin_expect(slowm != 0ull, 0)) {
+            PIVSTAT(1);
+#ifdef MI355X_PIVSTAT
+            was_slow = true;
+#endif
             const int bi = (av1 > av0) ? lane + 64 : lane;       // this lane's best candidate row
             const double ztol = fmax(small, ZERO_REL * cm0[j]);     // zero threshold of candidate j
             const double uu = force ? 0.0 : u;
@@ -476,6 +501,9 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             int r = -1;
             bool zero = false;
             if (lam > 0.0) {
+#ifdef MI355X_PIVSTAT_COUNT
+                { const double rho = ajj / lam; if (threadIdx.x == 0) atomicAdd(&g_pivstat[rho >= 0.5 ? 12 : (rho >= 0.25 ? 13 : (rho >= 0.1 ? 14 : 15))], 1ull); if (threadIdx.x == 0 && rho < 0.01) atomicAdd(&g_pivstat[7], 1ull); }
+#endif
                 const unsigned long long hit = __ballot(av == lam);
                 const int src = __builtin_amdgcn_readfirstlane(__ffsll((long long)hit) - 1);
                 r = __builtin_amdgcn_readlane(bi, src);
@@ -500,8 +528,9 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                 const bool quick = !force && ((pref == 0) ? (ajj > ztol && ajj >= um * G)
                                             : (pref == 1) ? (arr > ztr && arr >= um * G)
                                                           : (nz2 && (arr + ab) * G * um <= adet && (ab + ajj) * G * um <= adet));   // (forced pivots are counted exactly)
-                if (quick) sel = pref;
+                if (quick) { sel = pref; PIVSTAT(2); }
                 else {
+                    PIVSTAT(3);
                     const double gj = wave_max_all(ga);
                     const double gr = wave_max_all(hall);
                     const bool nj0 = lane != j, nj1 = lane + 64 != j;
@@ -521,12 +550,14 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
                     }
                 }
             } else {
+                PIVSTAT(6);
                 const double gj = wave_max_all(ga);
                 if (ajj > ztol && ajj >= uu * gj) { sel = 0; if (ajj < u * gj) ndelay += 1; }
                 else if (!(ajj > ztol) && !(gj > ztol)) { sel = 0; zero = true; }          // the whole remaining column is zero
             }
             if (sel < 0) {
                 if (!force) {          // pass over: retried once another elimination has updated the column
+                    PIVSTAT(4);
                     if (!WIDE || j < 64) tryb &= ~(1ull << j); else tryb1 &= ~(1ull << (j - 64));
                     if ((tryb | tryb1) == 0ull) { force = true; u2e = 0.0; tryb = alive; tryb1 = alive1; }   // every candidate failed: static pivoting
                     continue;
@@ -535,6 +566,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             }
             force = false; u2e = u2;
             if (sel == 2) {
+                PIVSTAT(5);
                 const int q = r;
                 const double a = colA[p], b = colA[q], c = colB[q];
                 const double det = a * c - b * b;
@@ -593,6 +625,9 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
             tryb = alive; tryb1 = alive1;
         }
     }
+#ifdef MI355X_PIVSTAT
+    if (n_f + n_s) { atomicAdd(&g_pivstat[8], acc_f); atomicAdd(&g_pivstat[9], acc_s); atomicAdd(&g_pivstat[10], n_f); atomicAdd(&g_pivstat[11], n_s); }
+#endif
     if (chgm != 0ull) chg = 1;
     __syncthreads();
 }
@@ -2594,7 +2629,7 @@ public:
         wave_kmax.assign(Sy.num_levels, 0);
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
         if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
-        if (!multi && !Sy.solve_group && chain_solve) {
+        if (!Sy.solve_group && chain_solve) {      // (multi-GPU: only runs of levels that belong entirely to the replicated top)
             auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
             auto Mr = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
             auto pure = [&](int sn) { return Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1 && Kc(sn) <= 64; };
@@ -2602,7 +2637,7 @@ public:
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
                 const int a = Sy.level_ptr[(size_t)lv * FC_COUNT], b = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT];
                 bool ok = b > a;
-                for (int q = a; q < b && ok; ++q) { const int sn = Sy.level_sn[q]; ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1; }
+                for (int q = a; q < b && ok; ++q) { const int sn = Sy.level_sn[q]; ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1 && (!multi || Sy.sn_owner[sn] < 0); }
                 lvok[lv] = ok ? 1 : 0;
             }
             std::vector<int> alias_parent(Sy.num_sn, -1);
@@ -3187,6 +3222,16 @@ public:
         auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
         for (int q = 0; q < Sy.num_levels; ++q) {
             const int lv = forward ? q : Sy.num_levels - 1 - q;
+            if (top_mode && !chain_segs.empty()) {      // runs of pure chain levels of the replicated top: the sync-free sweeps (pure links have no rank-owned children)
+                const int sgi = forward ? seg_at_lv0[lv] : seg_at_lv1[lv];
+                if (sgi >= 0) {
+                    const ChainSeg& sg = chain_segs[sgi];
+                    if (forward) hipLaunchKernelGGL(k_fwd_chain, dim3(sg.nwg_f), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    else if (sg.maxtail > 256) hipLaunchKernelGGL((k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    else hipLaunchKernelGGL((k_bwd_chain<256>), dim3(sg.nwg_b), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    q += sg.lv1 - sg.lv0; continue;
+                }
+            }
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc], b1 = sc.base + sc.ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
@@ -3270,6 +3315,7 @@ public:
         for (int r = 0; r < nrhs; ++r) {
             const double* src = dsrc + (size_t)r * lds_; double* col = drhs + (size_t)r * ld;
             hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, src);
+            if (!chain_segs.empty()) hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
             if (!launch_solve_sweep(sch_local, true, 0)) return false;
             if (top_count > 0) hipLaunchKernelGGL(k_top_rhs_assemble, dim3(top_count), dim3(256), 0, stream, V, top_list_base);
             if (!allreduce(V.top_rhs, toprhs_doubles, 0)) return false;
@@ -3311,6 +3357,7 @@ public:
         if (!ready || !multi) { err_ = "solve_fwd_local: not a multi-GPU handle"; return false; }
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, (const double*)drhs);
+        if (!chain_segs.empty()) hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
         if (!launch_solve_sweep(sch_local, true, 0)) return false;
         if (top_count > 0) hipLaunchKernelGGL(k_top_rhs_assemble, dim3(top_count), dim3(256), 0, stream, V, top_list_base);
         HIPCHK(hipGetLastError());
@@ -3346,7 +3393,14 @@ public:
     bool debug_clocks(unsigned long long* out) {
         DeviceGuard guard(dev);
         if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
-        HIPCHK(hipMemcpy(out, V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost)); return true;
+        HIPCHK(hipMemcpy(out, V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+#ifdef MI355X_PIVSTAT
+        unsigned long long ps[16]; HIPCHK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pivstat), sizeof ps));
+        fprintf(stderr, "PIVSTAT big pivot blocks: fast steps %llu mean %.0f cycles, slow steps %llu mean %.0f cycles\n", ps[10], (double)ps[8] / (double)std::max(1ull, ps[10]), ps[11], (double)ps[9] / (double)std::max(1ull, ps[11]));
+        fprintf(stderr, "PIVSTAT slow-path |a_jj|/lambda: >=0.5 %llu  [0.25,0.5) %llu  [0.1,0.25) %llu  <0.1 %llu (of which <0.01 %llu)\n", ps[12], ps[13], ps[14], ps[15], ps[7]);
+        fprintf(stderr, "PIVSTAT steps %llu slow %llu quick %llu exact %llu passover %llu twobytwo %llu nopartner %llu\n", ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6]);
+#endif
+        return true;
     }
     // eager (graph-less) factor + one solve with hip events around every launch; accumulates over `reps`
     bool profile(int reps, double* ms, int* launches) {

@@ -81,6 +81,7 @@ def factor_solve(sym, vals, rhs, only=None):
 # (num_two, num_delay, u_sensitive) with it.  TEST SUPPORT ONLY.
 # ------------------------------------------------------------------------------------------------------
 BK_ALPHA = 0.6403882032022076
+BK_ALPHA0 = 0.1     # |a_jj| >= BK_ALPHA0 * (whole remaining column): 1x1 at j without a partner search
 PIV_PERT = 1e-10
 ZERO_REL = 1e-14
 
@@ -111,7 +112,7 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True, cnorm=None):
         fs = [i for i in alive if i != j]
         gj = max(colmax(j, fs), colmax(j, upd))
         lam = colmax(j, fs) if fs else -1.0
-        bkneed = lam * BK_ALPHA > ajj
+        bkneed = gj * BK_ALPHA0 > ajj
         thfail = gj * u > ajj
         if not force and gj * u2 > ajj:
             st["chg"] = 1
