@@ -384,6 +384,7 @@ __device__ __forceinline__ void publish_col(double* buf, const double (&t)[TS][T
 }
 
 #ifdef MI355X_PIVSTAT
+__device__ unsigned long long g_fstat[32];
 __device__ unsigned long long g_pivstat[16];      // development build only: [0] pivots steps, [1] slow-path entries, [2] quick accepts, [3] exact path, [4] pass-overs, [5] 2x2, [6] no-partner
 #ifdef MI355X_PIVSTAT_COUNT
 #define PIVSTAT(i) do { if (threadIdx.x == 0) atomicAdd(&g_pivstat[i], 1ull); } while (0)
@@ -664,7 +665,7 @@ __device__ __forceinline__ double front_colmax(const double (&t)[TS][TS], double
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
 // write-back of the pivot-ordered panel, the contribution block (straight from registers), pivot data and L11^{-1}.
 template <int NT, int TS>
-__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS == 2) ? 6 : ((NT == 256 && TS == 6) ? 2 : 1))) void k_front_reg(DevView V, int list_off, int top_mode)
+__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS == 2) ? 6 : ((NT == 256 && TS == 6) ? 3 : 1))) void k_front_reg(DevView V, int list_off, int top_mode)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = (NT == 64) ? 8 : 16;
@@ -675,7 +676,14 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     const int ld = m | 1, ldi = k | 1;
     DBGSTAMP(4);
-    const int fdoubles = max(ld * m, k * ld + k * ldi);          // F, later overlaid by Lbuf (k columns) + the k x k inverse
+#ifdef MI355X_PIVSTAT
+    long long ph0 = clock64(), ph1 = 0, ph2 = 0, ph3 = 0, ph4 = 0;
+#endif
+    // F: the front's LOWER triangle, packed by columns (column c starts at c m - c (c - 1) / 2) -- half the LDS of a square, so
+    // twice as many fronts per CU on levels made of thousands of them (the pivot loop is a latency chain: co-resident fronts are
+    // what fills the SIMDs); later overlaid by Lbuf (k columns of stride ld) + the k x k inverse
+    const int npk = m * (m + 1) / 2;
+    const int fdoubles = max(npk, k * ld + k * ldi);
     double* F      = reinterpret_cast<double*>(smem_raw);
     double* colbuf = F + fdoubles;               // 4 * MAXM
     double* dinv_s = colbuf + 4 * MAXM;          // k
@@ -683,80 +691,99 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     double* cm0    = doff_s + k;                 // k   max |entry| of each fully-summed column of the assembled front
     int*    ord    = reinterpret_cast<int*>(cm0 + k);      // k
     int*    pt_s   = ord + k;                    // k
+    auto pk = [m](int i, int c) { return c * m - ((c * (c - 1)) >> 1) + (i - c); };      // i >= c
 
     // ---- (a)-(c) assembly in LDS (lower storage) ----
     const bool from_arena = top_mode && V.arena && V.arena_off[s] >= 0;   // replicated front at a subtree join
     const bool skip_owned = top_mode && V.arena;
     if (from_arena) {
         const double* Ar = V.arena + V.arena_off[s];
-        for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; F[i + c * ld] = Ar[idx]; }
+        for (int idx = tid; idx < m * m; idx += NT) { int i = idx % m, c = idx / m; if (i >= c) F[pk(i, c)] = Ar[idx]; }
     } else {
-        for (int idx = tid; idx < ld * m; idx += NT) F[idx] = 0.0;
+        for (int idx = tid; idx < npk; idx += NT) F[idx] = 0.0;
     }
     __syncthreads();
     {
         const int q0 = M.aq0, q1 = M.aq1;
-        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[i + c * ld] += V.aval[q]; }
+        for (int q = q0 + tid; q < q1; q += NT) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; F[pk(i, c)] += V.aval[q]; }
     }
     __syncthreads();
-    if (NT == 64 && MAXM <= 32) {
-        // one-wavefront fronts of order <= 32 (the LukVl regime): a child's whole contribution block (<= 32 x 32) is fetched in ONE
-        // batch of independent loads -- 16 per lane -- instead of a dependent round trip per column; the extend-add then runs out of
-        // registers.  (On this part a dependent global access costs 1.5-2 us: the assembly of such a front is made of round trips.)
+    // children: extend-add of each contribution block (lower triangle of an mc x mc square).  A dependent global access costs
+    // 1.5-2 us on this part, so a child is NOT walked column by column: its lower triangle is enumerated flat -- column b paired
+    // with column mc-1-b, mc+1 entries per pair -- and fetched in batches of 16 independent loads per thread, issued together
+    // with the load of its relative indices; the scatter into F then runs out of registers.
+    {
         int* relS = reinterpret_cast<int*>(colbuf);              // the child's relative indices (colbuf is free until the LDL^T)
         for (int cp = M.ch0; cp < M.ch1; ++cp) {
             const ChildMeta* Cp = V.cmeta + cp;
             if (skip_owned && Cp->owner >= 0) continue;
             const int mc = Cp->mc, ldt = Cp->ldt;
             const double* C = V.cb + Cp->cb_off;
-            const int rl = (lane < mc) ? V.rel[Cp->relbase + lane] : 0;
-            const unsigned inv = 65536u / (unsigned)max(mc, 1) + 1u;     // exact floor(e / mc) for e < 2048, mc <= 32
-            double cvv[16]; int ea[16], eb[16];
+            const int* relg = V.rel + Cp->relbase;
+            const unsigned d = (unsigned)(mc + 1), inv = 0xFFFFFFFFu / d + 1u;      // floor(e / d) = umulhi(e, inv) for e < 2^16
+            const int npr = (mc + 1) >> 1, total = npr * (mc + 1);
+            int r0v = (tid < mc) ? relg[tid] : 0, r1v = 0;
+            if (NT == 64 && tid + 64 < mc) r1v = relg[tid + 64];
+            auto decode = [&](int e, int& a, int& b) -> bool {      // flat index -> (row a >= column b) of the child's lower triangle
+                const int pr = (int)__umulhi((unsigned)e, inv), q = e - pr * (mc + 1);
+                const bool second = q >= mc - pr;
+                b = second ? mc - 1 - pr : pr;
+                a = second ? b + (q - (mc - pr)) : pr + q;
+                return e < total && !(second && 2 * pr == mc - 1);        // (mc odd: the middle column pairs with itself)
+            };
+            constexpr int U = (TS <= 6) ? 8 : 16;                     // loads in flight per thread (the small-tile instantiations are register-capped)
+            for (int base = 0; base < total; base += NT * U) {
+                double cvv[U];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const int e = lane + 64 * u;
-                const int b = (int)(((unsigned)e * inv) >> 16), a = e - b * mc;
-                ea[u] = a; eb[u] = (b < mc && a >= b) ? b : -1;
-                cvv[u] = (eb[u] >= 0) ? C[a + (size_t)b * ldt] : 0.0;
+                for (int u = 0; u < U; ++u) { int a, b; cvv[u] = decode(base + tid + NT * u, a, b) ? C[a + (size_t)b * ldt] : 0.0; }
+                if (base == 0) {
+                    if (tid < mc) relS[tid] = r0v;
+                    if (NT == 64 && tid + 64 < mc) relS[tid + 64] = r1v;
+                    __syncthreads();
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { int a, b; if (decode(base + tid + NT * u, a, b)) F[pk(relS[a], relS[b])] += cvv[u]; }
             }
-            if (lane < 32) relS[lane] = rl;
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < 16; ++u) if (eb[u] >= 0) F[relS[ea[u]] + relS[eb[u]] * ld] += cvv[u];
             __syncthreads();
         }
-    } else
-    for (int cp = M.ch0; cp < M.ch1; ++cp) {
-        const ChildMeta Cm = V.cmeta[cp];
-        if (skip_owned && Cm.owner >= 0) continue;
-        const int mc = Cm.mc;
-        const int* relc = V.rel + Cm.relbase;
-        const double* C = V.cb + Cm.cb_off;
-        for (int b = wave; b < mc; b += NW) {
-            const int rb = relc[b];
-            for (int a = b + lane; a < mc; a += 64) F[relc[a] + rb * ld] += C[a + (size_t)b * Cm.ldt];
-        }
-        __syncthreads();
     }
+#ifdef MI355X_PIVSTAT
+    ph1 = clock64();
+#endif
     // ---- tiles -> registers (full symmetric) ----
     const int ti = tid % G, tj = tid / G, row0 = ti * TS, col0 = tj * TS;
     double t[TS][TS];
+    {
+        int rbase[TS];                                 // packed start of column (row0 + x), minus its index: F(c, i) for c > i sits at rbase[x] + c
 #pragma unroll
-    for (int x = 0; x < TS; ++x)
+        for (int x = 0; x < TS; ++x) { const int i = row0 + x; rbase[x] = i * m - ((i * (i - 1)) >> 1) - i; }
 #pragma unroll
         for (int y = 0; y < TS; ++y) {
-            const int i = row0 + x, c = col0 + y;
-            t[x][y] = (i < m && c < m) ? ((i >= c) ? F[i + c * ld] : F[c + i * ld]) : 0.0;
+            const int c = col0 + y;
+            const int cbase = c * m - ((c * (c - 1)) >> 1) - c;
+#pragma unroll
+            for (int x = 0; x < TS; ++x) {
+                const int i = row0 + x;
+                const int idx = (i >= c) ? cbase + i : rbase[x] + c;
+                t[x][y] = (i < m && c < m) ? F[idx] : 0.0;
+            }
         }
+    }
     __syncthreads();                                   // F is dead from here on: its storage becomes Lbuf
     // ---- (d) LDL^T ----
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(5);
+#ifdef MI355X_PIVSTAT
+    ph2 = clock64();
+#endif
     const double cmx = front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
     ldlt_reg<NT, TS, false>(t, m, k, F, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, cmx, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(6);
+#ifdef MI355X_PIVSTAT
+    ph3 = clock64();
+#endif
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[14] = (unsigned long long)k * 1000 + m;
     // ---- (e) write back: pivot-ordered panel, pivot data, contribution block from the registers ----
     double* Lg = V.L + M.panel_off;
@@ -783,6 +810,10 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     invert_unit_lower<NT>(Li, ldi, k);
     double* Mg = V.minv + M.minv_off;
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Li[i + c * ldi] : (i == c ? 1.0 : 0.0); }
+#ifdef MI355X_PIVSTAT
+    ph4 = clock64();
+    if (NT == 256 && tid == 0) { const int o = (TS == 6) ? 16 : 24; atomicAdd(&g_fstat[o + 0], (unsigned long long)(ph1 - ph0)); atomicAdd(&g_fstat[o + 1], (unsigned long long)(ph2 - ph1)); atomicAdd(&g_fstat[o + 2], (unsigned long long)(ph3 - ph2)); atomicAdd(&g_fstat[o + 3], (unsigned long long)(ph4 - ph3)); atomicAdd(&g_fstat[o + 4], 1ull); atomicAdd(&g_fstat[o + 5], (unsigned long long)k); atomicAdd(&g_fstat[o + 6], (unsigned long long)(M.ch1 - M.ch0)); }
+#endif
 }
 
 // pivot block of a BIG front on the register-tiled core: 4x4 tiles on 16x16 threads for k <= 64, on 32x32 threads (two-word
@@ -2579,7 +2610,7 @@ public:
             while (q < b1 && order_of(lvl_list[q]) <= 96) {
                 const int sn = lvl_list[q];
                 const size_t m = order_of(sn), k = Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn], ld = m | 1, ldi = k | 1;
-                mid_lds[lv] = std::max(mid_lds[lv], (std::max(ld * m, k * ld + k * ldi) + 4 * 96 + 3 * k) * sizeof(double) + 2 * k * sizeof(int) + 64);
+                mid_lds[lv] = std::max(mid_lds[lv], (std::max(m * (m + 1) / 2, k * ld + k * ldi) + 4 * 96 + 3 * k) * sizeof(double) + 2 * k * sizeof(int) + 64);
                 ++q;
             }
             mid_split[lv] = (q - b0 >= 256) ? q - b0 : 0;
@@ -2882,7 +2913,7 @@ public:
             const size_t m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s], k = Sy.sn_colptr[s + 1] - Sy.sn_colptr[s];
             const size_t ld = m | 1, ldi = k | 1;
             const size_t maxm = Sy.sn_class[s] == FC_WAVE ? 32 : (Sy.sn_class[s] == FC_LDS64 ? 64 : 128);
-            const size_t need = (std::max(ld * m, k * ld + k * ldi) + 4 * maxm + 3 * k) * sizeof(double) + 2 * k * sizeof(int) + 64;
+            const size_t need = (std::max(m * (m + 1) / 2, k * ld + k * ldi) + 4 * maxm + 3 * k) * sizeof(double) + 2 * k * sizeof(int) + 64;
             size_t& r = reg_lds[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]];
             r = std::max(r, need);
         }
@@ -3396,6 +3427,9 @@ public:
         HIPCHK(hipMemcpy(out, V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 #ifdef MI355X_PIVSTAT
         unsigned long long ps[16]; HIPCHK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pivstat), sizeof ps));
+        unsigned long long fs[32]; HIPCHK(hipMemcpyFromSymbol(fs, HIP_SYMBOL(g_fstat), sizeof fs));
+        for (int o = 16; o <= 24; o += 8) { const double nf = (double)std::max(1ull, fs[o + 4]);
+            fprintf(stderr, "PIVSTAT k_front_reg<256,%d>: %llu fronts, mean k %.1f, children %.1f; cycles per front: assembly %.0f, to registers %.0f, colmax+LDL^T %.0f, write-back+inverse %.0f\n", o == 16 ? 6 : 8, fs[o + 4], fs[o + 5] / nf, fs[o + 6] / nf, fs[o] / nf, fs[o + 1] / nf, fs[o + 2] / nf, fs[o + 3] / nf); }
         fprintf(stderr, "PIVSTAT big pivot blocks: fast steps %llu mean %.0f cycles, slow steps %llu mean %.0f cycles\n", ps[10], (double)ps[8] / (double)std::max(1ull, ps[10]), ps[11], (double)ps[9] / (double)std::max(1ull, ps[11]));
         fprintf(stderr, "PIVSTAT slow-path |a_jj|/lambda: >=0.5 %llu  [0.25,0.5) %llu  [0.1,0.25) %llu  <0.1 %llu (of which <0.01 %llu)\n", ps[12], ps[13], ps[14], ps[15], ps[7]);
         fprintf(stderr, "PIVSTAT steps %llu slow %llu quick %llu exact %llu passover %llu twobytwo %llu nopartner %llu\n", ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6]);

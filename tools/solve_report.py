@@ -19,3 +19,7 @@ for k, (t, n) in sorted(by.items(), key=lambda kv: -kv[1][0])[:12]:
 for r in S:
     if "chain" in r["k"]:
         print(f"    {(r['s'] - t0) / 1e3:9.1f} us  {(r['e'] - r['s']) / 1e3:8.1f} us  {r['k']:14s} grid {r.get('Grid_Size_X', r.get('Grid_Size', ''))}")
+if len(sys.argv) > 2:      # every launch of the last solve, one line each
+    with open(sys.argv[2], "w") as f:
+        for r in S:
+            f.write(f"{(r['s'] - t0) / 1e3:10.1f} {(r['e'] - r['s']) / 1e3:8.1f} {r['k'][:28]:28s} {r.get('Grid_Size_X', '')}x{r.get('Grid_Size_Y', '')} wg {r.get('Workgroup_Size_X', '')}\n")

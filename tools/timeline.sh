@@ -8,5 +8,6 @@ OUT=$R/gpurun_out/timeline_${WL}_$TAG
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o t -- python $R/tools/factor_loop.py $WL 4 > $OUT/run.log 2>&1
 f=$(find $OUT/t -name "*kernel_trace.csv" | head -1)
-python3 $R/tools/timeline_report.py "$f" | tee $OUT/summary.txt
+python3 $R/tools/timeline_report.py "$f" $OUT/all_launches.txt | tee $OUT/summary.txt
+python3 $R/tools/solve_report.py "$f" $OUT/solve_launches.txt > $OUT/solve_summary.txt
 rm -rf $OUT/t

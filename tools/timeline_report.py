@@ -36,3 +36,7 @@ print(f"  pivot blocks: {len(D)} launches, mean duration {sum((r['e'] - r['s']) 
 print("  schedule of the last 40 launches (start offset us, duration us, queue, kernel, grid):")
 for r in F[-44:-4]:
     print(f"    {(r['s'] - t0) / 1e3:10.1f} {(r['e'] - r['s']) / 1e3:8.1f}  q{r['q']:>3s}  {r['k'][:28]:28s} {r.get('Grid_Size_X', r.get('Grid_Size', ''))}x{r.get('Grid_Size_Y', '')}")
+if len(sys.argv) > 2:      # every launch of the last factorisation, one line each
+    with open(sys.argv[2], "w") as f:
+        for r in F:
+            f.write(f"{(r['s'] - t0) / 1e3:10.1f} {(r['e'] - r['s']) / 1e3:8.1f} q{r['q']:>3s} {r['k'][:28]:28s} {r.get('Grid_Size_X', '')}x{r.get('Grid_Size_Y', '')}\n")
