@@ -114,6 +114,7 @@ struct DevView {
     int* qstat;             // [0]: some pivot decision of this factorisation would differ at u = pivtol2
     double* cnorm;          // inf-norm of every column of the (scaled) INPUT matrix, permuted numbering: scale of the zero-pivot test
     const ChainLink* chlink; const ChainDesc* chdesc;     // chain solve tables
+    int* tcnt;                                                  // per front: panel-solve workgroups finished (fused pivot block + panel solve + narrow update launch), zeroed by the prologue
     int* sflag_f; int* sflag_b; int* sflag_d; int* sepoch;     // (sflag_d / sepoch[2]: pivot block done, fused pivot-block + panel-solve launch)              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
@@ -385,6 +386,7 @@ __device__ __forceinline__ void publish_col(double* buf, const double (&t)[TS][T
 
 #ifdef MI355X_PIVSTAT
 __device__ unsigned long long g_fstat[32];
+__device__ unsigned long long g_dt[16], g_dtacc[16];     // fused pivot block + panel solve, single front: wall-clock stamps of one launch / sums over launches
 __device__ unsigned long long g_pivstat[16];      // development build only: [0] pivots steps, [1] slow-path entries, [2] quick accepts, [3] exact path, [4] pass-overs, [5] 2x2, [6] no-partner
 #ifdef MI355X_PIVSTAT_COUNT
 #define PIVSTAT(i) do { if (threadIdx.x == 0) atomicAdd(&g_pivstat[i], 1ull); } while (0)
@@ -459,7 +461,7 @@ __device__ __forceinline__ void ldlt_reg(double (&t)[TS][TS], const int m, const
 #endif
     while ((alive | alive1) != 0ull) {
 #ifdef MI355X_PIVSTAT
-        if (NT == 256 && TS == 4 && tid == 0 && gridDim.y == 1 && blockIdx.x == 0) { const long long tn = clock64(); if (!first) { if (was_slow) { acc_s += tn - tprev; n_s++; } else { acc_f += tn - tprev; n_f++; } } tprev = tn; first = 0; was_slow = false; }
+        if (NT == 256 && TS == 4 && tid == 0 && gridDim.x == 1 && blockIdx.y == 0) { const long long tn = clock64(); if (!first) { if (was_slow) { acc_s += tn - tprev; n_s++; } else { acc_f += tn - tprev; n_f++; } } tprev = tn; first = 0; was_slow = false; }
 #endif
         double* colA = colbuf + bufsel * 2 * MAXM; bufsel ^= 1;
         double* colB = colA + MAXM;
@@ -819,8 +821,10 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
 // pivot block of a BIG front on the register-tiled core: 4x4 tiles on 16x16 threads for k <= 64, on 32x32 threads (two-word
 // alive mask) for the 128-column panels of the wide_panels option (19 ms against 28 ms with 8x8 tiles on 256 threads, but
 // still slower per column than two 64-column blocks: option off by default)
+__device__ __forceinline__ void chain_signal(int* flag, const int epoch);
+__device__ __forceinline__ void chain_wait(const int* flag, const int epoch, int* err);
 template <int TS, int NT>
-__device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta& M, char* smem_raw)
+__device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta& M, char* smem_raw, int* flag = nullptr, const int epoch = 0)
 {
     constexpr int G = (NT == 1024) ? 32 : 16, MAXM = G * TS;
     const int tid = threadIdx.x;
@@ -847,11 +851,18 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
         }
     int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
     DBGSTAMP(0);
+#ifdef MI355X_PIVSTAT
+    const bool dprobe = gridDim.x == 1 && gridDim.y > 1 && tid == 0 && NT == 256;
+    if (dprobe) g_dt[1] = wall_clock64();
+#endif
     const double cmx = front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
     ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, cmx, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
     __syncthreads();
     DBGSTAMP(1);
+#ifdef MI355X_PIVSTAT
+    if (dprobe) g_dt[2] = wall_clock64();
+#endif
     // pivot-ordered unit-lower block: the row permutation is done IN PLACE in LDS through registers (each thread owns
     // <= 16 entries: k*k <= 16*NT), the panel gets its copy on the way -- no second k x k buffer, no global round trip
     {
@@ -864,10 +875,20 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
     }
     for (int j = tid; j < k; j += NT) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+#ifdef MI355X_PIVSTAT
+    if (flag && dprobe) g_dt[5] = wall_clock64();
+#endif
+    if (flag) chain_signal(flag, epoch);        // fused launch: the panel workgroups need L11, D and the pivot order -- not the inverse below
     __syncthreads();
     DBGSTAMP(2);
+#ifdef MI355X_PIVSTAT
+    if (dprobe) g_dt[3] = wall_clock64();
+#endif
     invert_unit_lower<NT>(Lb, ld, k);
     DBGSTAMP(3);
+#ifdef MI355X_PIVSTAT
+    if (dprobe) g_dt[4] = wall_clock64();
+#endif
     double* Mg = V.minv + M.minv_off;
     for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Lb[i + c * ld] : (i == c ? 1.0 : 0.0); }
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[15] = (unsigned long long)k;
@@ -907,6 +928,7 @@ __global__ void k_zero_i32(int* p, int n) { if (threadIdx.x < n) p[threadIdx.x] 
 __global__ void k_factor_prologue(DevView V)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) { V.colfail[i] = 0; V.zpiv[i] = 0; }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.nsn; i += gridDim.x * blockDim.x) V.tcnt[i] = 0;
     if (blockIdx.x == 0 && threadIdx.x < 4) V.qstat[threadIdx.x] = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) V.sepoch[2] += 1;
 }
@@ -1830,136 +1852,359 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
     }
 }
 
-// rows below the pivot block:  W21 = (A21 P) L11^{-T}  as a GEMM with the stored inverse (fp64 MFMA, no substitution chain),
-// then L21 = W21 D^{-1}.  64 rows per workgroup, 16 rows per wavefront; A21 P is staged in LDS, the rows of L11^{-1} needed
-// by a 16-column tile are pulled straight into registers (<= 32 values per lane, L2 resident); the product is formed
-// transposed (A operand = rows of L11^{-1}, B operand = rows of A21 P) so that lanes hold consecutive rows.  k <= 128.
-__global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off, int rb0)
+// rows below the pivot block:  W21 = (A21 P) L11^{-T},  then L21 = W21 D^{-1}.  64 rows per workgroup, 16 rows per wavefront,
+// BLOCKED SUBSTITUTION with L11 itself, 16 columns at a time: the columns already solved are applied by fp64 MFMA, the 16 x 16
+// diagonal block through its inverse (each wavefront inverts one diagonal block first, a 16-lane register substitution), again by
+// MFMA -- NOT a product with the whole L11^{-1}: that inverse (needed by the triangular solves only) then leaves the critical
+// path of the factorisation, the pivot-block workgroup builds it while the panel is being solved.  In the column loop every
+// wavefront works on its own 16 rows: no workgroup barrier between the column blocks.  k <= 128.
+struct TrsmLds { double* As; double* Ls; double* Is; double* Ds; int* Ts; int* Lp; double* Au; int kp16, ldl; };
+__device__ __forceinline__ TrsmLds trsm_layout(char* smem_raw, const int k, const bool staged)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    TrsmLds T;
+    T.kp16 = (k + 15) & ~15; T.ldl = T.kp16 | 1;
+    T.As = reinterpret_cast<double*>(smem_raw);               // 64 x kp16: As[r + p*65] = (A21 P)(ibase+r, p), overwritten by W in place
+    T.Ls = T.As + (size_t)65 * T.kp16;                        // L11 (strictly lower part, pivot order), zero padded to kp16 x kp16
+    T.Is = T.Ls + (size_t)T.ldl * T.kp16;                     // inverses of the 16 x 16 diagonal blocks of L11: Is[b*272 + i + p*17]
+    T.Ds = T.Is + (size_t)17 * T.kp16;                        // dinv[k], doff[k]
+    T.Ts = reinterpret_cast<int*>(T.Ds + 2 * k);              // ptype[k]
+    T.Lp = T.Ts + k;                                          // lperm[k]
+    T.Au = staged ? reinterpret_cast<double*>(T.Lp + k + (k & 1)) : nullptr;   // 64 x k: my rows as they lie in the panel (unpermuted), staged before the pivot block is known
+    return T;
+}
+// (host side: bytes of the layout above)
+static size_t trsm_lds_bytes(int k, bool staged)
+{
+    const size_t kp16 = (size_t)((k + 15) & ~15), ldl = kp16 | 1;
+    return (65 * kp16 + ldl * kp16 + 17 * kp16 + 2 * (size_t)k) * sizeof(double) + (size_t)(2 * k + 2) * sizeof(int) + (staged ? (size_t)65 * k * sizeof(double) : 0) + 16;
+}
+__device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
     const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
-    const int ibase = k + ((int)blockIdx.x + rb0) * 64;       // rb0: first row block of this launch (chain look-ahead: block 0 alone, then the rest)
-    if (ibase >= m) return;
-    const int kp = (k + 3) & ~3;                              // K padded to the MFMA depth
-    double* As = reinterpret_cast<double*>(smem_raw);         // 64 x kp: As[r + p*65] = (A21 P)(ibase+r, p)
-    double* Ws = As;                                          // W overwrites A21 P in place (column tiles are processed last to first)
-    double* Ds = As + (size_t)65 * kp;                        // dinv[k], doff[k]
-    int*    Ts = reinterpret_cast<int*>(Ds + 2 * k);          // ptype[k]
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
     double* W = V.wbuf + M.wb;
-    const double* Mg = V.minv + M.minv_off;
-    for (int j = tid; j < k; j += 256) { Ds[j] = V.dinv[c0 + j]; Ds[k + j] = V.doff[c0 + j]; Ts[j] = V.ptype[c0 + j]; }
-    if (M.selfasm) {            // ... and those of the rows below by the workgroup that owns the rows
-        for (int q = M.aq0 + tid; q < M.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
-        __syncthreads();
-    }
-    for (int idx = tid; idx < 64 * kp; idx += 256) {
-        const int r = idx & 63, p = idx >> 6;
-        As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)V.lperm[c0 + p] * ldp] : 0.0;
+    double* As = T.As; const double* Ls = T.Ls; const double* Ds = T.Ds; const int* Ts = T.Ts;
+    const int kp16 = T.kp16, ldl = T.ldl;
+    // pivot data + L11 (written by the pivot-block workgroup / kernel)
+    for (int j = tid; j < k; j += 256) { T.Ds[j] = V.dinv[c0 + j]; T.Ds[k + j] = V.doff[c0 + j]; T.Ts[j] = V.ptype[c0 + j]; T.Lp[j] = V.lperm[c0 + j]; }
+    if (kp16 <= 64) {        // one batch of independent loads (a dependent global access behind the flag costs ~2 us)
+        const int i = tid & 63, cq = tid >> 6;
+        double lv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int c = cq + 4 * u; lv[u] = (i < k && c < k && i > c) ? P[i + (size_t)c * ldp] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int c = cq + 4 * u; if (i < kp16 && c < kp16) T.Ls[i + c * ldl] = lv[u]; }
+    } else {
+        for (int c = tid >> 6; c < kp16; c += 4)
+            for (int i = tid & 63; i < kp16; i += 64) T.Ls[i + c * ldl] = (i < k && c < k && i > c) ? P[i + (size_t)c * ldp] : 0.0;
     }
     __syncthreads();
+#ifdef MI355X_PIVSTAT
+    const bool bprobe = gridDim.x == 1 && blockIdx.y == 1 && tid == 0 && T.Au;
+    if (bprobe) g_dt[10] = wall_clock64();
+#endif
+    if (T.Au && kp16 <= 64) {      // (batched: the three LDS accesses of an element are a dependent chain)
+        const int r = tid & 63, pq = tid >> 6;
+        int lpv[16]; double av[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int p = pq + 4 * u; lpv[u] = (p < k) ? T.Lp[p] : -1; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) av[u] = (lpv[u] >= 0) ? T.Au[r + lpv[u] * 65] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int p = pq + 4 * u; if (p < kp16) As[r + p * 65] = av[u]; }
+    }
+    else if (T.Au) { for (int idx = tid; idx < 64 * kp16; idx += 256) { const int r = idx & 63, p = idx >> 6; As[r + p * 65] = (p < k) ? T.Au[r + T.Lp[p] * 65] : 0.0; } }
+    else      { for (int idx = tid; idx < 64 * kp16; idx += 256) { const int r = idx & 63, p = idx >> 6; As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)T.Lp[p] * ldp] : 0.0; } }
+    // inverses of the unit-lower 16 x 16 diagonal blocks: block b by wavefront b & 3, column c of the inverse by lane c
+    for (int b = wave; 16 * b < kp16; b += 4) {
+        if (lane < 16) {
+            const int o = 16 * b;
+            double x[16];                    // x = column `lane` of the inverse; column-oriented substitution: independent updates per step
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int pp = 0; pp < 15; ++pp) {
+                const double xp = (pp >= lane) ? x[pp] : 0.0;
+#pragma unroll
+                for (int i = pp + 1; i < 16; ++i) x[i] = fma(-Ls[(o + i) + (o + pp) * ldl], xp, x[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) T.Is[b * 272 + i + lane * 17] = x[i];
+        }
+    }
+    __syncthreads();
+#ifdef MI355X_PIVSTAT
+    if (bprobe) g_dt[11] = wall_clock64();
+#endif
     const int l15 = lane & 15, l4 = lane >> 4;
     const int r16 = wave * 16;
-    // W(:, tile) needs A(:, 0 .. tile end) only (L11^{-1} is lower triangular): going from the last column tile to the first,
-    // a finished tile can be stored over the A columns that no later (lower) tile reads => half the LDS, twice the occupancy
-    for (int c16 = ((k - 1) >> 4) << 4; c16 >= 0; c16 -= 16) {
-        const int col = c16 + l15;
-        const int pend = min(kp, c16 + 16);                   // Minv(col,p) = 0 for p > col
-        double mreg[32];                                      // Minv(col, p + l4), p = 0, 4, ..., pend-4
-#pragma unroll
-        for (int u = 0; u < 32; ++u) { const int p = 4 * u + l4; mreg[u] = (4 * u < pend && col < k && p < k) ? Mg[col + (size_t)p * k] : 0.0; }
+    for (int c16 = 0; c16 < kp16; c16 += 16) {
+        // columns [c16, c16+16) minus what the solved columns contribute: (16 x c16) . (c16 x 16), transposed product as in the updates
         v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+        if (c16 <= 48) {     // operands of the whole product in flight at once
+            double oa[12], ob[12];
 #pragma unroll
-        for (int u = 0; u < 32; ++u) if (4 * u < pend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[u], As[r16 + l15 + (4 * u + l4) * 65], acc, 0, 0, 0);
+            for (int u = 0; u < 12; ++u) { const bool v = 4 * u < c16; oa[u] = v ? Ls[(c16 + l15) + (4 * u + l4) * ldl] : 0.0; ob[u] = v ? As[r16 + l15 + (4 * u + l4) * 65] : 0.0; }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { const int cc = c16 + l4 + 4 * g; if (cc < k) Ws[r16 + l15 + cc * 65] = acc[g]; }
+            for (int u = 0; u < 12; ++u) if (4 * u < c16) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[u], ob[u], acc, 0, 0, 0);
+        } else {
+            for (int p = 0; p < c16; p += 4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(c16 + l15) + (p + l4) * ldl], As[r16 + l15 + (p + l4) * 65], acc, 0, 0, 0);
+        }
+        // the block A' = A - acc goes from accumulator layout to operand layout through LDS (rows of this wavefront only)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) As[r16 + l15 + (c16 + l4 + 4 * g) * 65] -= acc[g];
+        double bv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) bv[u] = As[r16 + l15 + (c16 + 4 * u + l4) * 65];
+        const double* Ib = T.Is + (c16 >> 4) * 272;
+        v4f64 w = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w = __builtin_amdgcn_mfma_f64_16x16x4f64(Ib[l15 + (4 * u + l4) * 17], bv[u], w, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) As[r16 + l15 + (c16 + l4 + 4 * g) * 65] = w[g];
     }
     __syncthreads();
+#ifdef MI355X_PIVSTAT
+    if (bprobe) g_dt[12] = wall_clock64();
+#endif
     // a posteriori threshold test on the rows below the pivot block (the in-block test of ldlt_reg cannot see them): a column
     // with a multiplier above 1/u is a FAILED pivot -- a delayed pivot in MA97/SSIDS, counted once per column here (num_delay)
+#pragma unroll 4
     for (int idx = tid; idx < 64 * k; idx += 256) {
         const int r = idx & 63, j = idx >> 6;
         const int i = ibase + r;
         const int pt = Ts[j];
-        const double wj = Ws[r + j * 65];
+        const double wj = As[r + j * 65];
         double l;
         if (pt == 1) l = wj * Ds[j];
-        else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * Ws[r + (j + 1) * 65];
-        else l = Ds[k + j - 1] * Ws[r + (j - 1) * 65] + Ds[j] * wj;
+        else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * As[r + (j + 1) * 65];
+        else l = Ds[k + j - 1] * As[r + (j - 1) * 65] + Ds[j] * wj;
         if (i < m) {
             W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l;
             if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
         }
     }
 }
+__global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off, int rb0)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const int k = M.k, m = M.m;
+    const int ibase = k + ((int)blockIdx.x + rb0) * 64;       // rb0: first row block of this launch (chain look-ahead: block 0 alone, then the rest)
+    if (ibase >= m) return;
+    double* P = V.L + M.panel_off;
+    const size_t ldp = (size_t)M.ldp;
+    if (M.selfasm) {            // pure in-place chain link: the A entries of the rows below are added by the workgroup that owns the rows
+        for (int q = M.aq0 + tid; q < M.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
+        __syncthreads();
+    }
+    const TrsmLds T = trsm_layout(smem_raw, k, false);
+    trsm_rows_body(V, M, T, ibase);
+}
+
+// 64 x 64 tile of the trailing update on one 256-thread workgroup (k_big_schur64; also the narrow updates fused into k_big_diag_trsm)
+__device__ __forceinline__ void schur64_tile(const DevView& V, const FrontMeta& M, const int t, const int mode)      // mode 0: every tile, 1: tile (0,0) only (look-ahead), 2: all but it
+{
+    const int k = M.k, m = M.m;
+    const int mu = m - k;
+    const int nt = (mu + 63) >> 6;
+    if ((mode == 2 && t == 0) || (mode == 1 && t != 0)) return;
+    int ti, tc, climit, j0;
+    if (M.grem > 0) {
+        const int ntc = (M.grem + 63) >> 6;
+        if (t >= nt * ntc) return;
+        ti = t / ntc; tc = t - ti * ntc; climit = M.grem; j0 = M.gpos;
+    } else {
+        if (t >= nt * (nt + 1) / 2) return;
+        ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while (ti * (ti + 1) / 2 > t) --ti;
+        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+        tc = t - ti * (ti + 1) / 2; climit = mu; j0 = 0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
+    if (i0 + 31 < cc0 || cc0 >= climit || i0 >= mu) return;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[r][q] = (v4f64){0.0, 0.0, 0.0, 0.0};
+    const int ca = cc0 + l15, cb_ = cc0 + 16 + l15, ia = i0 + l15, ib = i0 + 16 + l15;
+    for (int j = j0; j <= M.gpos; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        const int kj = G.k;
+        const double* Lp = V.L + G.panel_off + (G.m - mu);
+        const double* Wp = V.wbuf + G.wb + (G.m - mu);
+        for (int p = 0; p < kj; p += 4) {
+            const int pk = p + l4;
+            const bool v = pk < kj;
+            const size_t off = (size_t)pk * G.m, offp = (size_t)pk * G.ldp;
+            const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
+            const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
+            const double b0 = (v && ia < mu) ? Lp[ia + offp] : 0.0;
+            const double b1 = (v && ib < mu) ? Lp[ib + offp] : 0.0;
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+    double* T = V.cb + M.cb_off;
+    double tv[2][2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
+                tv[r][q][g] = (i < mu && c < climit && i >= c) ? T[i + (size_t)c * M.ldt] : 0.0;
+            }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
+                if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] = tv[r][q][g] - acc[r][q][g];
+            }
+}
+
+
+// the same tile for a NARROW update on the serial chain (this link's k <= 64 columns only): every operand of the product is
+// requested before the first MFMA -- behind the panel workgroups' flag each dependent access is a ~2 us trip to another XCD's data
+__device__ __forceinline__ void narrow_tile64(const DevView& V, const FrontMeta& M, const int t)
+{
+    const int k = M.k, m = M.m;
+    const int mu = m - k;
+    const int nt = (mu + 63) >> 6, ntc = (M.grem + 63) >> 6;
+    if (t >= nt * ntc) return;
+    const int ti = t / ntc, tc = t - ti * ntc, climit = M.grem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
+    if (i0 + 31 < cc0 || cc0 >= climit || i0 >= mu) return;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int ca = cc0 + l15, cb_ = cc0 + 16 + l15, ia = i0 + l15, ib = i0 + 16 + l15;
+    const GroupLink G = V.gtab[M.gbase + M.gpos];
+    const int kj = G.k;
+    const double* Lp = V.L + G.panel_off + (G.m - mu);
+    const double* Wp = V.wbuf + G.wb + (G.m - mu);
+    double a0[16], a1[16], b0[16], b1[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int pk = 4 * u + l4;
+        const bool v = pk < kj;
+        const size_t off = (size_t)pk * G.m, offp = (size_t)pk * G.ldp;
+        a0[u] = (v && ca < mu) ? Wp[ca + off] : 0.0;
+        a1[u] = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
+        b0[u] = (v && ia < mu) ? Lp[ia + offp] : 0.0;
+        b1[u] = (v && ib < mu) ? Lp[ib + offp] : 0.0;
+    }
+    double* T = V.cb + M.cb_off;
+    double tv[2][2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
+                tv[r][q][g] = (i < mu && c < climit && i >= c) ? T[i + (size_t)c * M.ldt] : 0.0;
+            }
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[r][q] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (4 * u < kj) {
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
+        }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
+                if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] = tv[r][q][g] - acc[r][q][g];
+            }
+}
 
 // Pivot block AND panel solve of a front in ONE launch (the top of the tree, where a level has a handful of fronts and both
 // kernels are a chain of dependent round trips rather than work): workgroup 0 of a front is the pivot-block kernel and raises the
-// front's flag; workgroups 1.. each own 64 panel rows, add their A entries and stage their rows in LDS BEFORE they wait, then
-// permute / solve / scale.  Same arithmetic as k_big_diag_reg + k_big_trsm, bit for bit.
-__global__ __launch_bounds__(256) void k_big_diag_trsm(DevView V, int list_off)
+// front's flag as soon as L11 and D are stored (its inverse follows, off the critical path); workgroups 1.. each own 64 panel
+// rows, add their A entries and stage their rows in LDS BEFORE they wait, then permute / solve / scale.  Same arithmetic as
+// k_big_diag_reg + k_big_trsm, bit for bit.
+__global__ __launch_bounds__(256) void k_big_diag_trsm(DevView V, int list_off, int nrb)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const FrontMeta M = V.fmeta[list_off + blockIdx.y];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];      // x = front, y = role: every pivot block is dispatched before the first waiting workgroup
+    const int role = blockIdx.y;
     const int epoch = V.sepoch[2];
-    if (blockIdx.x == 0) { big_diag_body<4, 256>(V, M, smem_raw); chain_signal(&V.sflag_d[M.s], epoch); return; }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
-    const int ibase = k + ((int)blockIdx.x - 1) * 64;
+#ifdef MI355X_PIVSTAT
+    const bool tprobe = gridDim.x == 1 && threadIdx.x == 0;
+    if (tprobe && role == 0) g_dt[0] = wall_clock64();
+    if (tprobe && role == 1) g_dt[6] = wall_clock64();
+#endif
+    if (role == 0) { big_diag_body<4, 256>(V, M, smem_raw, &V.sflag_d[M.s], epoch); return; }
+    const int tid = threadIdx.x;
+    const int s = M.s, k = M.k, m = M.m;
+    if (role > nrb) {
+        // workgroups behind the panel blocks: the NARROW trailing update of a chain link that is not the last of its group (64 x 64
+        // tiles over the group's remaining panel columns: a fraction of a GFlop, not worth a launch of its own on the serial chain)
+        const int t = role - 1 - nrb;
+        const int mu = m - k, nt = (mu + 63) >> 6;
+        if (M.grem <= 0 || t >= nt * ((M.grem + 63) >> 6)) return;
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(&V.tcnt[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < nt) { __builtin_amdgcn_s_sleep(16);      // (~0.4 us: a hundred pollers of one address must not saturate its memory channel)
+                if (++spins > (1 << 24)) { V.qstat[1] = 1; break; } }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        narrow_tile64(V, M, t);
+        return;
+    }
+    const int ibase = k + (role - 1) * 64;
     if (ibase >= m) return;
-    const int kp = (k + 3) & ~3;
-    double* As = reinterpret_cast<double*>(smem_raw);         // 64 x kp: (A21 P), later W
-    double* Ws = As;
-    double* Ds = As + (size_t)65 * kp;                        // dinv[k], doff[k]
-    int*    Ts = reinterpret_cast<int*>(Ds + 2 * k);          // ptype[k], then lperm[k]
-    int*    Lp = Ts + k;
-    double* Au = reinterpret_cast<double*>(Lp + k);           // 64 x k: my rows as they lie in the panel (unpermuted); (2k ints: 8-byte aligned)
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
-    double* W = V.wbuf + M.wb;
-    const double* Mg = V.minv + M.minv_off;
     if (M.selfasm) {
         for (int q = M.aq0 + tid; q < M.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
         __syncthreads();
     }
-    for (int idx = tid; idx < 64 * k; idx += 256) { const int r = idx & 63, c = idx >> 6; Au[r + c * 65] = (ibase + r < m) ? P[ibase + r + (size_t)c * ldp] : 0.0; }
-    chain_wait(&V.sflag_d[s], epoch, V.qstat + 1);            // the pivot block of this front is done
-    for (int j = tid; j < k; j += 256) { Ds[j] = V.dinv[c0 + j]; Ds[k + j] = V.doff[c0 + j]; Ts[j] = V.ptype[c0 + j]; Lp[j] = V.lperm[c0 + j]; }
+    const TrsmLds T = trsm_layout(smem_raw, k, true);
+    for (int idx = tid; idx < 64 * k; idx += 256) { const int r = idx & 63, c = idx >> 6; T.Au[r + c * 65] = (ibase + r < m) ? P[ibase + r + (size_t)c * ldp] : 0.0; }
+#ifdef MI355X_PIVSTAT
+    if (tprobe && role == 1) g_dt[7] = wall_clock64();
+#endif
+    chain_wait(&V.sflag_d[s], epoch, V.qstat + 1);            // L11 and D of this front are stored
+#ifdef MI355X_PIVSTAT
+    if (tprobe && role == 1) g_dt[8] = wall_clock64();
+#endif
+    trsm_rows_body(V, M, T, ibase);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // my rows of L21 / W21 are stored: one more panel block done
     __syncthreads();
-    for (int idx = tid; idx < 64 * kp; idx += 256) { const int r = idx & 63, p = idx >> 6; As[r + p * 65] = (p < k) ? Au[r + Lp[p] * 65] : 0.0; }
-    __syncthreads();
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int r16 = wave * 16;
-    for (int c16 = ((k - 1) >> 4) << 4; c16 >= 0; c16 -= 16) {
-        const int col = c16 + l15;
-        const int pend = min(kp, c16 + 16);
-        double mreg[32];
-#pragma unroll
-        for (int u = 0; u < 32; ++u) { const int p = 4 * u + l4; mreg[u] = (4 * u < pend && col < k && p < k) ? Mg[col + (size_t)p * k] : 0.0; }
-        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int u = 0; u < 32; ++u) if (4 * u < pend) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(mreg[u], As[r16 + l15 + (4 * u + l4) * 65], acc, 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) { const int cc = c16 + l4 + 4 * g; if (cc < k) Ws[r16 + l15 + cc * 65] = acc[g]; }
+    if (tid == 0) __hip_atomic_fetch_add(&V.tcnt[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef MI355X_PIVSTAT
+    if (tprobe && role == 1) {
+        const unsigned long long te = wall_clock64(), t0 = g_dt[0];
+        for (int q = 1; q <= 8; ++q) if (q != 3 && q != 4) g_dtacc[q] += g_dt[q] - t0;
+        g_dtacc[9] += te - t0; g_dtacc[0] += 1;
+        for (int q = 10; q <= 12; ++q) g_dtacc[q] += g_dt[q] - t0;
     }
-    __syncthreads();
-    for (int idx = tid; idx < 64 * k; idx += 256) {
-        const int r = idx & 63, j = idx >> 6;
-        const int i = ibase + r;
-        const int pt = Ts[j];
-        const double wj = Ws[r + j * 65];
-        double l;
-        if (pt == 1) l = wj * Ds[j];
-        else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * Ws[r + (j + 1) * 65];
-        else l = Ds[k + j - 1] * Ws[r + (j - 1) * 65] + Ds[j] * wj;
-        if (i < m) {
-            W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l;
-            if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
-        }
-    }
+#endif
 }
 
 // T(i,c) -= sum_p L21(i,p) W21(c,p),  i >= c, on 64x64 tiles; each of the 4 waves owns a 32x32 sub-tile made of
@@ -2114,75 +2359,10 @@ __global__ __launch_bounds__(1024) void k_big_schur(DevView V, int list_off, int
 // Small-front variant of the trailing update (levels whose largest front has <= 640 rows: thousands of fronts, a handful
 // of tiles each): 64 x 64 tile per 256-thread workgroup, 32 x 32 per wavefront, operands straight from L2.  The 128 x 128
 // LDS-staged kernel above leaves most of its 16 wavefronts idle on such fronts (PMC: 7.6 % MFMA utilisation).
-__global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off, int mode)      // mode 0: every tile, 1: tile (0,0) only (look-ahead), 2: all but it
+__global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off, int mode)
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
-    const int k = M.k, m = M.m;
-    const int mu = m - k;
-    const int nt = (mu + 63) >> 6;
-    const int t = blockIdx.x;
-    if ((mode == 2 && t == 0) || (mode == 1 && t != 0)) return;
-    int ti, tc, climit, j0;
-    if (M.grem > 0) {
-        const int ntc = (M.grem + 63) >> 6;
-        if (t >= nt * ntc) return;
-        ti = t / ntc; tc = t - ti * ntc; climit = M.grem; j0 = M.gpos;
-    } else {
-        if (t >= nt * (nt + 1) / 2) return;
-        ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while (ti * (ti + 1) / 2 > t) --ti;
-        while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-        tc = t - ti * (ti + 1) / 2; climit = mu; j0 = 0;
-    }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i0 = ti * 64 + (wave >> 1) * 32, cc0 = tc * 64 + (wave & 1) * 32;
-    if (i0 + 31 < cc0 || cc0 >= climit || i0 >= mu) return;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    v4f64 acc[2][2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) acc[r][q] = (v4f64){0.0, 0.0, 0.0, 0.0};
-    const int ca = cc0 + l15, cb_ = cc0 + 16 + l15, ia = i0 + l15, ib = i0 + 16 + l15;
-    for (int j = j0; j <= M.gpos; ++j) {
-        const GroupLink G = V.gtab[M.gbase + j];
-        const int kj = G.k;
-        const double* Lp = V.L + G.panel_off + (G.m - mu);
-        const double* Wp = V.wbuf + G.wb + (G.m - mu);
-        for (int p = 0; p < kj; p += 4) {
-            const int pk = p + l4;
-            const bool v = pk < kj;
-            const size_t off = (size_t)pk * G.m, offp = (size_t)pk * G.ldp;
-            const double a0 = (v && ca < mu) ? Wp[ca + off] : 0.0;
-            const double a1 = (v && cb_ < mu) ? Wp[cb_ + off] : 0.0;
-            const double b0 = (v && ia < mu) ? Lp[ia + offp] : 0.0;
-            const double b1 = (v && ib < mu) ? Lp[ib + offp] : 0.0;
-            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-    double* T = V.cb + M.cb_off;
-    double tv[2][2][4];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
-                tv[r][q][g] = (i < mu && c < climit && i >= c) ? T[i + (size_t)c * M.ldt] : 0.0;
-            }
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int c = cc0 + r * 16 + l4 + 4 * g, i = i0 + q * 16 + l15;
-                if (i < mu && c < climit && i >= c) T[i + (size_t)c * M.ldt] = tv[r][q][g] - acc[r][q][g];
-            }
+    schur64_tile(V, M, blockIdx.x, mode);
 }
 
 // ================================================================================================
@@ -2317,12 +2497,14 @@ public:
         return true;
     }
     std::vector<int> big_maxm, big_maxk, big_tiles, big_tiles64, big_last0, big_last1;
+    std::vector<int> lv_narrow_tiles;   // > 0: every big front of the level is a chain link with a narrow update; the 64 x 64 tiles of the largest one
     std::vector<char> lv_asm_skip;      // every big front of the level is a pure in-place chain link: no assembly launch at all
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
     bool pair_solve = true; std::vector<int> wave_kmax;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
     bool fuse_dt = true;                               // pivot block + panel solve in one launch where a level has few fronts
+    int fuse_dt_maxwg = 448;                           // ... few = this many workgroups (pivot blocks + 64-row panel blocks) at most
     bool chain_solve = true; int chain_maxc = 8;       // only where few chains run side by side (the latency-bound top of the tree)
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
@@ -2656,6 +2838,7 @@ public:
         chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
+        if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
         pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
         wave_kmax.assign(Sy.num_levels, 0);
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
@@ -2811,6 +2994,19 @@ public:
                 }
                 lv_asm_skip[lv] = (cnt > 0 && all) ? 1 : 0;
             }
+        // levels whose big fronts are ALL chain links that are not the last of their group: the (narrow) trailing updates ride in
+        // the fused pivot-block + panel-solve launch
+        lv_narrow_tiles.assign(Sy.num_levels, 0);
+        if (!multi && getenv("MI355X_KKT_NO_FUSE_UPD") == nullptr)
+            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                bool all = true; int cnt = 0, tl = 0;
+                for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1]; ++q) {
+                    const int sn = Sy.level_sn[q]; ++cnt;
+                    if (Sy.grp_rem[sn] <= 0) all = false;
+                    tl = std::max(tl, schur_tiles64(Sy, sn));
+                }
+                lv_narrow_tiles[lv] = (cnt > 0 && all) ? tl : 0;
+            }
         lv_chain.assign(Sy.num_levels, 0);
         if (!multi && selfasm_on && chain_la)
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
@@ -2890,7 +3086,7 @@ public:
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
-            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
+            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         if (opt.scaling == 3) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
@@ -2944,7 +3140,7 @@ public:
         const int nt = (mu + 127) / 128;
         return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 127) / 128) : tri_tiles(nt);
     }
-    static size_t trsm_lds(int kk) { return (size_t)(65 * ((kk + 3) & ~3) + 2 * kk) * sizeof(double) + kk * sizeof(int) + 16; }
+    static size_t trsm_lds(int kk) { return trsm_lds_bytes(kk, false); }
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
 
@@ -3017,11 +3213,13 @@ public:
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         const int nrb = (mm + 63) / 64;
-        if (fuse_dt && single && !top_mode && !prof_on && kk <= 64 && nball * (1 + nrb) <= 448) {      // (the per-kernel profile keeps the two kernels apart)
+        if (fuse_dt && single && !top_mode && !prof_on && kk <= 64 && nball * (1 + nrb) <= fuse_dt_maxwg) {      // (the per-kernel profile keeps the two kernels apart)
             // few fronts on the level: pivot block + panel solve in one flag-synchronised launch (k_big_diag_trsm)
             const size_t lds = std::max((size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64,
-                                        trsm_lds(kk) + (size_t)(kk + 2) * sizeof(int) + (size_t)65 * kk * sizeof(double) + 16);
-            LAUNCH(KK_BIG_DIAG, k_big_diag_trsm, dim3(1 + nrb, nball), dim3(256), lds, stream, V, b0);
+                                        trsm_lds_bytes(kk, true));
+            const int ntu = (lv_narrow_tiles[lv] > 0 && nball * (1 + nrb + lv_narrow_tiles[lv]) <= 256) ? lv_narrow_tiles[lv] : 0;      // (one workgroup per CU: the far part of a group-end update may own the rest of the chip)
+            LAUNCH(KK_BIG_DIAG, k_big_diag_trsm, dim3(nball, 1 + nrb + ntu), dim3(256), lds, stream, V, b0, nrb);
+            if (ntu > 0) return true;         // ... and so did the narrow updates
             goto updates;
         }
         if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
@@ -3430,6 +3628,10 @@ public:
         unsigned long long fs[32]; HIPCHK(hipMemcpyFromSymbol(fs, HIP_SYMBOL(g_fstat), sizeof fs));
         for (int o = 16; o <= 24; o += 8) { const double nf = (double)std::max(1ull, fs[o + 4]);
             fprintf(stderr, "PIVSTAT k_front_reg<256,%d>: %llu fronts, mean k %.1f, children %.1f; cycles per front: assembly %.0f, to registers %.0f, colmax+LDL^T %.0f, write-back+inverse %.0f\n", o == 16 ? 6 : 8, fs[o + 4], fs[o + 5] / nf, fs[o + 6] / nf, fs[o] / nf, fs[o + 1] / nf, fs[o + 2] / nf, fs[o + 3] / nf); }
+        unsigned long long da[16]; HIPCHK(hipMemcpyFromSymbol(da, HIP_SYMBOL(g_dtacc), sizeof da));
+        { const double nl = (double)std::max(1ull, da[0]) * 100.0;      // 100 MHz ticks -> us
+          fprintf(stderr, "PIVSTAT fused pivot block + panel solve, one front per launch (%llu launches), us after the pivot workgroup started: tiles loaded %.1f, LDL^T done %.1f, permuted + written %.1f, inverse done %.1f (previous launch), flag about to be raised %.1f | panel workgroup 1: started %.1f, rows staged %.1f, flag seen %.1f, L11 + D loaded %.1f, permuted + diagonal blocks inverted %.1f, solved %.1f, done %.1f\n",
+                  da[0], da[1] / nl, da[2] / nl, da[3] / nl, da[4] / nl, da[5] / nl, da[6] / nl, da[7] / nl, da[8] / nl, da[10] / nl, da[11] / nl, da[12] / nl, da[9] / nl); }
         fprintf(stderr, "PIVSTAT big pivot blocks: fast steps %llu mean %.0f cycles, slow steps %llu mean %.0f cycles\n", ps[10], (double)ps[8] / (double)std::max(1ull, ps[10]), ps[11], (double)ps[9] / (double)std::max(1ull, ps[11]));
         fprintf(stderr, "PIVSTAT slow-path |a_jj|/lambda: >=0.5 %llu  [0.25,0.5) %llu  [0.1,0.25) %llu  <0.1 %llu (of which <0.01 %llu)\n", ps[12], ps[13], ps[14], ps[15], ps[7]);
         fprintf(stderr, "PIVSTAT steps %llu slow %llu quick %llu exact %llu passover %llu twobytwo %llu nopartner %llu\n", ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], ps[6]);
