@@ -155,6 +155,31 @@ double* mi355x_kkt_assembly_buffer(mi355x_kkt_handle h, int seg);
 int  mi355x_kkt_assembly_upload(mi355x_kkt_handle h, int seg);
 int  mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const double* shift, int* num_neg, int* num_zero);
 
+/* ---- the 8-block primal-dual system on the device -------------------------------------------------------
+ * What PDFullSpaceSolver does around the augmented-system solves on host vectors -- eliminate the bound rows into the
+ * right-hand side and expand the solution again (SolveOnce, IpPDFullSpaceSolver.cpp:418-424,653-659), form the residual of the
+ * UNREDUCED system (ComputeResiduals, :666-793) and its max norms (ComputeResidualRatio, :795-820) for iterative refinement --
+ * with the vectors resident in device memory: one upload of the right-hand side and one download of the result per Solve
+ * instead of two PCIe round trips and two single-threaded host sparse products per refinement step.  A primal-dual vector is
+ * the concatenation x | s | y_c | y_d | z_L | z_U | v_L | v_U (IteratesVector's component order); the handle owns
+ * MI355X_KKT_PD_NVEC of them.  W, J_c and J_d are read from the device-resident sources of the value assembly (segments
+ * `segs`), the expansion matrices P are their index lists (ExpansionMatrix::ExpandedPosIndices, 0-based), the iterate's
+ * multipliers and slacks are uploaded with _pd_put_data.  The inertia-correction loop, the choice of the perturbations and
+ * the refinement control stay with the caller (ipopt_adapter/IpMi355xPDSystemSolver.cpp).
+ *   dims8   = { n_x, n_s, n_c, n_d, n_xL, n_xU, n_sL, n_sU }          (n_x + n_s + n_c + n_d = the analysed dimension)
+ *   data8   = { z_L, z_U, v_L, v_U, slack_x_L, slack_x_U, slack_s_L, slack_s_U }
+ *   _pd_solve_once: res <- alpha sol + beta res with sol the solution for right-hand side `rhs` through the CURRENT factorisation
+ *   _pd_residual:   resid <- K8 res - rhs with the perturbations deltas4 = { delta_x, delta_s, delta_c, delta_d };
+ *                   norms3 = max norms of rhs, res, resid */
+#define MI355X_KKT_PD_NVEC 4
+int  mi355x_kkt_pd_define(mi355x_kkt_handle h, const int32_t* dims8, const int32_t* idx_xl, const int32_t* idx_xu, const int32_t* idx_sl,
+                          const int32_t* idx_su, const int32_t* irn, const int32_t* jcn, const int32_t* segs, int nsegs);
+int  mi355x_kkt_pd_put_data(mi355x_kkt_handle h, const double* const* data8);
+int  mi355x_kkt_pd_put(mi355x_kkt_handle h, int vec, const double* const* blocks8);
+int  mi355x_kkt_pd_get(mi355x_kkt_handle h, int vec, double* const* blocks8);
+int  mi355x_kkt_pd_solve_once(mi355x_kkt_handle h, int rhs, int res, double alpha, double beta);
+int  mi355x_kkt_pd_residual(mi355x_kkt_handle h, int rhs, int res, int resid, const double* deltas4, double* norms3);
+
 /* Solve A X = B in place for nrhs right-hand sides, rhs[irhs*ld + i], host memory. */
 int  mi355x_kkt_solve(mi355x_kkt_handle h, int nrhs, double* rhs_inout, int ld);
 /* Same with rhs/solution resident in device memory (nrhs columns, leading dimension ld). */

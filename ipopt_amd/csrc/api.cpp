@@ -206,6 +206,26 @@ int mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const 
     } catch (...) { h->err = "factor_assembled: unexpected exception"; return MI355X_KKT_FATAL; }
 }
 
+#define PD_CALL(name, cond, call) \
+    if (!h || !(cond)) return MI355X_KKT_FATAL; \
+    if (!h->analysed || !h->numeric_ready) { h->err = name ": analyse() + a usable HIP device needed (no CPU fallback)"; return MI355X_KKT_FATAL; } \
+    try { if (!h->num->call) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } \
+    catch (...) { h->err = name ": unexpected exception"; return MI355X_KKT_FATAL; }
+int mi355x_kkt_pd_define(mi355x_kkt_handle h, const int32_t* dims8, const int32_t* ixl, const int32_t* ixu, const int32_t* isl, const int32_t* isu,
+                         const int32_t* irn, const int32_t* jcn, const int32_t* segs, int nsegs)
+{ PD_CALL("pd_define", dims8 && irn && jcn && segs && nsegs > 0, pd_define(dims8, ixl, ixu, isl, isu, irn, jcn, segs, nsegs)) }
+int mi355x_kkt_pd_put_data(mi355x_kkt_handle h, const double* const* data8) { PD_CALL("pd_put_data", data8, pd_put_data(data8)) }
+int mi355x_kkt_pd_put(mi355x_kkt_handle h, int vec, const double* const* blocks8) { PD_CALL("pd_put", blocks8, pd_put(vec, blocks8)) }
+int mi355x_kkt_pd_get(mi355x_kkt_handle h, int vec, double* const* blocks8) { PD_CALL("pd_get", blocks8, pd_get(vec, blocks8)) }
+int mi355x_kkt_pd_solve_once(mi355x_kkt_handle h, int rhs, int res, double alpha, double beta)
+{
+    if (h && !h->factored) { h->err = "pd_solve_once: no factorisation available"; return MI355X_KKT_FATAL; }
+    PD_CALL("pd_solve_once", true, pd_solve_once(rhs, res, alpha, beta))
+}
+int mi355x_kkt_pd_residual(mi355x_kkt_handle h, int rhs, int res, int resid, const double* deltas4, double* norms3)
+{ PD_CALL("pd_residual", deltas4 && norms3, pd_residual(rhs, res, resid, deltas4, norms3)) }
+#undef PD_CALL
+
 int mi355x_kkt_solve(mi355x_kkt_handle h, int nrhs, double* rhs, int ld)
 {
     if (!h) return MI355X_KKT_FATAL;

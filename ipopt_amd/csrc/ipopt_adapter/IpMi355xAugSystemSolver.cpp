@@ -14,7 +14,7 @@ Mi355xAugSystemSolver::Mi355xAugSystemSolver()
    : handle_(NULL), structured_(false), analysed_(false), have_factor_(false), pivtol_changed_(false),
      warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1), n_x_(0), n_s_(0), n_c_(0), n_d_(0),
      dim_(0), nnz_(0), nnz_w_(0), nnz_jc_(0), nnz_jd_(0), w_tag_(0), jc_tag_(0), jd_tag_(0), dx_tag_(0), ds_tag_(0), dc_tag_(0),
-     dd_tag_(0), uploaded_bytes_(0), nfact_noupload_(0)
+     dd_tag_(0), uploaded_bytes_(0), nfact_noupload_(0), pd_wanted_(false), pd_defined_(false), singular_(false)
 {
    mi355x_kkt_default_options(&kopts_);
    for( int q = 0; q < NSEG; ++q )
@@ -56,6 +56,7 @@ bool Mi355xAugSystemSolver::InitializeImpl(const OptionsList& options, const std
       }
       structured_ = false;
       analysed_ = false;
+      pd_defined_ = false;
    }
    else
    {
@@ -65,6 +66,7 @@ bool Mi355xAugSystemSolver::InitializeImpl(const OptionsList& options, const std
       mi355x_kkt_set_pivtolmax(handle_, pivtolmax_);
    }
    have_factor_ = false;
+   singular_ = false;
    pivtol_changed_ = false;
    negevals_ = -1;
    w_tag_ = jc_tag_ = jd_tag_ = dx_tag_ = ds_tag_ = dc_tag_ = dd_tag_ = 0;
@@ -218,23 +220,11 @@ bool Mi355xAugSystemSolver::UpdateSources(const SymMatrix* W, Number W_factor, c
    return changed;
 }
 
-ESymSolverStatus Mi355xAugSystemSolver::MultiSolve(const SymMatrix* W, Number W_factor, const Vector* D_x, Number delta_x,
+ESymSolverStatus Mi355xAugSystemSolver::EnsureFactorization(const SymMatrix* W, Number W_factor, const Vector* D_x, Number delta_x,
       const Vector* D_s, Number delta_s, const Matrix* J_c, const Vector* D_c, Number delta_c, const Matrix* J_d,
-      const Vector* D_d, Number delta_d, std::vector<SmartPtr<const Vector> >& rhs_xV, std::vector<SmartPtr<const Vector> >& rhs_sV,
-      std::vector<SmartPtr<const Vector> >& rhs_cV, std::vector<SmartPtr<const Vector> >& rhs_dV, std::vector<SmartPtr<Vector> >& sol_xV,
-      std::vector<SmartPtr<Vector> >& sol_sV, std::vector<SmartPtr<Vector> >& sol_cV, std::vector<SmartPtr<Vector> >& sol_dV,
-      bool check_NegEVals, Index numberOfNegEVals)
+      const Vector* D_d, Number delta_d, bool check_NegEVals, Index numberOfNegEVals)
 {
-   if( !J_c || !J_d )
-   {
-      return SYMSOLVER_FATAL_ERROR;    // as the reference: J_c and J_d MUST be given (IpStdAugSystemSolver.cpp:108)
-   }
-   if( HaveIpData() )
-   {
-      IpData().TimingStats().StdAugSystemSolverMultiSolve().Start();
-   }
    ESymSolverStatus retval = SYMSOLVER_SUCCESS;
-   const Index nrhs = (Index) rhs_xV.size();
    do
    {
       if( !structured_ )
@@ -268,6 +258,10 @@ ESymSolverStatus Mi355xAugSystemSolver::MultiSolve(const SymMatrix* W, Number W_
          {
             st = mi355x_kkt_assembly_define(handle_, NSEG, (const int64_t*) seg_off_, (const int64_t*) seg_len_);
          }
+         if( st == MI355X_KKT_SUCCESS && pd_wanted_ && !DefinePrimalDualWorkspace() )
+         {
+            st = MI355X_KKT_FATAL;
+         }
          if( HaveIpData() )
          {
             IpData().TimingStats().LinearSystemSymbolicFactorization().End();
@@ -289,8 +283,7 @@ ESymSolverStatus Mi355xAugSystemSolver::MultiSolve(const SymMatrix* W, Number W_
             uploaded_bytes_ += 8ll * seg_len_[q];
          }
          std::vector<Number>().swap(first_vals_);
-         std::vector<Index>().swap(irn_);
-         std::vector<Index>().swap(jcn_);
+         // (irn_ / jcn_ stay: the primal-dual workspace may be asked for later)
          analysed_ = true;
          new_matrix = true;
       }
@@ -327,6 +320,7 @@ ESymSolverStatus Mi355xAugSystemSolver::MultiSolve(const SymMatrix* W, Number W_
             break;
          }
          have_factor_ = true;
+         singular_ = (st == MI355X_KKT_SINGULAR);
          negevals_ = nneg;
          Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X aug factor: %d negative eigenvalues, %d zero pivots (status %d)\n", nneg, nzero, st);
          if( st == MI355X_KKT_SINGULAR )
@@ -340,7 +334,41 @@ ESymSolverStatus Mi355xAugSystemSolver::MultiSolve(const SymMatrix* W, Number W_
             break;
          }
       }
+      else if( singular_ )
+      {
+         retval = SYMSOLVER_SINGULAR;      // the matrix has not changed: neither has the answer
+         break;
+      }
 
+   }
+   while( false );
+   return retval;
+}
+
+ESymSolverStatus Mi355xAugSystemSolver::MultiSolve(const SymMatrix* W, Number W_factor, const Vector* D_x, Number delta_x,
+      const Vector* D_s, Number delta_s, const Matrix* J_c, const Vector* D_c, Number delta_c, const Matrix* J_d,
+      const Vector* D_d, Number delta_d, std::vector<SmartPtr<const Vector> >& rhs_xV, std::vector<SmartPtr<const Vector> >& rhs_sV,
+      std::vector<SmartPtr<const Vector> >& rhs_cV, std::vector<SmartPtr<const Vector> >& rhs_dV, std::vector<SmartPtr<Vector> >& sol_xV,
+      std::vector<SmartPtr<Vector> >& sol_sV, std::vector<SmartPtr<Vector> >& sol_cV, std::vector<SmartPtr<Vector> >& sol_dV,
+      bool check_NegEVals, Index numberOfNegEVals)
+{
+   if( !J_c || !J_d )
+   {
+      return SYMSOLVER_FATAL_ERROR;    // as the reference: J_c and J_d MUST be given (IpStdAugSystemSolver.cpp:108)
+   }
+   if( HaveIpData() )
+   {
+      IpData().TimingStats().StdAugSystemSolverMultiSolve().Start();
+   }
+   const Index nrhs = (Index) rhs_xV.size();
+   ESymSolverStatus retval = EnsureFactorization(W, W_factor, D_x, delta_x, D_s, delta_s, J_c, D_c, delta_c, J_d, D_d, delta_d,
+                                                 check_NegEVals, numberOfNegEVals);
+   do
+   {
+      if( retval != SYMSOLVER_SUCCESS )
+      {
+         break;
+      }
       // right-hand sides: the four blocks of each system packed into one contiguous column (what CompoundVector +
       // TripletHelper::FillValuesFromVector do in TSymLinearSolver::MultiSolve, IpTSymLinearSolver.cpp:201-230)
       std::vector<Number> rhs((size_t) dim_ * nrhs);
@@ -382,6 +410,60 @@ ESymSolverStatus Mi355xAugSystemSolver::MultiSolve(const SymMatrix* W, Number W_
       IpData().TimingStats().StdAugSystemSolverMultiSolve().End();
    }
    return retval;
+}
+
+ESymSolverStatus Mi355xAugSystemSolver::Factorize(const SymMatrix* W, Number W_factor, const Vector* D_x, Number delta_x, const Vector* D_s,
+      Number delta_s, const Matrix* J_c, const Vector* D_c, Number delta_c, const Matrix* J_d, const Vector* D_d, Number delta_d,
+      bool check_NegEVals, Index numberOfNegEVals)
+{
+   if( !J_c || !J_d )
+   {
+      return SYMSOLVER_FATAL_ERROR;
+   }
+   if( HaveIpData() )
+   {
+      IpData().TimingStats().StdAugSystemSolverMultiSolve().Start();
+   }
+   const ESymSolverStatus retval = EnsureFactorization(W, W_factor, D_x, delta_x, D_s, delta_s, J_c, D_c, delta_c, J_d, D_d, delta_d,
+                                   check_NegEVals, numberOfNegEVals);
+   if( HaveIpData() )
+   {
+      IpData().TimingStats().StdAugSystemSolverMultiSolve().End();
+   }
+   return retval;
+}
+
+void Mi355xAugSystemSolver::WantPrimalDualWorkspace(const Index dims[8], const Index* idx_xl, const Index* idx_xu, const Index* idx_sl,
+      const Index* idx_su)
+{
+   pd_wanted_ = true;
+   for( int q = 0; q < 8; ++q )
+   {
+      pd_dims_[q] = dims[q];
+   }
+   const Index* src[4] = {idx_xl, idx_xu, idx_sl, idx_su};
+   for( int q = 0; q < 4; ++q )
+   {
+      pd_idx_[q].assign(src[q], src[q] + dims[4 + q]);
+   }
+   if( analysed_ && !pd_defined_ )     // the analysis has already happened (least-square multipliers come first)
+   {
+      DefinePrimalDualWorkspace();
+   }
+}
+
+bool Mi355xAugSystemSolver::DefinePrimalDualWorkspace()
+{
+   // the primal-dual workspace reads W, J_c, J_d from the assembly sources (Mi355xPDSystemSolver)
+   const int32_t segs[3] = {SEG_W, SEG_JC, SEG_JD};
+   const int st = mi355x_kkt_pd_define(handle_, pd_dims_, pd_idx_[0].empty() ? NULL : &pd_idx_[0][0], pd_idx_[1].empty() ? NULL : &pd_idx_[1][0],
+                                       pd_idx_[2].empty() ? NULL : &pd_idx_[2][0], pd_idx_[3].empty() ? NULL : &pd_idx_[3][0], &irn_[0], &jcn_[0], segs, 3);
+   pd_defined_ = (st == MI355X_KKT_SUCCESS);
+   if( !pd_defined_ )
+   {
+      Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_pd_define failed: %s\n", mi355x_kkt_last_error(handle_));
+   }
+   return pd_defined_;
 }
 
 bool Mi355xAugSystemSolver::IncreaseQuality()

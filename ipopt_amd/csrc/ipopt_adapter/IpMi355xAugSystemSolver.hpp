@@ -49,6 +49,31 @@ public:
    }
    bool IncreaseQuality();
 
+   /** @name what Mi355xPDSystemSolver needs besides the AugSystemSolver contract */
+   ///@{
+   /** bring the factorisation of the given augmented system up to date WITHOUT solving: same change test, uploads, statuses
+    *  (SINGULAR / WRONG_INERTIA) as MultiSolve */
+   ESymSolverStatus Factorize(const SymMatrix* W, Number W_factor, const Vector* D_x, Number delta_x, const Vector* D_s, Number delta_s,
+                              const Matrix* J_c, const Vector* D_c, Number delta_c, const Matrix* J_d, const Vector* D_d, Number delta_d,
+                              bool check_NegEVals, Index numberOfNegEVals);
+   /** ask for the primal-dual device workspace (mi355x_kkt_pd_define) to be created with the analysis; dims = {n_x, n_s, n_c, n_d,
+    *  n_xL, n_xU, n_sL, n_sU}, idx_* = ExpansionMatrix::ExpandedPosIndices of Px_L, Px_U, Pd_L, Pd_U.  Call before the first Factorize. */
+   void WantPrimalDualWorkspace(const Index dims[8], const Index* idx_xl, const Index* idx_xu, const Index* idx_sl, const Index* idx_su);
+   bool HasPrimalDualWorkspace() const
+   {
+      return pd_defined_;
+   }
+   /** the next Factorize / MultiSolve factors again (and answers the inertia question again) even if nothing changed */
+   void ForgetFactorization()
+   {
+      have_factor_ = false;
+   }
+   mi355x_kkt_handle Handle() const
+   {
+      return handle_;
+   }
+   ///@}
+
    /** bytes uploaded for matrix values so far / number of factorisations that uploaded nothing (tests, logging) */
    long long UploadedBytes() const
    {
@@ -66,6 +91,10 @@ private:
    enum Segment { SEG_W = 0, SEG_DX, SEG_DS, SEG_JC, SEG_DC, SEG_JD, SEG_ID, SEG_DD, NSEG };
 
    void BuildStructure(const SymMatrix& W, const Matrix& J_c, const Matrix& J_d);
+   bool DefinePrimalDualWorkspace();
+   ESymSolverStatus EnsureFactorization(const SymMatrix* W, Number W_factor, const Vector* D_x, Number delta_x, const Vector* D_s,
+                                        Number delta_s, const Matrix* J_c, const Vector* D_c, Number delta_c, const Matrix* J_d,
+                                        const Vector* D_d, Number delta_d, bool check_NegEVals, Index numberOfNegEVals);
    /** refresh the segments whose source object changed; returns true if the matrix differs from the factored one */
    bool UpdateSources(const SymMatrix* W, Number W_factor, const Vector* D_x, Number delta_x, const Vector* D_s, Number delta_s,
                       const Matrix& J_c, const Vector* D_c, Number delta_c, const Matrix& J_d, const Vector* D_d, Number delta_d,
@@ -86,6 +115,9 @@ private:
    std::vector<Number> first_vals_;    // host copy of the sources before the (lazy) analysis has created the device buffers
    long long uploaded_bytes_;
    Index nfact_noupload_;
+   bool pd_wanted_, pd_defined_, singular_;
+   int32_t pd_dims_[8];
+   std::vector<int32_t> pd_idx_[4];
 };
 
 /** AlgorithmBuilder that installs the custom AugSystemSolver through the reference's own constructor argument

@@ -61,6 +61,13 @@ public:
     double* assembly_buffer(int seg);                      // pinned staging of the segment's source values
     bool   assembly_upload(int seg);                       // async H2D on the solver's stream
     bool   factor_assembled(const double* scale, const double* shift, FactorStats& st);
+    // the 8-block primal-dual system on the device: vectors are {x, s, y_c, y_d, z_L, z_U, v_L, v_U} concatenated
+    bool   pd_define(const int* dims8, const int* ixl, const int* ixu, const int* isl, const int* isu, const int* irn, const int* jcn, const int* segs, int nsegs);
+    bool   pd_put_data(const double* const* arr8);
+    bool   pd_put(int vec, const double* const* blocks8);
+    bool   pd_get(int vec, double* const* blocks8);
+    bool   pd_solve_once(int rhs, int res, double alpha, double beta);
+    bool   pd_residual(int rhs, int res, int resid, const double* deltas4, double* norms3);
     // communicator of a multi-GPU handle: with one set, factor()/solve_*() run the whole distributed sequence themselves
     bool   set_comm_rccl(const void* unique_id128);                                   // RCCL (dlopen'ed), ncclCommInitRank(nranks, id, rank)
     bool   set_comm_callback(int (*allreduce)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream), void* ctx);

@@ -2365,6 +2365,120 @@ __global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off, in
     schur64_tile(V, M, blockIdx.x, mode);
 }
 
+
+// ================================================================================================
+// The 8-block primal-dual system on the device (reference IpPDFullSpaceSolver.cpp:377-664 SolveOnce,
+// :666-793 ComputeResiduals, :795-820 ComputeResidualRatio).  A primal-dual vector is ONE array
+//   [ x (nx) | s (ns) | y_c (nc) | y_d (nd) | z_L (nxl) | z_U (nxu) | v_L (nsl) | v_U (nsu) ];
+// the bound-expansion matrices P are index lists, the iterate data (multipliers, slacks) live next to them, and W, J_c,
+// J_d are the device-resident sources of the value assembly, read through a row view of those segments.
+// ================================================================================================
+struct PdView {
+    int nx, ns, nc, nd, nxl, nxu, nsl, nsu;
+    const int* ixl; const int* ixu; const int* isl; const int* isu;                 // positions of the bounded entries in x resp. s
+    const double* zl; const double* zu; const double* vl; const double* vu;         // bound multipliers of the current iterate
+    const double* sxl; const double* sxu; const double* ssl; const double* ssu;     // slacks of the current iterate
+    const int* rptr; const int* rcol; const int* rslot;                             // row view of the W, J_c, J_d triplets (both triangles), slot order
+    const double* tvals;                                                            // assembled triplet values (W_factor = 1: the plain W, J)
+    unsigned long long* norms;                                                      // 3 order-preserving max accumulators
+};
+__device__ __forceinline__ int pd_off(const PdView& P, int blk)
+{
+    int o = 0;
+    if (blk > 0) o += P.nx;  if (blk > 1) o += P.ns;  if (blk > 2) o += P.nc;  if (blk > 3) o += P.nd;
+    if (blk > 4) o += P.nxl; if (blk > 5) o += P.nxu; if (blk > 6) o += P.nsl;
+    return o;
+}
+// right-hand side of the augmented system (SolveOnce :418-424): the bound rows are eliminated into the x and s rows.
+// pass 0: copy x | s | c | d;  pass 1: += P_L (rhs_zL / slack_L);  pass 2: -= P_U (rhs_zU / slack_U)   (the reference's order)
+__global__ void k_pd_reduce(PdView P, const double* rhs, double* aug, int pass)
+{
+    const int n4 = P.nx + P.ns + P.nc + P.nd;
+    const int tid0 = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (pass == 0) { for (int i = tid0; i < n4; i += nth) aug[i] = rhs[i]; return; }
+    if (pass == 1) {
+        const double* rz = rhs + pd_off(P, 4); const double* rv = rhs + pd_off(P, 6);
+        for (int i = tid0; i < P.nxl; i += nth) aug[P.ixl[i]] += rz[i] / P.sxl[i];
+        for (int i = tid0; i < P.nsl; i += nth) aug[P.nx + P.isl[i]] += rv[i] / P.ssl[i];
+    } else {
+        const double* rz = rhs + pd_off(P, 5); const double* rv = rhs + pd_off(P, 7);
+        for (int i = tid0; i < P.nxu; i += nth) aug[P.ixu[i]] -= rz[i] / P.sxu[i];
+        for (int i = tid0; i < P.nsu; i += nth) aug[P.nx + P.isu[i]] -= rv[i] / P.ssu[i];
+    }
+}
+// back to eight blocks (SolveOnce :653-659): sol_z = S^{-1} (rhs_z -/+ Z P^T sol_x), then res = alpha sol + beta res
+__device__ __forceinline__ double pd_combine(double alpha, double sol, double beta, double res)
+{
+    if (beta == 0.0) return (alpha == 1.0) ? sol : alpha * sol;
+    if (beta == 1.0) return (alpha == 1.0) ? res + sol : ((alpha == -1.0) ? res - sol : res + alpha * sol);
+    return alpha * sol + beta * res;
+}
+__global__ void k_pd_expand(PdView P, const double* rhs, const double* sol4, double* res, double alpha, double beta)
+{
+    const int n4 = P.nx + P.ns + P.nc + P.nd;
+    const int tid0 = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    for (int i = tid0; i < n4; i += nth) res[i] = pd_combine(alpha, sol4[i], beta, res[i]);
+    const int o4 = pd_off(P, 4), o5 = pd_off(P, 5), o6 = pd_off(P, 6), o7 = pd_off(P, 7);
+    for (int i = tid0; i < P.nxl; i += nth) res[o4 + i] = pd_combine(alpha, (rhs[o4 + i] - P.zl[i] * sol4[P.ixl[i]]) / P.sxl[i], beta, res[o4 + i]);
+    for (int i = tid0; i < P.nxu; i += nth) res[o5 + i] = pd_combine(alpha, (rhs[o5 + i] + P.zu[i] * sol4[P.ixu[i]]) / P.sxu[i], beta, res[o5 + i]);
+    for (int i = tid0; i < P.nsl; i += nth) res[o6 + i] = pd_combine(alpha, (rhs[o6 + i] - P.vl[i] * sol4[P.nx + P.isl[i]]) / P.ssl[i], beta, res[o6 + i]);
+    for (int i = tid0; i < P.nsu; i += nth) res[o7 + i] = pd_combine(alpha, (rhs[o7 + i] + P.vu[i] * sol4[P.nx + P.isu[i]]) / P.ssu[i], beta, res[o7 + i]);
+}
+__device__ __forceinline__ void pd_amax(unsigned long long* acc, double v)
+{
+    // |v| of a lane, maximum over the wavefront, one atomic per wavefront (non-negative doubles order like their bit patterns)
+    double a = fabs(v);
+    if (!(a == a)) a = __longlong_as_double(0x7ff0000000000000ll);     // NaN counts as +inf: the ratio test must fail loudly
+    a = wave_max_all(a);
+    if ((threadIdx.x & 63) == 0 && a > 0.0) atomicMax(acc, (unsigned long long)__double_as_longlong(a));
+}
+// residual of the UNREDUCED system (ComputeResiduals :666-793), rows x | s | c | d: one thread per row, entries in triplet order
+//   resid_x = W res_x + J_c^T res_c + J_d^T res_d - P_xL res_zL + P_xU res_zU + delta_x res_x - rhs_x
+//   resid_s = P_dU res_vU - P_dL res_vL - res_d - rhs_s + delta_s res_s
+//   resid_c = J_c res_x - delta_c res_c - rhs_c          resid_d = J_d res_x - res_s - rhs_d - delta_d res_d
+// (the P terms of the x and s rows are added by k_pd_resid_bounds, which also forms the four complementarity rows)
+__global__ void k_pd_resid_rows(PdView P, const double* rhs, const double* res, double* resid, double dx, double ds, double dc, double dd)
+{
+    const int n4 = P.nx + P.ns + P.nc + P.nd;
+    const int oS = P.nx, oC = P.nx + P.ns, oD = oC + P.nc;
+    for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < ((n4 + 63) & ~63); r += gridDim.x * blockDim.x) {
+        double out = 0.0;
+        if (r < n4) {
+            double acc = 0.0;
+            for (int q = P.rptr[r]; q < P.rptr[r + 1]; ++q) acc += P.tvals[P.rslot[q]] * res[P.rcol[q]];
+            if (r < oS)      out = acc + dx * res[r] - rhs[r];
+            else if (r < oC) { out = -res[oD + (r - oS)] - rhs[r]; if (ds != 0.0) out += ds * res[r]; }
+            else if (r < oD) out = acc - dc * res[r] - rhs[r];
+            else             { out = acc - res[oS + (r - oD)] - rhs[r]; if (dd != 0.0) out -= dd * res[r]; }
+            resid[r] = out;
+        }
+    }
+}
+// pass 1: resid_x -= P_xL res_zL, resid_s -= P_dL res_vL and the lower complementarity rows; pass 2: the upper ones
+//   resid_zL = Sl_xL res_zL + Z_L P_xL^T res_x - rhs_zL        resid_zU = Sl_xU res_zU - Z_U P_xU^T res_x - rhs_zU   (same for v / s)
+__global__ void k_pd_resid_bounds(PdView P, const double* rhs, const double* res, double* resid, int pass)
+{
+    const int tid0 = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    if (pass == 1) {
+        const int oz = pd_off(P, 4), ov = pd_off(P, 6);
+        for (int i = tid0; i < P.nxl; i += nth) { const int j = P.ixl[i]; resid[j] -= res[oz + i]; resid[oz + i] = res[oz + i] * P.sxl[i] + res[j] * P.zl[i] - rhs[oz + i]; }
+        for (int i = tid0; i < P.nsl; i += nth) { const int j = P.nx + P.isl[i]; resid[j] -= res[ov + i]; resid[ov + i] = res[ov + i] * P.ssl[i] + res[j] * P.vl[i] - rhs[ov + i]; }
+    } else {
+        const int oz = pd_off(P, 5), ov = pd_off(P, 7);
+        for (int i = tid0; i < P.nxu; i += nth) { const int j = P.ixu[i]; resid[j] += res[oz + i]; resid[oz + i] = res[oz + i] * P.sxu[i] - res[j] * P.zu[i] - rhs[oz + i]; }
+        for (int i = tid0; i < P.nsu; i += nth) { const int j = P.nx + P.isu[i]; resid[j] += res[ov + i]; resid[ov + i] = res[ov + i] * P.ssu[i] - res[j] * P.vu[i] - rhs[ov + i]; }
+    }
+}
+// max norms of rhs, res and resid over all eight blocks (ComputeResidualRatio :795-820)
+__global__ void k_pd_norms(PdView P, const double* rhs, const double* res, const double* resid, long long len8)
+{
+    const long long lenp = (len8 + 63) & ~63ll;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < lenp; i += (long long)gridDim.x * blockDim.x) {
+        const bool v = i < len8;
+        pd_amax(P.norms + 0, v ? rhs[i] : 0.0); pd_amax(P.norms + 1, v ? res[i] : 0.0); pd_amax(P.norms + 2, v ? resid[i] : 0.0);
+    }
+}
+
 // ================================================================================================
 // multi-GPU pieces (one process per GPU, subtrees sharded, top of the tree replicated)
 // ================================================================================================
@@ -2661,6 +2775,7 @@ public:
         if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
         if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
         asm_.nseg = 0;
+        pd_free();
         if (h_vals) { (void)hipHostFree(h_vals); h_vals = nullptr; }
         if (h_stats) { (void)hipHostFree(h_stats); h_stats = nullptr; }
         if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
@@ -3434,6 +3549,144 @@ public:
         return true;
     }
 
+
+    // ---------------- primal-dual (8-block) workspace: SURVEY 8(f)2 ----------------
+    PdView pd_{}; bool pd_ready = false; long long pd_len8 = 0; int pd_dim4 = 0;
+    static constexpr int PD_NVEC = 4;                      // RHS, RES, RESID, and one spare (the caller's copy)
+    double* pd_vec[PD_NVEC] = {nullptr, nullptr, nullptr, nullptr};
+    double* pd_aug = nullptr; double* pd_data = nullptr; int* pd_idx = nullptr; int* pd_rv = nullptr; double* pd_stage = nullptr;
+    unsigned long long* pd_norms_d = nullptr; unsigned long long* pd_norms_h = nullptr;
+    void pd_free() {
+        for (int q = 0; q < PD_NVEC; ++q) if (pd_vec[q]) { (void)hipFree(pd_vec[q]); pd_vec[q] = nullptr; }
+        if (pd_aug) { (void)hipFree(pd_aug); pd_aug = nullptr; }
+        if (pd_data) { (void)hipFree(pd_data); pd_data = nullptr; }
+        if (pd_idx) { (void)hipFree(pd_idx); pd_idx = nullptr; }
+        if (pd_rv) { (void)hipFree(pd_rv); pd_rv = nullptr; }
+        if (pd_stage) { (void)hipHostFree(pd_stage); pd_stage = nullptr; }
+        if (pd_norms_d) { (void)hipFree(pd_norms_d); pd_norms_d = nullptr; }
+        if (pd_norms_h) { (void)hipHostFree(pd_norms_h); pd_norms_h = nullptr; }
+        pd_ready = false;
+    }
+    // dims = {nx, ns, nc, nd, nxl, nxu, nsl, nsu}; idx*: 0-based positions of the bounded entries; (irn, jcn): the 1-based triplets of
+    // analyse(); segs: the assembly segments that hold W, J_c, J_d (everything else -- diagonals, -I -- is explicit in the kernels)
+    bool pd_define(const int* dims, const int* ixl, const int* ixu, const int* isl, const int* isu, const int* irn, const int* jcn, const int* segs, int nsegs) {
+        DeviceGuard guard(dev);
+        if (!ready || asm_.nseg == 0) { err_ = "pd_define: analyse() and assembly_define() first"; return false; }
+        pd_free();
+        PdView& P = pd_;
+        P.nx = dims[0]; P.ns = dims[1]; P.nc = dims[2]; P.nd = dims[3]; P.nxl = dims[4]; P.nxu = dims[5]; P.nsl = dims[6]; P.nsu = dims[7];
+        pd_dim4 = P.nx + P.ns + P.nc + P.nd;
+        if (pd_dim4 != S->n || P.ns != P.nd) { err_ = "pd_define: block dimensions do not match the analysed system"; return false; }
+        pd_len8 = (long long)pd_dim4 + P.nxl + P.nxu + P.nsl + P.nsu;
+        // row view of the selected segments, both triangles, entries of a row in triplet (slot) order
+        std::vector<int> cnt(pd_dim4 + 1, 0);
+        for (int q = 0; q < nsegs; ++q) {
+            const int sg = segs[q];
+            if (sg < 0 || sg >= asm_.nseg) { err_ = "pd_define: no such segment"; return false; }
+            for (long long t = asm_.off[sg]; t < asm_.off[sg] + asm_.len[sg]; ++t) {
+                const int r = irn[t] - 1, c = jcn[t] - 1;
+                if (r < 0 || c < 0 || r >= pd_dim4 || c >= pd_dim4) { err_ = "pd_define: triplet index out of range"; return false; }
+                cnt[r + 1]++; if (r != c) cnt[c + 1]++;
+            }
+        }
+        for (int i = 0; i < pd_dim4; ++i) cnt[i + 1] += cnt[i];
+        const int nent = cnt[pd_dim4];
+        std::vector<int> rv((size_t)pd_dim4 + 1 + 2 * (size_t)nent), fill(cnt.begin(), cnt.end() - 1);
+        std::copy(cnt.begin(), cnt.end(), rv.begin());
+        int* rcol = rv.data() + pd_dim4 + 1; int* rslot = rcol + nent;
+        std::vector<int> order(segs, segs + nsegs);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return asm_.off[a] < asm_.off[b]; });
+        for (int sg : order)
+            for (long long t = asm_.off[sg]; t < asm_.off[sg] + asm_.len[sg]; ++t) {
+                const int r = irn[t] - 1, c = jcn[t] - 1;
+                rcol[fill[r]] = c; rslot[fill[r]++] = (int)t;
+                if (r != c) { rcol[fill[c]] = r; rslot[fill[c]++] = (int)t; }
+            }
+        HIPCHK(hipMalloc((void**)&pd_rv, rv.size() * sizeof(int)));
+        HIPCHK(hipMemcpy(pd_rv, rv.data(), rv.size() * sizeof(int), hipMemcpyHostToDevice));
+        P.rptr = pd_rv; P.rcol = pd_rv + pd_dim4 + 1; P.rslot = P.rcol + nent;
+        const long long nb = (long long)P.nxl + P.nxu + P.nsl + P.nsu;
+        HIPCHK(hipMalloc((void**)&pd_idx, std::max<long long>(nb, 1) * sizeof(int)));
+        HIPCHK(hipMalloc((void**)&pd_data, std::max<long long>(2 * nb, 1) * sizeof(double)));
+        {
+            int* d = pd_idx;
+            P.ixl = d; if (P.nxl) HIPCHK(hipMemcpy(d, ixl, P.nxl * sizeof(int), hipMemcpyHostToDevice)); d += P.nxl;
+            P.ixu = d; if (P.nxu) HIPCHK(hipMemcpy(d, ixu, P.nxu * sizeof(int), hipMemcpyHostToDevice)); d += P.nxu;
+            P.isl = d; if (P.nsl) HIPCHK(hipMemcpy(d, isl, P.nsl * sizeof(int), hipMemcpyHostToDevice)); d += P.nsl;
+            P.isu = d; if (P.nsu) HIPCHK(hipMemcpy(d, isu, P.nsu * sizeof(int), hipMemcpyHostToDevice));
+            double* f = pd_data;
+            P.zl = f; f += P.nxl; P.zu = f; f += P.nxu; P.vl = f; f += P.nsl; P.vu = f; f += P.nsu;
+            P.sxl = f; f += P.nxl; P.sxu = f; f += P.nxu; P.ssl = f; f += P.nsl; P.ssu = f;
+        }
+        for (int q = 0; q < PD_NVEC; ++q) { HIPCHK(hipMalloc((void**)&pd_vec[q], std::max<long long>(pd_len8, 1) * sizeof(double))); HIPCHK(hipMemset(pd_vec[q], 0, std::max<long long>(pd_len8, 1) * sizeof(double))); }
+        HIPCHK(hipMalloc((void**)&pd_aug, std::max(pd_dim4, 1) * sizeof(double)));
+        HIPCHK(hipHostMalloc((void**)&pd_stage, std::max<long long>(std::max<long long>(pd_len8, 2 * nb), 1) * sizeof(double), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void**)&pd_norms_d, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipHostMalloc((void**)&pd_norms_h, 4 * sizeof(unsigned long long), hipHostMallocDefault));
+        P.norms = pd_norms_d; P.tvals = V.tvals;
+        pd_ready = true;
+        return true;
+    }
+    // the iterate's bound multipliers and slacks: arr = {z_L, z_U, v_L, v_U, slack_x_L, slack_x_U, slack_s_L, slack_s_U}
+    bool pd_put_data(const double* const* arr) {
+        DeviceGuard guard(dev);
+        if (!pd_ready) { err_ = "pd_put_data: pd_define first"; return false; }
+        const int len[8] = {pd_.nxl, pd_.nxu, pd_.nsl, pd_.nsu, pd_.nxl, pd_.nxu, pd_.nsl, pd_.nsu};
+        HIPCHK(hipStreamSynchronize(stream));                  // the staging buffer may still feed an earlier copy
+        long long o = 0;
+        for (int q = 0; q < 8; ++q) { if (len[q]) std::memcpy(pd_stage + o, arr[q], (size_t)len[q] * sizeof(double)); o += len[q]; }
+        if (o) HIPCHK(hipMemcpyAsync(pd_data, pd_stage, (size_t)o * sizeof(double), hipMemcpyHostToDevice, stream));
+        return true;
+    }
+    int pd_blocklen(int b) const { const int len[8] = {pd_.nx, pd_.ns, pd_.nc, pd_.nd, pd_.nxl, pd_.nxu, pd_.nsl, pd_.nsu}; return len[b]; }
+    bool pd_put(int vec, const double* const* blocks) {
+        DeviceGuard guard(dev);
+        if (!pd_ready || vec < 0 || vec >= PD_NVEC) { err_ = "pd_put: pd_define first / no such vector"; return false; }
+        HIPCHK(hipStreamSynchronize(stream));
+        long long o = 0;
+        for (int b = 0; b < 8; ++b) { const int l = pd_blocklen(b); if (l) std::memcpy(pd_stage + o, blocks[b], (size_t)l * sizeof(double)); o += l; }
+        if (o) HIPCHK(hipMemcpyAsync(pd_vec[vec], pd_stage, (size_t)o * sizeof(double), hipMemcpyHostToDevice, stream));
+        return true;
+    }
+    bool pd_get(int vec, double* const* blocks) {
+        DeviceGuard guard(dev);
+        if (!pd_ready || vec < 0 || vec >= PD_NVEC) { err_ = "pd_get: pd_define first / no such vector"; return false; }
+        if (pd_len8) HIPCHK(hipMemcpyAsync(pd_stage, pd_vec[vec], (size_t)pd_len8 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        long long o = 0;
+        for (int b = 0; b < 8; ++b) { const int l = pd_blocklen(b); if (l) std::memcpy(blocks[b], pd_stage + o, (size_t)l * sizeof(double)); o += l; }
+        return true;
+    }
+    // res <- alpha sol + beta res,  sol = the solution of the 8-block system with right-hand side `rhs` through the CURRENT factorisation
+    // of the augmented system (reduce, 4-block solve, expand: SolveOnce without its inertia-correction loop, which stays with the caller)
+    bool pd_solve_once(int rhs, int res, double alpha, double beta) {
+        DeviceGuard guard(dev);
+        if (!pd_ready || rhs < 0 || rhs >= PD_NVEC || res < 0 || res >= PD_NVEC) { err_ = "pd_solve_once: pd_define first / no such vector"; return false; }
+        const int g4 = grid1d(pd_dim4), gb = grid1d(std::max(std::max(pd_.nxl, pd_.nxu), std::max(pd_.nsl, pd_.nsu)));
+        hipLaunchKernelGGL(k_pd_reduce, dim3(g4), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], pd_aug, 0);
+        hipLaunchKernelGGL(k_pd_reduce, dim3(gb), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], pd_aug, 1);
+        hipLaunchKernelGGL(k_pd_reduce, dim3(gb), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], pd_aug, 2);
+        if (!solve_device(1, pd_aug, pd_dim4, pd_aug, pd_dim4, false)) return false;
+        hipLaunchKernelGGL(k_pd_expand, dim3(g4), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], (const double*)pd_aug, pd_vec[res], alpha, beta);
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+    // resid <- residual of the unreduced system at `res`; norms = {|rhs|_inf, |res|_inf, |resid|_inf}
+    bool pd_residual(int rhs, int res, int resid, const double* deltas, double* norms) {
+        DeviceGuard guard(dev);
+        if (!pd_ready || rhs < 0 || rhs >= PD_NVEC || res < 0 || res >= PD_NVEC || resid < 0 || resid >= PD_NVEC) { err_ = "pd_residual: pd_define first / no such vector"; return false; }
+        const int g4 = grid1d(pd_dim4), gb = grid1d(std::max(std::max(pd_.nxl, pd_.nxu), std::max(pd_.nsl, pd_.nsu)));
+        hipLaunchKernelGGL(k_zero_u64, dim3(1), dim3(64), 0, stream, pd_norms_d, 4);
+        hipLaunchKernelGGL(k_pd_resid_rows, dim3(g4), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], (const double*)pd_vec[res], pd_vec[resid], deltas[0], deltas[1], deltas[2], deltas[3]);
+        hipLaunchKernelGGL(k_pd_resid_bounds, dim3(gb), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], (const double*)pd_vec[res], pd_vec[resid], 1);
+        hipLaunchKernelGGL(k_pd_resid_bounds, dim3(gb), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], (const double*)pd_vec[res], pd_vec[resid], 2);
+        hipLaunchKernelGGL(k_pd_norms, dim3(grid1d(pd_len8)), dim3(256), 0, stream, pd_, (const double*)pd_vec[rhs], (const double*)pd_vec[res], (const double*)pd_vec[resid], pd_len8);
+        HIPCHK(hipMemcpyAsync(pd_norms_h, pd_norms_d, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (int q = 0; q < 3; ++q) { double v; std::memcpy(&v, &pd_norms_h[q], sizeof v); norms[q] = v; }
+        return true;
+    }
+
     // ---------------- multi-GPU orchestration (eager launches) ----------------
     bool launch_fronts(const Sched& sc, int top_mode) {
         const Symbolic& Sy = *S;
@@ -3701,6 +3954,12 @@ bool Numeric::assembly_define(int nseg, const int64_t* off, const int64_t* len) 
 double* Numeric::assembly_buffer(int seg) { return p_->assembly_buffer(seg); }
 bool Numeric::assembly_upload(int seg) { return p_->assembly_upload(seg); }
 bool Numeric::factor_assembled(const double* scale, const double* shift, FactorStats& st) { return p_->factor_assembled(scale, shift, st); }
+bool Numeric::pd_define(const int* dims, const int* ixl, const int* ixu, const int* isl, const int* isu, const int* irn, const int* jcn, const int* segs, int nsegs) { return p_->pd_define(dims, ixl, ixu, isl, isu, irn, jcn, segs, nsegs); }
+bool Numeric::pd_put_data(const double* const* arr) { return p_->pd_put_data(arr); }
+bool Numeric::pd_put(int vec, const double* const* blocks) { return p_->pd_put(vec, blocks); }
+bool Numeric::pd_get(int vec, double* const* blocks) { return p_->pd_get(vec, blocks); }
+bool Numeric::pd_solve_once(int rhs, int res, double alpha, double beta) { return p_->pd_solve_once(rhs, res, alpha, beta); }
+bool Numeric::pd_residual(int rhs, int res, int resid, const double* deltas, double* norms) { return p_->pd_residual(rhs, res, resid, deltas, norms); }
 bool Numeric::ruiz_triplet(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int base, int sweeps, double* out, std::string& err)
 {
     int ndev = 0;

@@ -69,6 +69,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
     "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
     "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
+    "mi355x_kkt_pd_define", "mi355x_kkt_pd_put_data", "mi355x_kkt_pd_put", "mi355x_kkt_pd_get", "mi355x_kkt_pd_solve_once", "mi355x_kkt_pd_residual",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
                 "stats", "solve_perm", "fwd_wave", "fwd_lds", "fwd_big", "bwd_wave", "bwd_lds", "bwd_big", "fwd_big_upd", "bwd_big_dot"]
@@ -124,6 +125,12 @@ def load_library():
     lib.mi355x_kkt_assembly_buffer.restype = dp
     lib.mi355x_kkt_assembly_upload.argtypes = [vp, C.c_int]
     lib.mi355x_kkt_factor_assembled.argtypes = [vp, vp, vp, ip, ip]
+    lib.mi355x_kkt_pd_define.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
+    lib.mi355x_kkt_pd_put_data.argtypes = [vp, vp]
+    lib.mi355x_kkt_pd_put.argtypes = [vp, C.c_int, vp]
+    lib.mi355x_kkt_pd_get.argtypes = [vp, C.c_int, vp]
+    lib.mi355x_kkt_pd_solve_once.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double]
+    lib.mi355x_kkt_pd_residual.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.mi355x_kkt_set_comm_rccl.argtypes = [vp, vp]
     lib.mi355x_kkt_set_comm_callbacks.argtypes = [vp, ALLREDUCE_FN, vp]
     _LIB = lib
@@ -254,6 +261,48 @@ class KKTSolver:
             raise KKTError("factor_assembled: " + self.last_error())
         self._neg = neg.value
         return st, neg.value, zero.value
+
+    # --- the 8-block primal-dual system on the device: vectors are lists of 8 arrays x|s|y_c|y_d|z_L|z_U|v_L|v_U ---
+    def pd_define(self, dims8, idx_xl, idx_xu, idx_sl, idx_su, irn, jcn, segs):
+        d = np.ascontiguousarray(dims8, dtype=np.int32)
+        ix = [np.ascontiguousarray(a, dtype=np.int32) for a in (idx_xl, idx_xu, idx_sl, idx_su)]
+        r = np.ascontiguousarray(irn, dtype=np.int32); c = np.ascontiguousarray(jcn, dtype=np.int32); sg = np.ascontiguousarray(segs, dtype=np.int32)
+        if self.lib.mi355x_kkt_pd_define(self._h, d.ctypes.data, ix[0].ctypes.data, ix[1].ctypes.data, ix[2].ctypes.data, ix[3].ctypes.data,
+                                         r.ctypes.data, c.ctypes.data, sg.ctypes.data, len(sg)) != 0:
+            raise KKTError("pd_define: " + self.last_error())
+        self._pd_len = [int(v) for v in d]
+
+    @staticmethod
+    def _ptr_array(arrs):
+        keep = [np.ascontiguousarray(a, dtype=np.float64) for a in arrs]
+        return (C.c_void_p * 8)(*[a.ctypes.data if a.size else None for a in keep]), keep
+
+    def pd_put_data(self, data8):
+        pa, keep = self._ptr_array(data8)
+        if self.lib.mi355x_kkt_pd_put_data(self._h, pa) != 0:
+            raise KKTError("pd_put_data: " + self.last_error())
+
+    def pd_put(self, vec, blocks8):
+        pa, keep = self._ptr_array(blocks8)
+        if self.lib.mi355x_kkt_pd_put(self._h, int(vec), pa) != 0:
+            raise KKTError("pd_put: " + self.last_error())
+
+    def pd_get(self, vec):
+        out = [np.zeros(n) for n in self._pd_len]
+        pa = (C.c_void_p * 8)(*[a.ctypes.data if a.size else None for a in out])
+        if self.lib.mi355x_kkt_pd_get(self._h, int(vec), pa) != 0:
+            raise KKTError("pd_get: " + self.last_error())
+        return out
+
+    def pd_solve_once(self, rhs, res, alpha=1.0, beta=0.0):
+        if self.lib.mi355x_kkt_pd_solve_once(self._h, int(rhs), int(res), float(alpha), float(beta)) != 0:
+            raise KKTError("pd_solve_once: " + self.last_error())
+
+    def pd_residual(self, rhs, res, resid, deltas4):
+        d = np.ascontiguousarray(deltas4, dtype=np.float64); nr = np.zeros(3)
+        if self.lib.mi355x_kkt_pd_residual(self._h, int(rhs), int(res), int(resid), d.ctypes.data, nr.ctypes.data) != 0:
+            raise KKTError("pd_residual: " + self.last_error())
+        return nr
 
     # --- multi-GPU communicator (include/mi355x_kkt.h): after one of these, multi_solve / factor_device / solve_device* of a
     #     handle created with nranks > 1 run the distributed sequence inside the library ---

@@ -80,7 +80,7 @@ $(OUT)/scalable.a: $(SCAL_OBJS)
 # --- the product's Ipopt adapter (B1), compiled against the reference headers where they lie.  The
 #     adapter SOURCE is product code (ipopt_amd/csrc/ipopt_adapter); only its build needs the reference. ---
 KKTLIB := ipopt_amd/lib
-ADAPTER_SRC := ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp
+ADAPTER_SRC := ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xPDSystemSolver.cpp
 $(OUT)/libmi355x_ipopt.so: $(ADAPTER_SRC) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h $(OUT)/libipopt_ref.so
 	$(CXX) -O2 -fPIC -shared -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter $(ADAPTER_SRC) -o $@ \
 	  -L$(OUT) -lipopt_ref -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib'

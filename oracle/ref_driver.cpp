@@ -16,7 +16,7 @@
 // (--set linear_solver ma97 --set hsllib .../libmi355x_kkt.so = route B2; --set linear_solver mi355x with the patched
 // library oracle/_ref/libipopt_ref_mi355x.so = route B1').
 //
-// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|mi355x-aug|stock] [--record file] [--max-records K]
+// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|mi355x-aug|mi355x-pd|stock] [--record file] [--max-records K]
 //                   [--set name value]... [--optfile ipopt.opt] [--reoptimize] [--quiet]
 //   --reoptimize: after the first solve, set warm_start_same_structure=yes and call ReOptimizeNLP (second DRIVER_SUMMARY line)
 #include "IpIpoptApplication.hpp"
@@ -37,6 +37,7 @@
 #ifdef WITH_MI355X
 #include "IpMi355xSolverInterface.hpp"
 #include "IpMi355xAugSystemSolver.hpp"
+#include "IpMi355xPDSystemSolver.hpp"
 #endif
 #include <cstdio>
 #include <cstdlib>
@@ -253,6 +254,11 @@ int main(int argc, char** argv)
       aug = new Mi355xAugSystemSolver();
       builder = new AlgorithmBuilder(GetRawPtr(aug), "mi355x-ldlt (device-side KKT assembly)");
    }
+   else if( solver == "mi355x-pd" )
+   {  // the full device route: custom AugSystemSolver + PDSystemSolver with the primal-dual vectors resident on the GPU
+      app->Options()->SetStringValue("linear_solver", "custom");
+      builder = MakeMi355xPDSystemAlgorithmBuilder();
+   }
 #endif
    else builder = new DriverAlgBuilder(solver, record, max_records);
    auto t0 = std::chrono::steady_clock::now();
@@ -284,6 +290,11 @@ int main(int argc, char** argv)
 #ifdef WITH_MI355X
    if( IsValid(aug) )
       printf("AUG_STATS {\"uploaded_value_bytes\": %lld, \"factorizations_without_upload\": %d}\n", aug->UploadedBytes(), (int) aug->FactorizationsWithoutUpload());
+   {
+      Index ndev = 0, nhost = 0, nref = 0;
+      if( GetMi355xPDSystemStatistics(builder, ndev, nhost, nref) )
+         printf("PD_STATS {\"device_solves\": %d, \"host_solves\": %d, \"refinement_steps\": %d}\n", (int) ndev, (int) nhost, (int) nref);
+   }
 #endif
    return (status == Solve_Succeeded || status == Solved_To_Acceptable_Level) ? 0 : 1;
 }

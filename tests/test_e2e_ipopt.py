@@ -169,6 +169,28 @@ def test_custom_aug_system_solver_with_device_side_assembly(name, problem, n, tm
         assert aug["factorizations_without_upload"] >= 4          # the delta_x escalation 1e-4 -> 1e-2 -> 1 -> 100 of iteration 1
 
 
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,problem,n", [("hs071", "hs071", 0), ("lukvle1_100", "LukVlE1", 100), ("lukvle1_10000", "LukVlE1", 10000),
+                                            ("mbndry1_100", "MBndryCntrl1", 100), ("lukvli1_10000", "LukVlI1", 10000), ("mbndry2_100", "MBndryCntrl2", 100),
+                                            ("mdist1_100", "MDistCntrl1", 100), ("lukvle1_1000000", "LukVlE1", 1000000)])
+def test_device_resident_primal_dual_solver(name, problem, n, tmp_path, golden_dir):
+    """Mi355xPDSystemSolver through the reference's virtual PDSystemSolverFactory (IpAlgBuilder.hpp:138) -- reduce /
+    solve / expand / residual / refinement of the 8-block system on the device (mi355x_kkt_pd_*), the reference's own perturbation
+    handler and refinement control.  Same iteration table as the reference CPU run (bounds on x: LukVlI1, MBndryCntrl*, hs071;
+    inequality constraints with slacks: hs071), every Solve answered on the device."""
+    iters, summ, out = _run(DRIVER, [problem, str(n), "--solver", "mi355x-pd", "--set", "print_level", "5"] +
+                            (["--set", "tol", "3.82e-6", "--set", "mu_strategy", "adaptive"] if problem == "hs071" else []), tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
+    assert summ[0]["iterations"] == gsum["iterations"]
+    assert abs(summ[0]["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
+    _same_iterations(iters, open(os.path.join(golden_dir, name + ".iters")).read().splitlines())
+    pd = json.loads(next(ln for ln in out.splitlines() if ln.startswith("PD_STATS"))[len("PD_STATS "):])
+    assert pd["device_solves"] >= gsum["iterations"] and pd["host_solves"] == 0
+    assert pd["refinement_steps"] >= gsum["iterations"]           # min_refinement_steps = 1 per search direction (IpPDFullSpaceSolver.cpp:46-52;
+                                                                  # the adaptive-mu oracle of hs071 also solves with allow_inexact: no refinement there)
+
+
 @pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref not built")
 def test_dependency_detector_mi355x_removes_the_dependent_constraint(tmp_path):
     """ProvidesDegeneracyDetection / DetermineDependentRows (IpSparseSymLinearSolverInterface.hpp:240-255) through
