@@ -150,6 +150,10 @@ def e2e_block():
     try:
         run("mi355x", 1)                                   # warm-up (page-in, clocks)
         g = run("mi355x", 1)                               # Ipopt's own BLAS-1 on one host thread
+        try:                                               # the full device route (SURVEY 8(f)1+2): custom AugSystemSolver + PDSystemSolver
+            run("mi355x-pd", 1); gp = run("mi355x-pd", 1)
+        except Exception:
+            gp = None
         ncores = os.cpu_count() or 1
         cpu = {t: run("pardisomkl", t) for t in sorted({1, min(16, ncores), min(64, ncores)})}
         best_t = min(cpu, key=lambda t: cpu[t]["PDSystemSolverTotal"])
@@ -162,7 +166,13 @@ def e2e_block():
                 "cpu_PDSystemSolverTotal_by_threads": {str(t): cpu[t]["PDSystemSolverTotal"] for t in cpu},
                 "iterations_equal": bool(g["iterations"] == cb["iterations"]),
                 "speedup_PDSystemSolverTotal": cb["PDSystemSolverTotal"] / g["PDSystemSolverTotal"],
-                "speedup_wall_total": cb["wall_total"] / g["wall_total"]}
+                "speedup_wall_total": cb["wall_total"] / g["wall_total"],
+                # same problem with the device-resident primal-dual solver plugged into the reference's PDSystemSolverFactory
+                # (device-side KKT assembly, reduce / solve / expand / residual / refinement of the 8-block system on the GPU)
+                "mi355x_device_route": None if gp is None else ({k: gp[k] for k in keys} | {"iterations": gp["iterations"], "objective": gp["objective"], "status": gp["status"],
+                                                                                             "iterations_equal": bool(gp["iterations"] == cb["iterations"]),
+                                                                                             "speedup_PDSystemSolverTotal": cb["PDSystemSolverTotal"] / gp["PDSystemSolverTotal"],
+                                                                                             "speedup_wall_total": cb["wall_total"] / gp["wall_total"]})}
     except Exception as e:
         return {"error": str(e)[:300]}
 

@@ -30,6 +30,7 @@
 #include <cmath>
 #include <chrono>
 #include <vector>
+#include <thread>
 #include <map>
 #include <string>
 #include <algorithm>
@@ -3550,6 +3551,21 @@ public:
     }
 
 
+    // host copy between the caller's vectors and the pinned staging buffer: a single thread moves ~10 GB/s, a Solve at n = 10^6 moves
+    // 2 x 32 MB -- the largest single item of the device route's PDSystemSolverTotal -- so large copies are split over a few threads
+    static void par_memcpy(void* dst, const void* src, size_t bytes) {
+        const size_t chunk = 4u << 20;
+        const int nt = (int)std::min<size_t>(8, bytes / chunk);
+        if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+        std::vector<std::thread> th;
+        const size_t per = ((bytes / nt) + 63) & ~(size_t)63;
+        for (int t = 0; t < nt; ++t) {
+            const size_t o = (size_t)t * per; if (o >= bytes) break;
+            const size_t len = std::min(per, bytes - o);
+            th.emplace_back([=]() { std::memcpy((char*)dst + o, (const char*)src + o, len); });
+        }
+        for (auto& x : th) x.join();
+    }
     // ---------------- primal-dual (8-block) workspace: SURVEY 8(f)2 ----------------
     PdView pd_{}; bool pd_ready = false; long long pd_len8 = 0; int pd_dim4 = 0;
     static constexpr int PD_NVEC = 4;                      // RHS, RES, RESID, and one spare (the caller's copy)
@@ -3634,7 +3650,7 @@ public:
         const int len[8] = {pd_.nxl, pd_.nxu, pd_.nsl, pd_.nsu, pd_.nxl, pd_.nxu, pd_.nsl, pd_.nsu};
         HIPCHK(hipStreamSynchronize(stream));                  // the staging buffer may still feed an earlier copy
         long long o = 0;
-        for (int q = 0; q < 8; ++q) { if (len[q]) std::memcpy(pd_stage + o, arr[q], (size_t)len[q] * sizeof(double)); o += len[q]; }
+        for (int q = 0; q < 8; ++q) { if (len[q]) par_memcpy(pd_stage + o, arr[q], (size_t)len[q] * sizeof(double)); o += len[q]; }
         if (o) HIPCHK(hipMemcpyAsync(pd_data, pd_stage, (size_t)o * sizeof(double), hipMemcpyHostToDevice, stream));
         return true;
     }
@@ -3644,7 +3660,7 @@ public:
         if (!pd_ready || vec < 0 || vec >= PD_NVEC) { err_ = "pd_put: pd_define first / no such vector"; return false; }
         HIPCHK(hipStreamSynchronize(stream));
         long long o = 0;
-        for (int b = 0; b < 8; ++b) { const int l = pd_blocklen(b); if (l) std::memcpy(pd_stage + o, blocks[b], (size_t)l * sizeof(double)); o += l; }
+        for (int b = 0; b < 8; ++b) { const int l = pd_blocklen(b); if (l) par_memcpy(pd_stage + o, blocks[b], (size_t)l * sizeof(double)); o += l; }
         if (o) HIPCHK(hipMemcpyAsync(pd_vec[vec], pd_stage, (size_t)o * sizeof(double), hipMemcpyHostToDevice, stream));
         return true;
     }
@@ -3654,7 +3670,7 @@ public:
         if (pd_len8) HIPCHK(hipMemcpyAsync(pd_stage, pd_vec[vec], (size_t)pd_len8 * sizeof(double), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         long long o = 0;
-        for (int b = 0; b < 8; ++b) { const int l = pd_blocklen(b); if (l) std::memcpy(blocks[b], pd_stage + o, (size_t)l * sizeof(double)); o += l; }
+        for (int b = 0; b < 8; ++b) { const int l = pd_blocklen(b); if (l) par_memcpy(blocks[b], pd_stage + o, (size_t)l * sizeof(double)); o += l; }
         return true;
     }
     // res <- alpha sol + beta res,  sol = the solution of the 8-block system with right-hand side `rhs` through the CURRENT factorisation

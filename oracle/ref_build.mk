@@ -99,12 +99,13 @@ $(OUT)/ipopt_mi355x_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/
 	  -L$(OUT) -lipopt_ref -lmi355x_ipopt -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib' $(MKLLINK)
 
 # --- route B1': the reference WITH the `linear_solver=mi355x` patch a maintainer would carry (oracle/patches/linear_solver_mi355x.patch:
-#     one factory arm in IpAlgBuilder.cpp:427-526, option registration in IpLinearSolversRegOp.cpp:84-90).  The two patched
+#     factory arms in IpAlgBuilder.cpp:427-526 (mi355x), :568-600 and :644-664 (mi355x-device: AugSystemSolver + PDSystemSolver), option
+#     registration in IpLinearSolversRegOp.cpp:84-90).  The two patched
 #     translation units are produced in the build directory, compiled and removed again; everything else is the unmodified objects. ---
 PATCH   := oracle/patches/linear_solver_mi355x.patch
 PSRC    := Algorithm/IpAlgBuilder.cpp Algorithm/LinearSolvers/IpLinearSolversRegOp.cpp Interfaces/IpTNLPAdapter.cpp
 POBJS   := $(OUT)/obj_patched/IpAlgBuilder.o $(OUT)/obj_patched/IpLinearSolversRegOp.o $(OUT)/obj_patched/IpTNLPAdapter.o \
-           $(OUT)/obj_patched/IpMi355xSolverInterface.o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o
+           $(OUT)/obj_patched/IpMi355xSolverInterface.o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o $(OUT)/obj_patched/IpMi355xPDSystemSolver.o
 $(OUT)/obj_patched/.stamp: $(PATCH) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.cpp) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h
 	rm -rf $(OUT)/obj_patched $(OUT)/patched_src; mkdir -p $(OUT)/obj_patched $(OUT)/patched_src/src/Algorithm/LinearSolvers $(OUT)/patched_src/src/Interfaces
 	for f in $(PSRC); do cp $(REF)/src/$$f $(OUT)/patched_src/src/$$f; done
@@ -112,6 +113,7 @@ $(OUT)/obj_patched/.stamp: $(PATCH) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.cp
 	for f in $(PSRC); do $(CXX) $(CXXFLAGS_REF) -DIPOPT_HAS_MI355X $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c $(OUT)/patched_src/src/$$f -o $(OUT)/obj_patched/`basename $$f .cpp`.o || exit 1; done
 	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp -o $(OUT)/obj_patched/IpMi355xSolverInterface.o
 	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp -o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o
+	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xPDSystemSolver.cpp -o $(OUT)/obj_patched/IpMi355xPDSystemSolver.o
 	rm -rf $(OUT)/patched_src
 	touch $@
 $(OUT)/libipopt_ref_mi355x.so: $(OBJS) $(OUT)/obj_patched/.stamp $(OUT)/mkl/.stamp

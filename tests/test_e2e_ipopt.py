@@ -111,6 +111,22 @@ def test_registered_linear_solver_mi355x_from_ipopt_opt(tmp_path, golden_dir):
     _same_iterations(iters, open(os.path.join(golden_dir, "lukvle1_10000.iters")).read().splitlines())
 
 
+@pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref not built")
+@pytest.mark.parametrize("name,problem,n", [("lukvli1_10000", "LukVlI1", 10000), ("mbndry1_100", "MBndryCntrl1", 100)])
+def test_registered_linear_solver_mi355x_device_from_ipopt_opt(name, problem, n, tmp_path, golden_dir):
+    """Route B1' for the full device route: `linear_solver mi355x-device` in ipopt.opt makes the patched AlgorithmBuilder use
+    Mi355xAugSystemSolver (device-side KKT assembly) and put Mi355xPDSystemSolver (device-resident refinement of the 8-block system)
+    in front of its PDFullSpaceSolver (IpAlgBuilder.cpp:568-600, :644-664)."""
+    (tmp_path / "ipopt.opt").write_text("linear_solver mi355x-device\nprint_timing_statistics yes\n")
+    iters, summ, out = _run(PATCHED, [problem, str(n), "--solver", "stock", "--optfile", "ipopt.opt"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
+    assert summ[0]["iterations"] == gsum["iterations"]
+    _same_iterations(iters, open(os.path.join(golden_dir, name + ".iters")).read().splitlines())
+    # the reference's own residual computation never ran: its timer stays at zero unless OUR class started it (it does, around the kernels)
+    assert summ[0]["LinearSystemStructureConverter"] == 0.0          # no TripletToCSRConverter, no TSymLinearSolver in this route
+
+
 @pytest.mark.skipif(not os.path.exists(STOCK), reason="oracle/_ref not built")
 @pytest.mark.parametrize("name,problem,n", [("mbndry1_100", "MBndryCntrl1", 100), ("lukvle1_10000", "LukVlE1", 10000)])
 def test_hsllib_route_on_scalable_problems_with_default_dynamic_scaling(name, problem, n, tmp_path, golden_dir):
