@@ -1803,7 +1803,7 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, int top_mode)
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
-    if (M.selfasm && !top_mode) return;       // pure in-place chain link: its A entries are added by its own pivot-block / TRSM kernels
+    if (M.selfasm) return;                    // pure in-place chain link: its A entries are added by its own pivot-block / TRSM kernels
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
     (void)0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -3152,7 +3152,8 @@ public:
             M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
             M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
             M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.ttab = ttab_of[sn]; M.ttab2 = ttab2_of[sn];
-            M.selfasm = (!multi && selfasm_on && Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1) ? 1 : 0; M.pad2_ = 0;
+            // (multi-GPU: not for a front at a subtree join -- its square comes out of the all-reduced arena)
+            M.selfasm = ((!multi || aoff[sn] < 0) && selfasm_on && Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1) ? 1 : 0; M.pad2_ = 0;
             {   // 1: in-place chain link whose only child is the chain child, 2: no children at all => the fused forward kernel applies
                 const int nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
                 M.solo = (Sy.alias_child[sn] >= 0 && nch == 1) ? 1 : ((Sy.alias_child[sn] < 0 && nch == 0) ? 2 : 0);
@@ -3329,7 +3330,7 @@ public:
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         const int nrb = (mm + 63) / 64;
-        if (fuse_dt && single && !top_mode && !prof_on && kk <= 64 && nball * (1 + nrb) <= fuse_dt_maxwg) {      // (the per-kernel profile keeps the two kernels apart)
+        if (fuse_dt && (single || multi) && !prof_on && kk <= 64 && nball * (1 + nrb) <= fuse_dt_maxwg) {      // (the per-kernel profile keeps the two kernels apart; multi-GPU: local subtrees and replicated top alike)
             // few fronts on the level: pivot block + panel solve in one flag-synchronised launch (k_big_diag_trsm)
             const size_t lds = std::max((size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64,
                                         trsm_lds_bytes(kk, true));
