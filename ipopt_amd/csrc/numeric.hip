@@ -2278,47 +2278,63 @@ __device__ __forceinline__ void schur_tile(const DevView& V, const FrontMeta& M,
     // staging role of this thread: row (tid & 127) of the tile, panel columns (tid >> 7) and (tid >> 7) + 8 of the chunk
     const int srow = tid & 127, scol = tid >> 7;
     const bool arow_ok = cc0 + srow < mu, brow_ok = i0 + srow < mu;
-    double ga[2], gb[2];
-    auto fetch = [&](int j, int p0) -> int {
-        const GroupLink G = V.gtab[M.gbase + j];
-        const double* Lp = V.L + G.panel_off + (G.m - mu) + i0 + srow;
-        const double* Wp = V.wbuf + G.wb + (G.m - mu) + cc0 + srow;
+    // software pipeline of depth 2 over the 16-column chunks: while chunk i is multiplied out of LDS, chunk i+1 sits in registers on its
+    // way to LDS and chunk i+2 is in flight from L2 / HBM -- on the chain levels a launch is a handful of workgroups and the per-chunk
+    // cost is the load latency, not the 16 MFMAs; the link record (gtab) is re-read only when the link changes, not once per chunk.
+    // (The order in which a tile element accumulates its products is unchanged: results are bit-identical.)
+    GroupLink Gc = V.gtab[M.gbase + j0];
+    int gj = j0;
+    double ga0[2], gb0[2], ga1[2], gb1[2];                 // two register stages (statically named: no indexed register arrays)
+    auto fetch = [&](int j, int p0, double (&ga)[2], double (&gb)[2]) {
+        if (j != gj) { Gc = V.gtab[M.gbase + j]; gj = j; }
+        const double* Lp = V.L + Gc.panel_off + (Gc.m - mu) + i0 + srow;
+        const double* Wp = V.wbuf + Gc.wb + (Gc.m - mu) + cc0 + srow;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int pk = p0 + scol + 8 * u;
-            const bool v = pk < G.k;
-            ga[u] = (v && arow_ok) ? Wp[(size_t)pk * G.m] : 0.0;
-            gb[u] = (v && brow_ok) ? Lp[(size_t)pk * G.ldp] : 0.0;
+            const bool v = pk < Gc.k;
+            ga[u] = (v && arow_ok) ? Wp[(size_t)pk * Gc.m] : 0.0;
+            gb[u] = (v && brow_ok) ? Lp[(size_t)pk * Gc.ldp] : 0.0;
         }
-        return G.k;
     };
-    int j = j0, p0 = 0, buf = 0;
-    int kcur = fetch(j, p0);
-    As[0][scol][srow] = ga[0]; As[0][scol + 8][srow] = ga[1]; Bs[0][scol][srow] = gb[0]; Bs[0][scol + 8][srow] = gb[1];
+    // chunk sequence: (link j, first column p), j = j0 .. M.gpos, p = 0, KC, ... < k_j.  advance() is called right after the fetch of
+    // chunk (j, p), so the cached link record is that of j.
+    auto advance = [&](int& j, int& p) -> bool { p += KC; if (p >= Gc.k) { ++j; p = 0; } return j <= M.gpos; };
+    auto to_lds = [&](int b, const double (&ga)[2], const double (&gb)[2]) { As[b][scol][srow] = ga[0]; As[b][scol + 8][srow] = ga[1]; Bs[b][scol][srow] = gb[0]; Bs[b][scol + 8][srow] = gb[1]; };
+    auto multiply = [&](int b) {
+        if (!work) return;
+#pragma unroll
+        for (int st = 0; st < KC / 4; ++st) {
+            const int kk = 4 * st + l4;
+            const double a0 = As[b][kk][wc + l15], a1 = As[b][kk][wc + 16 + l15];
+            const double b0 = Bs[b][kk][wr + l15], b1 = Bs[b][kk][wr + 16 + l15];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    };
+    int jn = j0, pn = 0;                   // the chunk most recently fetched
+    fetch(jn, pn, ga0, gb0);
+    to_lds(0, ga0, gb0);                   // chunk 0 -> LDS
+    bool have1 = advance(jn, pn);          // chunk 1 exists -> stage 0
+    if (have1) fetch(jn, pn, ga0, gb0);
+    bool have2 = have1 && advance(jn, pn); // chunk 2 exists -> stage 1
+    if (have2) fetch(jn, pn, ga1, gb1);
     __syncthreads();
     while (true) {
-        int jn = j, pn = p0 + KC;
-        if (pn >= kcur) { jn = j + 1; pn = 0; }
-        const bool more = jn <= M.gpos;
-        int knext = kcur;
-        if (more) knext = fetch(jn, pn);
-        if (work) {
-#pragma unroll
-            for (int st = 0; st < KC / 4; ++st) {
-                const int kk = 4 * st + l4;
-                const double a0 = As[buf][kk][wc + l15], a1 = As[buf][kk][wc + 16 + l15];
-                const double b0 = Bs[buf][kk][wr + l15], b1 = Bs[buf][kk][wr + 16 + l15];
-                acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
-            }
-        }
-        if (!more) break;
-        buf ^= 1;
-        As[buf][scol][srow] = ga[0]; As[buf][scol + 8][srow] = ga[1]; Bs[buf][scol][srow] = gb[0]; Bs[buf][scol + 8][srow] = gb[1];
+        multiply(0);
+        if (!have1) break;
+        to_lds(1, ga0, gb0);
+        have1 = have2;
+        if (have2) { have2 = advance(jn, pn); if (have2) fetch(jn, pn, ga0, gb0); }
         __syncthreads();
-        j = jn; p0 = pn; kcur = knext;
+        multiply(1);
+        if (!have1) break;
+        to_lds(0, ga1, gb1);
+        have1 = have2;
+        if (have2) { have2 = advance(jn, pn); if (have2) fetch(jn, pn, ga1, gb1); }
+        __syncthreads();
     }
     if (!work) return;
     double* T = V.cb + M.cb_off;
