@@ -4,11 +4,76 @@
 #include "IpTripletHelper.hpp"
 #include "IpIpoptData.hpp"
 #include "IpTimingStatistics.hpp"
+#include "IpSymTMatrix.hpp"
+#include "IpGenTMatrix.hpp"
+#include "IpDenseVector.hpp"
 #include <cmath>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 namespace Ipopt
 {
+
+// Leaf copies into the pinned staging buffers.  TripletHelper::FillValues (IpTripletHelper.cpp:249-362) ends, for the matrix types
+// a TNLP produces, in one single-threaded copy of Values(); at n = 10^6 those copies (56 MB per iteration) are a third of what is
+// left of PDSystemSolverTotal once everything else runs on the GPU, so the plain types are copied by a few threads here and
+// everything else goes through TripletHelper as before.
+static void ParallelCopy(Number* dst, const Number* src, size_t n)
+{
+   const size_t chunk = (size_t) 1 << 19;        // doubles per thread at least (4 MB)
+   const int nt = (int) std::min<size_t>(8, n / chunk);
+   if( nt <= 1 )
+   {
+      std::memcpy(dst, src, n * sizeof(Number));
+      return;
+   }
+   std::vector<std::thread> th;
+   const size_t per = (n + nt - 1) / nt;
+   for( int t = 0; t < nt; ++t )
+   {
+      const size_t o = (size_t) t * per;
+      if( o >= n )
+      {
+         break;
+      }
+      const size_t len = std::min(per, n - o);
+      th.emplace_back([=]() { std::memcpy(dst + o, src + o, len * sizeof(Number)); });
+   }
+   for( size_t t = 0; t < th.size(); ++t )
+   {
+      th[t].join();
+   }
+}
+
+static void FillMatrixValues(Index n_entries, const Matrix& M, Number* dst)
+{
+   if( const SymTMatrix* st = dynamic_cast<const SymTMatrix*>(&M) )
+   {
+      ParallelCopy(dst, st->Values(), (size_t) n_entries);
+   }
+   else if( const GenTMatrix* gt = dynamic_cast<const GenTMatrix*>(&M) )
+   {
+      ParallelCopy(dst, gt->Values(), (size_t) n_entries);
+   }
+   else
+   {
+      TripletHelper::FillValues(n_entries, M, dst);
+   }
+}
+
+static void FillVectorValues(Index n, const Vector& v, Number* dst)
+{
+   const DenseVector* d = dynamic_cast<const DenseVector*>(&v);
+   if( d && !d->IsHomogeneous() )
+   {
+      ParallelCopy(dst, d->Values(), (size_t) n);
+   }
+   else
+   {
+      TripletHelper::FillValuesFromVector(n, v, dst);
+   }
+}
 
 Mi355xAugSystemSolver::Mi355xAugSystemSolver()
    : handle_(NULL), structured_(false), analysed_(false), have_factor_(false), pivtol_changed_(false),
@@ -189,25 +254,25 @@ bool Mi355xAugSystemSolver::UpdateSources(const SymMatrix* W, Number W_factor, c
       switch( q )
       {
          case SEG_W:
-            TripletHelper::FillValues(nnz_w_, *W, dst);
+            FillMatrixValues(nnz_w_, *W, dst);
             break;
          case SEG_JC:
-            TripletHelper::FillValues(nnz_jc_, J_c, dst);
+            FillMatrixValues(nnz_jc_, J_c, dst);
             break;
          case SEG_JD:
-            TripletHelper::FillValues(nnz_jd_, J_d, dst);
+            FillMatrixValues(nnz_jd_, J_d, dst);
             break;
          case SEG_DX:
-            TripletHelper::FillValuesFromVector(n_x_, *D_x, dst);
+            FillVectorValues(n_x_, *D_x, dst);
             break;
          case SEG_DS:
-            TripletHelper::FillValuesFromVector(n_s_, *D_s, dst);
+            FillVectorValues(n_s_, *D_s, dst);
             break;
          case SEG_DC:
-            TripletHelper::FillValuesFromVector(n_c_, *D_c, dst);
+            FillVectorValues(n_c_, *D_c, dst);
             break;
          default:
-            TripletHelper::FillValuesFromVector(n_d_, *D_d, dst);
+            FillVectorValues(n_d_, *D_d, dst);
             break;
       }
       if( upload )
