@@ -207,6 +207,22 @@ def test_device_resident_primal_dual_solver(name, problem, n, tmp_path, golden_d
                                                                   # the adaptive-mu oracle of hs071 also solves with allow_inexact: no refinement there)
 
 
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+def test_device_route_hands_uncovered_modes_to_the_reference_solver(tmp_path):
+    """What Mi355xPDSystemSolver does not cover is answered by the reference PDFullSpaceSolver it wraps (same augmented-system solver, same
+    perturbation handler): the inertia-free curvature test (neg_curv_test_tol > 0, IpPDFullSpaceSolver.cpp:592-639) works on host vectors;
+    a second optimisation of the same structure (warm_start_same_structure) goes back to the device."""
+    iters, summ, out = _run(DRIVER, ["hs071", "0", "--solver", "mi355x-pd", "--set", "neg_curv_test_tol", "1e-12"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    pd = json.loads(next(ln for ln in out.splitlines() if ln.startswith("PD_STATS"))[len("PD_STATS "):])
+    assert pd["device_solves"] == 0 and pd["host_solves"] > 0
+    iters, summ, out = _run(DRIVER, ["LukVlI1", "10000", "--solver", "mi355x-pd", "--reoptimize"], tmp_path)
+    assert out.count("EXIT: Optimal Solution Found.") == 2, out[-1500:]
+    assert summ[0]["iterations"] == summ[1]["iterations"] and summ[1]["LinearSystemSymbolicFactorization"] == 0.0
+    pd = json.loads(next(ln for ln in out.splitlines() if ln.startswith("PD_STATS"))[len("PD_STATS "):])
+    assert pd["host_solves"] == 0 and pd["device_solves"] >= 2 * summ[0]["iterations"]
+
+
 @pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref not built")
 def test_dependency_detector_mi355x_removes_the_dependent_constraint(tmp_path):
     """ProvidesDegeneracyDetection / DetermineDependentRows (IpSparseSymLinearSolverInterface.hpp:240-255) through
