@@ -39,6 +39,12 @@
 #include "IpMi355xAugSystemSolver.hpp"
 #include "IpMi355xPDSystemSolver.hpp"
 #endif
+#include "IpPDSystemSolver.hpp"
+#include "IpTripletHelper.hpp"
+#include "IpExpansionMatrix.hpp"
+#include "IpIpoptCalculatedQuantities.hpp"
+#include "IpIpoptData.hpp"
+#include "IpIpoptNLP.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -148,11 +154,108 @@ private:
    Number* vals_;
 };
 
+
+// ------------------------------------------------------------------------------------------
+// recording decorator of the PDSystemSolver boundary: what PDFullSpaceSolver::Solve was given -- the pieces of the
+// 8-block system of the current iterate and the right-hand side -- and what it returned.  Golden fixtures for oracle/pd_oracle.py.
+//   file: "PDREC1\n", then per call: int hdr[16] = {nx, ns, nc, nd, nxl, nxu, nsl, nsu, nnzW, nnzJc, nnzJd, allow_inexact, improve_solution, ok, 0, 0},
+//   double {alpha, beta, delta_x, delta_s, delta_c, delta_d}; int index lists of the 4 expansion matrices (0-based); int (irow, jcol) 1-based +
+//   double values of W, J_c, J_d; double z_L, z_U, v_L, v_U, slack_x_L, slack_x_U, slack_s_L, slack_s_U, sigma_x, sigma_s;
+//   double rhs (8 blocks), res on entry (8 blocks), res on return (8 blocks)
+// ------------------------------------------------------------------------------------------
+class RecordingPDSolver: public PDSystemSolver
+{
+public:
+   RecordingPDSolver(SmartPtr<PDSystemSolver> inner, const std::string& file, int max_records)
+      : inner_(inner), f_(NULL), nrec_(0), max_records_(max_records)
+   {
+      f_ = fopen(file.c_str(), "wb");
+      if( f_ ) fwrite("PDREC1\n", 1, 7, f_);
+   }
+   ~RecordingPDSolver() { if( f_ ) fclose(f_); }
+   bool InitializeImpl(const OptionsList& options, const std::string& prefix)
+   {
+      return inner_->Initialize(Jnlst(), IpNLP(), IpData(), IpCq(), options, prefix);
+   }
+   bool Solve(Number alpha, Number beta, const IteratesVector& rhs, IteratesVector& res, bool allow_inexact, bool improve_solution)
+   {
+      const bool rec = f_ && (max_records_ < 0 || nrec_ < max_records_);
+      std::vector<Number> res_in;
+      if( rec && (beta != 0. || improve_solution) ) Blocks(res, res_in);      // (otherwise `res` may be uninitialised memory)
+      const bool ok = inner_->Solve(alpha, beta, rhs, res, allow_inexact, improve_solution);
+      if( rec )
+      {
+         SmartPtr<const SymMatrix> W = IpData().W();
+         SmartPtr<const Matrix> Jc = IpCq().curr_jac_c(), Jd = IpCq().curr_jac_d();
+         const ExpansionMatrix* P[4] = {dynamic_cast<const ExpansionMatrix*>(GetRawPtr(IpNLP().Px_L())), dynamic_cast<const ExpansionMatrix*>(GetRawPtr(IpNLP().Px_U())),
+                                        dynamic_cast<const ExpansionMatrix*>(GetRawPtr(IpNLP().Pd_L())), dynamic_cast<const ExpansionMatrix*>(GetRawPtr(IpNLP().Pd_U()))};
+         if( P[0] && P[1] && P[2] && P[3] )
+         {
+            const Index nW = TripletHelper::GetNumberEntries(*W), nJc = TripletHelper::GetNumberEntries(*Jc), nJd = TripletHelper::GetNumberEntries(*Jd);
+            int hdr[16] = {rhs.x()->Dim(), rhs.s()->Dim(), rhs.y_c()->Dim(), rhs.y_d()->Dim(), P[0]->NCols(), P[1]->NCols(), P[2]->NCols(), P[3]->NCols(),
+                           nW, nJc, nJd, allow_inexact ? 1 : 0, improve_solution ? 1 : 0, ok ? 1 : 0, 0, 0};
+            fwrite(hdr, sizeof(int), 16, f_);
+            Number dx, ds, dc, dd;
+            IpData().getPDPert(dx, ds, dc, dd);
+            double sc[6] = {alpha, beta, dx, ds, dc, dd};
+            fwrite(sc, sizeof(double), 6, f_);
+            for( int q = 0; q < 4; ++q ) if( P[q]->NCols() > 0 ) fwrite(P[q]->ExpandedPosIndices(), sizeof(Index), P[q]->NCols(), f_);
+            Trip(nW, *W); Trip(nJc, *Jc); Trip(nJd, *Jd);
+            const Vector* dat[10] = {GetRawPtr(IpData().curr()->z_L()), GetRawPtr(IpData().curr()->z_U()), GetRawPtr(IpData().curr()->v_L()), GetRawPtr(IpData().curr()->v_U()),
+                                     GetRawPtr(IpCq().curr_slack_x_L()), GetRawPtr(IpCq().curr_slack_x_U()), GetRawPtr(IpCq().curr_slack_s_L()), GetRawPtr(IpCq().curr_slack_s_U()),
+                                     GetRawPtr(IpCq().curr_sigma_x()), GetRawPtr(IpCq().curr_sigma_s())};
+            for( int q = 0; q < 10; ++q ) Vec(*dat[q]);
+            std::vector<Number> b;
+            Blocks(rhs, b); fwrite(b.data(), sizeof(Number), b.size(), f_);
+            if( res_in.empty() ) res_in.assign(b.size(), 0.);
+            fwrite(res_in.data(), sizeof(Number), res_in.size(), f_);
+            Blocks(res, b); fwrite(b.data(), sizeof(Number), b.size(), f_);
+            ++nrec_;
+         }
+      }
+      return ok;
+   }
+private:
+   void Vec(const Vector& v)
+   {
+      std::vector<Number> a(v.Dim() > 0 ? v.Dim() : 1);
+      if( v.Dim() > 0 ) { TripletHelper::FillValuesFromVector(v.Dim(), v, a.data()); fwrite(a.data(), sizeof(Number), v.Dim(), f_); }
+   }
+   void Trip(Index n, const Matrix& M)
+   {
+      if( n <= 0 ) return;
+      std::vector<Index> r(n), c(n); std::vector<Number> v(n);
+      TripletHelper::FillRowCol(n, M, r.data(), c.data());
+      TripletHelper::FillValues(n, M, v.data());
+      fwrite(r.data(), sizeof(Index), n, f_); fwrite(c.data(), sizeof(Index), n, f_); fwrite(v.data(), sizeof(Number), n, f_);
+   }
+   static void Blocks(const IteratesVector& it, std::vector<Number>& out)
+   {
+      const Vector* b[8] = {GetRawPtr(it.x()), GetRawPtr(it.s()), GetRawPtr(it.y_c()), GetRawPtr(it.y_d()), GetRawPtr(it.z_L()), GetRawPtr(it.z_U()), GetRawPtr(it.v_L()), GetRawPtr(it.v_U())};
+      out.clear();
+      for( int q = 0; q < 8; ++q )
+      {
+         const size_t o = out.size();
+         out.resize(o + b[q]->Dim());
+         if( b[q]->Dim() > 0 ) TripletHelper::FillValuesFromVector(b[q]->Dim(), *b[q], &out[o]);
+      }
+   }
+   SmartPtr<PDSystemSolver> inner_;
+   FILE* f_;
+   int nrec_, max_records_;
+};
+
 class DriverAlgBuilder: public AlgorithmBuilder
 {
 public:
-   DriverAlgBuilder(const std::string& solver, const std::string& record, int max_records)
-      : solver_(solver), record_(record), max_records_(max_records) { }
+   DriverAlgBuilder(const std::string& solver, const std::string& record, int max_records, const std::string& record_pd = "")
+      : solver_(solver), record_(record), record_pd_(record_pd), max_records_(max_records) { }
+   virtual SmartPtr<PDSystemSolver> PDSystemSolverFactory(const Journalist& jnlst, const OptionsList& options, const std::string& prefix)
+   {
+      SmartPtr<PDSystemSolver> pd = AlgorithmBuilder::PDSystemSolverFactory(jnlst, options, prefix);      // the reference's PDFullSpaceSolver
+      if( !record_pd_.empty() ) pd = new RecordingPDSolver(pd, record_pd_, max_records_);
+      return pd;
+   }
    virtual SmartPtr<SymLinearSolver> SymLinearSolverFactory(const Journalist& jnlst, const OptionsList& options, const std::string& prefix)
    {
 #ifdef WITH_MI355X
@@ -170,7 +273,7 @@ public:
       return new TSymLinearSolver(iface, none);
    }
 private:
-   std::string solver_, record_;
+   std::string solver_, record_, record_pd_;
    int max_records_;
 };
 
@@ -181,7 +284,7 @@ int main(int argc, char** argv)
    if( argc < 3 ) { fprintf(stderr, "usage: %s <problem> <N> [--solver s] [--record f] [--max-records k] [--set k v]... [--quiet]\n", argv[0]); return 2; }
    std::string problem = argv[1];
    int N = atoi(argv[2]);
-   std::string solver = "pardisomkl", record;
+   std::string solver = "pardisomkl", record, record_pd;
    int max_records = -1;
    bool quiet = false, reopt = false;
    std::string optfile;
@@ -191,6 +294,7 @@ int main(int argc, char** argv)
       std::string a = argv[i];
       if( a == "--solver" && i + 1 < argc ) solver = argv[++i];
       else if( a == "--record" && i + 1 < argc ) record = argv[++i];
+      else if( a == "--record-pd" && i + 1 < argc ) record_pd = argv[++i];
       else if( a == "--max-records" && i + 1 < argc ) max_records = atoi(argv[++i]);
       else if( a == "--set" && i + 2 < argc ) { sets.push_back(std::make_pair(std::string(argv[i + 1]), std::string(argv[i + 2]))); i += 2; }
       else if( a == "--quiet" ) quiet = true;
@@ -260,7 +364,7 @@ int main(int argc, char** argv)
       builder = MakeMi355xPDSystemAlgorithmBuilder();
    }
 #endif
-   else builder = new DriverAlgBuilder(solver, record, max_records);
+   else builder = new DriverAlgBuilder(solver, record, max_records, record_pd);
    auto t0 = std::chrono::steady_clock::now();
    ApplicationReturnStatus status = app->OptimizeNLP(nlp, builder);
    double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

@@ -33,3 +33,7 @@ run mdist1_100 MDistCntrl1 100 norec
 run mbndry3d_12 MBndryCntrl_3D 12 norec
 run mbndry1_300 MBndryCntrl1 300 norec
 ls -la
+# the PDSystemSolver boundary: pieces of the 8-block system, right-hand side and result of the reference's
+# PDFullSpaceSolver::Solve, every call of hs071 and the first 8 of LukVlI1 n = 20 (bounds on every variable); reader: oracle/pd_oracle.py
+$D/ref_driver hs071 0 --record-pd hs071.pdrec --quiet > /dev/null
+$D/ref_driver LukVlI1 20 --record-pd lukvli1_20.pdrec --max-records 8 --quiet > /dev/null

@@ -111,6 +111,57 @@ def test_pd_solve_once_and_residual_match_the_dense_eight_block_system(seed):
     assert np.abs(mix - (0.5 * ref + 2.0 * pert)).max() <= 1e-9 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("name", ["hs071", "lukvli1_20"])
+def test_pd_kernels_reproduce_the_recorded_solves_of_the_reference(name):
+    """Golden fixtures from the UNMODIFIED reference (tests/golden/*.pdrec: what PDFullSpaceSolver::Solve was given and returned, every
+    call of hs071 / the first 8 of LukVlI1 n = 20): device-side assembly of the recorded W, J_c, J_d, Sigma and perturbations, then
+    solve_once + one refinement step on the device must land on the vector the reference returned, and pd_residual on the oracle's."""
+    import os
+    from oracle import pd_oracle as po
+    recs = po.read_pdrec(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name + ".pdrec"))
+    checked = 0
+    for r in recs:
+        if r["beta"] != 0.0 or r["alpha"] == 0.0:
+            continue
+        nx, ns, nc, nd = r["nx"], r["ns"], r["nc"], r["nd"]
+        dx, ds, dc, dd = r["deltas"]
+        (wr, wc, wv), (jcr, jcc, jcv), (jdr, jdc, jdv) = r["W"], r["Jc"], r["Jd"]
+        ar = lambda n, o: np.arange(n) + o
+        # SymTMatrix triplets may sit in either triangle: the KKT triplet of W is (max, min)
+        irn = np.concatenate([np.maximum(wr, wc), ar(nx, 0), ar(ns, nx), jcr + nx + ns, ar(nc, nx + ns), jdr + nx + ns + nc, ar(nd, nx + ns + nc), ar(nd, nx + ns + nc)]) + 1
+        jcn = np.concatenate([np.minimum(wr, wc), ar(nx, 0), ar(ns, nx), jcc, ar(nc, nx + ns), jdc, ar(ns, nx), ar(nd, nx + ns + nc)]) + 1
+        lens = [len(wv), nx, ns, len(jcv), nc, len(jdv), ns, nd]
+        srcs = [wv, r["sigma_x"], r["sigma_s"], jcv, np.zeros(nc), jdv, np.zeros(ns), np.zeros(nd)]
+        scale = np.array([1, 1, 1, 1, 0, 1, 0, 0], dtype=float); shift = np.array([0, dx, ds, 0, -dc, 0, -1, -dd], dtype=float)
+        vals0 = np.concatenate([sc * np.asarray(v) + sh for sc, sh, v in zip(scale, shift, srcs)])
+        s = ipopt_amd.KKTSolver()
+        s.initialize_structure(nx + ns + nc + nd, irn, jcn, vals=vals0)
+        s.assembly_define(lens)
+        for q, v in enumerate(srcs):
+            s.assembly_set(q, v)
+        st, neg, zero = s.factor_assembled(scale, shift)
+        assert st == 0 and neg == nc + nd                      # the perturbations recorded are those of an accepted factorisation
+        nb = [len(r["ixl"]), len(r["ixu"]), len(r["isl"]), len(r["isu"])]
+        s.pd_define([nx, ns, nc, nd] + nb, r["ixl"], r["ixu"], r["isl"], r["isu"], irn, jcn, [0, 3, 5])
+        s.pd_put_data([r["zl"], r["zu"], r["vl"], r["vu"], r["sxl"], r["sxu"], r["ssl"], r["ssu"]])
+        s.pd_put(0, po.split(r, r["rhs"]))
+        s.pd_solve_once(0, 1, 1.0, 0.0)
+        nr = s.pd_residual(0, 1, 2, [dx, ds, dc, dd])
+        res1 = np.concatenate(s.pd_get(1))
+        resid_o, ratio_o = po.residual(r, r["rhs"], res1)
+        assert np.abs(np.concatenate(s.pd_get(2)) - resid_o).max() <= 1e-12 * max(1.0, np.abs(r["rhs"]).max() + np.abs(res1).max() * np.abs(po.k8_dense(r)).sum(axis=1).max())
+        assert np.allclose(nr[:2], [np.abs(r["rhs"]).max(), np.abs(res1).max()], rtol=1e-13, atol=0)
+        s.pd_solve_once(2, 1, -1.0, 1.0)                          # one refinement step, as min_refinement_steps = 1 makes the reference do
+        res = np.concatenate(s.pd_get(1))
+        want = r["res_out"] / r["alpha"]
+        assert np.abs(res - want).max() <= 1e-7 * max(1.0, np.abs(want).max()), (name, np.abs(res - want).max())
+        _, ratio = po.residual(r, r["rhs"], res)
+        assert ratio <= 1e-9
+        s.close()
+        checked += 1
+    assert checked >= 6
+
+
 def test_pd_calls_fail_loudly_without_a_workspace():
     s = ipopt_amd.KKTSolver()
     n = 4
