@@ -1865,8 +1865,9 @@ __device__ __forceinline__ TrsmLds trsm_layout(char* smem_raw, const int k, cons
     TrsmLds T;
     T.kp16 = (k + 15) & ~15; T.ldl = T.kp16 | 1;
     T.As = reinterpret_cast<double*>(smem_raw);               // 64 x kp16: As[r + p*65] = (A21 P)(ibase+r, p), overwritten by W in place
-    T.Ls = T.As + (size_t)65 * T.kp16;                        // L11 (strictly lower part, pivot order), zero padded to kp16 x kp16
-    T.Is = T.Ls + (size_t)T.ldl * T.kp16;                     // inverses of the 16 x 16 diagonal blocks of L11: Is[b*272 + i + p*17]
+    T.Ls = T.As + (size_t)65 * T.kp16;                        // L11 (strictly lower part, pivot order), zero padded to kp16 x kp16 -- staged only for
+    const size_t lsz = (T.kp16 <= 64) ? (size_t)T.ldl * T.kp16 : 0;   // k <= 64; the 128-column panels of the wide_panels option read it from L2 (LDS budget)
+    T.Is = T.Ls + lsz;                     // inverses of the 16 x 16 diagonal blocks of L11: Is[b*272 + i + p*17]
     T.Ds = T.Is + (size_t)17 * T.kp16;                        // dinv[k], doff[k]
     T.Ts = reinterpret_cast<int*>(T.Ds + 2 * k);              // ptype[k]
     T.Lp = T.Ts + k;                                          // lperm[k]
@@ -1877,7 +1878,7 @@ __device__ __forceinline__ TrsmLds trsm_layout(char* smem_raw, const int k, cons
 static size_t trsm_lds_bytes(int k, bool staged)
 {
     const size_t kp16 = (size_t)((k + 15) & ~15), ldl = kp16 | 1;
-    return (65 * kp16 + ldl * kp16 + 17 * kp16 + 2 * (size_t)k) * sizeof(double) + (size_t)(2 * k + 2) * sizeof(int) + (staged ? (size_t)65 * k * sizeof(double) : 0) + 16;
+    return (65 * kp16 + (kp16 <= 64 ? ldl * kp16 : 0) + 17 * kp16 + 2 * (size_t)k) * sizeof(double) + (size_t)(2 * k + 2) * sizeof(int) + (staged ? (size_t)65 * k * sizeof(double) : 0) + 16;
 }
 __device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase)
 {
@@ -1888,6 +1889,11 @@ __device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta
     double* W = V.wbuf + M.wb;
     double* As = T.As; const double* Ls = T.Ls; const double* Ds = T.Ds; const int* Ts = T.Ts;
     const int kp16 = T.kp16, ldl = T.ldl;
+    const bool staged_l = kp16 <= 64;
+    auto Lat = [&](int i, int c) -> double {          // L11(i, c), strictly lower part, zero elsewhere
+        if (staged_l) return Ls[i + c * ldl];
+        return (i < k && c < k && i > c) ? P[i + (size_t)c * ldp] : 0.0;
+    };
     // pivot data + L11 (written by the pivot-block workgroup / kernel)
     for (int j = tid; j < k; j += 256) { T.Ds[j] = V.dinv[c0 + j]; T.Ds[k + j] = V.doff[c0 + j]; T.Ts[j] = V.ptype[c0 + j]; T.Lp[j] = V.lperm[c0 + j]; }
     if (kp16 <= 64) {        // one batch of independent loads (a dependent global access behind the flag costs ~2 us)
@@ -1897,10 +1903,7 @@ __device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta
         for (int u = 0; u < 16; ++u) { const int c = cq + 4 * u; lv[u] = (i < k && c < k && i > c) ? P[i + (size_t)c * ldp] : 0.0; }
 #pragma unroll
         for (int u = 0; u < 16; ++u) { const int c = cq + 4 * u; if (i < kp16 && c < kp16) T.Ls[i + c * ldl] = lv[u]; }
-    } else {
-        for (int c = tid >> 6; c < kp16; c += 4)
-            for (int i = tid & 63; i < kp16; i += 64) T.Ls[i + c * ldl] = (i < k && c < k && i > c) ? P[i + (size_t)c * ldp] : 0.0;
-    }
+    }      // (k > 64: read through Lat() from L2)
     __syncthreads();
 #ifdef MI355X_PIVSTAT
     const bool bprobe = gridDim.x == 1 && blockIdx.y == 1 && tid == 0 && T.Au;
@@ -1929,7 +1932,7 @@ __device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta
             for (int pp = 0; pp < 15; ++pp) {
                 const double xp = (pp >= lane) ? x[pp] : 0.0;
 #pragma unroll
-                for (int i = pp + 1; i < 16; ++i) x[i] = fma(-Ls[(o + i) + (o + pp) * ldl], xp, x[i]);
+                for (int i = pp + 1; i < 16; ++i) x[i] = fma(-Lat(o + i, o + pp), xp, x[i]);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) T.Is[b * 272 + i + lane * 17] = x[i];
@@ -1947,12 +1950,12 @@ __device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta
         if (c16 <= 48) {     // operands of the whole product in flight at once
             double oa[12], ob[12];
 #pragma unroll
-            for (int u = 0; u < 12; ++u) { const bool v = 4 * u < c16; oa[u] = v ? Ls[(c16 + l15) + (4 * u + l4) * ldl] : 0.0; ob[u] = v ? As[r16 + l15 + (4 * u + l4) * 65] : 0.0; }
+            for (int u = 0; u < 12; ++u) { const bool v = 4 * u < c16; oa[u] = v ? Lat(c16 + l15, 4 * u + l4) : 0.0; ob[u] = v ? As[r16 + l15 + (4 * u + l4) * 65] : 0.0; }
 #pragma unroll
             for (int u = 0; u < 12; ++u) if (4 * u < c16) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(oa[u], ob[u], acc, 0, 0, 0);
         } else {
             for (int p = 0; p < c16; p += 4)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ls[(c16 + l15) + (p + l4) * ldl], As[r16 + l15 + (p + l4) * 65], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lat(c16 + l15, p + l4), As[r16 + l15 + (p + l4) * 65], acc, 0, 0, 0);
         }
         // the block A' = A - acc goes from accumulator layout to operand layout through LDS (rows of this wavefront only)
 #pragma unroll

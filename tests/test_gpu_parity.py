@@ -174,12 +174,17 @@ def test_internal_refinement_improves_an_ill_conditioned_solve():
                          ids=["wide_panels", "tree_merge", "leaf_cols", "md_ordering", "no_scaling", "no_graph", "solve_group", "no_chain_group", "chain_group2"])
 def test_optional_code_paths_stay_exact(opts):
     """every non-default analysis / kernel option must give the same inertia and a converged solve"""
-    n, r, c, v, neg = kktgen.grid_kkt(48, 44, dof=3, ncon=2, seed=23)      # separator fronts > 512 rows: 128-column panels kick in
+    if opts.get("wide_panels"):
+        n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)   # separator fronts of ~1 200 rows: 128-column panels kick in
+    else:
+        n, r, c, v, neg = kktgen.grid_kkt(48, 44, dof=3, ncon=2, seed=23)
     K = kktgen.to_scipy(n, r, c, v)
     b = K @ np.ones(n)
     s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg, **opts)
     assert st == 0 and s.number_of_neg_evals() == neg
     assert sres(K, x, b) <= RES_TOL
+    if opts.get("wide_panels"):
+        assert s.info().maxsupernode > 96          # the panel solve of a > 96-column panel does not stage L11 in LDS (budget): that path ran
 
 
 def test_lookahead_split_updates_are_exact_and_reproducible(monkeypatch):
