@@ -1860,13 +1860,13 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
 // path of the factorisation, the pivot-block workgroup builds it while the panel is being solved.  In the column loop every
 // wavefront works on its own 16 rows: no workgroup barrier between the column blocks.  k <= 128.
 struct TrsmLds { double* As; double* Ls; double* Is; double* Ds; int* Ts; int* Lp; double* Au; int kp16, ldl; };
-__device__ __forceinline__ TrsmLds trsm_layout(char* smem_raw, const int k, const bool staged)
+__device__ __forceinline__ TrsmLds trsm_layout(char* smem_raw, const int k, const bool staged, const bool no_ls = false)
 {
     TrsmLds T;
     T.kp16 = (k + 15) & ~15; T.ldl = T.kp16 | 1;
     T.As = reinterpret_cast<double*>(smem_raw);               // 64 x kp16: As[r + p*65] = (A21 P)(ibase+r, p), overwritten by W in place
     T.Ls = T.As + (size_t)65 * T.kp16;                        // L11 (strictly lower part, pivot order), zero padded to kp16 x kp16 -- staged only for
-    const size_t lsz = (T.kp16 <= 64) ? (size_t)T.ldl * T.kp16 : 0;   // k <= 64; the 128-column panels of the wide_panels option read it from L2 (LDS budget)
+    const size_t lsz = no_ls ? 0 : (size_t)T.ldl * T.kp16;            // k <= 64; the 128-column panels of the wide_panels option read it from L2 (LDS budget)
     T.Is = T.Ls + lsz;                     // inverses of the 16 x 16 diagonal blocks of L11: Is[b*272 + i + p*17]
     T.Ds = T.Is + (size_t)17 * T.kp16;                        // dinv[k], doff[k]
     T.Ts = reinterpret_cast<int*>(T.Ds + 2 * k);              // ptype[k]
@@ -1875,12 +1875,13 @@ __device__ __forceinline__ TrsmLds trsm_layout(char* smem_raw, const int k, cons
     return T;
 }
 // (host side: bytes of the layout above)
-static size_t trsm_lds_bytes(int k, bool staged)
+static size_t trsm_lds_bytes(int k, bool staged)       // (levels with k > 64 launch the variant without the LDS copy of L11)
 {
     const size_t kp16 = (size_t)((k + 15) & ~15), ldl = kp16 | 1;
     return (65 * kp16 + (kp16 <= 64 ? ldl * kp16 : 0) + 17 * kp16 + 2 * (size_t)k) * sizeof(double) + (size_t)(2 * k + 2) * sizeof(int) + (staged ? (size_t)65 * k * sizeof(double) : 0) + 16;
 }
-__device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase)
+template <bool STAGED_L>       // L11 staged in LDS (k <= 64) or read from L2 (the 128-column panels of the wide_panels option)
+__device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
@@ -1889,14 +1890,13 @@ __device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta
     double* W = V.wbuf + M.wb;
     double* As = T.As; const double* Ls = T.Ls; const double* Ds = T.Ds; const int* Ts = T.Ts;
     const int kp16 = T.kp16, ldl = T.ldl;
-    const bool staged_l = kp16 <= 64;
     auto Lat = [&](int i, int c) -> double {          // L11(i, c), strictly lower part, zero elsewhere
-        if (staged_l) return Ls[i + c * ldl];
+        if (STAGED_L) return Ls[i + c * ldl];
         return (i < k && c < k && i > c) ? P[i + (size_t)c * ldp] : 0.0;
     };
     // pivot data + L11 (written by the pivot-block workgroup / kernel)
     for (int j = tid; j < k; j += 256) { T.Ds[j] = V.dinv[c0 + j]; T.Ds[k + j] = V.doff[c0 + j]; T.Ts[j] = V.ptype[c0 + j]; T.Lp[j] = V.lperm[c0 + j]; }
-    if (kp16 <= 64) {        // one batch of independent loads (a dependent global access behind the flag costs ~2 us)
+    if (STAGED_L) {          // one batch of independent loads (a dependent global access behind the flag costs ~2 us)
         const int i = tid & 63, cq = tid >> 6;
         double lv[16];
 #pragma unroll
@@ -1992,6 +1992,7 @@ __device__ __forceinline__ void trsm_rows_body(const DevView& V, const FrontMeta
         }
     }
 }
+template <bool WIDEK>          // WIDEK: the level has panels of more than 64 columns (wide_panels option): L11 is not staged in LDS
 __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off, int rb0)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -2006,8 +2007,8 @@ __global__ __launch_bounds__(256) void k_big_trsm(DevView V, int list_off, int r
         for (int q = M.aq0 + tid; q < M.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
         __syncthreads();
     }
-    const TrsmLds T = trsm_layout(smem_raw, k, false);
-    trsm_rows_body(V, M, T, ibase);
+    const TrsmLds T = trsm_layout(smem_raw, k, false, WIDEK);
+    trsm_rows_impl<!WIDEK>(V, M, T, ibase);
 }
 
 // 64 x 64 tile of the trailing update on one 256-thread workgroup (k_big_schur64; also the narrow updates fused into k_big_diag_trsm)
@@ -2197,7 +2198,7 @@ __global__ __launch_bounds__(256) void k_big_diag_trsm(DevView V, int list_off, 
 #ifdef MI355X_PIVSTAT
     if (tprobe && role == 1) g_dt[8] = wall_clock64();
 #endif
-    trsm_rows_body(V, M, T, ibase);
+    trsm_rows_impl<true>(V, M, T, ibase);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");       // my rows of L21 / W21 are stored: one more panel block done
     __syncthreads();
     if (tid == 0) __hip_atomic_fetch_add(&V.tcnt[s], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -3249,7 +3250,8 @@ public:
             size_t& r = reg_lds[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]];
             r = std::max(r, need);
         }
-        HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
@@ -3318,12 +3320,12 @@ public:
         hipLaunchKernelGGL(k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         HIPCHK(hipEventRecord(chD[lv], stream));
         if (ch_bulk_pending) HIPCHK(hipStreamWaitEvent(stream, ch_bulk_last, 0));      // this panel's first row block was finalised by the previous level's bulk update
-        hipLaunchKernelGGL(k_big_trsm, dim3(1, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
+        hipLaunchKernelGGL(k_big_trsm<false>, dim3(1, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
         hipLaunchKernelGGL(k_big_schur64, dim3(1, nball), dim3(256), 0, stream, V, b0, 1);
         HIPCHK(hipEventRecord(chLA[lv], stream));
         // ---- bulk (stream3): the rest of the panel solve, then the trailing update minus the block done above ----
         HIPCHK(hipStreamWaitEvent(stream3, chD[lv], 0));
-        if (nrb > 1) hipLaunchKernelGGL(k_big_trsm, dim3(nrb - 1, nball), dim3(256), trsm_lds(kk), stream3, V, b0, 1);
+        if (nrb > 1) hipLaunchKernelGGL(k_big_trsm<false>, dim3(nrb - 1, nball), dim3(256), trsm_lds(kk), stream3, V, b0, 1);
         HIPCHK(hipStreamWaitEvent(stream3, chLA[lv], 0));
         if (bs > b0 && tiles_small > 0) hipLaunchKernelGGL(k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream3, V, b0, 2);
         if (b1 > bs) {
@@ -3360,7 +3362,8 @@ public:
         }
         if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
         else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-        LAUNCH(KK_BIG_TRSM, k_big_trsm, dim3((mm + 63) / 64, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
+        if (kk <= 64) LAUNCH(KK_BIG_TRSM, k_big_trsm<false>, dim3((mm + 63) / 64, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
+        else          LAUNCH(KK_BIG_TRSM, k_big_trsm<true>, dim3((mm + 63) / 64, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
       updates:
         if (bs > b0 && tiles_small > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream, V, b0, 0);
         if (b1 == bs) return true;

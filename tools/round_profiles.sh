@@ -6,13 +6,15 @@ TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/$TAG; mkdir -p $O
 cd $R
-python bench.py > $O/bench_synth_1e6.json 2> $O/bench_synth_1e6.err
-for wl in grid_1e5 lukvle1_1e6 lukvle1_1e4; do python bench.py --workload $wl --no-e2e > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+# PMC traffic first: bench.py only reports roofline.traffic from a profiles/traffic_latest.json measured with the CURRENT kernel sources
 tools/prof.sh synth_1e6 k_big_schur > $O/prof_synth_1e6.log 2>&1
 cp gpurun_out/prof_synth_1e6/kernel_stats.csv $O/synth_1e6_kernel_stats.csv 2>/dev/null
 cp gpurun_out/prof_synth_1e6/pmc_summary.json $O/synth_1e6_pmc_summary.json 2>/dev/null
 cp gpurun_out/prof_synth_1e6/traffic_latest.json $O/traffic_latest.json 2>/dev/null
+cp gpurun_out/prof_synth_1e6/traffic_latest.json profiles/traffic_latest.json 2>/dev/null      # (this copy of the tree; commit the one under $O)
 cp gpurun_out/prof_synth_1e6/bench_under_trace.json $O/synth_1e6_bench_under_rocprof.json 2>/dev/null
+python bench.py > $O/bench_synth_1e6.json 2> $O/bench_synth_1e6.err
+for wl in grid_1e5 lukvle1_1e6 lukvle1_1e4; do python bench.py --workload $wl --no-e2e > $O/bench_$wl.json 2> $O/bench_$wl.err; done
 tools/timeline.sh synth_1e6 $TAG > $O/synth_1e6_timeline.txt 2>&1
 python tools/clocks.py synth_1e6 > $O/synth_1e6_pivot_block_phases.txt 2>&1
 tools/prof.sh lukvle1_1e6 k_front_reg > $O/prof_lukvle1_1e6.log 2>&1
