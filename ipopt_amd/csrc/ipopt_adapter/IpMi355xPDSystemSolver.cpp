@@ -111,7 +111,7 @@ bool Mi355xPDSystemSolver::DeviceUsable(const IteratesVector& rhs, const Iterate
    return true;
 }
 
-bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool pretend_singular, const Data& D, Index n_cd, int rhs_vec, int res_vec, Number alpha,
+bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool treat_as_singular, const Data& D, Index n_cd, int rhs_vec, int res_vec, Number alpha,
       Number beta)
 {
    // SolveOnce (IpPDFullSpaceSolver.cpp:377-664) with the reduction / expansion of the bound blocks on the device
@@ -133,15 +133,15 @@ bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool pretend_singular, const Data& 
    deps[11] = GetRawPtr(D.sigma_x);
    deps[12] = GetRawPtr(D.sigma_s);
    void* dummy = NULL;
-   const bool uptodate = matrix_cache_.GetCachedResult(dummy, deps);
-   if( !uptodate )
+   const bool unchanged = matrix_cache_.GetCachedResult(dummy, deps);
+   if( !unchanged )
    {
       matrix_cache_.AddCachedResult(dummy, deps);
       augsys_improved_ = false;
    }
 
    Number delta_x, delta_s, delta_c, delta_d;
-   if( uptodate && !pretend_singular )
+   if( unchanged && !treat_as_singular )
    {
       // same matrix, same perturbations: the factorisation is reused (the augmented-system solver sees no change)
       pert_->CurrentPerturbation(delta_x, delta_s, delta_c, delta_d);
@@ -162,16 +162,16 @@ bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool pretend_singular, const Data& 
       ESymSolverStatus st = SYMSOLVER_SINGULAR;
       while( st != SYMSOLVER_SUCCESS )
       {
-         if( pretend_singular )
+         if( treat_as_singular )
          {
             st = SYMSOLVER_SINGULAR;
-            pretend_singular = false;
+            treat_as_singular = false;
          }
          else
          {
             ++count;
             Jnlst().Printf(J_MOREDETAILED, J_LINEAR_ALGEBRA,
-                           "Solving system with delta_x=%e delta_s=%e\n                    delta_c=%e delta_d=%e\n", delta_x, delta_s, delta_c,
+                           "MI355X PD: factorising with delta_x=%e delta_s=%e delta_c=%e delta_d=%e\n", delta_x, delta_s, delta_c,
                            delta_d);
             st = aug_->Factorize(GetRawPtr(D.W), 1.0, GetRawPtr(D.sigma_x), delta_x, GetRawPtr(D.sigma_s), delta_s, GetRawPtr(D.J_c), NULL,
                                  delta_c, GetRawPtr(D.J_d), NULL, delta_d, true, n_cd);
@@ -190,29 +190,29 @@ bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool pretend_singular, const Data& 
             ok = pert_->PerturbForSingularity(delta_x, delta_s, delta_c, delta_d);
             if( !ok )
             {
-               Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "PerturbForSingularity can't be done\n");
+               Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: no further perturbation for a singular system available.\n");
             }
          }
          else if( st == SYMSOLVER_WRONG_INERTIA && aug_->NumberOfNegEVals() < n_cd )
          {
             // too few negative eigenvalues: numerically singular?  first ask for better pivoting, once per matrix (:541-579)
-            Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Number of negative eigenvalues too small!\n");
-            bool assume_singular = true;
+            Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: fewer negative eigenvalues than constraints.\n");
+            bool perturb_as_singular = true;
             if( !augsys_improved_ )
             {
-               Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Asking augmented system solver to improve quality of its solutions.\n");
+               Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: asking the factorisation for a tighter pivot tolerance.\n");
                augsys_improved_ = aug_->IncreaseQuality();
                if( augsys_improved_ )
                {
                   IpData().Append_info_string("q");
-                  assume_singular = false;
+                  perturb_as_singular = false;
                }
                else
                {
-                  Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Quality could not be improved\n");
+                  Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: the pivot tolerance is at its maximum.\n");
                }
             }
-            if( assume_singular )
+            if( perturb_as_singular )
             {
                ok = pert_->PerturbForSingularity(delta_x, delta_s, delta_c, delta_d);
                if( ok )
@@ -221,7 +221,7 @@ bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool pretend_singular, const Data& 
                }
                else
                {
-                  Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "PerturbForSingularity can't be done for assume singular.\n");
+                  Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: no further perturbation available (system treated as singular).\n");
                }
             }
          }
@@ -231,7 +231,7 @@ bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool pretend_singular, const Data& 
             ok = pert_->PerturbForWrongInertia(delta_x, delta_s, delta_c, delta_d);
             if( !ok )
             {
-               Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "PerturbForWrongInertia can't be done for wrong interia or singular.\n");
+               Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: no further perturbation for wrong inertia available.\n");
             }
          }
          if( !ok )
@@ -240,9 +240,9 @@ bool Mi355xPDSystemSolver::SolveOnceOnDevice(bool pretend_singular, const Data& 
             return false;
          }
       }
-      Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Number of trial factorizations performed: %" IPOPT_INDEX_FORMAT "\n", count);
+      Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: %" IPOPT_INDEX_FORMAT " trial factorisation(s)\n", count);
       Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA,
-                     "Perturbation parameters: delta_x=%e delta_s=%e\n                         delta_c=%e delta_d=%e\n", delta_x, delta_s, delta_c,
+                     "MI355X PD: accepted perturbations delta_x=%e delta_s=%e delta_c=%e delta_d=%e\n", delta_x, delta_s, delta_c,
                      delta_d);
       IpData().setPDPert(delta_x, delta_s, delta_c, delta_d);
    }
@@ -275,7 +275,7 @@ bool Mi355xPDSystemSolver::ResidualRatioOnDevice(int rhs_vec, int res_vec, int r
       return false;
    }
    const Number nrm_rhs = norms[0], nrm_res = norms[1], nrm_resid = norms[2];
-   Jnlst().Printf(J_MOREDETAILED, J_LINEAR_ALGEBRA, "nrm_rhs = %8.2e nrm_sol = %8.2e nrm_resid = %8.2e\n", nrm_rhs, nrm_res, nrm_resid);
+   Jnlst().Printf(J_MOREDETAILED, J_LINEAR_ALGEBRA, "MI355X PD: max norms rhs %8.2e sol %8.2e resid %8.2e\n", nrm_rhs, nrm_res, nrm_resid);
    if( nrm_rhs + nrm_res == 0. )
    {
       ratio = nrm_resid;
@@ -285,7 +285,7 @@ bool Mi355xPDSystemSolver::ResidualRatioOnDevice(int rhs_vec, int res_vec, int r
       const Number max_cond = 1e6;
       ratio = nrm_resid / (Min(nrm_res, max_cond * nrm_rhs) + nrm_rhs);
    }
-   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "residual_ratio = %e\n", ratio);
+   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: residual ratio %e\n", ratio);
    return true;
 }
 
@@ -329,9 +329,9 @@ bool Mi355xPDSystemSolver::Solve(Number alpha, Number beta, const IteratesVector
    }
 
    bool done = false;
-   bool resolve_with_better_quality = false;   // the pivot tolerance was raised: factor and solve again
-   bool pretend_singular = false;              // refinement failed: see whether a perturbed system does better
-   bool pretend_singular_last_time = false;
+   bool refactor_with_new_pivtol = false;   // the pivot tolerance was raised: factor and solve again
+   bool treat_as_singular = false;              // refinement failed: see whether a perturbed system does better
+   bool singular_already_tried = false;
    bool uploaded = false;
    bool ok = true;
 
@@ -395,15 +395,15 @@ bool Mi355xPDSystemSolver::Solve(Number alpha, Number beta, const IteratesVector
       }
 
       // with improve_solution the caller hands over a solution: the first solve is skipped (:213-222)
-      bool solve_retval = true;
+      bool solved = true;
       if( !improve_solution )
       {
-         solve_retval = SolveOnceOnDevice(pretend_singular, D, n_cd, VEC_RHS, VEC_RES, 1., 0.);
-         resolve_with_better_quality = false;
-         pretend_singular = false;
+         solved = SolveOnceOnDevice(treat_as_singular, D, n_cd, VEC_RHS, VEC_RES, 1., 0.);
+         refactor_with_new_pivtol = false;
+         treat_as_singular = false;
       }
       improve_solution = false;
-      if( !solve_retval )
+      if( !solved )
       {
          // not solvable as it stands: the caller deals with it (:224-230)
          IpData().TimingStats().PDSystemSolverTotal().End();
@@ -420,12 +420,12 @@ bool Mi355xPDSystemSolver::Solve(Number alpha, Number beta, const IteratesVector
          ok = false;
          break;
       }
-      Number residual_ratio_old = residual_ratio;
+      Number ratio_before = residual_ratio;
 
       // iterative refinement on the unreduced system (:262-346)
-      Index num_iter_ref = 0;
-      bool quit_refinement = false;
-      while( !quit_refinement && (num_iter_ref < min_refinement_steps_ || residual_ratio > residual_ratio_max_) )
+      Index nsteps = 0;
+      bool give_up = false;
+      while( !give_up && (nsteps < min_refinement_steps_ || residual_ratio > residual_ratio_max_) )
       {
          // res <- res - K8^{-1} resid
          if( !SolveOnceOnDevice(false, D, n_cd, VEC_RESID, VEC_RES, -1., 1.) )
@@ -438,61 +438,61 @@ bool Mi355xPDSystemSolver::Solve(Number alpha, Number beta, const IteratesVector
             ok = false;
             break;
          }
-         ++num_iter_ref;
+         ++nsteps;
          ++n_refine_;
          // give up? (:285-342)
-         if( residual_ratio > residual_ratio_max_ && num_iter_ref > min_refinement_steps_
-             && (num_iter_ref > max_refinement_steps_ || residual_ratio > residual_improvement_factor_ * residual_ratio_old) )
+         if( residual_ratio > residual_ratio_max_ && nsteps > min_refinement_steps_
+             && (nsteps > max_refinement_steps_ || residual_ratio > residual_improvement_factor_ * ratio_before) )
          {
-            Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Iterative refinement failed with residual_ratio = %e\n", residual_ratio);
-            quit_refinement = true;
-            resolve_with_better_quality = false;
-            if( !pretend_singular_last_time )
+            Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: refinement stalled at residual ratio %e\n", residual_ratio);
+            give_up = true;
+            refactor_with_new_pivtol = false;
+            if( !singular_already_tried )
             {
                // first a better factorisation (once per linear system), then "the modification is singular" -- and that only when
                // the residual is really bad
                if( !augsys_improved_ )
                {
-                  Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Asking augmented system solver to improve quality of its solutions.\n");
+                  Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: asking the factorisation for a tighter pivot tolerance.\n");
                   augsys_improved_ = aug_->IncreaseQuality();
                   if( augsys_improved_ )
                   {
                      IpData().Append_info_string("q");
-                     resolve_with_better_quality = true;
+                     refactor_with_new_pivtol = true;
                   }
                   else
                   {
-                     pretend_singular = true;
+                     treat_as_singular = true;
                   }
                }
                else
                {
-                  pretend_singular = true;
+                  treat_as_singular = true;
                }
-               pretend_singular_last_time = pretend_singular;
-               if( pretend_singular )
+               singular_already_tried = treat_as_singular;
+               if( treat_as_singular )
                {
                   if( residual_ratio < residual_ratio_singular_ )
                   {
-                     pretend_singular = false;
+                     treat_as_singular = false;
                      IpData().Append_info_string("S");
-                     Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Just accept current solution.\n");
+                     Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: residual small enough, solution kept.\n");
                   }
                   else
                   {
                      IpData().Append_info_string("s");
-                     Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "Pretend that the current system (including modifications) is singular.\n");
+                     Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X PD: perturbing the system as if it were singular.\n");
                   }
                }
             }
             else
             {
-               pretend_singular = false;
+               treat_as_singular = false;
             }
          }
-         residual_ratio_old = residual_ratio;
+         ratio_before = residual_ratio;
       }
-      done = !resolve_with_better_quality && !pretend_singular;
+      done = !refactor_with_new_pivtol && !treat_as_singular;
    }
 
    if( !ok )
