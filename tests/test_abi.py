@@ -64,6 +64,21 @@ def test_no_cpu_fallback_factor_fails_loudly():
         s.multi_solve(True, np.ones(2))
 
 
+@pytest.mark.skipif(_has_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback_primal_dual_workspace_fails_loudly():
+    """the 8-block entry points (mi355x_kkt_pd_*) need the device like factor/solve do: without one they return FATAL with a message,
+    they do not compute anything on the host"""
+    s = ipopt_amd.KKTSolver()
+    n = 6
+    s.initialize_structure(n, np.arange(1, n + 1), np.arange(1, n + 1), vals=np.ones(n))       # the analysis is host code: works
+    with pytest.raises(ipopt_amd.KKTError, match="HIP device|no CPU fallback"):
+        s.pd_define([n, 0, 0, 0, 0, 0, 0, 0], [], [], [], [], np.arange(1, n + 1), np.arange(1, n + 1), [0])
+    with pytest.raises(ipopt_amd.KKTError):
+        s.pd_solve_once(0, 1)
+    with pytest.raises(ipopt_amd.KKTError):
+        s.pd_residual(0, 1, 2, [0, 0, 0, 0])
+
+
 def test_matching_scaling_is_a_maximum_product_scaling():
     """mi355x_kkt_matching_scaling (host, the job of MC64: Duff & Koster 2001): |s_i a_ij s_j| <= 1 everywhere, = 1 on a
     transversal (so every row and column of the scaled matrix has inf-norm exactly 1), also with zero diagonals and entries
