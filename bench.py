@@ -134,7 +134,7 @@ def cpu_baseline(n, r, c, v, b, x_gpu, neg_gpu, nsolve):
                 sample="same KKT system, one factor+solves with oracle/ldlt_oracle.c")
 
 
-def e2e_block():
+def e2e_block(problem="LukVlE1", size=1000000, cpu_threads=None):
     """IpPDFullSpaceSolver::Solve wall clock (Ipopt's own PDSystemSolverTotal timer, IpTimingStatistics.hpp:123-170) on the
     north-star instance LukVlE1 n = 10^6: the UNMODIFIED reference host with the MI355X backend against the same host with
     its CPU linear solver (MKL PARDISO; MUMPS is not installable offline), same box, iteration counts side by side."""
@@ -144,7 +144,7 @@ def e2e_block():
 
     def run(solver, threads):
         env = dict(os.environ, MKL_NUM_THREADS=str(threads), OMP_NUM_THREADS=str(threads), MKL_DYNAMIC="FALSE")
-        out = subprocess.run([drv, "LukVlE1", "1000000", "--solver", solver, "--quiet"], capture_output=True, text=True, timeout=900, cwd="/tmp", env=env).stdout
+        out = subprocess.run([drv, problem, str(size), "--solver", solver, "--quiet"], capture_output=True, text=True, timeout=1800, cwd="/tmp", env=env).stdout
         return json.loads(next(ln for ln in out.splitlines() if ln.startswith("DRIVER_SUMMARY"))[len("DRIVER_SUMMARY "):])
 
     try:
@@ -155,11 +155,11 @@ def e2e_block():
         except Exception:
             gp = None
         ncores = os.cpu_count() or 1
-        cpu = {t: run("pardisomkl", t) for t in sorted({1, min(16, ncores), min(64, ncores)})}
+        cpu = {t: run("pardisomkl", t) for t in (cpu_threads or sorted({1, min(16, ncores), min(64, ncores)}))}
         best_t = min(cpu, key=lambda t: cpu[t]["PDSystemSolverTotal"])
         cb = cpu[best_t]
         keys = ("PDSystemSolverTotal", "LinearSystemFactorization", "LinearSystemBackSolve", "LinearSystemSymbolicFactorization", "wall_total")
-        return {"problem": "ScalableProblems LukVlE1 n=1000000 (KKT dim 1999998)", "timer": "PDSystemSolverTotal = IpPDFullSpaceSolver::Solve wall seconds",
+        return {"problem": f"ScalableProblems {problem} {size}" + (" (n = 10^6, KKT dim 1999998)" if (problem, size) == ("LukVlE1", 1000000) else ""), "timer": "PDSystemSolverTotal = IpPDFullSpaceSolver::Solve wall seconds",
                 "mi355x": {k: g[k] for k in keys} | {"iterations": g["iterations"], "objective": g["objective"], "status": g["status"]},
                 "cpu_reference": {k: cb[k] for k in keys} | {"iterations": cb["iterations"], "objective": cb["objective"], "status": cb["status"],
                                                              "solver": "pardisomkl (oneMKL PARDISO)", "mkl_threads": best_t},
@@ -186,7 +186,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
+    ap.add_argument("--e2e-only", default="", help="PROBLEM:SIZE[:threads,...] -- print only the end-to-end block of that ScalableProblems instance (e.g. MBndryCntrl1:700:1,16)")
     args = ap.parse_args()
+    if args.e2e_only:
+        f = args.e2e_only.split(":")
+        thr = [int(t) for t in f[2].split(",")] if len(f) > 2 else None
+        print(json.dumps({"e2e": e2e_block(f[0], int(f[1]), thr)}))
+        return
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 or world > 1 or os.environ.get("MI355X_KKT_FORCE_MULTI"):
         from ipopt_amd import multigpu
