@@ -110,7 +110,9 @@ typedef struct mi355x_kkt_info {
     double  time_solve_ms;   /* device ms, last solve                                                   */
     double  pivtol;          /* the u the next factorisation will use                                   */
     int     u_sensitive;     /* last factorisation: 1 if some pivot decision would differ at u=pivtolmax */
-    int     reserved_i;
+    int     num_fast_blocks; /* last factorisation: pivot blocks of big fronts accepted on the blocked a-posteriori path  */
+                             /* (natural order, every multiplier <= 1/max(u, pivtolmax, 0.01)); the other big fronts'    */
+                             /* pivot blocks took the strict threshold-pivoting loop                                     */
     double  reserved[6];
 } mi355x_kkt_info;
 

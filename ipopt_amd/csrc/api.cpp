@@ -305,6 +305,7 @@ int mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info)
     info->num_pairs = S.num_pairs; info->num_big_fronts = S.num_big;
     info->num_neg = h->last.num_neg; info->num_zero = h->last.num_zero; info->num_two = h->last.num_two; info->num_small = h->last.num_small;
     info->u_sensitive = h->factored ? h->last.u_sensitive : 1; info->pivtol = h->opts.pivtol;
+    info->num_fast_blocks = h->factored ? h->last.num_fast : 0;
     info->time_analyse = S.time_analyse;
     if (h->num) { info->time_factor_ms = h->num->last_factor_ms(); info->time_solve_ms = h->num->last_solve_ms(); }
     return MI355X_KKT_SUCCESS;
@@ -339,10 +340,10 @@ int mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches,
 }
 
 /* development aid, not part of the public header: phase time stamps of one workgroup */
-int mi355x_kkt_debug_clocks(mi355x_kkt_handle h, unsigned long long* out16)
+int mi355x_kkt_debug_clocks(mi355x_kkt_handle h, unsigned long long* out64)
 {
     if (!h || !h->numeric_ready) return MI355X_KKT_FATAL;
-    try { return h->num->debug_clocks(out16) ? 0 : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
+    try { return h->num->debug_clocks(out64) ? 0 : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
 }
 
 // ---- multi-GPU ----

@@ -22,7 +22,8 @@ struct NumericOptions {
 
 // num_small = failed pivots (num_delay of MA97/SSIDS): eliminated although they failed the threshold test, because the static
 // structure cannot delay them to the parent front; u_sensitive != 0: some pivot decision would differ at u = pivtolmax
-struct FactorStats { int num_neg = 0, num_zero = 0, num_two = 0, num_small = 0, u_sensitive = 1; };
+// num_fast = pivot blocks of big fronts accepted on the blocked a-posteriori path (the others took the strict loop)
+struct FactorStats { int num_neg = 0, num_zero = 0, num_two = 0, num_small = 0, u_sensitive = 1, num_fast = 0; };
 
 class NumericImpl;
 
@@ -44,7 +45,7 @@ public:
     const std::string& error() const;
     static constexpr int kNumKernelKinds = 18;
     bool   profile(int reps, double* ms, int* launches);
-    bool   debug_clocks(unsigned long long* out16);        // development aid (MI355X_KKT_DEBUG_CLOCKS=1)   // per-kernel-kind device time (hip events), eager launches
+    bool   debug_clocks(unsigned long long* out64);        // development aid (MI355X_KKT_DEBUG_CLOCKS=1)   // per-kernel-kind device time (hip events), eager launches
     // multi-GPU pieces
     bool   factor_local(const double* dvals_or_null);
     bool   top_arena(double** dptr, int64_t* ndoubles);

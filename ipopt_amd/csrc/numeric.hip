@@ -46,6 +46,7 @@ namespace mi355x {
 enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_LDS128, KK_BIG_ASSEMBLE, KK_BIG_DIAG, KK_BIG_TRSM,
                   KK_BIG_SCHUR, KK_STATS, KK_SOLVE_PERM, KK_FWD_WAVE, KK_FWD_LDS, KK_FWD_BIG, KK_BWD_WAVE, KK_BWD_LDS, KK_BWD_BIG, KK_FWD_BIG_UPD, KK_BWD_BIG_DOT, KK_COUNT };
 #define DBGSTAMP(slot) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { V.dbg[2 * (slot)] = clock64(); V.dbg[2 * (slot) + 1] = wall_clock64(); } } while (0)
+#define DBGT(i) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) V.dbg[16 + (i)] = clock64(); } while (0)
 #define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); } while (0)
 
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
@@ -62,7 +63,7 @@ struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long pan
                    long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, solo, selfasm, pad2_; };
 struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase, inv; };
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
-struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; };
+struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; long long t_off; int ldt, s, selfasm, aq0, aq1, pad_; };     // t_off/ldt: the link's trailing block (V.cb + t_off)
 
 // Sync-free triangular solves along pure in-place separator chains (a run of consecutive tree levels whose fronts are all chain
 // links): ONE launch per sweep for the whole run instead of 1 (forward) / 2 (backward) launches per level.  One workgroup per link
@@ -116,9 +117,11 @@ struct DevView {
     double* cnorm;          // inf-norm of every column of the (scaled) INPUT matrix, permuted numbering: scale of the zero-pivot test
     const ChainLink* chlink; const ChainDesc* chdesc;     // chain solve tables
     int* tcnt;                                                  // per front: panel-solve workgroups finished (fused pivot block + panel solve + narrow update launch), zeroed by the prologue
+    int* sflag_s;           // [4 * link + q]: rows of the group's link q have stored their W / L against this link (k_grp_fused)
     int* sflag_f; int* sflag_b; int* sflag_d; int* sepoch;     // (sflag_d / sepoch[2]: pivot block done, fused pivot-block + panel-solve launch)              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
+    int fastpiv;            // pivot blocks of the big fronts: blocked LDL^T accepted a posteriori first, the strict loop as fall-back (ldlt_blocked_static)
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
 };
 
@@ -819,6 +822,193 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
 #endif
 }
 
+// ================================================================================================
+// Blocked LDL^T of a pivot block with A POSTERIORI acceptance (the fast path of the big fronts' pivot blocks; SSIDS calls the
+// idea a-posteriori threshold pivoting, IpSpralSolverInterface.cpp:199-204 "pivot method block").  The strict loop above decides
+// one pivot at a time behind a workgroup barrier (~1 400 cycles per pivot, 255 CUs idle on the separator chains); here
+//   * the k x k block sits in LDS; 16 columns at a time, ONE wavefront eliminates the 16 x 16 diagonal block in registers in natural
+//     order with 1x1 pivots -- the pivot row travels by DPP inside the wavefront, no LDS, no barrier -- and inverts its unit-lower
+//     factor the same way;
+//   * the rows below and the remaining columns follow by v_mfma_f64_16x16x4_f64 (ldlt_blocked_static below);
+//   * nothing is decided per pivot.  The block is ACCEPTED afterwards iff every pivot is clear of the zero threshold and every
+//     multiplier of the block is <= gmax = 1 / max(u, u2, 0.01) -- the threshold test of MA57/MA97 at their default u = 0.01, far
+//     tighter than the 1e-8 Ipopt asks for, so an accepted block satisfies the strict rule's tests at u AND at u2 (no u-sensitive
+//     decision).  Otherwise nothing has been written and the caller runs the strict loop on the untouched block.
+// Returns (workgroup-uniform) true when accepted: Lb = unit-lower L (strictly lower part, natural order), dinv_s = 1 / d.
+// ================================================================================================
+// ---- one 16 x 16 diagonal block in ONE wavefront, no LDS, no barrier: lane (i = lane & 15) holds row i, the four 16-lane DPP rows hold
+// identical copies, a[c] = column c.  The pivot row travels inside the DPP row: v_fmac_f64_dpp ... row_newbcast:c (DP-ALU DPP supports
+// exactly this control on gfx950) does  a[c] += a_j[lane c] * (-l)  in one instruction -- 15 - j instructions per pivot instead of a
+// workgroup barrier, a column publication and 16 register-tile FMAs per thread. ----
+template <int N> __device__ __forceinline__ double bcast16(const double x) { return __builtin_amdgcn_update_dpp(x, x, 0x150 + N, 0xF, 0xF, false); }      // row_newbcast:N
+#define MI_FD(c) "v_fmac_f64_dpp %" #c ", %16, -%17 row_newbcast:" #c " row_mask:0xf bank_mask:0xf\n\t"
+#define MI_R15 ""
+#define MI_R14 MI_FD(15)
+#define MI_R13 MI_FD(14) MI_R14
+#define MI_R12 MI_FD(13) MI_R13
+#define MI_R11 MI_FD(12) MI_R12
+#define MI_R10 MI_FD(11) MI_R11
+#define MI_R9 MI_FD(10) MI_R10
+#define MI_R8 MI_FD(9) MI_R9
+#define MI_R7 MI_FD(8) MI_R8
+#define MI_R6 MI_FD(7) MI_R7
+#define MI_R5 MI_FD(6) MI_R6
+#define MI_R4 MI_FD(5) MI_R5
+#define MI_R3 MI_FD(4) MI_R4
+#define MI_R2 MI_FD(3) MI_R3
+#define MI_R1 MI_FD(2) MI_R2
+#define MI_R0 MI_FD(1) MI_R1
+#define MI_AOPS "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8]), "+v"(a[9]), "+v"(a[10]), "+v"(a[11]), "+v"(a[12]), "+v"(a[13]), "+v"(a[14]), "+v"(a[15])
+// a[c] -= t[lane c of the row] * l   for c = J+1 .. 15   (s_nop 1: a VALU-written VGPR needs two wait states before a DPP read, and the
+// compiler does not pad inside an asm statement)
+template <int J> __device__ __forceinline__ void rank1_dpp16(double (&a)[16], const double t, const double l)
+{
+#define MI_CASE(j) if constexpr (J == j) asm("s_nop 1\n\t" MI_R##j : MI_AOPS : "v"(t), "v"(l));
+    MI_CASE(0) MI_CASE(1) MI_CASE(2) MI_CASE(3) MI_CASE(4) MI_CASE(5) MI_CASE(6) MI_CASE(7) MI_CASE(8) MI_CASE(9) MI_CASE(10) MI_CASE(11) MI_CASE(12) MI_CASE(13) MI_CASE(14)
+#undef MI_CASE
+}
+// x += x[lane J of the row] * m   (one step of the row-oriented substitution for L^{-1})
+template <int J> __device__ __forceinline__ void subst_dpp16(double& x, const double m)
+{
+    asm("s_nop 1\n\tv_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(m), "n"(J));
+}
+template <int J> __device__ __forceinline__ void diag16_step(double (&a)[16], double& rsave, const int l15)
+{
+    const double t = a[J];
+    const double d = bcast16<J>(t);
+    const double ri = fast_rcp(d);
+    rsave = (l15 == J) ? ri : rsave;
+    const double l = t * ri;
+    rank1_dpp16<J>(a, t, l);
+    a[J] = l;
+}
+template <int J> __device__ __forceinline__ void inv16_step(const double (&a)[16], double (&x)[4], const int l15)
+{
+    const double m = (l15 > J) ? -a[J] : 0.0;         // rows up to J are finished
+    subst_dpp16<J>(x[0], m);
+    if constexpr (J >= 4) subst_dpp16<J>(x[1], m);
+    if constexpr (J >= 8) subst_dpp16<J>(x[2], m);
+    if constexpr (J >= 12) subst_dpp16<J>(x[3], m);
+}
+
+// Blocked LDL^T of the k x k block in Lb (both triangles valid, ld), natural order, 16 columns at a time:
+//   A  wavefront 0: the 16 x 16 diagonal block in registers (diag16_step), its inverse X = L^{-1} by the same DPP substitution, kept in
+//      the operand layout of v_mfma_f64_16x16x4_f64 (lane (i, r) holds X(i, r), X(i, 4 + r), X(i, 8 + r), X(i, 12 + r));
+//   B  the rows below, 16 per wavefront: W21 = A21 X^T (4 MFMAs), L21 = W21 D^{-1};
+//   C  the trailing 16 x 16 tiles:  T(i, c) -= L21(i, :) W21(c, :)^T  (4 MFMAs each), spread over the wavefronts.
+// Nothing is decided per pivot: the block is accepted A POSTERIORI (see above).  Isb receives the four X blocks (Isb[b*272 + i + p*17]):
+// the blocked substitution of the panel rows (trsm_rows_impl) needs exactly these.
+__device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, const int k, double* Wb, double* dinv_s, double* Isb, int* shflag,
+                                                    const double zmax, const double gmax, int& nneg, unsigned long long* dbg = nullptr)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int nb = (k + 15) >> 4;
+    if (tid == 0) *shflag = 0;
+    __syncthreads();
+    int neg = 0;
+#define PSTAMP(i) do { if (dbg && b == 0 && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) dbg[40 + (i)] = clock64(); } while (0)
+    for (int b = 0; b < nb; ++b) {
+        const int c16 = 16 * b;
+        if (wave == 0) {
+            const int row = c16 + l15;
+            double a[16];
+            PSTAMP(0);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {                           // (identity beyond k; the load itself is unconditional: no branch per column)
+                const double v = Lb[min(row, k - 1) + min(c16 + c, k - 1) * ld];
+                a[c] = (row < k && c16 + c < k) ? v : ((l15 == c) ? 1.0 : 0.0);
+            }
+            double rsave = 1.0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); PSTAMP(1);
+            diag16_step<0>(a, rsave, l15); diag16_step<1>(a, rsave, l15); diag16_step<2>(a, rsave, l15); diag16_step<3>(a, rsave, l15);
+            diag16_step<4>(a, rsave, l15); diag16_step<5>(a, rsave, l15); diag16_step<6>(a, rsave, l15); diag16_step<7>(a, rsave, l15);
+            diag16_step<8>(a, rsave, l15); diag16_step<9>(a, rsave, l15); diag16_step<10>(a, rsave, l15); diag16_step<11>(a, rsave, l15);
+            diag16_step<12>(a, rsave, l15); diag16_step<13>(a, rsave, l15); diag16_step<14>(a, rsave, l15); diag16_step<15>(a, rsave, l15);
+            PSTAMP(2);
+            // a posteriori: multipliers of the block, pivots against the zero threshold (|d| > zmax  <=>  |1/d| < 1/zmax; inf / NaN fail)
+            double gm = 0.0;
+#pragma unroll
+            for (int c = 0; c < 15; ++c) gm = fmax(gm, (l15 > c) ? fabs(a[c]) : 0.0);
+            const bool mine = row < k;
+            bool bad = __ballot(gm > gmax) != 0ull;
+            bad |= __ballot(mine && !(fabs(rsave) * zmax < 1.0)) != 0ull;
+            neg += __popcll(__ballot(mine && l4 == 0 && rsave < 0.0));
+            PSTAMP(3);
+            double x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
+            inv16_step<0>(a, x, l15); inv16_step<1>(a, x, l15); inv16_step<2>(a, x, l15); inv16_step<3>(a, x, l15); inv16_step<4>(a, x, l15);
+            inv16_step<5>(a, x, l15); inv16_step<6>(a, x, l15); inv16_step<7>(a, x, l15); inv16_step<8>(a, x, l15); inv16_step<9>(a, x, l15);
+            inv16_step<10>(a, x, l15); inv16_step<11>(a, x, l15); inv16_step<12>(a, x, l15); inv16_step<13>(a, x, l15); inv16_step<14>(a, x, l15);
+            PSTAMP(4);
+            if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) dbg[24 + 2 * b] = clock64();
+            if (bad) { if (lane == 0) *shflag = 1; }
+            else {
+                if (l4 == 0 && mine) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) if (c16 + c < k) Lb[row + (c16 + c) * ld] = (l15 > c) ? a[c] : 0.0;
+                    dinv_s[row] = rsave;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) Isb[b * 272 + l15 + (4 * q + l4) * 17] = x[q];
+            }
+            PSTAMP(5);
+        }
+        __syncthreads();
+        if (*shflag) return false;
+        if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) dbg[25 + 2 * b] = clock64();
+        if (b + 1 >= nb) break;
+        // ---- B: rows below the diagonal block ----
+        for (int t = wave; t < nb - b - 1; t += nw) {
+            const int r = c16 + 16 * (t + 1) + l15;
+            v4f64_ acc = (v4f64_){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const double av = Isb[b * 272 + l15 + (4 * u + l4) * 17];                       // X(c = l15, p = 4u + l4)
+                const double bv = (r < k) ? Lb[r + (c16 + 4 * u + l4) * ld] : 0.0;              // A21(r, p)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+            bool big = false;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {                                                        // acc[g] = W21(r, c = l4 + 4g)
+                const int c = l4 + 4 * g;
+                const double l = acc[g] * dinv_s[c16 + c];
+                Wb[(r - c16) + c * 65] = acc[g];
+                if (r < k && c16 + c < k) { Lb[r + (c16 + c) * ld] = l; big |= fabs(l) > gmax; }
+            }
+            if (__ballot(big) != 0ull && lane == 0) *shflag = 1;
+        }
+        __syncthreads();
+        if (wave == 0) PSTAMP(6);
+        if (*shflag) return false;
+        // ---- C: rank-16 update of the trailing tiles: T(i, c) -= sum_p L(i, c16 + p) W(c, p) ----
+        {
+            int q = 0;
+            for (int tc = b + 1; tc < nb; ++tc)
+                for (int ti = tc; ti < nb; ++ti, ++q) {
+                    if (q % nw != wave) continue;
+                    v4f64_ acc = (v4f64_){0.0, 0.0, 0.0, 0.0};
+                    const int ri = 16 * ti + l15;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const double av = (ri < k) ? Lb[ri + (c16 + 4 * t + l4) * ld] : 0.0;
+                        const double bv = Wb[(16 * tc - c16 + l15) + (4 * t + l4) * 65];
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                    }
+                    const int cc = 16 * tc + l15;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { const int rr = 16 * ti + l4 + 4 * g; if (rr < k && cc < k) Lb[rr + cc * ld] -= acc[g]; }
+                }
+        }
+        __syncthreads();
+        if (wave == 0) PSTAMP(7);
+    }
+#undef PSTAMP
+    nneg += neg;
+    return true;
+}
+
 // pivot block of a BIG front on the register-tiled core: 4x4 tiles on 16x16 threads for k <= 64, on 32x32 threads (two-word
 // alive mask) for the 128-column panels of the wide_panels option (19 ms against 28 ms with 8x8 tiles on 256 threads, but
 // still slower per column than two 64-column blocks: option off by default)
@@ -837,6 +1027,71 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
     int* ord = reinterpret_cast<int*>(cm0 + k); int* pt_s = ord + k;
     double* P = V.L + M.panel_off;
     const size_t ldp = (size_t)M.ldp;
+    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
+    DBGSTAMP(0);
+#ifdef MI355X_PIVSTAT
+    const bool dprobe = gridDim.x == 1 && gridDim.y > 1 && tid == 0 && NT == 256;
+    if (dprobe) g_dt[1] = wall_clock64();
+#endif
+    if (V.dbg && blockIdx.x == 0 && blockIdx.y < 4 && tid == 0) { V.dbg[32 + 8 * blockIdx.y + 5] = wall_clock64(); }
+    bool fast = false;
+    if constexpr (NT == 256) {
+        if (V.fastpiv && k <= 64) {
+            // ---- fast path: blocked LDL^T in natural order, accepted a posteriori (ldlt_blocked_static) ----
+            double* Wp = reinterpret_cast<double*>(pt_s + k + (k & 1));         // 64 x 16 (ld 65): W = L D of the panel in flight
+            double* Isb = Wp + 16 * 65;                                          // 4 x 272: inverses of the 16 x 16 diagonal blocks of L11
+            int* shflag = reinterpret_cast<int*>(Isb + 4 * 272);
+            const int i = tid & 63, cq = tid >> 6;
+            DBGT(0);
+            {   // the block (lower part in the panel storage) -> LDS, mirrored; a chain link's own A entries are added in LDS
+                double pv[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; pv[e] = (i < k && c < k && i >= c) ? P[i + (size_t)c * ldp] : 0.0; }
+                int apos_[2]; double aval_[2]; int na = 0;
+                if (M.selfasm) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) { const int q = M.aq0 + tid + e * NT; if (q < M.aq1) { apos_[e] = V.apos[q]; aval_[e] = V.aval[q]; na = e + 1; } }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; if (i < k && c < k && i >= c) { Lb[i + c * ld] = pv[e]; Lb[c + i * ld] = pv[e]; } }
+                __syncthreads();
+                if (M.selfasm) {
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) if (e < na) { const int ii = apos_[e] % M.m, cc = apos_[e] / M.m; if (ii < k) { Lb[ii + cc * ld] += aval_[e]; if (ii != cc) Lb[cc + ii * ld] += aval_[e]; } }
+                    for (int q = M.aq0 + tid + 2 * NT; q < M.aq1; q += NT) { const int pos = V.apos[q]; const int ii = pos % M.m, cc = pos / M.m; if (ii < k) { const double v = V.aval[q]; Lb[ii + cc * ld] += v; if (ii != cc) Lb[cc + ii * ld] += v; } }
+                    __syncthreads();
+                }
+            }
+            DBGT(1);
+            // zero-pivot scale: the largest column scale of the block (a pivot that clears it clears its own column's)
+            double cmx;
+            {
+                const int c = tid >> 2, part = tid & 3;
+                double mx = 0.0;
+                if (c < k) for (int r = part; r < k; r += 4) mx = fmax(mx, fabs(Lb[r + c * ld]));
+                mx = fmax(mx, dpp_f64<0xB1>(mx)); mx = fmax(mx, dpp_f64<0x4E>(mx));
+                if (c < k && part == 0) mx = fmax(mx, V.cnorm[c0 + c]); else if (c >= k) mx = 0.0;
+                cmx = wave_max_all(mx);
+                if ((tid & 63) == 0) colbuf[tid >> 6] = cmx;
+                __syncthreads();
+                cmx = fmax(fmax(colbuf[0], colbuf[1]), fmax(colbuf[2], colbuf[3]));
+            }
+            const double zmax = fmax(V.small, ZERO_REL * cmx);
+            const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), 0.01);
+            DBGT(2);
+            fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Isb, shflag, zmax, gmax, nneg, V.dbg);
+            DBGT(3);
+            if (fast) {
+                DBGSTAMP(1);
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; if (i < k && c < k) { const double v = (i > c) ? Lb[i + c * ld] : 0.0; P[i + (size_t)c * ldp] = v; if (i <= c) Lb[i + c * ld] = 0.0; } }
+                for (int j = tid; j < k; j += NT) { doff_s[j] = 0.0; pt_s[j] = 1; ord[j] = j; }
+                if (tid == 0) atomicAdd(&V.qstat[3], 1);
+                __syncthreads();
+            } else if (tid == 0) atomicAdd(&V.qstat[2], 1);
+        }
+    }
+    if (!fast) {
     if (M.selfasm) {            // pure in-place chain link (no assembly launch): the A entries of the pivot rows are added here
         for (int q = M.aq0 + tid; q < M.aq1; q += NT) { const int pos = V.apos[q]; const int i = pos % M.m, c = pos / M.m; if (i < k) P[i + (size_t)c * ldp] += V.aval[q]; }
         __syncthreads();
@@ -850,12 +1105,7 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
             const int i = row0 + x, c = col0 + y;
             t[x][y] = (i < k && c < k) ? ((i >= c) ? P[i + (size_t)c * ldp] : P[c + (size_t)i * ldp]) : 0.0;
         }
-    int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
-    DBGSTAMP(0);
-#ifdef MI355X_PIVSTAT
-    const bool dprobe = gridDim.x == 1 && gridDim.y > 1 && tid == 0 && NT == 256;
-    if (dprobe) g_dt[1] = wall_clock64();
-#endif
+    nneg = 0;
     const double cmx = front_colmax<NT, TS>(t, cm0, k, V.cnorm + c0);
     ldlt_reg<NT, TS, (G * TS > 64)>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, cmx, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
     if (chg && tid == 0) V.qstat[0] = 1;
@@ -874,12 +1124,14 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
 #pragma unroll
         for (int e = 0; e < 16; ++e) { const int idx = tid + e * NT; const int i = idx % k, c = idx / k; if (idx < k * k) { Lb[i + c * ld] = tmp[e]; P[i + (size_t)c * ldp] = tmp[e]; } }
     }
+    }
     for (int j = tid; j < k; j += NT) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
     if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
 #ifdef MI355X_PIVSTAT
     if (flag && dprobe) g_dt[5] = wall_clock64();
 #endif
     if (flag) chain_signal(flag, epoch);        // fused launch: the panel workgroups need L11, D and the pivot order -- not the inverse below
+    if (V.dbg && blockIdx.x == 0 && blockIdx.y < 4 && tid == 0) { V.dbg[32 + 8 * blockIdx.y + 6] = wall_clock64(); }
     __syncthreads();
     DBGSTAMP(2);
 #ifdef MI355X_PIVSTAT
@@ -895,6 +1147,11 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
     if (V.dbg && blockIdx.x == 0 && tid == 0) V.dbg[15] = (unsigned long long)k;
 }
 
+// (host side: bytes of big_diag_body's LDS layout; maxm = 64 for the 256-thread, 128 for the 1024-thread instantiation)
+static size_t diag_lds_bytes(int kk, int maxm)
+{
+    return (size_t)((kk | 1) * kk + 4 * maxm + 3 * kk) * sizeof(double) + (size_t)(2 * kk + 2) * sizeof(int) + (size_t)(16 * 65 + 4 * 272) * sizeof(double) + 64;
+}
 template <int TS, int NT = 256>
 __global__ __launch_bounds__(NT) void k_big_diag_reg(DevView V, int list_off)
 {
@@ -1881,7 +2138,7 @@ static size_t trsm_lds_bytes(int k, bool staged)       // (levels with k > 64 la
     return (65 * kp16 + (kp16 <= 64 ? ldl * kp16 : 0) + 17 * kp16 + 2 * (size_t)k) * sizeof(double) + (size_t)(2 * k + 2) * sizeof(int) + (staged ? (size_t)65 * k * sizeof(double) : 0) + 16;
 }
 template <bool STAGED_L>       // L11 staged in LDS (k <= 64) or read from L2 (the 128-column panels of the wide_panels option)
-__device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase)
+__device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase, const int rlim = 64)      // rlim: rows of the block that are this workgroup's
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
@@ -1986,7 +2243,7 @@ __device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta
         if (pt == 1) l = wj * Ds[j];
         else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * As[r + (j + 1) * 65];
         else l = Ds[k + j - 1] * As[r + (j - 1) * 65] + Ds[j] * wj;
-        if (i < m) {
+        if (i < m && r < rlim) {
             W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l;
             if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
         }
@@ -2388,6 +2645,487 @@ __global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off, in
 
 
 // ================================================================================================
+// CHAIN GROUPS FACTORED AS ONE UNIT (the single-GPU schedule).  A chain group = up to 4 consecutive links of an in-place separator
+// chain (<= 256 columns); every link after the first has the chain child as its ONLY child, so the whole group can be factored at
+// the tree level of its first link: no launch per link, no flags between workgroups.  Three launches per level:
+//   k_grp_diag   ONE 512-thread workgroup per group walks the group's leading (<= 256)^2 block link by link: pivot block (blocked
+//                a-posteriori LDL^T, strict threshold pivoting as fall-back), the rows of the group's LATER pivots solved against it
+//                (blocked substitution, fp64 MFMA), their rank-k update of the rest of the leading block -- the serial spine of a
+//                separator chain, 8 wavefronts on one CU, everything between two pivot blocks staged through LDS / L2;
+//   k_grp_rows   the rows BELOW the group's columns, 64 per workgroup, right-looking over the group's links: solve against link p
+//                (k_big_trsm's arithmetic), then update the own rows' entries in the columns of the later links -- a workgroup
+//                depends on k_grp_diag's results only, never on another row block;
+//   k_big_schur  the rank-(<= 256) update of the contribution block by all the group's panels (unchanged).
+// (k_big_inverse builds the L11^{-1} the triangular solves use, for all big fronts in one launch at the end of the factorisation.)
+// ================================================================================================
+constexpr int GX_ROWS = 192, GX_LD = 208;      // staged rows of the later pivots; GX_LD = 16 mod 32 doubles: the 16 x 2 (row, column) operand reads of a half wave hit 32 banks
+static size_t grp_lds_bytes() { return (size_t)(64 * 65 + 256 + 3 * 64 + 4 * 272 + 16 * 65 + 64 * GX_LD) * sizeof(double) + (size_t)(4 * 64 + 8) * sizeof(int) + 64; }
+
+__global__ __launch_bounds__(512) void k_grp_diag(const DevView* __restrict__ Vp, int list_off)
+{
+    const DevView& V = *Vp;          // (by reference: the 90-pointer view by value costs ~200 spilled SGPRs in this kernel)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int NT = 512, NW = NT / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];              // the LAST link of the group
+    const int g = M.gpos + 1;
+    double* Lb     = reinterpret_cast<double*>(smem_raw);            // pivot block, 64 x 65
+    double* colbuf = Lb + 64 * 65;                                   // 4 x 64 (strict loop: published pivot columns)
+    double* dinv_s = colbuf + 256; double* doff_s = dinv_s + 64; double* cm0 = doff_s + 64;
+    double* Is     = cm0 + 64;                                       // inverses of the 16 x 16 diagonal blocks of L11: Is[b*272 + i + p*17]
+    double* Wp     = Is + 4 * 272;                                   // 64 x 16 (ld 65): W panel of the blocked factorisation
+    double* Xs     = Wp + 16 * 65;                                   // rows of the later pivots (R x k, ld GX_LD): A21 P -> W21
+    int* ord = reinterpret_cast<int*>(Xs + 64 * GX_LD); int* pt_s = ord + 64; int* iord = pt_s + 64; int* shflag = iord + 64;
+    int done = 0;
+    for (int j = 0; j < g; ++j) {
+        const GroupLink G = V.gtab[M.gbase + j];
+        const int k = G.k, m = G.m, c0 = G.c0, s = G.s;
+        const int R = M.gcols - done - k;                            // the group's later pivots = the first R rows below this link's pivot block
+        done += k;
+        constexpr int ld = 65;                                       // (fixed: rows / columns beyond k are kept zero)
+        const int kp16 = (k + 15) & ~15;
+        double* P = V.L + G.panel_off;
+        const size_t ldp = (size_t)G.ldp;
+        // ---- loads: pivot block, rows of the later pivots (kept in registers until the pivot order is known), the link's own A entries ----
+        const int bi = tid & 63, bq = tid >> 6;                      // pivot block: row bi, columns bq + 8 e
+        auto load_block = [&]() {
+            double pv[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; pv[e] = (bi < k && c < k && bi >= c) ? P[bi + (size_t)c * ldp] : 0.0; }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi >= c) { Lb[bi + c * ld] = pv[e]; Lb[c + bi * ld] = pv[e]; } }
+        };
+        // rows of the later pivots -> Xs, column p of Xs = column ord[p] of the panel (identity until the strict loop says otherwise)
+        auto load_rows = [&](const bool permuted) {                   // thread (bi, bq): rows bi + 64 h, columns bq + 8 e
+#pragma unroll 1
+            for (int h = 0; h < 3; ++h) {
+                const int r = bi + 64 * h;
+                if (64 * h >= R) break;
+                double xr[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; xr[e] = (r < R && c < k) ? P[(k + r) + (size_t)c * ldp] : 0.0; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (c < k) Xs[r + (permuted ? iord[c] : c) * GX_LD] = xr[e]; else if (c < kp16) Xs[r + c * GX_LD] = 0.0; }
+            }
+        };
+        constexpr int NA = 4;                                        // A entries kept in registers per thread (the others are re-read)
+        int apos_[NA]; double aval_[NA]; int na = 0;
+        if (G.selfasm) {
+#pragma unroll
+            for (int e = 0; e < NA; ++e) { const int q = G.aq0 + tid + e * NT; if (q < G.aq1) { apos_[e] = V.apos[q]; aval_[e] = V.aval[q]; na = e + 1; } }
+        }
+        // mode 0: pivot block + rows (natural column order), 1: pivot block only, 2: rows only (column order iord)
+        auto add_a = [&](const int pos, const double v, const int mode) {
+            const int ii = pos % m, cc = pos / m;
+            if (ii < k) { if (mode != 2) { Lb[ii + cc * ld] += v; if (ii != cc) Lb[cc + ii * ld] += v; } }
+            else if (ii < k + R && mode != 1) Xs[(ii - k) + (mode == 2 ? iord[cc] : cc) * GX_LD] += v;
+        };
+        auto a_entries = [&](const int mode) {
+            if (!G.selfasm) return;
+#pragma unroll
+            for (int e = 0; e < NA; ++e) if (e < na) add_a(apos_[e], aval_[e], mode);
+            for (int q = G.aq0 + tid + NA * NT; q < G.aq1; q += NT) add_a(V.apos[q], V.aval[q], mode);
+            __syncthreads();
+        };
+        load_block();
+        if (R > 0) load_rows(false);
+        __syncthreads();
+        a_entries(0);
+        // ---- pivot block ----
+        int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
+        bool fast = false;
+        if (V.fastpiv) {
+            double cmx;
+            {
+                const int c = tid >> 3, part = tid & 7;
+                double mx = 0.0;
+                if (c < k) for (int r = part; r < k; r += 8) mx = fmax(mx, fabs(Lb[r + c * ld]));
+                if (c < k && part == 0) mx = fmax(mx, V.cnorm[c0 + c]);
+                cmx = wave_max_all(mx);
+                if (lane == 0) colbuf[wave] = cmx;
+                __syncthreads();
+                cmx = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) cmx = fmax(cmx, colbuf[w]);
+            }
+            const double zmax = fmax(V.small, ZERO_REL * cmx);
+            const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), 0.01);
+            fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Is, shflag, zmax, gmax, nneg);
+            if (fast) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi < k && c < k && bi <= c) Lb[bi + c * ld] = 0.0; }
+                for (int q = tid; q < k; q += NT) { doff_s[q] = 0.0; pt_s[q] = 1; ord[q] = q; iord[q] = q; }
+                if (tid == 0) atomicAdd(&V.qstat[3], 1);
+            } else {
+                if (tid == 0) atomicAdd(&V.qstat[2], 1);
+                __syncthreads();
+                load_block();
+                __syncthreads();
+                a_entries(1);
+            }
+        }
+        if (!fast) {
+            // strict threshold pivoting (ldlt_reg) on 16 x 16 threads with 4 x 4 register tiles, exactly as in k_big_diag_reg: the other
+            // 256 threads of the workgroup ride along on empty tiles beyond column 64 (they keep the barriers matched)
+            constexpr int TS = 4, GG = 16;
+            const int ti = tid % GG, tj = tid / GG, row0 = ti * TS, col0 = tj * TS;
+            double t[TS][TS];
+#pragma unroll
+            for (int x = 0; x < TS; ++x)
+#pragma unroll
+                for (int y = 0; y < TS; ++y) { const int i = row0 + x, c = col0 + y; t[x][y] = (i < k && c < k) ? Lb[i + c * ld] : 0.0; }
+            __syncthreads();
+            nneg = 0;
+            const double cmx = front_colmax<256, TS>(t, cm0, k, V.cnorm + c0);
+            ldlt_reg<256, TS, false>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, cmx, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
+            if (chg && tid == 0) V.qstat[0] = 1;
+            __syncthreads();
+            double tmp[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; tmp[e] = (bi < k && c < k && bi > c) ? Lb[ord[bi] + c * ld] : 0.0; }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi < k && c < k) Lb[bi + c * ld] = tmp[e]; }
+            for (int q = tid; q < k; q += NT) iord[ord[q]] = q;
+        }
+        __syncthreads();
+        // ---- L11, D, pivot order -> global (the triangular solves, k_grp_rows, k_big_inverse) ----
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi < k && c < k) P[bi + (size_t)c * ldp] = Lb[bi + c * ld]; }
+        for (int q = tid; q < k; q += NT) { V.dinv[c0 + q] = dinv_s[q]; V.doff[c0 + q] = doff_s[q]; V.ptype[c0 + q] = pt_s[q]; V.lperm[c0 + q] = ord[q]; }
+        if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+        if (R <= 0) continue;                                        // (last link: the rows below are k_grp_rows' business)
+        // ---- rows of the later pivots:  W = (A21 P) L11^{-T},  L21 = W D^{-1} ----
+        if (!fast) {                                                 // the strict loop permuted the pivots: stage the rows again in pivot order
+            load_rows(true);
+            __syncthreads();
+            a_entries(2);
+        }
+        auto Lat = [&](const int i, const int c) -> double { return Lb[i + c * ld]; };      // (strictly lower part; zero on and above the diagonal and beyond k)
+        if (!fast && wave < 4 && 16 * wave < kp16 && lane < 16) {    // inverses of the unit-lower 16 x 16 diagonal blocks (column `lane` by lane; the blocked factorisation left them in Is)
+            const int o = 16 * wave;
+            double x[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
+#pragma unroll
+            for (int pp = 0; pp < 15; ++pp) {
+                const double xp = (pp >= lane) ? x[pp] : 0.0;
+                double lc[15];
+#pragma unroll
+                for (int i = pp + 1; i < 16; ++i) lc[i - 1] = Lat(o + i, o + pp);
+#pragma unroll
+                for (int i = pp + 1; i < 16; ++i) x[i] = fma(-lc[i - 1], xp, x[i]);
+                asm volatile("" ::: "memory");                       // one column of L in flight at a time (hoisting all 120 loads spills)
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) Is[wave * 272 + i + lane * 17] = x[i];
+        }
+        __syncthreads();
+        const int nrt = (R + 15) >> 4;
+        for (int rt = wave; rt < nrt; rt += NW) {
+            const int r16 = rt * 16;
+            for (int c16 = 0; c16 < kp16; c16 += 16) {
+                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+                for (int p = 0; p < c16; p += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lat(c16 + l15, p + l4), Xs[r16 + l15 + (p + l4) * GX_LD], acc, 0, 0, 0);
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) Xs[r16 + l15 + (c16 + l4 + 4 * gg) * GX_LD] -= acc[gg];
+                double bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[u] = Xs[r16 + l15 + (c16 + 4 * u + l4) * GX_LD];
+                const double* Ib = Is + (c16 >> 4) * 272;
+                v4f64 w = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) w = __builtin_amdgcn_mfma_f64_16x16x4f64(Ib[l15 + (4 * u + l4) * 17], bv[u], w, 0, 0, 0);
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) Xs[r16 + l15 + (c16 + l4 + 4 * gg) * GX_LD] = w[gg];
+            }
+        }
+        __syncthreads();
+        // L21 = W D^{-1} of one row: 1x1 pivots scale, a 2x2 pivot mixes its two columns
+        auto lval = [&](const int r, const int q) -> double {
+            const int pt = pt_s[q];
+            const double wq = Xs[r + q * GX_LD];
+            if (pt == 1) return wq * dinv_s[q];
+            if (pt == 2) return dinv_s[q] * wq + doff_s[q] * Xs[r + (q + 1) * GX_LD];
+            return doff_s[q - 1] * Xs[r + (q - 1) * GX_LD] + dinv_s[q] * wq;
+        };
+        {
+            double* W = V.wbuf + G.wb;
+#pragma unroll 1
+            for (int h = 0; h < 3; ++h) {
+                const int r = bi + 64 * h;
+                if (r >= R) continue;
+#pragma unroll 2
+                for (int q = bq; q < k; q += 8) {
+                    const double l = lval(r, q);
+                    W[(k + r) + (size_t)q * m] = Xs[r + q * GX_LD]; P[(k + r) + (size_t)q * ldp] = l;
+                    if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + q], 1) == 0) atomicAdd(&V.fstat[s].w, 1);      // a posteriori threshold test (see k_big_trsm)
+                }
+            }
+        }
+        // ---- rank-k update of the rest of the leading block: T(i, c) -= sum_q L21(i, q) W21(c, q), i >= c, 16 x 16 tiles ----
+        {
+            double* T = V.cb + G.t_off;
+            const size_t ldt = (size_t)G.ldt;
+            const int ntile = nrt * (nrt + 1) / 2;
+            for (int t = wave; t < ntile; t += NT / 64) {
+                int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+                while (ti * (ti + 1) / 2 > t) --ti;
+                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+                const int tc = t - ti * (ti + 1) / 2;
+                const int ra = 16 * tc + l15, rb = 16 * ti + l15;      // W row (-> T column), L row (-> T row) of this lane's operands
+                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+                for (int q = 0; q < kp16; q += 4) {
+                    const int qq = q + l4;
+                    const double av = (ra < R) ? Xs[ra + qq * GX_LD] : 0.0;
+                    const double bv = (rb < R && qq < k) ? lval(rb, qq) : 0.0;
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+                double tv[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) { const int c = 16 * tc + l4 + 4 * gg; tv[gg] = (rb < R && c < R && rb >= c) ? T[rb + (size_t)c * ldt] : 0.0; }
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) { const int c = 16 * tc + l4 + 4 * gg; if (rb < R && c < R && rb >= c) T[rb + (size_t)c * ldt] = tv[gg] - acc[gg]; }
+            }
+        }
+        __syncthreads();              // the next link reads its pivot block and rows out of what was just updated
+    }
+}
+
+// Rows below a chain group's columns, 64 per workgroup, right-looking over the links of the group (see above).
+__global__ __launch_bounds__(256) void k_grp_rows(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.y];              // the LAST link of the group
+    const int tail = M.m - M.k;                                      // rows below the group's columns (the same rows in every link)
+    const int e0 = 64 * (int)blockIdx.x;
+    if (e0 >= tail) return;
+    const int g = M.gpos + 1;
+    int done = 0;
+    for (int p = 0; p < g; ++p) {
+        const GroupLink G = V.gtab[M.gbase + p];
+        const int k = G.k, m = G.m;
+        const int R = M.gcols - done - k;
+        done += k;
+        const int ibase = k + R + e0;                                // my first row in this link's front
+        double* P = V.L + G.panel_off;
+        const size_t ldp = (size_t)G.ldp;
+        if (G.selfasm) {
+            for (int q = G.aq0 + tid; q < G.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
+            __syncthreads();
+        }
+        FrontMeta Mp = M;
+        Mp.s = G.s; Mp.c0 = G.c0; Mp.k = k; Mp.m = m; Mp.panel_off = G.panel_off; Mp.ldp = G.ldp; Mp.wb = G.wb;
+        const TrsmLds T = trsm_layout(smem_raw, k, false);
+        trsm_rows_impl<true>(V, Mp, T, ibase);
+        if (R <= 0) break;
+        __syncthreads();
+        // my rows' entries in the columns of the later links:  T(i, c) -= sum_q L21(i, q) W21(c, q),  c < R  (W21 of those rows: k_grp_diag)
+        {
+            const double* Ds = T.Ds; const int* Ts = T.Ts; const double* As = T.As;
+            auto lval = [&](const int r, const int q) -> double {
+                const int pt = Ts[q];
+                const double wq = As[r + q * 65];
+                if (pt == 1) return wq * Ds[q];
+                if (pt == 2) return Ds[q] * wq + Ds[k + q] * As[r + (q + 1) * 65];
+                return Ds[k + q - 1] * As[r + (q - 1) * 65] + Ds[q] * wq;
+            };
+            const int kp16 = T.kp16;
+            double bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int qq = 4 * u + l4; bv[u] = (qq < k) ? lval(16 * wave + l15, qq) : 0.0; }
+            const double* Wg = V.wbuf + G.wb + k;                    // W21 rows of the later pivots
+            double* Tt = V.cb + G.t_off;
+            const size_t ldt = (size_t)G.ldt;
+            const int irow = R + e0 + 16 * wave + l15;               // my row in T
+            const bool rowok = e0 + 16 * wave + l15 < tail;
+            const int nct = (R + 15) >> 4;
+            for (int tc = 0; tc < nct; tc += 2) {
+                double a0[16], a1[16];
+                const int ra = 16 * tc + l15, rb = ra + 16;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    const int qq = 4 * u + l4;
+                    a0[u] = (ra < R && qq < k) ? Wg[ra + (size_t)qq * m] : 0.0;
+                    a1[u] = (rb < R && qq < k) ? Wg[rb + (size_t)qq * m] : 0.0;
+                }
+                double t0[4], t1[4];
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int c = 16 * tc + l4 + 4 * gg;
+                    t0[gg] = (rowok && c < R) ? Tt[irow + (size_t)c * ldt] : 0.0;
+                    t1[gg] = (rowok && c + 16 < R) ? Tt[irow + (size_t)(c + 16) * ldt] : 0.0;
+                }
+                v4f64 c0v = (v4f64){0.0, 0.0, 0.0, 0.0}, c1v = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (4 * u < kp16) {
+                        c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bv[u], c0v, 0, 0, 0);
+                        c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bv[u], c1v, 0, 0, 0);
+                    }
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    const int c = 16 * tc + l4 + 4 * gg;
+                    if (rowok && c < R) Tt[irow + (size_t)c * ldt] = t0[gg] - c0v[gg];
+                    if (rowok && c + 16 < R) Tt[irow + (size_t)(c + 16) * ldt] = t1[gg] - c1v[gg];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// A chain group as ONE launch of row-block workgroups (the default of the grouped schedule): grid = (groups, 4 + row blocks below the
+// group).  Role q < 4 owns the pivot rows of the group's link q, role 4 + b the b-th block of 64 rows below the group's columns.  A
+// row block walks the links p before its own (all of them for the rows below): rows staged in LDS, wait for link p's pivot block
+// (flag), solve against it (k_big_trsm's arithmetic), publish W / L of its rows (flag), then update its own rows' entries in the
+// columns of the later links r, waiting per r for the rows that hold W(r, p).  A pivot-row block then factors its own pivot block
+// (big_diag_body: blocked a-posteriori LDL^T or the strict loop) and raises the flag the blocks after it wait for.  Every wait is on
+// a workgroup with a SMALLER role of the same group: with workgroups dispatched in linear order (roles are the slow grid dimension)
+// a waiting workgroup never holds up the one it waits for; the spins are bounded all the same (qstat[1]).
+// Critical path per link: pivot block -> flag -> one 64 x 64 panel solve -> one 64 x 64 x 64 update -> next pivot block.
+__global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int staged)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];              // the LAST link of the group
+    const int g = M.gpos + 1, role = blockIdx.y;
+    const int tail = M.m - M.k;                                      // rows below the group's columns
+    int myq = -1, e0 = 0;
+    if (role < 4) { if (role >= g) return; myq = role; }
+    else { e0 = 64 * (role - 4); if (e0 >= tail) return; }
+    const int epoch = V.sepoch[2];
+#define GSTAMP(i) do { if (V.dbg && blockIdx.x == 0 && role < 4 && tid == 0) V.dbg[32 + 8 * role + (i)] = wall_clock64(); } while (0)
+    GSTAMP(0);
+    int kk[4], koff[5];
+    koff[0] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { kk[j] = (j < g) ? V.gtab[M.gbase + j].k : 0; koff[j + 1] = koff[j] + kk[j]; }
+    const int last_p = (myq >= 0) ? myq - 1 : g - 1;
+    int myrows = min(64, tail - e0), mystart = M.gcols + e0;          // my rows, counted from the first column of the group
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (j == myq) { myrows = kk[j]; mystart = koff[j]; }
+    for (int p = 0; p <= last_p; ++p) {
+        const GroupLink G = V.gtab[M.gbase + p];
+        const int k = G.k, m = G.m;
+        int kend = 0;                                                 // columns of the group up to and including link p
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j == p) kend = koff[j + 1];
+        const int ibase = k + (mystart - kend);                       // my first row in this link's front
+        double* P = V.L + G.panel_off;
+        const size_t ldp = (size_t)G.ldp;
+        if (G.selfasm) {
+            for (int q = G.aq0 + tid; q < G.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + myrows) P[i + (size_t)c * ldp] += V.aval[q]; }
+            __syncthreads();
+        }
+        FrontMeta Mp = M;
+        Mp.s = G.s; Mp.c0 = G.c0; Mp.k = k; Mp.m = m; Mp.panel_off = G.panel_off; Mp.ldp = G.ldp; Mp.wb = G.wb;
+        const TrsmLds T = trsm_layout(smem_raw, k, staged != 0);      // (levels with hundreds of groups: no staging copy, two workgroups per CU)
+        if (staged) for (int idx = tid; idx < 64 * k; idx += 256) { const int r = idx & 63, c = idx >> 6; T.Au[r + c * 65] = (r < myrows && ibase + r < m) ? P[ibase + r + (size_t)c * ldp] : 0.0; }
+        chain_wait(&V.sflag_d[G.s], epoch, V.qstat + 1);              // L11, D and the pivot order of link p are stored
+        if (p == last_p) GSTAMP(1);
+        trsm_rows_impl<true>(V, Mp, T, ibase, myrows);
+        if (p == last_p) GSTAMP(2);
+        if (myq >= 0) chain_signal(&V.sflag_s[4 * G.s + myq], epoch); // W(my rows, p) and L(my rows, p) are stored: the blocks after me may use them
+        else __syncthreads();
+        if (p == last_p) GSTAMP(3);
+        // my rows' entries in the columns of the later links:  T(i, c) -= sum_q L21(i, q) W21(c, q)
+        {
+            const double* Ds = T.Ds; const int* Ts = T.Ts; const double* As = T.As;
+            auto lval = [&](const int r, const int q) -> double {
+                const int pt = Ts[q];
+                const double wq = As[r + q * 65];
+                if (pt == 1) return wq * Ds[q];
+                if (pt == 2) return Ds[q] * wq + Ds[k + q] * As[r + (q + 1) * 65];
+                return Ds[k + q - 1] * As[r + (q - 1) * 65] + Ds[q] * wq;
+            };
+            const int kp16 = T.kp16;
+            double bv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int qq = 4 * u + l4; bv[u] = (qq < k) ? lval(16 * wave + l15, qq) : 0.0; }
+            double* Tt = V.cb + G.t_off;
+            const size_t ldt = (size_t)G.ldt;
+            const int irow = (mystart - kend) + 16 * wave + l15;      // my row in T
+            const bool rowok = 16 * wave + l15 < myrows;
+            const int rmax = (myq >= 0) ? myq : g - 1;
+            for (int r = p + 1; r <= rmax; ++r) {
+                int cs = 0, cn = 0;                                   // columns of link r, counted from the first column after link p
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (j == r) { cs = koff[j] - kend; cn = kk[j]; }
+                if (r != myq) chain_wait(&V.sflag_s[4 * G.s + r], epoch, V.qstat + 1);
+                const double* Wg = V.wbuf + G.wb + k + cs;            // W21 rows of link r's pivots
+                const int nct = (cn + 15) >> 4;
+                for (int tc = 0; tc < nct; tc += 2) {
+                    double a0[16], a1[16];
+                    const int ra = 16 * tc + l15, rb = ra + 16;
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int qq = 4 * u + l4;
+                        a0[u] = (ra < cn && qq < k) ? Wg[ra + (size_t)qq * m] : 0.0;
+                        a1[u] = (rb < cn && qq < k) ? Wg[rb + (size_t)qq * m] : 0.0;
+                    }
+                    double t0[4], t1[4];
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int c = 16 * tc + l4 + 4 * gg;
+                        t0[gg] = (rowok && c < cn) ? Tt[irow + (size_t)(cs + c) * ldt] : 0.0;
+                        t1[gg] = (rowok && c + 16 < cn) ? Tt[irow + (size_t)(cs + c + 16) * ldt] : 0.0;
+                    }
+                    v4f64 c0v = (v4f64){0.0, 0.0, 0.0, 0.0}, c1v = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int u = 0; u < 16; ++u)
+                        if (4 * u < kp16) {
+                            c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bv[u], c0v, 0, 0, 0);
+                            c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bv[u], c1v, 0, 0, 0);
+                        }
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const int c = 16 * tc + l4 + 4 * gg;
+                        if (rowok && c < cn) Tt[irow + (size_t)(cs + c) * ldt] = t0[gg] - c0v[gg];
+                        if (rowok && c + 16 < cn) Tt[irow + (size_t)(cs + c + 16) * ldt] = t1[gg] - c1v[gg];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (p == last_p) GSTAMP(4);
+    }
+    if (myq < 0) return;
+    {   // my own pivot block
+        GroupLink G = V.gtab[M.gbase];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) if (j == myq) G = V.gtab[M.gbase + j];
+        FrontMeta Mq = M;
+        Mq.s = G.s; Mq.c0 = G.c0; Mq.k = G.k; Mq.m = G.m; Mq.panel_off = G.panel_off; Mq.ldp = G.ldp; Mq.wb = G.wb; Mq.minv_off = G.minv_off;
+        Mq.selfasm = G.selfasm; Mq.aq0 = G.aq0; Mq.aq1 = G.aq1;
+        big_diag_body<4, 256>(V, Mq, smem_raw, &V.sflag_d[G.s], epoch);
+        GSTAMP(7);
+    }
+#undef GSTAMP
+}
+
+// L11^{-1} of the big fronts (the triangular solves multiply by it): one workgroup per front, L11 as stored by the pivot-block kernels
+__global__ __launch_bounds__(256) void k_big_inverse(DevView V, int list_off)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
+    const int tid = threadIdx.x, k = M.k, ld = k | 1;
+    double* Lb = reinterpret_cast<double*>(smem_raw);
+    const double* P = V.L + M.panel_off;
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Lb[i + c * ld] = (i > c) ? P[i + (size_t)c * M.ldp] : 0.0; }
+    __syncthreads();
+    invert_unit_lower<256>(Lb, ld, k);
+    double* Mg = V.minv + M.minv_off;
+    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Lb[i + c * ld] : (i == c ? 1.0 : 0.0); }
+}
+
+
+// ================================================================================================
 // The 8-block primal-dual system on the device (reference IpPDFullSpaceSolver.cpp:377-664 SolveOnce,
 // :666-793 ComputeResiduals, :795-820 ComputeResidualRatio).  A primal-dual vector is ONE array
 //   [ x (nx) | s (ns) | y_c (nc) | y_d (nd) | z_L (nxl) | z_U (nxu) | v_L (nsl) | v_U (nsu) ];
@@ -2645,6 +3383,21 @@ public:
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
     std::vector<int> la_tiles1, la_tiles2; std::vector<char> la_full;     // la_full: the level has a full (group-last) update
+    // grouped schedule (single GPU): per level the chain groups whose FIRST link sits there (entries = FrontMeta of the LAST link, sorted by
+    // order, split at 1024 rows like the BIG buckets), launch geometry, look-ahead tiles; all big fronts once more for k_big_inverse
+    bool grouped = false, grp_fused = true;
+    DevView* d_view = nullptr; bool view_dirty = true; double sv_u = -1.0, sv_u2 = -1.0, sv_small = -1.0;     // device copy of V for the kernels that take the view by reference
+    bool sync_view() {
+        if (!d_view) return true;
+        if (view_dirty || sv_u != V.pivtol || sv_u2 != V.pivtol2 || sv_small != V.small) {
+            HIPCHK(hipMemcpyAsync(d_view, &V, sizeof(DevView), hipMemcpyHostToDevice, stream)); HIPCHK(hipStreamSynchronize(stream));
+            view_dirty = false; sv_u = V.pivtol; sv_u2 = V.pivtol2; sv_small = V.small;
+        }
+        return true;
+    }
+    std::vector<int> grp0, grp1, grp_split, grp_nrb, grp_tiles64, grp_tiles, grp_la1, grp_la2;
+    std::vector<hipEvent_t> grp_evA, grp_evB;
+    int allbig_base = 0, allbig_count = 0, allbig_maxk = 0;
     std::vector<hipEvent_t> la_evA, la_evB;
     // chain look-ahead (single-GPU schedule, levels whose fronts are all pure in-place chain links): the critical path
     //   pivot block (k_big_diag_reg) -> first row block of the panel (k_big_trsm, 1 workgroup) -> the NEXT link's 64 x 64 pivot
@@ -2791,7 +3544,7 @@ public:
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
         for (void* p : allocs) (void)hipFree(p);
-        allocs.clear();
+        allocs.clear(); d_view = nullptr;
         if (d_rhs) { (void)hipFree(d_rhs); d_rhs = nullptr; d_rhs_cap = 0; }
         if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
         if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
@@ -2804,6 +3557,9 @@ public:
         for (auto e : la_evA) if (e) (void)hipEventDestroy(e);
         for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
         la_evA.clear(); la_evB.clear();
+        for (auto e : grp_evA) if (e) (void)hipEventDestroy(e);
+        for (auto e : grp_evB) if (e) (void)hipEventDestroy(e);
+        grp_evA.clear(); grp_evB.clear();
         for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
         if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
         if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
@@ -2974,6 +3730,7 @@ public:
         chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
+        V.fastpiv = getenv("MI355X_KKT_NO_FASTPIV") == nullptr ? 1 : 0;
         if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
         pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
         wave_kmax.assign(Sy.num_levels, 0);
@@ -3041,6 +3798,8 @@ public:
                 G.panel_off = Sy.panel_off[l]; G.wb = Sy.wb_off[l]; G.minv_off = Sy.minv_off[l]; G.cv = Sy.cv_off[l]; G.tr = troff[l];
                 G.c0 = Sy.sn_colptr[l]; G.k = Sy.sn_colptr[l + 1] - G.c0; G.r0 = Sy.sn_rowptr[l]; G.m = Sy.sn_rowptr[l + 1] - G.r0;
                 G.ldp = Sy.sn_ldp[l]; G.ch0 = Sy.child_ptr[l]; G.ch1 = Sy.child_ptr[l + 1]; G.alias = Sy.alias_child[l] >= 0 ? 1 : 0;
+                G.t_off = Sy.cb_off[l]; G.ldt = Sy.sn_ldt[l]; G.s = l; G.aq0 = Sy.acolptr[G.c0]; G.aq1 = Sy.acolptr[G.c0 + G.k]; G.pad_ = 0;
+                G.selfasm = ((!multi || aoff[l] < 0) && getenv("MI355X_KKT_NO_SELFASM") == nullptr && Sy.alias_child[l] >= 0 && Sy.child_ptr[l + 1] - Sy.child_ptr[l] == 1) ? 1 : 0;
                 gt.push_back(G); gcols_of[sn] += G.k;
             }
         }
@@ -3162,6 +3921,44 @@ public:
                 for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) HIPCHK(hipEventCreateWithFlags(&(*v)[lv], hipEventDisableTiming));
             if (opt.verbose) fprintf(stderr, "[mi355x_kkt] chain look-ahead on %d of %d levels\n", nchain >= 8 ? nchain : 0, Sy.num_levels);
         }
+        // ---- grouped schedule: every chain group is factored at the level of its first link (k_grp_diag / k_grp_rows / update) ----
+        grouped = !multi && Sy.maxsupernode <= 64 && selfasm_on && getenv("MI355X_KKT_NO_GROUPED") == nullptr;
+        grp_fused = getenv("MI355X_KKT_GRP_SPLIT") == nullptr;
+        grp0.assign(Sy.num_levels, 0); grp1.assign(Sy.num_levels, 0); grp_split.assign(Sy.num_levels, 0); grp_nrb.assign(Sy.num_levels, 0);
+        grp_tiles64.assign(Sy.num_levels, 0); grp_tiles.assign(Sy.num_levels, 0); grp_la1.assign(Sy.num_levels, 0); grp_la2.assign(Sy.num_levels, 0);
+        grp_evA.assign(Sy.num_levels, nullptr); grp_evB.assign(Sy.num_levels, nullptr);
+        if (grouped) {
+            auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
+            auto cols_of = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
+            std::vector<std::vector<int>> at(Sy.num_levels);
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
+                int first = sn;
+                for (int j = Sy.grp_pos[sn]; j > 0; --j) first = Sy.alias_child[first];
+                if (Sy.sn_level[first] >= Sy.grp_cut_level) at[Sy.sn_level[first]].push_back(sn);      // (groups do not straddle the cut: symbolic.cpp)
+            }
+            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                std::stable_sort(at[lv].begin(), at[lv].end(), [&](int a, int b) { return order_of(a) < order_of(b); });
+                grp0[lv] = (int)lvl_list.size();
+                int nsmall = 0;
+                for (int sn : at[lv]) {
+                    lvl_list.push_back(sn);
+                    const int mu = order_of(sn) - cols_of(sn), nt = (mu + 127) / 128;
+                    grp_nrb[lv] = std::max(grp_nrb[lv], (mu + 63) / 64);
+                    if (order_of(sn) <= 1024) { ++nsmall; grp_tiles64[lv] = std::max(grp_tiles64[lv], schur_tiles64(Sy, sn)); }
+                    else {
+                        grp_tiles[lv] = std::max(grp_tiles[lv], schur_tiles(Sy, sn));
+                        grp_la1[lv] = std::max(grp_la1[lv], split_of[sn] ? 2 * nt - 1 : tri_tiles(nt));
+                        if (split_of[sn]) grp_la2[lv] = std::max(grp_la2[lv], ((nt - 2) * (nt - 1) / 2 + 7) / 8 * 8);
+                    }
+                }
+                grp_split[lv] = nsmall; grp1[lv] = (int)lvl_list.size();
+                if (grp_la2[lv] > 0) { HIPCHK(hipEventCreateWithFlags(&grp_evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&grp_evB[lv], hipEventDisableTiming)); }
+            }
+            allbig_base = (int)lvl_list.size();
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG) { lvl_list.push_back(sn); allbig_maxk = std::max(allbig_maxk, cols_of(sn)); }
+            allbig_count = (int)lvl_list.size() - allbig_base;
+            if (opt.verbose) { int ng = 0; for (int lv = 0; lv < Sy.num_levels; ++lv) ng += grp1[lv] - grp0[lv]; fprintf(stderr, "[mi355x_kkt] grouped schedule: %d chain groups for %d big fronts\n", ng, allbig_count); }
+        }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -3223,13 +4020,13 @@ public:
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
-            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
+            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         if (opt.scaling == 3) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
-        if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 16)) return false; }
+        if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 64)) return false; }
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
@@ -3253,6 +4050,10 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_grp_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_grp_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_grp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
@@ -3262,6 +4063,7 @@ public:
             big_tiles[lv] = std::max(big_tiles[lv], schur_tiles(Sy, s));
             big_tiles64[lv] = std::max(big_tiles64[lv], schur_tiles64(Sy, s));
         }
+        { DevView* dv = nullptr; if (!dalloc(&dv, 1)) return false; d_view = dv; view_dirty = true; }
         ready = true; return true;
     }
 
@@ -3299,6 +4101,11 @@ public:
             if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
         } else {
             const bool single = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_BIG]) && !multi;       // the single-GPU schedule
+            if (single && grouped && lv >= S->grp_cut_level) {
+                if (!drain_chain()) return false;
+                if (!lv_asm_skip[lv]) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
+                return launch_groups(lv);
+            }
             if (!single) { const bool sm = mm <= 640; return launch_big(lv, b0, sm ? b1 : b0, b1, top_mode, mm, kk, sm ? tiles64 : 0, sm ? 0 : tiles, false); }
             return launch_big(lv, b0, b0 + big_split[lv], b1, top_mode, mm, kk, part_tiles[0][lv], part_tiles[1][lv], true);
         }
@@ -3317,7 +4124,7 @@ public:
         const int nball = b1 - b0, nrb = (mm + 63) / 64;
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
         // ---- critical path (main stream) ----
-        hipLaunchKernelGGL(k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        hipLaunchKernelGGL(k_big_diag_reg<4>, dim3(nball), dim3(256), diag_lds_bytes(kk, 64), stream, V, b0);
         HIPCHK(hipEventRecord(chD[lv], stream));
         if (ch_bulk_pending) HIPCHK(hipStreamWaitEvent(stream, ch_bulk_last, 0));      // this panel's first row block was finalised by the previous level's bulk update
         hipLaunchKernelGGL(k_big_trsm<false>, dim3(1, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
@@ -3345,6 +4152,31 @@ public:
         HIPCHK(hipGetLastError());
         return true;
     }
+    // the chain groups whose first link sits on level lv: pivot blocks + leading blocks, rows below, rank-(<= 256) updates
+    bool launch_groups(int lv) {
+        const int b0 = grp0[lv], b1 = grp1[lv], bs = b0 + grp_split[lv];
+        if (b1 == b0) return true;
+        if (grp_fused) {
+            const int st = (b1 - b0) * (4 + grp_nrb[lv]) <= 256 ? 1 : 0;
+            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + grp_nrb[lv]), dim3(256), std::max(diag_lds_bytes(64, 64), trsm_lds_bytes(64, st != 0)), stream, V, b0, st);
+        } else {
+            LAUNCH(KK_BIG_DIAG, k_grp_diag, dim3(b1 - b0), dim3(512), grp_lds_bytes(), stream, (const DevView*)d_view, b0);
+            if (grp_nrb[lv] > 0) LAUNCH(KK_BIG_TRSM, k_grp_rows, dim3(grp_nrb[lv], b1 - b0), dim3(256), trsm_lds_bytes(64, false), stream, V, b0);
+        }
+        if (bs > b0 && grp_tiles64[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(grp_tiles64[lv], bs - b0), dim3(256), 0, stream, V, b0, 0);
+        if (b1 == bs) return true;
+        const int nb = b1 - bs;
+        if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }      // a full update may touch what an earlier part 2 is still writing
+        if (grp_la2[lv] > 0 && !prof_on) {
+            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(grp_la1[lv], nb), dim3(1024), 0, stream, V, bs, 1, 0, 0);
+            HIPCHK(hipEventRecord(grp_evA[lv], stream));
+            HIPCHK(hipStreamWaitEvent(stream2, grp_evA[lv], 0));
+            hipLaunchKernelGGL(k_big_schur, dim3(std::min(grp_la2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, bs, 2, grp_la2[lv], 0);
+            HIPCHK(hipEventRecord(grp_evB[lv], stream2));
+            la_last = grp_evB[lv]; la_pending = true;
+        } else if (grp_tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(grp_tiles[lv], nb), dim3(1024), 0, stream, V, bs, 0, 0, 0);
+        return true;
+    }
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
         if (single && lv_chain[lv] && !prof_on && !top_mode) return launch_big_chain(lv, b0, bs, b1, mm, kk, tiles_small, tiles);
         if (!drain_chain()) return false;
@@ -3353,15 +4185,15 @@ public:
         const int nrb = (mm + 63) / 64;
         if (fuse_dt && (single || multi) && !prof_on && kk <= 64 && nball * (1 + nrb) <= fuse_dt_maxwg) {      // (the per-kernel profile keeps the two kernels apart; multi-GPU: local subtrees and replicated top alike)
             // few fronts on the level: pivot block + panel solve in one flag-synchronised launch (k_big_diag_trsm)
-            const size_t lds = std::max((size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64,
+            const size_t lds = std::max(diag_lds_bytes(kk, 64),
                                         trsm_lds_bytes(kk, true));
             const int ntu = (lv_narrow_tiles[lv] > 0 && nball * (1 + nrb + lv_narrow_tiles[lv]) <= 256) ? lv_narrow_tiles[lv] : 0;      // (one workgroup per CU: the far part of a group-end update may own the rest of the chip)
             LAUNCH(KK_BIG_DIAG, k_big_diag_trsm, dim3(nball, 1 + nrb + ntu), dim3(256), lds, stream, V, b0, nrb);
             if (ntu > 0) return true;         // ... and so did the narrow updates
             goto updates;
         }
-        if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), (size_t)((kk | 1) * kk + 4 * 64 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
-        else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), (size_t)((kk | 1) * kk + 4 * 128 + 3 * kk) * sizeof(double) + 2 * kk * sizeof(int) + 64, stream, V, b0);
+        if (kk <= 64) LAUNCH(KK_BIG_DIAG, k_big_diag_reg<4>, dim3(nball), dim3(256), diag_lds_bytes(kk, 64), stream, V, b0);
+        else          LAUNCH(KK_BIG_DIAG, (k_big_diag_reg<4, 1024>), dim3(nball), dim3(1024), diag_lds_bytes(kk, 128), stream, V, b0);
         if (kk <= 64) LAUNCH(KK_BIG_TRSM, k_big_trsm<false>, dim3((mm + 63) / 64, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
         else          LAUNCH(KK_BIG_TRSM, k_big_trsm<true>, dim3((mm + 63) / 64, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
       updates:
@@ -3413,6 +4245,7 @@ public:
         }
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
         if (!drain_chain()) return false;
+        if (grouped && !grp_fused && allbig_count > 0) LAUNCH(KK_BIG_DIAG, k_big_inverse, dim3(allbig_count), dim3(256), (size_t)allbig_maxk * (allbig_maxk | 1) * sizeof(double) + 64, stream, V, allbig_base);
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
         LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());
@@ -3425,6 +4258,7 @@ public:
         if (multi) return factor_dist(dvals, reuse, st);          // needs a communicator (set_comm_*), fails loudly otherwise
         const Symbolic& Sy = *S;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
+        if (!sync_view()) return false;
         if (!reuse) {
             if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -3458,7 +4292,7 @@ public:
         HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
-        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4];
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4]; st.num_fast = h_stats[7];
         if (h_stats[5] != 0) { err_ = "factor: a panel workgroup timed out waiting for its pivot block"; return false; }
         return true;
     }
@@ -3792,6 +4626,7 @@ public:
         if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
         const Symbolic& Sy = *S; const int n = Sy.n;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
+        if (!sync_view()) return false;
         if (!reuse) {
             if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -3825,7 +4660,7 @@ public:
         HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
-        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4] != 0;
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4] != 0; st.num_fast = h_stats[7];
         return true;
     }
     // distributed solve of one right-hand side (identical on every rank), solution on every rank:
@@ -3861,7 +4696,7 @@ public:
         hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
         HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4];
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4]; st.num_fast = h_stats[7];
         if (opt.rank == 0) {
             hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
             hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
@@ -3914,7 +4749,7 @@ public:
     bool debug_clocks(unsigned long long* out) {
         DeviceGuard guard(dev);
         if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
-        HIPCHK(hipMemcpy(out, V.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out, V.dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 #ifdef MI355X_PIVSTAT
         unsigned long long ps[16]; HIPCHK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pivstat), sizeof ps));
         unsigned long long fs[32]; HIPCHK(hipMemcpyFromSymbol(fs, HIP_SYMBOL(g_fstat), sizeof fs));
@@ -3939,7 +4774,7 @@ public:
                                         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
         prof_on = true;
         for (int r = 0; r < reps; ++r) {
-            if (!enqueue_factor() || !enqueue_solve(d_rhs, d_rhs)) { prof_on = false; return false; }
+            if (!sync_view() || !enqueue_factor() || !enqueue_solve(d_rhs, d_rhs)) { prof_on = false; return false; }
             prof_collect();
         }
         prof_on = false;

@@ -945,11 +945,22 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         const int gmax = std::max(1, std::min(opt.chain_group, 4));
         S.solve_group = opt.solve_group;
         S.grp_pos.assign(nsn, 0); S.grp_rem.assign(nsn, 0);
+        {   // the latency-bound top of the tree: the levels from which on no level has more than `maxch` BIG fronts
+            int maxch = 8;
+            if (const char* e = getenv("MI355X_KKT_GRP_MAXCHAINS")) maxch = std::max(0, atoi(e));
+            vector<int> nbig(S.num_levels, 0);
+            for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) nbig[S.sn_level[s]]++;
+            S.grp_cut_level = S.num_levels;
+            for (int lv = S.num_levels - 1; lv >= 0 && nbig[lv] <= maxch; --lv) S.grp_cut_level = lv;
+        }
         vector<int> gcols(nsn, 0), alias_parent(nsn, -1);
         for (int s = 0; s < nsn; ++s) {
             const int ac = S.alias_child[s];
             gcols[s] = (int)K(s);
-            if (ac >= 0 && S.grp_pos[ac] + 1 < gmax && gcols[ac] + K(s) <= 256 && S.sn_level[s] == S.sn_level[ac] + 1) {
+            // (a link joins its chain child's group only if that child is its ONLY child: nothing but the chain itself writes into the
+            //  front, so a whole group can be factored in one launch sequence at the level of its first link -- numeric.hip, k_grp_*)
+            if (ac >= 0 && S.grp_pos[ac] + 1 < gmax && gcols[ac] + K(s) <= 256 && S.sn_level[s] == S.sn_level[ac] + 1 &&
+                S.child_ptr[s + 1] - S.child_ptr[s] == 1 && !(S.sn_level[s] >= S.grp_cut_level && S.sn_level[ac] < S.grp_cut_level)) {
                 S.grp_pos[s] = S.grp_pos[ac] + 1; gcols[s] = gcols[ac] + (int)K(s); alias_parent[ac] = s;
             }
         }

@@ -79,6 +79,8 @@ struct Symbolic {
     std::vector<int64_t> gpart_off;        // [num_sn] (group-last BIG fronts) offset of the backward partial sums
     int64_t cvec_doubles = 0, gpart_doubles = 0;
     int solve_group = 0;                   // copy of the option: solves per chain group (1) or per link (0)
+    int grp_cut_level = 0;                 // from this tree level up every level has only a handful of BIG fronts (the latency-bound top of the tree):
+                                           // chain groups do not straddle it, the numeric phase factors the groups above it in one launch each
     std::vector<int64_t> wb_off;           // [num_sn] offset (doubles) of the m x k scaled-panel copy W = L*D of a BIG front
                                            // inside the per-level scratch (reused level after level), -1 otherwise
     int64_t wbuf_doubles = 0;

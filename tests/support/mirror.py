@@ -206,11 +206,40 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True, cnorm=None):
 
 
 BIG_FRONT = 128      # fronts above this order take the blocked path: in-block test + a posteriori test on the rows below
+FAST_U = 0.01        # a pivot block taken in natural order is accepted iff every multiplier is <= 1 / max(u, u2, FAST_U)
 
 
-def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20):
+def ldlt_block_static(A, k, u, u2, small=1e-20, cnorm=None):
+    """The fast path of a big front's pivot block (numeric.hip: ldlt_blocked_static): the k x k block is eliminated in NATURAL
+    order with 1x1 pivots, nothing is decided per pivot, and the result is accepted A POSTERIORI iff every pivot is clear of the
+    zero threshold of the block and every multiplier inside the block is <= 1 / max(u, u2, FAST_U).  Returns the same dict as
+    ldlt_front, or None when the block is rejected (the caller then runs the strict rule on the untouched block)."""
+    A = A.copy()
+    cm = np.abs(A).max(axis=0) if k else np.zeros(0)
+    if cnorm is not None:
+        cm = np.maximum(cm, cnorm)
+    zmax = max(small, ZERO_REL * (cm.max() if k else 0.0))
+    gmax = 1.0 / max(u, u2, FAST_U)
+    L = np.zeros((k, k)); dinv = np.zeros(k); nneg = 0
+    for j in range(k):
+        d = A[j, j]
+        if not abs(d) > zmax:
+            return None
+        w = A[j + 1:, j].copy()
+        l = w / d
+        if l.size and np.abs(l).max() > gmax:
+            return None
+        L[j + 1:, j] = l
+        A[j + 1:, j + 1:] -= np.outer(l, w)
+        dinv[j] = 1.0 / d
+        nneg += int(d < 0)
+    return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0)
+
+
+def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_blocks=True):
     """multifrontal LDL^T with the pivoting rules of the HIP kernels (no scaling: use scaling=0 on the GPU side).
-    Returns (x, dict(num_neg, num_zero, num_two, num_delay, u_sensitive))."""
+    Returns (x, dict(num_neg, num_zero, num_two, num_delay, u_sensitive, num_fast)); num_fast = pivot blocks of big fronts
+    accepted on the natural-order a-posteriori path (ldlt_block_static), the others took the strict rule."""
     I = sym["info"]
     n, nsn = I.n, I.num_sn
     aval = np.zeros(I.nnz_a)
@@ -221,7 +250,7 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20):
         if parent[s] >= 0:
             children[parent[s]].append(s)
     fac, cbs, cvec = [None] * nsn, [None] * nsn, [None] * nsn
-    tot = dict(num_neg=0, num_zero=0, num_two=0, num_delay=0, u_sensitive=0)
+    tot = dict(num_neg=0, num_zero=0, num_two=0, num_delay=0, u_sensitive=0, num_fast=0)
     b = rhs[sym["perm"]].astype(float).copy()
     # inf-norm of every column of the (symmetric) input matrix, permuted numbering
     cn = np.zeros(n)
@@ -254,7 +283,11 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20):
             cb = F[k:, k:].copy()
         else:
             A11 = F[:k, :k].copy()
-            st = ldlt_front(A11, k, u, u2, small, see_update_rows=False, cnorm=cn[c0:c1])
+            st = ldlt_block_static(A11, k, u, u2, small, cnorm=cn[c0:c1]) if (fast_blocks and k <= 64) else None
+            if st is not None:
+                tot["num_fast"] += 1
+            else:
+                st = ldlt_front(A11, k, u, u2, small, see_update_rows=False, cnorm=cn[c0:c1])
             P = st["ord"]
             L11 = np.tril(st["L"][P, :], -1) + np.eye(k)
             D = np.zeros((k, k))

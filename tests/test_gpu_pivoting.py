@@ -104,6 +104,7 @@ def test_seeded_systems_at_several_u(u):
         I = s.info()
         assert st == 0 and I.num_neg == neg == spec["num_neg"]
         assert (I.num_two, I.num_small) == (spec["num_two"], spec["num_delay"])
+        assert I.num_fast_blocks == spec["num_fast"]                   # pivot blocks accepted on the natural-order a-posteriori path
         res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
         assert res <= 1e-12
 

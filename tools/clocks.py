@@ -6,7 +6,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "grid_1e5"
 n, r, c, v, neg = bench.make_workload(wl)
 s = ipopt_amd.KKTSolver(use_graph=0); s.initialize_structure(n, r, c, vals=v); s.values()[:] = v
 for _ in range(3): s.multi_solve(True, np.ones(n))
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 64)()
 s.lib.mi355x_kkt_debug_clocks(s._h, out)
 o = list(out)
 print("k =", o[15])
@@ -19,3 +19,22 @@ print("front kernel (last level launched, block 0): k,m =", km // 1000, km % 100
 for a, b, name in [(4, 5, "assemble"), (5, 6, "ldlt_reg")]:
     cyc = o[2*b] - o[2*a]; wall = o[2*b+1] - o[2*a+1]
     print(f"{name:10s} shader cycles={cyc:8d} -> {wall/100:.2f} us, cycles/pivot={cyc/max(km//1000,1):.0f}")
+
+e = o[16:40]
+print("fast pivot block (block 0 of the last launch), shader cycles from entry:")
+print("  loaded+asm %d  colmax %d  factor %d" % (e[1] - e[0], e[2] - e[1], e[3] - e[2]))
+for b in range(4):
+    prev = e[2] if b == 0 else e[9 + 2 * (b - 1)]
+    print("  sub-block %d: panel done +%d, after barrier +%d (from previous)" % (b, e[8 + 2 * b] - prev, e[9 + 2 * b] - prev))
+
+g = o[32:64]
+t0 = g[0]
+print("fused group launch, group 0 of the last launch: us after role 0 started (100 MHz wall clock)")
+names = ["start", "F(q-1) seen", "solved", "S flag", "updated", "F start", "F flag", "end"]
+for q in range(4):
+    row = g[8 * q:8 * q + 8]
+    if row[0] == 0: continue
+    print("  role %d: " % q + "  ".join("%s %.1f" % (names[i], (row[i] - t0) / 100.0) for i in range(8) if row[i] >= t0))
+
+ps = o[40:48]
+print("sub-block 0, wavefront 0 (cycles): load %d  factor %d  checks %d  inverse %d  store %d | to barrier B %d, to barrier C %d" % (ps[1]-ps[0], ps[2]-ps[1], ps[3]-ps[2], ps[4]-ps[3], ps[5]-ps[4], ps[6]-ps[5], ps[7]-ps[6]))

@@ -16,3 +16,9 @@ for i in range(reps):
     t1 = time.perf_counter()
     s.solve_device2(db.data_ptr(), dx.data_ptr())
     print(f"rep {i}: status {st} factor wall {1e3 * (t1 - t0):.2f} ms (device {s.info().time_factor_ms:.2f}) solve device {s.info().time_solve_ms:.2f} ms", flush=True)
+I = s.info()
+x = dx.cpu().numpy()
+from tests.support import kktgen
+K = kktgen.to_scipy(n, r, c, v)
+res = np.abs(K @ x - 1.0).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + 1.0)
+print(f"num_neg {I.num_neg} (expected {neg}) num_two {I.num_two} num_delay {I.num_small} u_sensitive {I.u_sensitive} big fronts {I.num_big_fronts} fast pivot blocks {I.num_fast_blocks} scaled residual {res:.2e}", flush=True)
