@@ -340,10 +340,10 @@ int mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches,
 }
 
 /* development aid, not part of the public header: phase time stamps of one workgroup */
-int mi355x_kkt_debug_clocks(mi355x_kkt_handle h, unsigned long long* out64)
+int mi355x_kkt_debug_clocks(mi355x_kkt_handle h, unsigned long long* out128)
 {
     if (!h || !h->numeric_ready) return MI355X_KKT_FATAL;
-    try { return h->num->debug_clocks(out64) ? 0 : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
+    try { return h->num->debug_clocks(out128) ? 0 : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
 }
 
 // ---- multi-GPU ----

@@ -52,6 +52,7 @@ enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_L
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
 static constexpr double BK_ALPHA0 = 0.1;                 // a diagonal within this factor of its whole remaining column is taken as it comes (no partner search)
 static constexpr double PIV_PERT = 1e-10;                // replacement magnitude for a zero pivot
+static constexpr int ISG_STRIDE = 8 * 272;               // doubles per big front in DevView::isg
 static constexpr double ZERO_REL = 1e-14;                // zero-pivot test relative to the largest entry assembled into the pivot's column
 
 // ------------------------------------------------------------------------------------------------
@@ -60,10 +61,10 @@ static constexpr double ZERO_REL = 1e-14;                // zero-pivot test rela
 // per-front / per-child records in LAUNCH order: one 64-byte load replaces a chain of 4-5 dependent index loads at the
 // head of every front kernel (each of them an HBM/MALL round trip on the critical path of a tree level)
 struct FrontMeta { int s, c0, k, r0, m, aq0, aq1, ch0, ch1, alias; long long panel_off, cb_off, minv_off; int ldp, ldt;
-                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, solo, selfasm, pad2_; };
+                   long long cv, wb, gpart; int gbase, gpos, grem, gcols, split, ttab, ttab2, solo, selfasm, bigidx; };      // bigidx: the front's slot in the per-big-front arrays (isg)
 struct ChildMeta { int ch, mc, relbase, owner; long long cb_off; int ldt, aliased; long long cvbase, inv; };
 // one link of a chain group as seen from a later link of the same group (trailing update, fused solves)
-struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; long long t_off; int ldt, s, selfasm, aq0, aq1, pad_; };     // t_off/ldt: the link's trailing block (V.cb + t_off)
+struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp, r0, ch0, ch1, alias; long long t_off; int ldt, s, selfasm, aq0, aq1, bigidx; };     // t_off/ldt: the link's trailing block (V.cb + t_off)
 
 // Sync-free triangular solves along pure in-place separator chains (a run of consecutive tree levels whose fronts are all chain
 // links): ONE launch per sweep for the whole run instead of 1 (forward) / 2 (backward) launches per level.  One workgroup per link
@@ -117,6 +118,7 @@ struct DevView {
     double* cnorm;          // inf-norm of every column of the (scaled) INPUT matrix, permuted numbering: scale of the zero-pivot test
     const ChainLink* chlink; const ChainDesc* chdesc;     // chain solve tables
     int* tcnt;                                                  // per front: panel-solve workgroups finished (fused pivot block + panel solve + narrow update launch), zeroed by the prologue
+    double* isg; int* hasis;      // per big front: the four 16 x 16 diagonal-block inverses of L11 left by the blocked factorisation (hasis: valid), for the panel solves
     int* sflag_s;           // [4 * link + q]: rows of the group's link q have stored their W / L against this link (k_grp_fused)
     int* sflag_f; int* sflag_b; int* sflag_d; int* sepoch;     // (sflag_d / sepoch[2]: pivot block done, fused pivot-block + panel-solve launch)              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
@@ -966,7 +968,8 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const double av = Isb[b * 272 + l15 + (4 * u + l4) * 17];                       // X(c = l15, p = 4u + l4)
-                const double bv = (r < k) ? Lb[r + (c16 + 4 * u + l4) * ld] : 0.0;              // A21(r, p)
+                const double bl = Lb[min(r, k - 1) + min(c16 + 4 * u + l4, k - 1) * ld];       // (unconditional load, clamped: no branch per operand)
+                const double bv = (r < k && c16 + 4 * u + l4 < k) ? bl : 0.0;                    // A21(r, p)
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
             }
             bool big = false;
@@ -992,7 +995,8 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
                     const int ri = 16 * ti + l15;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const double av = (ri < k) ? Lb[ri + (c16 + 4 * t + l4) * ld] : 0.0;
+                        const double al = Lb[min(ri, k - 1) + min(c16 + 4 * t + l4, k - 1) * ld];
+                        const double av = (ri < k && c16 + 4 * t + l4 < k) ? al : 0.0;
                         const double bv = Wb[(16 * tc - c16 + l15) + (4 * t + l4) * 65];
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
                     }
@@ -1014,8 +1018,12 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
 // still slower per column than two 64-column blocks: option off by default)
 __device__ __forceinline__ void chain_signal(int* flag, const int epoch);
 __device__ __forceinline__ void chain_wait(const int* flag, const int epoch, int* err);
-template <int TS, int NT>
-__device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta& M, char* smem_raw, int* flag = nullptr, const int epoch = 0)
+// PRE: the caller has left the assembled, fully updated block in Lb (lower triangle) AND in the panel storage; late_*: a row block's L21 the
+// caller kept back in LDS, stored once the flag is up (off the critical chain)
+__device__ __forceinline__ void trsm_store_l(const DevView& V, const FrontMeta& M, const double* Lr, const int ibase, const int rlim);
+template <int TS, int NT, bool PRE = false>
+__device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta& M, char* smem_raw, int* flag = nullptr, const int epoch = 0, unsigned long long* ts = nullptr,
+                                              const double* late_Lr = nullptr, const FrontMeta& late_M = FrontMeta(), const int late_ibase = 0, const int late_rows = 0)
 {
     constexpr int G = (NT == 1024) ? 32 : 16, MAXM = G * TS;
     const int tid = threadIdx.x;
@@ -1043,7 +1051,7 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
             int* shflag = reinterpret_cast<int*>(Isb + 4 * 272);
             const int i = tid & 63, cq = tid >> 6;
             DBGT(0);
-            {   // the block (lower part in the panel storage) -> LDS, mirrored; a chain link's own A entries are added in LDS
+            if constexpr (!PRE) {   // the block (lower part in the panel storage) -> LDS, mirrored; a chain link's own A entries are added in LDS
                 double pv[16];
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; pv[e] = (i < k && c < k && i >= c) ? P[i + (size_t)c * ldp] : 0.0; }
@@ -1063,12 +1071,13 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
                 }
             }
             DBGT(1);
+            if (ts) ts[8] = clock64();
             // zero-pivot scale: the largest column scale of the block (a pivot that clears it clears its own column's)
             double cmx;
             {
                 const int c = tid >> 2, part = tid & 3;
                 double mx = 0.0;
-                if (c < k) for (int r = part; r < k; r += 4) mx = fmax(mx, fabs(Lb[r + c * ld]));
+                if (c < k) for (int r = part; r < k; r += 4) mx = fmax(mx, fabs(PRE ? Lb[max(r, c) + min(r, c) * ld] : Lb[r + c * ld]));
                 mx = fmax(mx, dpp_f64<0xB1>(mx)); mx = fmax(mx, dpp_f64<0x4E>(mx));
                 if (c < k && part == 0) mx = fmax(mx, V.cnorm[c0 + c]); else if (c >= k) mx = 0.0;
                 cmx = wave_max_all(mx);
@@ -1079,13 +1088,20 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
             const double zmax = fmax(V.small, ZERO_REL * cmx);
             const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), 0.01);
             DBGT(2);
+            if (ts) ts[9] = clock64();
             fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Isb, shflag, zmax, gmax, nneg, V.dbg);
             DBGT(3);
+            if (ts) ts[10] = clock64();
             if (fast) {
                 DBGSTAMP(1);
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; if (i < k && c < k) { const double v = (i > c) ? Lb[i + c * ld] : 0.0; P[i + (size_t)c * ldp] = v; if (i <= c) Lb[i + c * ld] = 0.0; } }
                 for (int j = tid; j < k; j += NT) { doff_s[j] = 0.0; pt_s[j] = 1; ord[j] = j; }
+                {   // the diagonal-block inverses travel with L11: the panel solves need exactly these
+                    double* Ig = V.isg + (size_t)M.bigidx * ISG_STRIDE;
+                    const int nis = ((k + 15) >> 4) * 272;
+                    for (int idx = tid; idx < nis; idx += NT) Ig[idx] = Isb[idx];
+                }
                 if (tid == 0) atomicAdd(&V.qstat[3], 1);
                 __syncthreads();
             } else if (tid == 0) atomicAdd(&V.qstat[2], 1);
@@ -1126,11 +1142,14 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
     }
     }
     for (int j = tid; j < k; j += NT) { V.dinv[c0 + j] = dinv_s[j]; V.doff[c0 + j] = doff_s[j]; V.ptype[c0 + j] = pt_s[j]; V.lperm[c0 + j] = ord[j]; }
-    if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
+    if (tid == 0) { V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall); V.hasis[s] = fast ? 1 : 0; }
 #ifdef MI355X_PIVSTAT
     if (flag && dprobe) g_dt[5] = wall_clock64();
 #endif
+    if (ts) ts[11] = clock64();
     if (flag) chain_signal(flag, epoch);        // fused launch: the panel workgroups need L11, D and the pivot order -- not the inverse below
+    if (ts) ts[12] = clock64();
+    if (late_Lr) trsm_store_l(V, late_M, late_Lr, late_ibase, late_rows);
     if (V.dbg && blockIdx.x == 0 && blockIdx.y < 4 && tid == 0) { V.dbg[32 + 8 * blockIdx.y + 6] = wall_clock64(); }
     __syncthreads();
     DBGSTAMP(2);
@@ -2056,6 +2075,7 @@ __global__ __launch_bounds__(NT) void k_bwd_chain(DevView V, int desc0, int ndes
 //   k_big_schur     T -= L21 W21^T on 64x64 tiles, v_mfma_f64_16x16x4_f64 (the frontal GEMM)
 // ================================================================================================
 typedef double v4f64 __attribute__((ext_vector_type(4)));
+typedef double double2a __attribute__((ext_vector_type(2), aligned(8)));      // two consecutive doubles, 8-byte aligned: one 16-byte access
 
 __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, int top_mode)
 {
@@ -2135,10 +2155,12 @@ __device__ __forceinline__ TrsmLds trsm_layout(char* smem_raw, const int k, cons
 static size_t trsm_lds_bytes(int k, bool staged)       // (levels with k > 64 launch the variant without the LDS copy of L11)
 {
     const size_t kp16 = (size_t)((k + 15) & ~15), ldl = kp16 | 1;
-    return (65 * kp16 + (kp16 <= 64 ? ldl * kp16 : 0) + 17 * kp16 + 2 * (size_t)k) * sizeof(double) + (size_t)(2 * k + 2) * sizeof(int) + (staged ? (size_t)65 * k * sizeof(double) : 0) + 16;
+    return (65 * kp16 + (kp16 <= 64 ? ldl * kp16 : 0) + 17 * kp16 + 2 * (size_t)k) * sizeof(double) + (size_t)(2 * k + 2) * sizeof(int) + (staged ? (size_t)65 * kp16 * sizeof(double) : 0) + 16;
 }
 template <bool STAGED_L>       // L11 staged in LDS (k <= 64) or read from L2 (the 128-column panels of the wide_panels option)
-__device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase, const int rlim = 64)      // rlim: rows of the block that are this workgroup's
+__device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta& M, const TrsmLds& T, const int ibase, const int rlim = 64, unsigned long long* ts = nullptr, const bool in_as = false, const int store_mode = 3)
+// rlim: rows of the block that are this workgroup's; ts: phase clocks (development); in_as: the caller has staged the rows in As (panel column order);
+// store_mode: bit 0 = W21 -> wbuf, bit 1 = L21 -> panel (a caller on the critical chain stores L21 later, out of T.Au: trsm_store_l)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int s = M.s, c0 = M.c0, k = M.k, m = M.m;
@@ -2153,6 +2175,15 @@ __device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta
     };
     // pivot data + L11 (written by the pivot-block workgroup / kernel)
     for (int j = tid; j < k; j += 256) { T.Ds[j] = V.dinv[c0 + j]; T.Ds[k + j] = V.doff[c0 + j]; T.Ts[j] = V.ptype[c0 + j]; T.Lp[j] = V.lperm[c0 + j]; }
+    // the diagonal-block inverses the blocked pivot-block factorisation left behind (fetched in the same batch; used when valid)
+    const int his = V.hasis[s];
+    double isv[5];
+    {
+        const double* Ig = V.isg + (size_t)M.bigidx * ISG_STRIDE;
+        const int nis = (kp16 >> 4) * 272;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int idx = tid + 256 * u; isv[u] = (idx < nis) ? Ig[idx] : 0.0; }
+    }
     if (STAGED_L) {          // one batch of independent loads (a dependent global access behind the flag costs ~2 us)
         const int i = tid & 63, cq = tid >> 6;
         double lv[16];
@@ -2161,12 +2192,31 @@ __device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta
 #pragma unroll
         for (int u = 0; u < 16; ++u) { const int c = cq + 4 * u; if (i < kp16 && c < kp16) T.Ls[i + c * ldl] = lv[u]; }
     }      // (k > 64: read through Lat() from L2)
+    if (his) {
+        const int nis = (kp16 >> 4) * 272;
+#pragma unroll
+        for (int u = 0; u < 5; ++u) { const int idx = tid + 256 * u; if (idx < nis) T.Is[idx] = isv[u]; }
+    }
     __syncthreads();
+    if (ts) ts[0] = clock64();
 #ifdef MI355X_PIVSTAT
     const bool bprobe = gridDim.x == 1 && blockIdx.y == 1 && tid == 0 && T.Au;
     if (bprobe) g_dt[10] = wall_clock64();
 #endif
-    if (T.Au && kp16 <= 64) {      // (batched: the three LDS accesses of an element are a dependent chain)
+    if (in_as) {
+        // the rows sit in As already, in PANEL column order: nothing to do behind the blocked factorisation (natural pivot order), a
+        // column permutation in place behind the strict loop
+        if (!his) {
+            const int r = tid & 63, pq = tid >> 6;
+            double av[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int p = pq + 4 * u; av[u] = (p < k) ? As[r + T.Lp[p] * 65] : 0.0; }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int p = pq + 4 * u; if (p < kp16) As[r + p * 65] = av[u]; }
+        }
+    }
+    else if (T.Au && kp16 <= 64) {      // (batched: the three LDS accesses of an element are a dependent chain)
         const int r = tid & 63, pq = tid >> 6;
         int lpv[16]; double av[16];
 #pragma unroll
@@ -2179,7 +2229,8 @@ __device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta
     else if (T.Au) { for (int idx = tid; idx < 64 * kp16; idx += 256) { const int r = idx & 63, p = idx >> 6; As[r + p * 65] = (p < k) ? T.Au[r + T.Lp[p] * 65] : 0.0; } }
     else      { for (int idx = tid; idx < 64 * kp16; idx += 256) { const int r = idx & 63, p = idx >> 6; As[r + p * 65] = (p < k && ibase + r < m) ? P[ibase + r + (size_t)T.Lp[p] * ldp] : 0.0; } }
     // inverses of the unit-lower 16 x 16 diagonal blocks: block b by wavefront b & 3, column c of the inverse by lane c
-    for (int b = wave; 16 * b < kp16; b += 4) {
+    // (only after the strict pivot loop: the blocked factorisation hands them over)
+    for (int b = wave; 16 * b < kp16 && !his; b += 4) {
         if (lane < 16) {
             const int o = 16 * b;
             double x[16];                    // x = column `lane` of the inverse; column-oriented substitution: independent updates per step
@@ -2196,6 +2247,7 @@ __device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta
         }
     }
     __syncthreads();
+    if (ts) ts[1] = clock64();
 #ifdef MI355X_PIVSTAT
     if (bprobe) g_dt[11] = wall_clock64();
 #endif
@@ -2228,25 +2280,50 @@ __device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta
         for (int g = 0; g < 4; ++g) As[r16 + l15 + (c16 + l4 + 4 * g) * 65] = w[g];
     }
     __syncthreads();
+    if (ts) ts[2] = clock64();
 #ifdef MI355X_PIVSTAT
     if (bprobe) g_dt[12] = wall_clock64();
 #endif
     // a posteriori threshold test on the rows below the pivot block (the in-block test of ldlt_reg cannot see them): a column
     // with a multiplier above 1/u is a FAILED pivot -- a delayed pivot in MA97/SSIDS, counted once per column here (num_delay)
-#pragma unroll 4
-    for (int idx = tid; idx < 64 * k; idx += 256) {
-        const int r = idx & 63, j = idx >> 6;
+    // (two consecutive rows per lane: 16-byte stores -- a CU issues stores at ~10 bytes per cycle whatever their width)
+    {
+        const int r = 2 * (tid & 31), jq = tid >> 5;
         const int i = ibase + r;
-        const int pt = Ts[j];
-        const double wj = As[r + j * 65];
-        double l;
-        if (pt == 1) l = wj * Ds[j];
-        else if (pt == 2) l = Ds[j] * wj + Ds[k + j] * As[r + (j + 1) * 65];
-        else l = Ds[k + j - 1] * As[r + (j - 1) * 65] + Ds[j] * wj;
-        if (i < m && r < rlim) {
-            W[i + (size_t)j * m] = wj; P[i + (size_t)j * ldp] = l;
-            if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
+        const bool ok0 = i < m && r < rlim, ok1 = i + 1 < m && r + 1 < rlim;
+        if (T.Au) for (int j = k + jq; j < kp16; j += 8) { T.Au[r + j * 65] = 0.0; T.Au[r + 1 + j * 65] = 0.0; }
+#pragma unroll 2
+        for (int j = jq; j < k; j += 8) {
+            const int pt = Ts[j];
+            const double w0 = As[r + j * 65], w1 = As[r + 1 + j * 65];
+            double l0, l1;
+            if (pt == 1) { l0 = w0 * Ds[j]; l1 = w1 * Ds[j]; }
+            else if (pt == 2) { l0 = Ds[j] * w0 + Ds[k + j] * As[r + (j + 1) * 65]; l1 = Ds[j] * w1 + Ds[k + j] * As[r + 1 + (j + 1) * 65]; }
+            else { l0 = Ds[k + j - 1] * As[r + (j - 1) * 65] + Ds[j] * w0; l1 = Ds[k + j - 1] * As[r + 1 + (j - 1) * 65] + Ds[j] * w1; }
+            if (T.Au) { T.Au[r + j * 65] = l0; T.Au[r + 1 + j * 65] = l1; }      // (the staging copy is dead: L21 of my rows stays in LDS for the updates that follow)
+            if (ok1) {
+                if (store_mode & 1) *reinterpret_cast<double2a*>(&W[i + (size_t)j * m]) = (double2a){w0, w1};
+                if (store_mode & 2) *reinterpret_cast<double2a*>(&P[i + (size_t)j * ldp]) = (double2a){l0, l1};
+            } else if (ok0) {
+                if (store_mode & 1) W[i + (size_t)j * m] = w0;
+                if (store_mode & 2) P[i + (size_t)j * ldp] = l0;
+            }
+            if (((ok0 && fabs(l0) * V.pivtol > 1.0) || (ok1 && fabs(l1) * V.pivtol > 1.0)) && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
         }
+    }
+    if (ts) ts[3] = clock64();
+}
+// L21 of a row block out of its LDS copy (T.Au) into the panel -- for a caller that kept it back (store_mode 1)
+__device__ __forceinline__ void trsm_store_l(const DevView& V, const FrontMeta& M, const double* Lr, const int ibase, const int rlim)
+{
+    const int tid = threadIdx.x, k = M.k, m = M.m;
+    double* P = V.L + M.panel_off;
+    const size_t ldp = (size_t)M.ldp;
+    const int r = 2 * (tid & 31), jq = tid >> 5, i = ibase + r;
+    const bool ok0 = i < m && r < rlim, ok1 = i + 1 < m && r + 1 < rlim;
+    for (int j = jq; j < k; j += 8) {
+        if (ok1) *reinterpret_cast<double2a*>(&P[i + (size_t)j * ldp]) = (double2a){Lr[r + j * 65], Lr[r + 1 + j * 65]};
+        else if (ok0) P[i + (size_t)j * ldp] = Lr[r + j * 65];
     }
 }
 template <bool WIDEK>          // WIDEK: the level has panels of more than 64 columns (wide_panels option): L11 is not staged in LDS
@@ -2988,6 +3065,7 @@ __global__ __launch_bounds__(256) void k_grp_rows(DevView V, int list_off)
 // a workgroup with a SMALLER role of the same group: with workgroups dispatched in linear order (roles are the slow grid dimension)
 // a waiting workgroup never holds up the one it waits for; the spins are bounded all the same (qstat[1]).
 // Critical path per link: pivot block -> flag -> one 64 x 64 panel solve -> one 64 x 64 x 64 update -> next pivot block.
+constexpr size_t GRP_DB_BYTES = (size_t)64 * 65 * sizeof(double);      // a pivot-row block's own pivot block, LDS-resident from the start of the launch
 __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int staged)
 {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -3002,6 +3080,10 @@ __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int 
     const int epoch = V.sepoch[2];
 #define GSTAMP(i) do { if (V.dbg && blockIdx.x == 0 && role < 4 && tid == 0) V.dbg[32 + 8 * role + (i)] = wall_clock64(); } while (0)
     GSTAMP(0);
+    unsigned long long tsv[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tsv[q] = 0ull;
+    unsigned long long* const tsp = (V.dbg && blockIdx.x == 0 && role == 1) ? tsv : nullptr;
     int kk[4], koff[5];
     koff[0] = 0;
 #pragma unroll
@@ -3010,6 +3092,30 @@ __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int 
     int myrows = min(64, tail - e0), mystart = M.gcols + e0;          // my rows, counted from the first column of the group
 #pragma unroll
     for (int j = 0; j < 4; ++j) if (j == myq) { myrows = kk[j]; mystart = koff[j]; }
+    // ---- a pivot-row block keeps its own pivot block in LDS (lower triangle) from the start: the updates of the links before it
+    //      are applied there, the factorisation at the end reads it there -- the block never makes a round trip through L2 ----
+    double* Db = reinterpret_cast<double*>(smem_raw);
+    const int ldb = myrows | 1;
+    GroupLink Gq = V.gtab[M.gbase];
+    if (myq >= 0) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) if (j == myq) Gq = V.gtab[M.gbase + j];
+        const double* Pq = V.L + Gq.panel_off;
+        const size_t ldq = (size_t)Gq.ldp;
+        const int i = tid & 63, cq = tid >> 6, kq = Gq.k;
+        double pv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; pv[e] = (i < kq && c < kq && i >= c) ? Pq[i + (size_t)c * ldq] : 0.0; }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; if (i < kq && c < kq && i >= c) Db[i + c * ldb] = pv[e]; }
+        __syncthreads();
+        if (Gq.selfasm) {
+            for (int q = Gq.aq0 + tid; q < Gq.aq1; q += 256) { const int pos = V.apos[q]; const int ii = pos % Gq.m, cc = pos / Gq.m; if (ii < kq) Db[ii + cc * ldb] += V.aval[q]; }
+            __syncthreads();
+        }
+    }
+    char* tsm = smem_raw + GRP_DB_BYTES;
+    const double* crit_Lr = nullptr; FrontMeta crit_Mp = M; int crit_ibase = 0;      // the kept-back L21 of the last link before my pivot block
     for (int p = 0; p <= last_p; ++p) {
         const GroupLink G = V.gtab[M.gbase + p];
         const int k = G.k, m = G.m;
@@ -3019,25 +3125,38 @@ __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int 
         const int ibase = k + (mystart - kend);                       // my first row in this link's front
         double* P = V.L + G.panel_off;
         const size_t ldp = (size_t)G.ldp;
-        if (G.selfasm) {
+        FrontMeta Mp = M;
+        Mp.s = G.s; Mp.c0 = G.c0; Mp.k = k; Mp.m = m; Mp.panel_off = G.panel_off; Mp.ldp = G.ldp; Mp.wb = G.wb;
+        const TrsmLds T = trsm_layout(tsm, k, staged != 0);           // (levels with hundreds of groups: no staging copy, more workgroups per CU)
+        Mp.bigidx = G.bigidx;
+        if (staged) {
+            // my rows as they lie in the panel (and the link's own A entries for them) go to LDS before the pivot block is known --
+            // straight into the working block: behind the blocked factorisation the pivot order is the panel's column order
+            for (int idx = tid; idx < 64 * T.kp16; idx += 256) { const int r = idx & 63, c = idx >> 6; T.As[r + c * 65] = (c < k && r < myrows && ibase + r < m) ? P[ibase + r + (size_t)c * ldp] : 0.0; }
+            if (G.selfasm) {
+                __syncthreads();
+                for (int q = G.aq0 + tid; q < G.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + myrows) T.As[(i - ibase) + c * 65] += V.aval[q]; }
+            }
+        } else if (G.selfasm) {
             for (int q = G.aq0 + tid; q < G.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + myrows) P[i + (size_t)c * ldp] += V.aval[q]; }
             __syncthreads();
         }
-        FrontMeta Mp = M;
-        Mp.s = G.s; Mp.c0 = G.c0; Mp.k = k; Mp.m = m; Mp.panel_off = G.panel_off; Mp.ldp = G.ldp; Mp.wb = G.wb;
-        const TrsmLds T = trsm_layout(smem_raw, k, staged != 0);      // (levels with hundreds of groups: no staging copy, two workgroups per CU)
-        if (staged) for (int idx = tid; idx < 64 * k; idx += 256) { const int r = idx & 63, c = idx >> 6; T.Au[r + c * 65] = (r < myrows && ibase + r < m) ? P[ibase + r + (size_t)c * ldp] : 0.0; }
-        chain_wait(&V.sflag_d[G.s], epoch, V.qstat + 1);              // L11, D and the pivot order of link p are stored
+        const bool crit = staged && myq >= 0 && p == last_p;          // the link before my own pivot block: L21 of my rows goes to the panel AFTER my pivot block
+        if (crit) { crit_Lr = T.Au; crit_Mp = Mp; crit_ibase = ibase; }
+        chain_wait(&V.sflag_d[G.s], epoch, V.qstat + 1);              // L11, D, the pivot order (and the diagonal-block inverses) of link p are stored
         if (p == last_p) GSTAMP(1);
-        trsm_rows_impl<true>(V, Mp, T, ibase, myrows);
+        if (tsp) tsp[4] = clock64();
+        trsm_rows_impl<true>(V, Mp, T, ibase, myrows, tsp, staged != 0, crit ? 1 : 3);
         if (p == last_p) GSTAMP(2);
         if (myq >= 0) chain_signal(&V.sflag_s[4 * G.s + myq], epoch); // W(my rows, p) and L(my rows, p) are stored: the blocks after me may use them
         else __syncthreads();
         if (p == last_p) GSTAMP(3);
+        if (tsp) tsp[5] = clock64();
         // my rows' entries in the columns of the later links:  T(i, c) -= sum_q L21(i, q) W21(c, q)
         {
-            const double* Ds = T.Ds; const int* Ts = T.Ts; const double* As = T.As;
+            const double* Ds = T.Ds; const int* Ts = T.Ts; const double* As = T.As; const double* Lr = T.Au;
             auto lval = [&](const int r, const int q) -> double {
+                if (Lr) return Lr[r + q * 65];                        // (kept by the panel solve)
                 const int pt = Ts[q];
                 const double wq = As[r + q * 65];
                 if (pt == 1) return wq * Ds[q];
@@ -3045,65 +3164,105 @@ __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int 
                 return Ds[k + q - 1] * As[r + (q - 1) * 65] + Ds[q] * wq;
             };
             const int kp16 = T.kp16;
-            double bv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { const int qq = 4 * u + l4; bv[u] = (qq < k) ? lval(16 * wave + l15, qq) : 0.0; }
-            double* Tt = V.cb + G.t_off;
-            const size_t ldt = (size_t)G.ldt;
-            const int irow = (mystart - kend) + 16 * wave + l15;      // my row in T
-            const bool rowok = 16 * wave + l15 < myrows;
             const int rmax = (myq >= 0) ? myq : g - 1;
-            for (int r = p + 1; r <= rmax; ++r) {
-                int cs = 0, cn = 0;                                   // columns of link r, counted from the first column after link p
+            // (a) the columns of OTHER links: W21 of their pivot rows comes from their row blocks (global), the target lives in L2
+            if ((myq >= 0) ? (myq > p + 1) : (g - 1 > p)) {
+                double bv[16];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (j == r) { cs = koff[j] - kend; cn = kk[j]; }
-                if (r != myq) chain_wait(&V.sflag_s[4 * G.s + r], epoch, V.qstat + 1);
-                const double* Wg = V.wbuf + G.wb + k + cs;            // W21 rows of link r's pivots
-                const int nct = (cn + 15) >> 4;
-                for (int tc = 0; tc < nct; tc += 2) {
-                    double a0[16], a1[16];
-                    const int ra = 16 * tc + l15, rb = ra + 16;
+                for (int u = 0; u < 16; ++u) { const int qq = 4 * u + l4; bv[u] = (qq < k) ? lval(16 * wave + l15, qq) : 0.0; }
+                double* Tt = V.cb + G.t_off;
+                const size_t ldt = (size_t)G.ldt;
+                const int irow = (mystart - kend) + 16 * wave + l15;  // my row in T
+                const bool rowok = 16 * wave + l15 < myrows;
+                for (int r = p + 1; r <= rmax; ++r) {
+                    if (r == myq) continue;
+                    int cs = 0, cn = 0;                               // columns of link r, counted from the first column after link p
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int qq = 4 * u + l4;
-                        a0[u] = (ra < cn && qq < k) ? Wg[ra + (size_t)qq * m] : 0.0;
-                        a1[u] = (rb < cn && qq < k) ? Wg[rb + (size_t)qq * m] : 0.0;
-                    }
-                    double t0[4], t1[4];
+                    for (int j = 0; j < 4; ++j) if (j == r) { cs = koff[j] - kend; cn = kk[j]; }
+                    chain_wait(&V.sflag_s[4 * G.s + r], epoch, V.qstat + 1);
+                    const double* Wg = V.wbuf + G.wb + k + cs;        // W21 rows of link r's pivots
+                    const int nct = (cn + 15) >> 4;
+                    for (int tc = 0; tc < nct; tc += 2) {
+                        double a0[16], a1[16];
+                        const int ra = 16 * tc + l15, rb = ra + 16;
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const int c = 16 * tc + l4 + 4 * gg;
-                        t0[gg] = (rowok && c < cn) ? Tt[irow + (size_t)(cs + c) * ldt] : 0.0;
-                        t1[gg] = (rowok && c + 16 < cn) ? Tt[irow + (size_t)(cs + c + 16) * ldt] : 0.0;
-                    }
-                    v4f64 c0v = (v4f64){0.0, 0.0, 0.0, 0.0}, c1v = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int u = 0; u < 16; ++u)
-                        if (4 * u < kp16) {
-                            c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bv[u], c0v, 0, 0, 0);
-                            c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bv[u], c1v, 0, 0, 0);
+                        for (int u = 0; u < 16; ++u) {
+                            const int qq = 4 * u + l4;
+                            a0[u] = (ra < cn && qq < k) ? Wg[ra + (size_t)qq * m] : 0.0;
+                            a1[u] = (rb < cn && qq < k) ? Wg[rb + (size_t)qq * m] : 0.0;
                         }
+                        double t0[4], t1[4];
 #pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const int c = 16 * tc + l4 + 4 * gg;
-                        if (rowok && c < cn) Tt[irow + (size_t)(cs + c) * ldt] = t0[gg] - c0v[gg];
-                        if (rowok && c + 16 < cn) Tt[irow + (size_t)(cs + c + 16) * ldt] = t1[gg] - c1v[gg];
+                        for (int gg = 0; gg < 4; ++gg) {
+                            const int c = 16 * tc + l4 + 4 * gg;
+                            t0[gg] = (rowok && c < cn) ? Tt[irow + (size_t)(cs + c) * ldt] : 0.0;
+                            t1[gg] = (rowok && c + 16 < cn) ? Tt[irow + (size_t)(cs + c + 16) * ldt] : 0.0;
+                        }
+                        v4f64 c0v = (v4f64){0.0, 0.0, 0.0, 0.0}, c1v = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int u = 0; u < 16; ++u)
+                            if (4 * u < kp16) {
+                                c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bv[u], c0v, 0, 0, 0);
+                                c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bv[u], c1v, 0, 0, 0);
+                            }
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) {
+                            const int c = 16 * tc + l4 + 4 * gg;
+                            if (rowok && c < cn) Tt[irow + (size_t)(cs + c) * ldt] = t0[gg] - c0v[gg];
+                            if (rowok && c + 16 < cn) Tt[irow + (size_t)(cs + c + 16) * ldt] = t1[gg] - c1v[gg];
+                        }
                     }
                 }
             }
+            if (tsp) tsp[6] = clock64();
+            // (b) my OWN pivot block: both operands and the target are in LDS (lower 16 x 16 tiles, v_mfma_f64_16x16x4_f64; a lone
+            //     wavefront issues one per ~150 cycles -- the same 1024 FMAs as 16 v_fmac_f64 take ~105, but those would want 8 LDS
+            //     operands per step instead of 2: measured slower, tools/micro/fma_lds_latency.hip).  All 16 operand pairs of a tile
+            //     are requested before its first MFMA.
+            if (myq >= 0) {
+                const int nt = (myrows + 15) >> 4;
+                if (tsp) tsp[13] = clock64();
+                int q = 0;
+                for (int tc = 0; tc < nt; ++tc)
+                    for (int ti = tc; ti < nt; ++ti, ++q) {
+                        if ((q & 3) != wave) continue;
+                        double av[16], bw[16];
+                        v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
+                        if (Lr && kp16 == 64) {      // (straight-line: both LDS blocks are zero beyond column k)
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) { av[u] = Lr[(16 * ti + l15) + (4 * u + l4) * 65]; bw[u] = As[(16 * tc + l15) + (4 * u + l4) * 65]; }
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bw[u], acc, 0, 0, 0);
+                        } else {
+                            for (int u = 0; 4 * u < kp16; ++u) {
+                                const int qq = 4 * u + l4;
+                                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((qq < k) ? lval(16 * ti + l15, qq) : 0.0, (qq < k) ? As[(16 * tc + l15) + qq * 65] : 0.0, acc, 0, 0, 0);
+                            }
+                        }
+                        const int cc = 16 * tc + l15;
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) { const int rr = 16 * ti + l4 + 4 * gg; if (rr < myrows && cc < myrows && rr >= cc) Db[rr + cc * ldb] -= acc[gg]; }
+                    }
+                if (tsp) tsp[14] = clock64();
+            }
         }
         __syncthreads();
+        if (tsp) tsp[7] = clock64();
         if (p == last_p) GSTAMP(4);
     }
     if (myq < 0) return;
-    {   // my own pivot block
-        GroupLink G = V.gtab[M.gbase];
+    {   // my own pivot block: a copy goes to the panel storage (the strict fall-back reads it there), then the factorisation in place
+        double* Pq = V.L + Gq.panel_off;
+        const size_t ldq = (size_t)Gq.ldp;
+        const int i = tid & 63, cq = tid >> 6, kq = Gq.k;
 #pragma unroll
-        for (int j = 1; j < 4; ++j) if (j == myq) G = V.gtab[M.gbase + j];
+        for (int e = 0; e < 16; ++e) { const int c = cq + 4 * e; if (i < kq && c < kq && i >= c) Pq[i + (size_t)c * ldq] = Db[i + c * ldb]; }
         FrontMeta Mq = M;
-        Mq.s = G.s; Mq.c0 = G.c0; Mq.k = G.k; Mq.m = G.m; Mq.panel_off = G.panel_off; Mq.ldp = G.ldp; Mq.wb = G.wb; Mq.minv_off = G.minv_off;
-        Mq.selfasm = G.selfasm; Mq.aq0 = G.aq0; Mq.aq1 = G.aq1;
-        big_diag_body<4, 256>(V, Mq, smem_raw, &V.sflag_d[G.s], epoch);
+        Mq.s = Gq.s; Mq.c0 = Gq.c0; Mq.k = Gq.k; Mq.m = Gq.m; Mq.panel_off = Gq.panel_off; Mq.ldp = Gq.ldp; Mq.wb = Gq.wb; Mq.minv_off = Gq.minv_off;
+        Mq.selfasm = 0; Mq.aq0 = Gq.aq0; Mq.aq1 = Gq.aq1; Mq.bigidx = Gq.bigidx;      // (the A entries are in already)
+        __syncthreads();
+        big_diag_body<4, 256, true>(V, Mq, smem_raw, &V.sflag_d[Gq.s], epoch, tsp, crit_Lr, crit_Mp, crit_ibase, myrows);
+        if (tsp && tid == 0) { for (int q = 0; q < 16; ++q) V.dbg[64 + q] = tsp[q]; }
         GSTAMP(7);
     }
 #undef GSTAMP
@@ -3783,6 +3942,8 @@ public:
             if (opt.verbose) { int nl = 0; for (auto& sg : chain_segs) nl += sg.lv1 - sg.lv0 + 1; fprintf(stderr, "[mi355x_kkt] sync-free chain sweeps: %d segments covering %d of %d levels\n", (int)chain_segs.size(), nl, Sy.num_levels); }
         }
         if (!upload(chl, &V.chlink) || !upload(chd, &V.chdesc)) return false;
+        std::vector<int> bigidx_of(Sy.num_sn, 0);
+        { int nbig = 0; for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG) bigidx_of[sn] = nbig++; }
         // chain-group tables: for every BIG front the links of its group up to and including itself
         std::vector<GroupLink> gt;
         std::vector<int> gbase_of(Sy.num_sn, 0), gcols_of(Sy.num_sn, 0);
@@ -3798,7 +3959,7 @@ public:
                 G.panel_off = Sy.panel_off[l]; G.wb = Sy.wb_off[l]; G.minv_off = Sy.minv_off[l]; G.cv = Sy.cv_off[l]; G.tr = troff[l];
                 G.c0 = Sy.sn_colptr[l]; G.k = Sy.sn_colptr[l + 1] - G.c0; G.r0 = Sy.sn_rowptr[l]; G.m = Sy.sn_rowptr[l + 1] - G.r0;
                 G.ldp = Sy.sn_ldp[l]; G.ch0 = Sy.child_ptr[l]; G.ch1 = Sy.child_ptr[l + 1]; G.alias = Sy.alias_child[l] >= 0 ? 1 : 0;
-                G.t_off = Sy.cb_off[l]; G.ldt = Sy.sn_ldt[l]; G.s = l; G.aq0 = Sy.acolptr[G.c0]; G.aq1 = Sy.acolptr[G.c0 + G.k]; G.pad_ = 0;
+                G.t_off = Sy.cb_off[l]; G.ldt = Sy.sn_ldt[l]; G.s = l; G.aq0 = Sy.acolptr[G.c0]; G.aq1 = Sy.acolptr[G.c0 + G.k]; G.bigidx = bigidx_of[l];
                 G.selfasm = ((!multi || aoff[l] < 0) && getenv("MI355X_KKT_NO_SELFASM") == nullptr && Sy.alias_child[l] >= 0 && Sy.child_ptr[l + 1] - Sy.child_ptr[l] == 1) ? 1 : 0;
                 gt.push_back(G); gcols_of[sn] += G.k;
             }
@@ -3970,7 +4131,7 @@ public:
             M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
             M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.ttab = ttab_of[sn]; M.ttab2 = ttab2_of[sn];
             // (multi-GPU: not for a front at a subtree join -- its square comes out of the all-reduced arena)
-            M.selfasm = ((!multi || aoff[sn] < 0) && selfasm_on && Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1) ? 1 : 0; M.pad2_ = 0;
+            M.selfasm = ((!multi || aoff[sn] < 0) && selfasm_on && Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1) ? 1 : 0; M.bigidx = bigidx_of[sn];
             {   // 1: in-place chain link whose only child is the chain child, 2: no children at all => the fused forward kernel applies
                 const int nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
                 M.solo = (Sy.alias_child[sn] >= 0 && nch == 1) ? 1 : ((Sy.alias_child[sn] < 0 && nch == 0) ? 2 : 0);
@@ -4002,6 +4163,11 @@ public:
             }
         }
         if (!upload(relinv, &V.relinv)) return false;
+        {   // per big front: room for the 16 x 16 diagonal-block inverses of its L11 (ISG_STRIDE doubles each, slot FrontMeta::bigidx)
+            long long nbig = 0;
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG) ++nbig;
+            if (!dalloc(&V.isg, (size_t)std::max<long long>(nbig * ISG_STRIDE, 1)) || !dalloc(&V.hasis, Sy.num_sn)) return false;
+        }
         lap("host-side schedules and tables");
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
@@ -4026,7 +4192,7 @@ public:
         else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
-        if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 64)) return false; }
+        if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 128)) return false; }
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
         // allow the large dynamic LDS sizes
@@ -4158,7 +4324,7 @@ public:
         if (b1 == b0) return true;
         if (grp_fused) {
             const int st = (b1 - b0) * (4 + grp_nrb[lv]) <= 256 ? 1 : 0;
-            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + grp_nrb[lv]), dim3(256), std::max(diag_lds_bytes(64, 64), trsm_lds_bytes(64, st != 0)), stream, V, b0, st);
+            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + grp_nrb[lv]), dim3(256), std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0)), stream, V, b0, st);
         } else {
             LAUNCH(KK_BIG_DIAG, k_grp_diag, dim3(b1 - b0), dim3(512), grp_lds_bytes(), stream, (const DevView*)d_view, b0);
             if (grp_nrb[lv] > 0) LAUNCH(KK_BIG_TRSM, k_grp_rows, dim3(grp_nrb[lv], b1 - b0), dim3(256), trsm_lds_bytes(64, false), stream, V, b0);
@@ -4749,7 +4915,7 @@ public:
     bool debug_clocks(unsigned long long* out) {
         DeviceGuard guard(dev);
         if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
-        HIPCHK(hipMemcpy(out, V.dbg, 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out, V.dbg, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 #ifdef MI355X_PIVSTAT
         unsigned long long ps[16]; HIPCHK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pivstat), sizeof ps));
         unsigned long long fs[32]; HIPCHK(hipMemcpyFromSymbol(fs, HIP_SYMBOL(g_fstat), sizeof fs));

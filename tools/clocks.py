@@ -6,7 +6,7 @@ wl = sys.argv[1] if len(sys.argv) > 1 else "grid_1e5"
 n, r, c, v, neg = bench.make_workload(wl)
 s = ipopt_amd.KKTSolver(use_graph=0); s.initialize_structure(n, r, c, vals=v); s.values()[:] = v
 for _ in range(3): s.multi_solve(True, np.ones(n))
-out = (C.c_ulonglong * 64)()
+out = (C.c_ulonglong * 128)()
 s.lib.mi355x_kkt_debug_clocks(s._h, out)
 o = list(out)
 print("k =", o[15])
@@ -38,3 +38,13 @@ for q in range(4):
 
 ps = o[40:48]
 print("sub-block 0, wavefront 0 (cycles): load %d  factor %d  checks %d  inverse %d  store %d | to barrier B %d, to barrier C %d" % (ps[1]-ps[0], ps[2]-ps[1], ps[3]-ps[2], ps[4]-ps[3], ps[5]-ps[4], ps[6]-ps[5], ps[7]-ps[6]))
+
+r = o[64:80]
+if r[4]:
+    base = r[4]
+    names = {4: "flag seen", 0: "L11/D/Is loaded", 1: "rows permuted (+inverses)", 2: "substitution done", 3: "W/L stored", 5: "S flag raised", 6: "other links' columns updated", 7: "own block updated",
+             8: "pivot block: entered colmax", 9: "colmax done", 10: "blocked LDL^T done", 11: "L11 / D / Is written", 12: "F flag raised"}
+    print("role 1 of group 0 (last launch), last link: shader cycles after the pivot-block flag was seen")
+    names.update({13: "own block: tile decoded", 14: "own block: products done", 15: "own block: written"})
+    for i in (4, 0, 1, 2, 3, 5, 6, 13, 14, 15, 7, 8, 9, 10, 11, 12):
+        print("  %-34s %8d" % (names[i], r[i] - base))
