@@ -18,6 +18,7 @@ struct mi355x_kkt_handle_s {
     Symbolic sym;
     Numeric* num = nullptr;
     bool analysed = false, numeric_ready = false, factored = false;
+    bool stats_stale = false;      // the scaling mode / factors changed since the factorisation `last` describes: its u_sensitive verdict no longer applies
     FactorStats last;
     std::string err;
     std::vector<double> host_vals_nodev;   // plain host staging buffer handed out when no device exists (values only, never computed on)
@@ -97,7 +98,7 @@ static int do_factor(mi355x_kkt_handle h, const double* dvals, bool reuse, int* 
         if (h->sym.n == 0) { h->last = FactorStats(); h->factored = true; if (num_neg) *num_neg = 0; if (num_zero) *num_zero = 0; return MI355X_KKT_SUCCESS; }
         FactorStats st;
         if (!h->num->factor(dvals, reuse, st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
-        h->last = st; h->factored = true;
+        h->last = st; h->factored = true; h->stats_stale = false;
         if (num_neg) *num_neg = st.num_neg;
         if (num_zero) *num_zero = st.num_zero;
         return st.num_zero > 0 ? MI355X_KKT_SINGULAR : MI355X_KKT_SUCCESS;
@@ -112,7 +113,7 @@ int mi355x_kkt_set_scaling(mi355x_kkt_handle h, int mode, const double* user_fac
 {
     if (!h) return MI355X_KKT_FATAL;
     if (!h->numeric_ready) { h->opts.scaling = mode == 2 ? 1 : mode; h->err = "set_scaling: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
-    try { if (!h->num->set_scaling(mode, user_factors)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } h->opts.scaling = mode; return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+    try { if (!h->num->set_scaling(mode, user_factors)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } h->opts.scaling = mode; h->stats_stale = true; return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
 int mi355x_kkt_get_scaling(mi355x_kkt_handle h, double* out)
 {
@@ -199,7 +200,7 @@ int mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const 
     try {
         FactorStats st;
         if (!h->num->factor_assembled(scale, shift, st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
-        h->last = st; h->factored = true;
+        h->last = st; h->factored = true; h->stats_stale = false;
         if (num_neg) *num_neg = st.num_neg;
         if (num_zero) *num_zero = st.num_zero;
         return st.num_zero > 0 ? MI355X_KKT_SINGULAR : MI355X_KKT_SUCCESS;
@@ -282,7 +283,7 @@ int mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u)
     if (!h) return 0;
     const double umax = h->opts.pivtolmax > h->opts.pivtol ? h->opts.pivtolmax : h->opts.pivtol;
     if (h->opts.pivtol >= umax) return 0;
-    if (h->factored && !h->last.u_sensitive) return 0;
+    if (h->factored && !h->stats_stale && !h->last.u_sensitive) return 0;
     double u = std::pow(h->opts.pivtol, 0.75);
     if (u > umax) u = umax;
     h->opts.pivtol = u;
@@ -371,7 +372,7 @@ int mi355x_kkt_factor_top(mi355x_kkt_handle h, int* nneg, int* nzero)
 {
     MG_GUARD
     try { FactorStats st; if (!h->num->factor_top(st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
-          h->last = st; h->factored = true; if (nneg) *nneg = st.num_neg; if (nzero) *nzero = st.num_zero; return 0; } catch (...) { return MI355X_KKT_FATAL; }
+          h->last = st; h->factored = true; h->stats_stale = false; if (nneg) *nneg = st.num_neg; if (nzero) *nzero = st.num_zero; return 0; } catch (...) { return MI355X_KKT_FATAL; }
 }
 int mi355x_kkt_solve_fwd_local(mi355x_kkt_handle h, double* d) { MG_GUARD try { if (!h->num->solve_fwd_local(d)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
 int mi355x_kkt_top_rhs(mi355x_kkt_handle h, double** d, int64_t* nd) { MG_GUARD try { if (!h->num->top_rhs(d, nd)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }

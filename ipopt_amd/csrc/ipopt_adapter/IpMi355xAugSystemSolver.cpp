@@ -122,6 +122,13 @@ bool Mi355xAugSystemSolver::InitializeImpl(const OptionsList& options, const std
       structured_ = false;
       analysed_ = false;
       pd_defined_ = false;
+      // a new handle starts without a primal-dual workspace REQUEST as well: the dimensions and bound positions of the previous NLP
+      // (ReOptimizeTNLP with changed bounds, an AlgorithmBuilder reused for another problem) must not define the new workspace
+      pd_wanted_ = false;
+      for( int q = 0; q < 4; ++q )
+      {
+         pd_idx_[q].clear();
+      }
    }
    else
    {
@@ -511,7 +518,7 @@ void Mi355xAugSystemSolver::WantPrimalDualWorkspace(const Index dims[8], const I
    {
       pd_idx_[q].assign(src[q], src[q] + dims[4 + q]);
    }
-   if( analysed_ && !pd_defined_ )     // the analysis has already happened (least-square multipliers come first)
+   if( analysed_ )     // the analysis has already happened (least-square multipliers come first): (re)define now -- pd_define frees an old workspace
    {
       DefinePrimalDualWorkspace();
    }

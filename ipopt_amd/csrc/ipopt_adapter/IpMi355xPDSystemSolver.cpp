@@ -402,6 +402,16 @@ bool Mi355xPDSystemSolver::Solve(Number alpha, Number beta, const IteratesVector
          refactor_with_new_pivtol = false;
          treat_as_singular = false;
       }
+      else
+      {
+         // no solve precedes the first residual: bring the device-side sources (W, J_c, J_d, Sigma) and the factorisation up to the CURRENT
+         // iterate first -- what was assembled last may belong to an earlier iterate or to a least-square / restoration call (W_factor = 0);
+         // nothing is uploaded or factored if nothing has changed since
+         Number dx, ds, dc, dd;
+         pert_->CurrentPerturbation(dx, ds, dc, dd);
+         solved = aug_->Factorize(GetRawPtr(D.W), 1.0, GetRawPtr(D.sigma_x), dx, GetRawPtr(D.sigma_s), ds, GetRawPtr(D.J_c), NULL, dc,
+                                  GetRawPtr(D.J_d), NULL, dd, false, 0) == SYMSOLVER_SUCCESS;
+      }
       improve_solution = false;
       if( !solved )
       {

@@ -10,13 +10,17 @@
 #include <cstdio>
 #include <string>
 #include <unistd.h>
+#include <fcntl.h>
+#include <ctime>
+#include <sys/stat.h>
+#include <sys/types.h>
 
 namespace Ipopt
 {
 
 Mi355xSolverInterface::Mi355xSolverInterface()
    : handle_(NULL), dim_(0), nonzeros_(0), ia_(NULL), ja_(NULL), analysed_(false), pivtol_changed_(false),
-     warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1), nranks_opt_(0), rank_opt_(-1), comm_ready_(false)
+     warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1), nranks_opt_(0), rank_opt_(-1), comm_ready_(false), comm_generation_(0)
 {
    mi355x_kkt_default_options(&kopts_);
 }
@@ -128,6 +132,24 @@ void Mi355xSolverInterface::ReadNumericOptions(const OptionsList& options, const
 bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std::string& prefix)
 {
    ReadNumericOptions(options, prefix, kopts_, pivtol_, pivtolmax_);
+   {
+      // mi355x_outer_scaling: the host scales through its TSymScalingMethod hook INSTEAD of the backend -- never both
+      std::string osv;
+      bool outer = no_internal_scaling_;
+      try
+      {
+         if( options.GetStringValue("mi355x_outer_scaling", osv, prefix) )
+         {
+            outer = outer || osv != "no";
+         }
+      }
+      catch( ... )
+      { }
+      if( outer )
+      {
+         kopts_.scaling = 0;
+      }
+   }
    try
    {
       Index iv;
@@ -390,31 +412,87 @@ ESymSolverStatus Mi355xSolverInterface::DetermineDependentRows(const Index* /*ia
    return SYMSOLVER_SUCCESS;
 }
 
+// Rendez-vous of the ranks of one job: rank 0 creates the ncclUniqueId and hands it to the others through a small file.
+//   * the record is {magic, job tag, generation, id}: the job tag comes from the launcher's environment (MI355X_KKT_JOB_ID, or torchrun's
+//     TORCHELASTIC_RUN_ID / MASTER_PORT, or SLURM_JOB_ID), the generation counts the communicators this process has set up (every rank
+//     sets them up in the same order) -- a reader only accepts the record of ITS job and ITS generation, a file left behind by an earlier
+//     run or by the previous set-up of the same run is ignored (and, without a launcher tag, so is any file older than this process);
+//   * rank 0 unlinks whatever is there first, writes a private temporary (O_EXCL, 0600) and renames it into place; it removes the file
+//     again once ncclCommInitRank has returned, i.e. once every rank has read it;
+//   * default location: a per-user directory (0700) under $XDG_RUNTIME_DIR or /tmp, not a fixed world-writable name.
+namespace
+{
+struct CommRecord
+{
+   unsigned int magic, generation;
+   unsigned long long job;
+   unsigned char id[128];
+};
+const unsigned int COMM_MAGIC = 0x4b4b4d49u;      // "IMKK"
+
+unsigned long long comm_job_tag()
+{
+   const char* names[4] = {"MI355X_KKT_JOB_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "MASTER_PORT"};
+   for( int q = 0; q < 4; ++q )
+   {
+      const char* e = getenv(names[q]);
+      if( e && *e )
+      {
+         unsigned long long h = 1469598103934665603ull;      // FNV-1a of "<name>=<value>"
+         for( const char* c = names[q]; *c; ++c ) { h = (h ^ (unsigned char) *c) * 1099511628211ull; }
+         for( const char* c = e; *c; ++c ) { h = (h ^ (unsigned char) *c) * 1099511628211ull; }
+         return h ? h : 1ull;
+      }
+   }
+   return 0ull;      // no launcher tag: readers fall back to "not older than this process"
+}
+
+std::string comm_default_path(unsigned long long job)
+{
+   const char* rt = getenv("XDG_RUNTIME_DIR");
+   char buf[64];
+   snprintf(buf, sizeof(buf), "/mi355x_kkt_%u", (unsigned) getuid());
+   const std::string dir = std::string((rt && *rt) ? rt : "/tmp") + buf;
+   (void) mkdir(dir.c_str(), 0700);
+   snprintf(buf, sizeof(buf), "/comm_id_%016llx", job);
+   return dir + buf;
+}
+const time_t g_process_start = time(NULL);
+}
+
 bool Mi355xSolverInterface::SetupCommunicator()
 {
-   // rank 0 creates the ncclUniqueId and publishes it through a file (write + rename = atomic); the others poll for it
-   unsigned char id[128];
-   const std::string path = comm_file_.empty() ? std::string("/tmp/mi355x_kkt_comm_id") : comm_file_;
+   CommRecord rec;
+   memset(&rec, 0, sizeof(rec));
+   const unsigned long long job = comm_job_tag();
+   const unsigned int generation = ++comm_generation_;
+   const std::string path = comm_file_.empty() ? comm_default_path(job) : comm_file_;
    if( kopts_.rank == 0 )
    {
-      if( mi355x_kkt_comm_unique_id(id) != MI355X_KKT_SUCCESS )
+      if( mi355x_kkt_comm_unique_id(rec.id) != MI355X_KKT_SUCCESS )
       {
          Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: could not create the RCCL unique id (librccl.so not loadable?)\n");
          return false;
       }
       if( kopts_.nranks > 1 )
       {
-         const std::string tmp = path + ".tmp";
-         FILE* f = fopen(tmp.c_str(), "wb");
-         if( !f || fwrite(id, 1, sizeof(id), f) != sizeof(id) )
+         rec.magic = COMM_MAGIC; rec.generation = generation; rec.job = job;
+         char sfx[48];
+         snprintf(sfx, sizeof(sfx), ".tmp.%ld.%u", (long) getpid(), generation);
+         const std::string tmp = path + sfx;
+         (void) unlink(path.c_str());                       // whatever an earlier run or set-up left behind
+         (void) unlink(tmp.c_str());
+         const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
+         if( fd < 0 || write(fd, &rec, sizeof(rec)) != (ssize_t) sizeof(rec) )
          {
             Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: cannot write %s\n", tmp.c_str());
-            if( f ) fclose(f);
+            if( fd >= 0 ) close(fd);
             return false;
          }
-         fclose(f);
+         close(fd);
          if( rename(tmp.c_str(), path.c_str()) != 0 )
          {
+            (void) unlink(tmp.c_str());
             return false;
          }
       }
@@ -424,11 +502,19 @@ bool Mi355xSolverInterface::SetupCommunicator()
       bool got = false;
       for( int tries = 0; tries < 6000 && !got; ++tries )   // up to 10 minutes: rank 0 may still be in its (longer) start-up
       {
+         struct stat sb;
          FILE* f = fopen(path.c_str(), "rb");
          if( f )
          {
-            got = fread(id, 1, sizeof(id), f) == sizeof(id);
+            CommRecord in;
+            const bool whole = fread(&in, 1, sizeof(in), f) == sizeof(in);
+            const bool fresh = job != 0ull || (fstat(fileno(f), &sb) == 0 && sb.st_mtime + 30 >= g_process_start);
             fclose(f);
+            if( whole && fresh && in.magic == COMM_MAGIC && in.job == job && in.generation == generation )
+            {
+               rec = in;
+               got = true;
+            }
          }
          if( !got )
          {
@@ -437,14 +523,18 @@ bool Mi355xSolverInterface::SetupCommunicator()
       }
       if( !got )
       {
-         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: rank %d never saw the communicator id file %s\n", kopts_.rank, path.c_str());
+         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: rank %d never saw generation %u of the communicator id file %s\n", kopts_.rank, generation, path.c_str());
          return false;
       }
    }
-   if( mi355x_kkt_set_comm_rccl(handle_, id) != MI355X_KKT_SUCCESS )
+   if( mi355x_kkt_set_comm_rccl(handle_, rec.id) != MI355X_KKT_SUCCESS )
    {
       Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_set_comm_rccl failed: %s\n", mi355x_kkt_last_error(handle_));
       return false;
+   }
+   if( kopts_.rank == 0 && kopts_.nranks > 1 )
+   {
+      (void) unlink(path.c_str());                          // ncclCommInitRank has returned: every rank has read the record
    }
    comm_ready_ = true;
    Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X: rank %d of %d joined the RCCL communicator (device %d)\n", kopts_.rank, kopts_.nranks, kopts_.device);
@@ -497,6 +587,8 @@ SmartPtr<SymLinearSolver> Mi355xAlgorithmBuilder::SymLinearSolverFactory(const J
    { }
    if( outer )
    {
+      // "instead of inside the backend": once linear_scaling_on_demand switches the outer scaling on, the backend must not scale a second time
+      static_cast<Mi355xSolverInterface*>(GetRawPtr(iface))->DisableInternalScaling();
       scaling = new Mi355xTSymScalingMethod(matching);
    }
    return new TSymLinearSolver(iface, scaling);

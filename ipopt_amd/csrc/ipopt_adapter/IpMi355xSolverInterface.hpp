@@ -36,6 +36,12 @@ public:
                                bool check_NegEVals, Index numberOfNegEVals);
    Index NumberOfNegEVals() const;
    bool IncreaseQuality();
+   /** The host scales OUTSIDE the backend (mi355x_outer_scaling: Mi355xTSymScalingMethod behind linear_scaling_on_demand): the backend's
+    *  own equilibration is switched off for good, whatever mi355x_scaling says -- otherwise the matrix would be scaled twice. */
+   void DisableInternalScaling()
+   {
+      no_internal_scaling_ = true;
+   }
    bool ProvidesInertia() const
    {
       return true;
@@ -77,6 +83,8 @@ private:
    Index nranks_opt_, rank_opt_;
    std::string comm_file_;
    bool comm_ready_;
+   bool no_internal_scaling_ = false;
+   unsigned int comm_generation_;      // communicators set up by this process so far (part of the rendez-vous record)
    bool SetupCommunicator();
 };
 

@@ -901,7 +901,7 @@ template <int J> __device__ __forceinline__ void inv16_step(const double (&a)[16
 // Nothing is decided per pivot: the block is accepted A POSTERIORI (see above).  Isb receives the four X blocks (Isb[b*272 + i + p*17]):
 // the blocked substitution of the panel rows (trsm_rows_impl) needs exactly these.
 __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, const int k, double* Wb, double* dinv_s, double* Isb, int* shflag,
-                                                    const double zmax, const double gmax, int& nneg, unsigned long long* dbg = nullptr)
+                                                    const double zmax, const double gmax, int& nneg, unsigned long long* dbg = nullptr, unsigned long long* ts = nullptr)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = (int)blockDim.x >> 6;
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -958,6 +958,7 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
             PSTAMP(5);
         }
         __syncthreads();
+        if (ts) { if (b == 0) ts[16] = clock64(); if (b == 1) ts[19] = clock64(); if (b == 2) ts[22] = clock64(); if (b == 3) ts[25] = clock64(); }
         if (*shflag) return false;
         if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) dbg[25 + 2 * b] = clock64();
         if (b + 1 >= nb) break;
@@ -983,6 +984,7 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
             if (__ballot(big) != 0ull && lane == 0) *shflag = 1;
         }
         __syncthreads();
+        if (ts) { if (b == 0) ts[17] = clock64(); if (b == 1) ts[20] = clock64(); if (b == 2) ts[23] = clock64(); }
         if (wave == 0) PSTAMP(6);
         if (*shflag) return false;
         // ---- C: rank-16 update of the trailing tiles: T(i, c) -= sum_p L(i, c16 + p) W(c, p) ----
@@ -1006,6 +1008,7 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
                 }
         }
         __syncthreads();
+        if (ts) { if (b == 0) ts[18] = clock64(); if (b == 1) ts[21] = clock64(); if (b == 2) ts[24] = clock64(); }
         if (wave == 0) PSTAMP(7);
     }
 #undef PSTAMP
@@ -1089,7 +1092,7 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
             const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), 0.01);
             DBGT(2);
             if (ts) ts[9] = clock64();
-            fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Isb, shflag, zmax, gmax, nneg, V.dbg);
+            fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Isb, shflag, zmax, gmax, nneg, V.dbg, ts);
             DBGT(3);
             if (ts) ts[10] = clock64();
             if (fast) {
@@ -2286,29 +2289,63 @@ __device__ __forceinline__ void trsm_rows_impl(const DevView& V, const FrontMeta
 #endif
     // a posteriori threshold test on the rows below the pivot block (the in-block test of ldlt_reg cannot see them): a column
     // with a multiplier above 1/u is a FAILED pivot -- a delayed pivot in MA97/SSIDS, counted once per column here (num_delay)
-    // (two consecutive rows per lane: 16-byte stores -- a CU issues stores at ~10 bytes per cycle whatever their width)
+    // (two consecutive rows per lane: 16-byte stores -- a CU issues stores at ~10 bytes per cycle whatever their width.  The loop-invariant
+    //  pieces of the view are pinned in VGPRs: with ~100 SGPRs of kernel arguments spilled, the compiler otherwise RELOADS them from the
+    //  kernarg segment inside the loop, a scalar-cache round trip per iteration)
     {
         const int r = 2 * (tid & 31), jq = tid >> 5;
         const int i = ibase + r;
         const bool ok0 = i < m && r < rlim, ok1 = i + 1 < m && r + 1 < rlim;
-        if (T.Au) for (int j = k + jq; j < kp16; j += 8) { T.Au[r + j * 65] = 0.0; T.Au[r + 1 + j * 65] = 0.0; }
-#pragma unroll 2
-        for (int j = jq; j < k; j += 8) {
-            const int pt = Ts[j];
-            const double w0 = As[r + j * 65], w1 = As[r + 1 + j * 65];
-            double l0, l1;
-            if (pt == 1) { l0 = w0 * Ds[j]; l1 = w1 * Ds[j]; }
-            else if (pt == 2) { l0 = Ds[j] * w0 + Ds[k + j] * As[r + (j + 1) * 65]; l1 = Ds[j] * w1 + Ds[k + j] * As[r + 1 + (j + 1) * 65]; }
-            else { l0 = Ds[k + j - 1] * As[r + (j - 1) * 65] + Ds[j] * w0; l1 = Ds[k + j - 1] * As[r + 1 + (j - 1) * 65] + Ds[j] * w1; }
-            if (T.Au) { T.Au[r + j * 65] = l0; T.Au[r + 1 + j * 65] = l1; }      // (the staging copy is dead: L21 of my rows stays in LDS for the updates that follow)
-            if (ok1) {
-                if (store_mode & 1) *reinterpret_cast<double2a*>(&W[i + (size_t)j * m]) = (double2a){w0, w1};
-                if (store_mode & 2) *reinterpret_cast<double2a*>(&P[i + (size_t)j * ldp]) = (double2a){l0, l1};
-            } else if (ok0) {
-                if (store_mode & 1) W[i + (size_t)j * m] = w0;
-                if (store_mode & 2) P[i + (size_t)j * ldp] = l0;
+        double* Wv = W + i; double* Pv = P + i; double uv = V.pivtol; double* Auv = T.Au ? T.Au + r : nullptr; const double* Asv = As + r;
+        asm volatile("" : "+v"(Wv), "+v"(Pv), "+v"(uv), "+v"(Auv), "+v"(Asv));
+        if (Auv) for (int j = k + jq; j < kp16; j += 8) { Auv[j * 65] = 0.0; Auv[1 + j * 65] = 0.0; }
+        bool big = false;
+        if (his) {        // behind the blocked factorisation every pivot is 1x1: straight-line body
+#pragma unroll 4
+            for (int j = jq; j < k; j += 8) {
+                const double d = Ds[j];
+                const double w0 = Asv[j * 65], w1 = Asv[1 + j * 65];
+                const double l0 = w0 * d, l1 = w1 * d;
+                if (Auv) { Auv[j * 65] = l0; Auv[1 + j * 65] = l1; }
+                if (ok1) {
+                    if (store_mode & 1) *reinterpret_cast<double2a*>(&Wv[(size_t)j * m]) = (double2a){w0, w1};
+                    if (store_mode & 2) *reinterpret_cast<double2a*>(&Pv[(size_t)j * ldp]) = (double2a){l0, l1};
+                } else if (ok0) {
+                    if (store_mode & 1) Wv[(size_t)j * m] = w0;
+                    if (store_mode & 2) Pv[(size_t)j * ldp] = l0;
+                }
+                big |= (ok0 && fabs(l0) * uv > 1.0) || (ok1 && fabs(l1) * uv > 1.0);
             }
-            if (((ok0 && fabs(l0) * V.pivtol > 1.0) || (ok1 && fabs(l1) * V.pivtol > 1.0)) && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
+        } else {
+            for (int j = jq; j < k; j += 8) {
+                const int pt = Ts[j];
+                const double w0 = Asv[j * 65], w1 = Asv[1 + j * 65];
+                double l0, l1;
+                if (pt == 1) { l0 = w0 * Ds[j]; l1 = w1 * Ds[j]; }
+                else if (pt == 2) { l0 = Ds[j] * w0 + Ds[k + j] * Asv[(j + 1) * 65]; l1 = Ds[j] * w1 + Ds[k + j] * Asv[1 + (j + 1) * 65]; }
+                else { l0 = Ds[k + j - 1] * Asv[(j - 1) * 65] + Ds[j] * w0; l1 = Ds[k + j - 1] * Asv[1 + (j - 1) * 65] + Ds[j] * w1; }
+                if (Auv) { Auv[j * 65] = l0; Auv[1 + j * 65] = l1; }      // (the staging copy is dead: L21 of my rows stays in LDS for the updates that follow)
+                if (ok1) {
+                    if (store_mode & 1) *reinterpret_cast<double2a*>(&Wv[(size_t)j * m]) = (double2a){w0, w1};
+                    if (store_mode & 2) *reinterpret_cast<double2a*>(&Pv[(size_t)j * ldp]) = (double2a){l0, l1};
+                } else if (ok0) {
+                    if (store_mode & 1) Wv[(size_t)j * m] = w0;
+                    if (store_mode & 2) Pv[(size_t)j * ldp] = l0;
+                }
+                big |= (ok0 && fabs(l0) * uv > 1.0) || (ok1 && fabs(l1) * uv > 1.0);
+            }
+        }
+        // a multiplier above 1/u somewhere in my rows (rare): find the columns and count each once
+        if (__ballot(big) != 0ull) {
+            for (int j = jq; j < k; j += 8) {
+                const int pt = Ts[j];
+                double l0, l1;
+                const double w0 = Asv[j * 65], w1 = Asv[1 + j * 65];
+                if (pt == 1) { l0 = w0 * Ds[j]; l1 = w1 * Ds[j]; }
+                else if (pt == 2) { l0 = Ds[j] * w0 + Ds[k + j] * Asv[(j + 1) * 65]; l1 = Ds[j] * w1 + Ds[k + j] * Asv[1 + (j + 1) * 65]; }
+                else { l0 = Ds[k + j - 1] * Asv[(j - 1) * 65] + Ds[j] * w0; l1 = Ds[k + j - 1] * Asv[1 + (j - 1) * 65] + Ds[j] * w1; }
+                if (((ok0 && fabs(l0) * uv > 1.0) || (ok1 && fabs(l1) * uv > 1.0)) && atomicExch(&V.colfail[c0 + j], 1) == 0) atomicAdd(&V.fstat[s].w, 1);
+            }
         }
     }
     if (ts) ts[3] = clock64();
@@ -3080,9 +3117,9 @@ __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int 
     const int epoch = V.sepoch[2];
 #define GSTAMP(i) do { if (V.dbg && blockIdx.x == 0 && role < 4 && tid == 0) V.dbg[32 + 8 * role + (i)] = wall_clock64(); } while (0)
     GSTAMP(0);
-    unsigned long long tsv[16];
+    unsigned long long tsv[28];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) tsv[q] = 0ull;
+    for (int q = 0; q < 28; ++q) tsv[q] = 0ull;
     unsigned long long* const tsp = (V.dbg && blockIdx.x == 0 && role == 1) ? tsv : nullptr;
     int kk[4], koff[5];
     koff[0] = 0;
@@ -3262,7 +3299,7 @@ __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int 
         Mq.selfasm = 0; Mq.aq0 = Gq.aq0; Mq.aq1 = Gq.aq1; Mq.bigidx = Gq.bigidx;      // (the A entries are in already)
         __syncthreads();
         big_diag_body<4, 256, true>(V, Mq, smem_raw, &V.sflag_d[Gq.s], epoch, tsp, crit_Lr, crit_Mp, crit_ibase, myrows);
-        if (tsp && tid == 0) { for (int q = 0; q < 16; ++q) V.dbg[64 + q] = tsp[q]; }
+        if (tsp && tid == 0) { for (int q = 0; q < 28; ++q) V.dbg[64 + q] = tsp[q]; }
         GSTAMP(7);
     }
 #undef GSTAMP
@@ -4349,7 +4386,7 @@ public:
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
         const int nrb = (mm + 63) / 64;
-        if (fuse_dt && (single || multi) && !prof_on && kk <= 64 && nball * (1 + nrb) <= fuse_dt_maxwg) {      // (the per-kernel profile keeps the two kernels apart; multi-GPU: local subtrees and replicated top alike)
+        if (fuse_dt && (single || multi) && kk <= 64 && nball * (1 + nrb) <= fuse_dt_maxwg) {      // (multi-GPU: local subtrees and replicated top alike; the per-kernel profile books the fused launch under the pivot blocks)
             // few fronts on the level: pivot block + panel solve in one flag-synchronised launch (k_big_diag_trsm)
             const size_t lds = std::max(diag_lds_bytes(kk, 64),
                                         trsm_lds_bytes(kk, true));

@@ -19,6 +19,8 @@
 // usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|mi355x-aug|mi355x-pd|stock] [--record file] [--max-records K]
 //                   [--set name value]... [--optfile ipopt.opt] [--reoptimize] [--quiet]
 //   --reoptimize: after the first solve, set warm_start_same_structure=yes and call ReOptimizeNLP (second DRIVER_SUMMARY line)
+//   --then-bounds lo hi: (LukVl problems) after the first solve, optimise a SECOND instance of the problem with constraint bounds [lo, hi]
+//                   through the SAME AlgorithmBuilder, without warm_start_same_structure: other bound sets, other workspace dimensions
 #include "IpIpoptApplication.hpp"
 #include "IpTNLPAdapter.hpp"
 #include "IpAlgBuilder.hpp"
@@ -286,7 +288,8 @@ int main(int argc, char** argv)
    int N = atoi(argv[2]);
    std::string solver = "pardisomkl", record, record_pd;
    int max_records = -1;
-   bool quiet = false, reopt = false;
+   bool quiet = false, reopt = false, then_bounds = false;
+   double tb_lo = 0., tb_hi = 0.;
    std::string optfile;
    std::vector<std::pair<std::string, std::string> > sets;
    for( int i = 3; i < argc; ++i )
@@ -299,6 +302,7 @@ int main(int argc, char** argv)
       else if( a == "--set" && i + 2 < argc ) { sets.push_back(std::make_pair(std::string(argv[i + 1]), std::string(argv[i + 2]))); i += 2; }
       else if( a == "--quiet" ) quiet = true;
       else if( a == "--reoptimize" ) reopt = true;
+      else if( a == "--then-bounds" && i + 2 < argc ) { then_bounds = true; tb_lo = atof(argv[i + 1]); tb_hi = atof(argv[i + 2]); i += 2; }
       else if( a == "--optfile" && i + 1 < argc ) optfile = argv[++i];
       else { fprintf(stderr, "bad argument %s\n", a.c_str()); return 2; }
    }
@@ -311,6 +315,7 @@ int main(int argc, char** argv)
       SmartPtr<RegisteredTNLP> r;
       if( problem == "LukVlE1" ) r = new LuksanVlcek1(0, 0);
       else if( problem == "LukVlI1" ) r = new LuksanVlcek1(-1., 0.);
+      else if( problem == "LukVlI1u" ) r = new LuksanVlcek1(-1., 1e20);      // the same with the upper constraint bound removed
       else if( problem == "LukVlE5" ) r = new LuksanVlcek5(0, 0);
       else if( problem == "MBndryCntrl1" ) r = new MittelmannBndryCntrlDiri1();
       else if( problem == "MBndryCntrl2" ) r = new MittelmannBndryCntrlDiri2();
@@ -369,9 +374,19 @@ int main(int argc, char** argv)
    ApplicationReturnStatus status = app->OptimizeNLP(nlp, builder);
    double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 
-   for( int pass = 0; pass < (reopt ? 2 : 1); ++pass )
+   for( int pass = 0; pass < ((reopt || then_bounds) ? 2 : 1); ++pass )
    {
-   if( pass == 1 )
+   if( pass == 1 && then_bounds )
+   {  // another instance (other bounds => other dimensions of the bound blocks) through the SAME builder, no warm start: everything the
+      // augmented-system solver remembers of the first problem must go
+      SmartPtr<RegisteredTNLP> r2 = new LuksanVlcek1(tb_lo, tb_hi);
+      if( !r2->InitializeProblem(N) ) return 2;
+      SmartPtr<NLP> nlp2 = new TNLPAdapter(GetRawPtr(r2), app->Jnlst());
+      t0 = std::chrono::steady_clock::now();
+      status = app->OptimizeNLP(nlp2, builder);
+      total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+   }
+   else if( pass == 1 )
    {  // same structure, same start: the backend must keep its symbolic analysis (IpMumpsSolverInterface.cpp:227-236 pattern)
       app->Options()->SetStringValue("warm_start_same_structure", "yes");
       t0 = std::chrono::steady_clock::now();

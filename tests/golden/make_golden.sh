@@ -32,6 +32,9 @@ run mbndry2_100 MBndryCntrl2 100 norec
 run mdist1_100 MDistCntrl1 100 norec
 run mbndry3d_12 MBndryCntrl_3D 12 norec
 run mbndry1_300 MBndryCntrl1 300 norec
+# the CUTEst-style ~10^6 stand-in of BASELINE.json configs[4] (n = 492 800, m = 490 000; examples/ScalableProblems/solve_problem.cpp:28-91),
+# 8 MKL threads (the iteration table does not depend on the thread count; one thread takes a minute per run)
+MKL_NUM_THREADS=8 OMP_NUM_THREADS=8 run mbndry1_700 MBndryCntrl1 700 norec
 ls -la
 # the PDSystemSolver boundary: pieces of the 8-block system, right-hand side and result of the reference's
 # PDFullSpaceSolver::Solve, every call of hs071 and the first 8 of LukVlI1 n = 20 (bounds on every variable); reader: oracle/pd_oracle.py

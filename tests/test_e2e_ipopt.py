@@ -30,7 +30,8 @@ def run_driver(problem, n, solver="mi355x"):
                                             ("lukvle1_10000", "LukVlE1", 10000), ("mbndry1_100", "MBndryCntrl1", 100),
                                             ("lukvle1_1000000", "LukVlE1", 1000000),     # the north-star target instance
                                             ("lukvli1_10000", "LukVlI1", 10000), ("lukvle5_10000", "LukVlE5", 10000), ("mbndry2_100", "MBndryCntrl2", 100),
-                                            ("mdist1_100", "MDistCntrl1", 100), ("mbndry3d_12", "MBndryCntrl_3D", 12), ("mbndry1_300", "MBndryCntrl1", 300)])
+                                            ("mdist1_100", "MDistCntrl1", 100), ("mbndry3d_12", "MBndryCntrl_3D", 12), ("mbndry1_300", "MBndryCntrl1", 300),
+                                            ("mbndry1_700", "MBndryCntrl1", 700)])     # BASELINE.json configs[4] stand-in (KKT dim 982 800)
 def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_dir):
     gold = open(os.path.join(golden_dir, name + ".iters")).read().splitlines()
     gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
@@ -42,13 +43,13 @@ def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_d
     for a, b in zip(iters, gold):
         fa, fb = a.split(), b.split()
         # iteration number, lg(mu), lg(rg) (the inertia-correction trace) and #line-search steps: identical strings;
-        # objective to 1e-7 relative; inf_pr / inf_du to the printed precision, with a 1e-11 floor for values that
-        # sit at rounding level (an infeasibility of 2e-15 is noise of the last solve, not an algorithmic quantity)
+        # objective to 1e-7 relative; inf_pr / inf_du to ONE UNIT of the last of the three printed digits (1e-2 relative), with a 1e-11
+        # floor for values that sit at rounding level (an infeasibility of 2e-15 is noise of the last solve, not an algorithmic quantity)
         assert (fa[0], fa[4], fa[5], fa[6]) == (fb[0], fb[4], fb[5], fb[6]), f"{a}   |   {b}"
         assert abs(float(fa[1]) - float(fb[1])) <= 1e-7 * max(1.0, abs(float(fb[1]))), f"{a}   |   {b}"
         for k in (2, 3):
             x, y = float(fa[k]), float(fb[k])
-            assert abs(x - y) <= 2e-2 * max(x, y) + 1e-11, f"{a}   |   {b}"
+            assert abs(x - y) <= 1e-2 * max(x, y) + 1e-11, f"{a}   |   {b}"
 
 
 HS071 = os.path.join(ROOT, "oracle", "_ref", "hs071_cpp")
@@ -221,6 +222,22 @@ def test_device_route_hands_uncovered_modes_to_the_reference_solver(tmp_path):
     assert summ[0]["iterations"] == summ[1]["iterations"] and summ[1]["LinearSystemSymbolicFactorization"] == 0.0
     pd = json.loads(next(ln for ln in out.splitlines() if ln.startswith("PD_STATS"))[len("PD_STATS "):])
     assert pd["host_solves"] == 0 and pd["device_solves"] >= 2 * summ[0]["iterations"]
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+def test_device_route_reused_for_another_problem_without_warm_start(tmp_path):
+    """the AlgorithmBuilder (and with it the cached Mi355xAugSystemSolver) is reused for a second NLP with OTHER bounds and no
+    warm_start_same_structure: the new handle must not inherit the first problem's primal-dual workspace request (dimensions, bound
+    positions).  LukVlI1 (constraints in [-1, 0]: n_sL = n_sU = m) is followed by the same problem with the upper bound removed
+    (n_sU = 0); the second solve must equal a fresh solve of that second problem, every Solve answered on the device."""
+    iters, summ, out = _run(DRIVER, ["LukVlI1", "2000", "--solver", "mi355x-pd", "--then-bounds", "-1", "1e20"], tmp_path)
+    assert out.count("EXIT: Optimal Solution Found.") == 2, out[-2000:]
+    pd = json.loads(next(ln for ln in out.splitlines() if ln.startswith("PD_STATS"))[len("PD_STATS "):])
+    assert pd["host_solves"] == 0
+    it2, s2, out2 = _run(DRIVER, ["LukVlI1u", "2000", "--solver", "mi355x-pd"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out2
+    assert summ[1]["iterations"] == s2[0]["iterations"]
+    assert abs(summ[1]["objective"] - s2[0]["objective"]) <= 1e-9 * max(1.0, abs(s2[0]["objective"]))
 
 
 @pytest.mark.skipif(not os.path.exists(PATCHED), reason="oracle/_ref not built")

@@ -107,3 +107,33 @@ def test_benign_kkt_systems_do_not_depend_on_u():
         _, x, st = spec_run(n, r, c, v, K @ np.ones(n), 1e-8, scaling=0)
         assert st["num_neg"] == neg and st["num_delay"] == 0 and st["u_sensitive"] == 0
         assert np.abs(x - 1).max() <= 1e-8
+
+
+def test_blocked_a_posteriori_rule_of_the_big_pivot_blocks():
+    """The fast path of a big front's pivot block (numeric.hip ldlt_blocked_static, mirror.ldlt_block_static): natural order, 1x1 pivots,
+    accepted a posteriori iff every multiplier of the block is <= 1 / max(u, u2, 0.01) and no pivot is at the zero threshold -- otherwise
+    the strict rule runs on the untouched block.  Either way: inertia as constructed, converged solve; a benign system takes the fast
+    path on (nearly) all blocks, a block with a tiny leading diagonal is rejected."""
+    n, r, c, v, neg = kktgen.grid_kkt(40, 36, dof=3, ncon=2, seed=5)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    s = ipopt_amd.KKTSolver(scaling=0)
+    s.initialize_structure(n, r, c, vals=v)
+    sym = mirror.fetch(s)
+    nbig = int(((sym["rowptr"][1:] - sym["rowptr"][:-1]) > mirror.BIG_FRONT).sum())
+    assert nbig > 5
+    out = {}
+    for fast in (True, False):
+        x, st = mirror.factor_solve_pivoted(sym, v, b, u=1e-8, u2=1e-4, fast_blocks=fast)
+        assert st["num_neg"] == neg and st["num_zero"] == 0
+        assert np.abs(K @ x - b).max() <= 1e-9 * (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+        out[fast] = st
+    assert out[False]["num_fast"] == 0 and 0.5 * nbig <= out[True]["num_fast"] <= nbig
+    # the rule itself on a dense block: accepted with modest multipliers, rejected when the first pivot is 1e-6 of its column
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((48, 48)); A = A + A.T + 40.0 * np.diag(rng.choice([-1.0, 1.0], 48))
+    ok = mirror.ldlt_block_static(A, 48, 1e-8, 1e-4)
+    assert ok is not None and ok["nneg"] == int((np.linalg.eigvalsh(A) < 0).sum()) and list(ok["ord"]) == list(range(48))
+    A[0, 0] = 1e-6
+    assert mirror.ldlt_block_static(A, 48, 1e-8, 1e-4) is None                       # multiplier ~1e6 > 100
+    assert mirror.ldlt_block_static(A, 48, 1e-8, 1e-4) is None and mirror.ldlt_front(A.copy(), 48, 1e-8, 1e-4)["nneg"] == int((np.linalg.eigvalsh(A) < 0).sum())

@@ -39,7 +39,7 @@ for q in range(4):
 ps = o[40:48]
 print("sub-block 0, wavefront 0 (cycles): load %d  factor %d  checks %d  inverse %d  store %d | to barrier B %d, to barrier C %d" % (ps[1]-ps[0], ps[2]-ps[1], ps[3]-ps[2], ps[4]-ps[3], ps[5]-ps[4], ps[6]-ps[5], ps[7]-ps[6]))
 
-r = o[64:80]
+r = o[64:92]
 if r[4]:
     base = r[4]
     names = {4: "flag seen", 0: "L11/D/Is loaded", 1: "rows permuted (+inverses)", 2: "substitution done", 3: "W/L stored", 5: "S flag raised", 6: "other links' columns updated", 7: "own block updated",
@@ -48,3 +48,11 @@ if r[4]:
     names.update({13: "own block: tile decoded", 14: "own block: products done", 15: "own block: written"})
     for i in (4, 0, 1, 2, 3, 5, 6, 13, 14, 15, 7, 8, 9, 10, 11, 12):
         print("  %-34s %8d" % (names[i], r[i] - base))
+
+if r[4] and r[16]:
+    print("  blocked LDL^T of role 1's pivot block, per 16-column sub-block (cycles): diagonal block + inverse | rows below | trailing tiles")
+    prev = r[9]
+    for b in range(4):
+        a_, b_, c_ = r[16 + 3 * b], r[17 + 3 * b] if b < 3 else 0, r[18 + 3 * b] if b < 3 else 0
+        print("    sub-block %d: %6d | %6d | %6d" % (b, a_ - prev, (b_ - a_) if b_ else 0, (c_ - b_) if c_ else 0))
+        prev = c_ if c_ else a_
