@@ -24,12 +24,25 @@ namespace {
 using std::vector;
 
 // static-chunk parallel loop on std::thread (the analysis is the only multi-threaded host code; T <= 16)
-int analysis_threads() { unsigned h = std::thread::hardware_concurrency(); int t = h ? (int)h : 1; const char* e = getenv("MI355X_KKT_THREADS"); if (e) t = atoi(e); return std::max(1, std::min(t, 16)); }
+int analysis_threads() { unsigned h = std::thread::hardware_concurrency(); int t = h ? std::min((int)h, 32) : 1; const char* e = getenv("MI355X_KKT_THREADS"); if (e) t = atoi(e); return std::max(1, std::min(t, 256)); }      // default: up to 32 (measured on the 2 x 64-core host of the GPU box); MI355X_KKT_THREADS overrides
 template <class F> void parallel_chunks(long long n, int T, F fn) {
     if (T <= 1 || n < 4096) { fn(0LL, n, 0); return; }
     std::vector<std::thread> th; th.reserve(T);
     for (int t = 0; t < T; ++t) { long long b = n * t / T, e = n * (t + 1) / T; th.emplace_back([=, &fn] { fn(b, e, t); }); }
     for (auto& x : th) x.join();
+}
+
+// Parallel bucketing of items 0..N-1 by key (0..nb-1): ptr[nb + 1] and the items of every bucket.  Counts and cursors are bumped with relaxed
+// atomic adds, so the order INSIDE a bucket depends on the thread timing: every caller sorts its buckets afterwards (they need sorted buckets
+// anyway), which makes the result deterministic again.
+template <class KeyFn> void parallel_bucket(long long N, int nb, int T, KeyFn key, vector<int>& ptr, vector<int>& items)
+{
+    ptr.assign((size_t)nb + 1, 0);
+    parallel_chunks(N, T, [&](long long b, long long e, int) { for (long long i = b; i < e; ++i) __atomic_fetch_add(&ptr[key(i) + 1], 1, __ATOMIC_RELAXED); });
+    for (int j = 0; j < nb; ++j) ptr[j + 1] += ptr[j];
+    items.resize((size_t)N);
+    vector<int> pos(ptr.begin(), ptr.end() - 1);
+    parallel_chunks(N, T, [&](long long b, long long e, int) { for (long long i = b; i < e; ++i) items[__atomic_fetch_add(&pos[key(i)], 1, __ATOMIC_RELAXED)] = (int)i; });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -44,12 +57,17 @@ bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int f
                    std::string& err)
 {
     vector<int> lo(nnz), hi(nnz);
+    const int T = analysis_threads();
     if (format == 0) {
-        for (int t = 0; t < nnz; ++t) {
-            int r = ri[t] - base, c = ci[t] - base;
-            if (r < 0 || r >= n || c < 0 || c >= n) { err = "analyse: index out of range"; return false; }
-            lo[t] = std::min(r, c); hi[t] = std::max(r, c);
-        }
+        std::atomic<int> bad(0);
+        parallel_chunks(nnz, T, [&](long long tb, long long te, int) {
+            for (long long t = tb; t < te; ++t) {
+                int r = ri[t] - base, c = ci[t] - base;
+                if (r < 0 || r >= n || c < 0 || c >= n) { bad.store(1, std::memory_order_relaxed); r = c = 0; }
+                lo[t] = std::min(r, c); hi[t] = std::max(r, c);
+            }
+        });
+        if (bad.load()) { err = "analyse: index out of range"; return false; }
     } else {  // CSR upper: ri = ia[n+1], ci = ja[nnz]
         if (ri[n] - base != nnz) { err = "analyse: ia[n] does not match nnz"; return false; }
         for (int i = 0; i < n; ++i)
@@ -60,15 +78,10 @@ bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int f
             }
     }
     // bucket by column (lo), then sort rows inside each column
-    vector<int> cnt(n + 1, 0);
-    for (int t = 0; t < nnz; ++t) cnt[lo[t] + 1]++;
-    for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
-    vector<int> order(nnz);
-    { vector<int> pos(cnt.begin(), cnt.end() - 1);
-      for (int t = 0; t < nnz; ++t) order[pos[lo[t]]++] = t; }
+    vector<int> cnt, order;
+    parallel_bucket(nnz, n, T, [&](long long t) { return lo[t]; }, cnt, order);
     // per column: sort the (row, triplet) pairs, count distinct rows (+ the always-present diagonal) -- columns are
     // independent, so both passes run on threads; the prefix sum in between is sequential
-    const int T = analysis_threads();
     vector<int> sorted_hi(nnz), sorted_t(nnz), ndist(n, 0);
     parallel_chunks(n, T, [&](long long jb, long long je, int) {
         vector<std::pair<int,int>> tmp;
@@ -103,14 +116,25 @@ bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int f
 // symmetric adjacency (no diagonal) from a lower pattern
 void build_adjacency(int n, const vector<int>& colptr, const vector<int>& row, vector<int>& xadj, vector<int>& adj)
 {
+    const int T = analysis_threads();
     xadj.assign(n + 1, 0);
-    for (int j = 0; j < n; ++j)
-        for (int p = colptr[j]; p < colptr[j + 1]; ++p) { int i = row[p]; if (i != j) { xadj[i + 1]++; xadj[j + 1]++; } }
+    parallel_chunks(n, T, [&](long long jb, long long je, int) {
+        for (int j = (int)jb; j < (int)je; ++j)
+            for (int p = colptr[j]; p < colptr[j + 1]; ++p) { const int i = row[p]; if (i != j) { __atomic_fetch_add(&xadj[i + 1], 1, __ATOMIC_RELAXED); __atomic_fetch_add(&xadj[j + 1], 1, __ATOMIC_RELAXED); } }
+    });
     for (int i = 0; i < n; ++i) xadj[i + 1] += xadj[i];
     adj.resize(xadj[n]);
     vector<int> pos(xadj.begin(), xadj.end() - 1);
-    for (int j = 0; j < n; ++j)
-        for (int p = colptr[j]; p < colptr[j + 1]; ++p) { int i = row[p]; if (i != j) { adj[pos[i]++] = j; adj[pos[j]++] = i; } }
+    parallel_chunks(n, T, [&](long long jb, long long je, int) {
+        for (int j = (int)jb; j < (int)je; ++j)
+            for (int p = colptr[j]; p < colptr[j + 1]; ++p) {
+                const int i = row[p];
+                if (i != j) { adj[__atomic_fetch_add(&pos[i], 1, __ATOMIC_RELAXED)] = j; adj[__atomic_fetch_add(&pos[j], 1, __ATOMIC_RELAXED)] = i; }
+            }
+    });
+    // (the fill order depends on the thread timing: sorted lists make the adjacency -- and every ordering built on it -- deterministic;
+    //  the serial construction produced exactly this order: neighbours below the node in column order, then the node's own column)
+    parallel_chunks(n, T, [&](long long ib, long long ie, int) { for (int i = (int)ib; i < (int)ie; ++i) std::sort(adj.begin() + xadj[i], adj.begin() + xadj[i + 1]); });
 }
 
 // ---------------------------------------------------------------------------------------
@@ -127,23 +151,28 @@ void zero_diag_matching(int n, const Pattern& P, const vector<int>& xadj, const 
     // summed slot values
     vector<double> sval(P.row.size(), 0.0);
     for (int t = 0; t < nnz; ++t) sval[P.t2slot[t]] += vals[t];
-    vector<double> diag(n, 0.0), rowmax(n, 0.0);
-    for (int j = 0; j < n; ++j)
-        for (int p = P.colptr[j]; p < P.colptr[j + 1]; ++p) {
-            int i = P.row[p]; double a = std::fabs(sval[p]);
-            if (i == j) diag[j] = sval[p];
-            else { rowmax[i] = std::max(rowmax[i], a); rowmax[j] = std::max(rowmax[j], a); }
+    // per-node edge weights |a_ij| aligned with the (sorted) adjacency lists, by binary search in the lower pattern; row maxima from them
+    const int T = analysis_threads();
+    vector<double> diag(n, 0.0), rowmax(n, 0.0), w(adj.size(), 0.0);
+    parallel_chunks(n, T, [&](long long ib, long long ie, int) {
+        for (int i = (int)ib; i < (int)ie; ++i) {
+            diag[i] = sval[P.colptr[i]];                                   // (the diagonal is the first entry of its column)
+            double mx = 0.0;
+            for (int p = xadj[i]; p < xadj[i + 1]; ++p) {
+                const int v = adj[p], c = std::min(i, v), r = std::max(i, v);
+                const int* b = P.row.data() + P.colptr[c]; const int* e = P.row.data() + P.colptr[c + 1];
+                const int q = (int)(std::lower_bound(b, e, r) - P.row.data());
+                const double a = std::fabs(sval[q]);
+                w[p] = a; mx = std::max(mx, a);
+            }
+            rowmax[i] = mx;
         }
+    });
     vector<char> isz(n, 0);
     int nz = 0;
     for (int i = 0; i < n; ++i)
         if (rowmax[i] > 0 && std::fabs(diag[i]) <= 1e-6 * rowmax[i]) { isz[i] = 1; ++nz; }
     if (nz == 0) return;
-    // weight lookup: |a_ij| for edge (i,j): build per-node weights aligned with adj
-    vector<double> w(adj.size(), 0.0);
-    { vector<int> pos(xadj.begin(), xadj.end() - 1);
-      for (int j = 0; j < n; ++j)
-          for (int p = P.colptr[j]; p < P.colptr[j + 1]; ++p) { int i = P.row[p]; if (i != j) { double a = std::fabs(sval[p]); w[pos[i]++] = a; w[pos[j]++] = a; } } }
     vector<int> match_v(n, -1);   // for non-zero-diag node v: matched zero row
     vector<int> match_z(n, -1);   // for zero row z: matched v
     // greedy: zero rows in index order, best available neighbour by weight
@@ -570,13 +599,10 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
                     pc[p] = std::min(a, b); pr[p] = std::max(a, b);
                 }
         });
-        vector<int> cnt(n + 1, 0);
-        for (int p = 0; p < nnzA; ++p) cnt[pc[p] + 1]++;
-        for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
-        S.acolptr = cnt;
         // place every entry into its (new) column, then sort the rows of each column -- columns are independent
-        vector<int> src(nnzA);
-        { vector<int> pos(cnt.begin(), cnt.end() - 1); for (int p = 0; p < nnzA; ++p) src[pos[pc[p]]++] = p; }
+        vector<int> cnt, src;
+        parallel_bucket(nnzA, n, T, [&](long long p) { return pc[p]; }, cnt, src);
+        S.acolptr = cnt;
         vector<int> old2new(nnzA); S.arow.resize(nnzA); S.acol.resize(nnzA);
         parallel_chunks(n, T, [&](long long jb, long long je, int) {
             vector<std::pair<int,int>> tmp;
@@ -591,12 +617,11 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         S.nnz_a = nnzA;
         S.trip2slot.resize(nnz);
         parallel_chunks(nnz, T, [&](long long tb, long long te, int) { for (long long t = tb; t < te; ++t) S.trip2slot[t] = old2new[P.t2slot[t]]; });
-        S.dup_ptr.assign(nnzA + 1, 0);
-        for (int t = 0; t < nnz; ++t) S.dup_ptr[S.trip2slot[t] + 1]++;
-        for (int q = 0; q < nnzA; ++q) S.dup_ptr[q + 1] += S.dup_ptr[q];
-        S.dup_src.resize(nnz);
-        { vector<int> pos(S.dup_ptr.begin(), S.dup_ptr.end() - 1);
-          for (int t = 0; t < nnz; ++t) S.dup_src[pos[S.trip2slot[t]]++] = t; }
+        // duplicate lists: the triplets of every slot in ascending order (the device sums them in this order => bitwise reproducible)
+        parallel_bucket(nnz, nnzA, T, [&](long long t) { return S.trip2slot[t]; }, S.dup_ptr, S.dup_src);
+        parallel_chunks(nnzA, T, [&](long long qb, long long qe, int) {
+            for (long long q = qb; q < qe; ++q) if (S.dup_ptr[q + 1] - S.dup_ptr[q] > 1) std::sort(S.dup_src.begin() + S.dup_ptr[q], S.dup_src.begin() + S.dup_ptr[q + 1]);
+        });
     };
     build_permuted_csc();
     lap("permuted CSC + maps");
@@ -816,34 +841,44 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     }
     // ---- 10. relative indices, A scatter positions, levels, offsets, stats ----
     S.rel.assign(S.sn_rows.size(), -1);
-    for (int s = 0; s < nsn; ++s) {
-        int p = S.sn_parent[s]; if (p < 0) continue;
-        int k = S.sn_colptr[s + 1] - S.sn_colptr[s];
-        int p0 = S.sn_colptr[p], p1 = S.sn_colptr[p + 1], kp = p1 - p0;
-        int q = S.sn_rowptr[p] + kp, qe = S.sn_rowptr[p + 1];
-        for (int t = S.sn_rowptr[s] + k; t < S.sn_rowptr[s + 1]; ++t) {
-            int r = S.sn_rows[t];
-            if (r < p1) { S.rel[t] = r - p0; continue; }
-            while (q < qe && S.sn_rows[q] < r) ++q;
-            if (q >= qe || S.sn_rows[q] != r) { S.error = "analyse: internal error (child row missing in parent front)"; return false; }
-            S.rel[t] = kp + (q - (S.sn_rowptr[p] + kp));
-        }
-    }
-    S.apos.resize(S.nnz_a);
-    for (int s = 0; s < nsn; ++s) {
-        int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1], k = c1 - c0;
-        int m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
-        for (int j = c0; j < c1; ++j) {
-            int q = S.sn_rowptr[s] + k, qe = S.sn_rowptr[s + 1];
-            for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) {
-                int i = S.arow[p], lr;
-                if (i < c1) lr = i - c0;
-                else { while (q < qe && S.sn_rows[q] < i) ++q;
-                       if (q >= qe || S.sn_rows[q] != i) { S.error = "analyse: internal error (A row missing in front)"; return false; }
-                       lr = k + (q - (S.sn_rowptr[s] + k)); }
-                S.apos[p] = lr + (j - c0) * m;
+    {
+        const int T = analysis_threads();
+        std::atomic<int> bad(0);
+        parallel_chunks(nsn, T, [&](long long sb, long long se, int) {        // (supernodes are independent; chunks of consecutive supernodes carry similar work)
+            for (int s = (int)sb; s < (int)se; ++s) {
+                int p = S.sn_parent[s]; if (p < 0) continue;
+                int k = S.sn_colptr[s + 1] - S.sn_colptr[s];
+                int p0 = S.sn_colptr[p], p1 = S.sn_colptr[p + 1], kp = p1 - p0;
+                int q = S.sn_rowptr[p] + kp, qe = S.sn_rowptr[p + 1];
+                for (int t = S.sn_rowptr[s] + k; t < S.sn_rowptr[s + 1]; ++t) {
+                    int r = S.sn_rows[t];
+                    if (r < p1) { S.rel[t] = r - p0; continue; }
+                    while (q < qe && S.sn_rows[q] < r) ++q;
+                    if (q >= qe || S.sn_rows[q] != r) { bad.store(1, std::memory_order_relaxed); break; }
+                    S.rel[t] = kp + (q - (S.sn_rowptr[p] + kp));
+                }
             }
-        }
+        });
+        if (bad.load()) { S.error = "analyse: internal error (child row missing in parent front)"; return false; }
+        S.apos.resize(S.nnz_a);
+        parallel_chunks(nsn, T, [&](long long sb, long long se, int) {
+            for (int s = (int)sb; s < (int)se; ++s) {
+                int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1], k = c1 - c0;
+                int m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+                for (int j = c0; j < c1; ++j) {
+                    int q = S.sn_rowptr[s] + k, qe = S.sn_rowptr[s + 1];
+                    for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) {
+                        int i = S.arow[p], lr;
+                        if (i < c1) lr = i - c0;
+                        else { while (q < qe && S.sn_rows[q] < i) ++q;
+                               if (q >= qe || S.sn_rows[q] != i) { bad.store(2, std::memory_order_relaxed); break; }
+                               lr = k + (q - (S.sn_rowptr[s] + k)); }
+                        S.apos[p] = lr + (j - c0) * m;
+                    }
+                }
+            }
+        });
+        if (bad.load()) { S.error = "analyse: internal error (A row missing in front)"; return false; }
     }
     S.sn_level.assign(nsn, 0);
     for (int s = 0; s < nsn; ++s) { int p = S.sn_parent[s]; if (p >= 0) S.sn_level[p] = std::max(S.sn_level[p], S.sn_level[s] + 1); }
