@@ -3591,8 +3591,8 @@ public:
         }
         return true;
     }
-    std::vector<int> grp0, grp1, grp_split, grp_nrb, grp_tiles64, grp_tiles, grp_la1, grp_la2;
-    std::vector<hipEvent_t> grp_evA, grp_evB;
+    struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2; std::vector<hipEvent_t> evA, evB; };
+    GrpSched gs_single, gs_local, gs_top;      // one-GPU schedule; multi-GPU: the rank's own subtrees / the replicated top
     int allbig_base = 0, allbig_count = 0, allbig_maxk = 0;
     std::vector<hipEvent_t> la_evA, la_evB;
     // chain look-ahead (single-GPU schedule, levels whose fronts are all pure in-place chain links): the critical path
@@ -3753,9 +3753,7 @@ public:
         for (auto e : la_evA) if (e) (void)hipEventDestroy(e);
         for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
         la_evA.clear(); la_evB.clear();
-        for (auto e : grp_evA) if (e) (void)hipEventDestroy(e);
-        for (auto e : grp_evB) if (e) (void)hipEventDestroy(e);
-        grp_evA.clear(); grp_evB.clear();
+        for (GrpSched* g : {&gs_single, &gs_local, &gs_top}) { for (auto e : g->evA) if (e) (void)hipEventDestroy(e); for (auto e : g->evB) if (e) (void)hipEventDestroy(e); g->evA.clear(); g->evB.clear(); }
         for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
         if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
         if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
@@ -4120,42 +4118,53 @@ public:
             if (opt.verbose) fprintf(stderr, "[mi355x_kkt] chain look-ahead on %d of %d levels\n", nchain >= 8 ? nchain : 0, Sy.num_levels);
         }
         // ---- grouped schedule: every chain group is factored at the level of its first link (k_grp_diag / k_grp_rows / update) ----
-        grouped = !multi && Sy.maxsupernode <= 64 && selfasm_on && getenv("MI355X_KKT_NO_GROUPED") == nullptr;
-        grp_fused = getenv("MI355X_KKT_GRP_SPLIT") == nullptr;
-        grp0.assign(Sy.num_levels, 0); grp1.assign(Sy.num_levels, 0); grp_split.assign(Sy.num_levels, 0); grp_nrb.assign(Sy.num_levels, 0);
-        grp_tiles64.assign(Sy.num_levels, 0); grp_tiles.assign(Sy.num_levels, 0); grp_la1.assign(Sy.num_levels, 0); grp_la2.assign(Sy.num_levels, 0);
-        grp_evA.assign(Sy.num_levels, nullptr); grp_evB.assign(Sy.num_levels, nullptr);
-        if (grouped) {
+        grouped = Sy.maxsupernode <= 64 && selfasm_on && getenv("MI355X_KKT_NO_GROUPED") == nullptr;
+        grp_fused = getenv("MI355X_KKT_GRP_SPLIT") == nullptr || multi;      // (the split variant is a one-GPU development path)
+        {
             auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
             auto cols_of = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
-            std::vector<std::vector<int>> at(Sy.num_levels);
-            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
-                int first = sn;
-                for (int j = Sy.grp_pos[sn]; j > 0; --j) first = Sy.alias_child[first];
-                if (Sy.sn_level[first] >= Sy.grp_cut_level) at[Sy.sn_level[first]].push_back(sn);      // (groups do not straddle the cut: symbolic.cpp)
-            }
-            for (int lv = 0; lv < Sy.num_levels; ++lv) {
-                std::stable_sort(at[lv].begin(), at[lv].end(), [&](int a, int b) { return order_of(a) < order_of(b); });
-                grp0[lv] = (int)lvl_list.size();
-                int nsmall = 0;
-                for (int sn : at[lv]) {
-                    lvl_list.push_back(sn);
-                    const int mu = order_of(sn) - cols_of(sn), nt = (mu + 127) / 128;
-                    grp_nrb[lv] = std::max(grp_nrb[lv], (mu + 63) / 64);
-                    if (order_of(sn) <= 1024) { ++nsmall; grp_tiles64[lv] = std::max(grp_tiles64[lv], schur_tiles64(Sy, sn)); }
-                    else {
-                        grp_tiles[lv] = std::max(grp_tiles[lv], schur_tiles(Sy, sn));
-                        grp_la1[lv] = std::max(grp_la1[lv], split_of[sn] ? 2 * nt - 1 : tri_tiles(nt));
-                        if (split_of[sn]) grp_la2[lv] = std::max(grp_la2[lv], ((nt - 2) * (nt - 1) / 2 + 7) / 8 * 8);
-                    }
+            // which: 0 = every front (one GPU), 1 = the rank's own subtrees, 2 = the replicated top (an in-place chain never crosses the
+            // ownership boundary -- symbolic.cpp only aliases fronts of one owner -- so neither does a group)
+            auto build_groups = [&](GrpSched& G, int which) -> bool {
+                for (auto* v : {&G.g0, &G.g1, &G.split, &G.nrb, &G.tiles64, &G.tiles, &G.la1, &G.la2}) v->assign(Sy.num_levels, 0);
+                G.evA.assign(Sy.num_levels, nullptr); G.evB.assign(Sy.num_levels, nullptr);
+                if (!grouped) return true;
+                std::vector<std::vector<int>> at(Sy.num_levels);
+                for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
+                    if ((which == 1 && Sy.sn_owner[sn] != opt.rank) || (which == 2 && Sy.sn_owner[sn] >= 0)) continue;
+                    int first = sn;
+                    for (int j = Sy.grp_pos[sn]; j > 0; --j) first = Sy.alias_child[first];
+                    if (Sy.sn_level[first] >= Sy.grp_cut_level) at[Sy.sn_level[first]].push_back(sn);      // (groups do not straddle the cut: symbolic.cpp)
                 }
-                grp_split[lv] = nsmall; grp1[lv] = (int)lvl_list.size();
-                if (grp_la2[lv] > 0) { HIPCHK(hipEventCreateWithFlags(&grp_evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&grp_evB[lv], hipEventDisableTiming)); }
-            }
+                int ng = 0;
+                for (int lv = 0; lv < Sy.num_levels; ++lv) {
+                    std::stable_sort(at[lv].begin(), at[lv].end(), [&](int a, int b) { return order_of(a) < order_of(b); });
+                    G.g0[lv] = (int)lvl_list.size();
+                    int nsmall = 0;
+                    for (int sn : at[lv]) {
+                        lvl_list.push_back(sn); ++ng;
+                        const int mu = order_of(sn) - cols_of(sn), nt = (mu + 127) / 128;
+                        G.nrb[lv] = std::max(G.nrb[lv], (mu + 63) / 64);
+                        if (order_of(sn) <= 1024) { ++nsmall; G.tiles64[lv] = std::max(G.tiles64[lv], schur_tiles64(Sy, sn)); }
+                        else {
+                            G.tiles[lv] = std::max(G.tiles[lv], schur_tiles(Sy, sn));
+                            G.la1[lv] = std::max(G.la1[lv], split_of[sn] ? 2 * nt - 1 : tri_tiles(nt));
+                            if (split_of[sn]) G.la2[lv] = std::max(G.la2[lv], ((nt - 2) * (nt - 1) / 2 + 7) / 8 * 8);
+                        }
+                    }
+                    G.split[lv] = nsmall; G.g1[lv] = (int)lvl_list.size();
+                    if (G.la2[lv] > 0) { HIPCHK(hipEventCreateWithFlags(&G.evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&G.evB[lv], hipEventDisableTiming)); }
+                }
+                if (opt.verbose) fprintf(stderr, "[mi355x_kkt] grouped schedule%s: %d chain groups factored in one launch each (tree levels >= %d)\n",
+                                         which == 0 ? "" : (which == 1 ? " (own subtrees)" : " (replicated top)"), ng, Sy.grp_cut_level);
+                return true;
+            };
+            if (!multi) { if (!build_groups(gs_single, 0)) return false; }
+            else { if (!build_groups(gs_local, 1) || !build_groups(gs_top, 2)) return false; }
             allbig_base = (int)lvl_list.size();
-            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG) { lvl_list.push_back(sn); allbig_maxk = std::max(allbig_maxk, cols_of(sn)); }
+            if (grouped && !grp_fused)
+                for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG) { lvl_list.push_back(sn); allbig_maxk = std::max(allbig_maxk, cols_of(sn)); }
             allbig_count = (int)lvl_list.size() - allbig_base;
-            if (opt.verbose) { int ng = 0; for (int lv = 0; lv < Sy.num_levels; ++lv) ng += grp1[lv] - grp0[lv]; fprintf(stderr, "[mi355x_kkt] grouped schedule: %d chain groups for %d big fronts\n", ng, allbig_count); }
         }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
@@ -4304,10 +4313,11 @@ public:
             if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
         } else {
             const bool single = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_BIG]) && !multi;       // the single-GPU schedule
-            if (single && grouped && lv >= S->grp_cut_level) {
+            if ((single || multi) && grouped && lv >= S->grp_cut_level) {
+                // the chain groups whose first link sits on this level, one launch each (the multi-GPU schedules have their own group lists)
                 if (!drain_chain()) return false;
-                if (!lv_asm_skip[lv]) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
-                return launch_groups(lv);
+                if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
+                return launch_groups(lv, single ? gs_single : (top_mode ? gs_top : gs_local));
             }
             if (!single) { const bool sm = mm <= 640; return launch_big(lv, b0, sm ? b1 : b0, b1, top_mode, mm, kk, sm ? tiles64 : 0, sm ? 0 : tiles, false); }
             return launch_big(lv, b0, b0 + big_split[lv], b1, top_mode, mm, kk, part_tiles[0][lv], part_tiles[1][lv], true);
@@ -4356,28 +4366,28 @@ public:
         return true;
     }
     // the chain groups whose first link sits on level lv: pivot blocks + leading blocks, rows below, rank-(<= 256) updates
-    bool launch_groups(int lv) {
-        const int b0 = grp0[lv], b1 = grp1[lv], bs = b0 + grp_split[lv];
+    bool launch_groups(int lv, GrpSched& G) {
+        const int b0 = G.g0[lv], b1 = G.g1[lv], bs = b0 + G.split[lv];
         if (b1 == b0) return true;
         if (grp_fused) {
-            const int st = (b1 - b0) * (4 + grp_nrb[lv]) <= 256 ? 1 : 0;
-            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + grp_nrb[lv]), dim3(256), std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0)), stream, V, b0, st);
+            const int st = (b1 - b0) * (4 + G.nrb[lv]) <= 256 ? 1 : 0;
+            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + G.nrb[lv]), dim3(256), std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0)), stream, V, b0, st);
         } else {
             LAUNCH(KK_BIG_DIAG, k_grp_diag, dim3(b1 - b0), dim3(512), grp_lds_bytes(), stream, (const DevView*)d_view, b0);
-            if (grp_nrb[lv] > 0) LAUNCH(KK_BIG_TRSM, k_grp_rows, dim3(grp_nrb[lv], b1 - b0), dim3(256), trsm_lds_bytes(64, false), stream, V, b0);
+            if (G.nrb[lv] > 0) LAUNCH(KK_BIG_TRSM, k_grp_rows, dim3(G.nrb[lv], b1 - b0), dim3(256), trsm_lds_bytes(64, false), stream, V, b0);
         }
-        if (bs > b0 && grp_tiles64[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(grp_tiles64[lv], bs - b0), dim3(256), 0, stream, V, b0, 0);
+        if (bs > b0 && G.tiles64[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(G.tiles64[lv], bs - b0), dim3(256), 0, stream, V, b0, 0);
         if (b1 == bs) return true;
         const int nb = b1 - bs;
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }      // a full update may touch what an earlier part 2 is still writing
-        if (grp_la2[lv] > 0 && !prof_on) {
-            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(grp_la1[lv], nb), dim3(1024), 0, stream, V, bs, 1, 0, 0);
-            HIPCHK(hipEventRecord(grp_evA[lv], stream));
-            HIPCHK(hipStreamWaitEvent(stream2, grp_evA[lv], 0));
-            hipLaunchKernelGGL(k_big_schur, dim3(std::min(grp_la2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, bs, 2, grp_la2[lv], 0);
-            HIPCHK(hipEventRecord(grp_evB[lv], stream2));
-            la_last = grp_evB[lv]; la_pending = true;
-        } else if (grp_tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(grp_tiles[lv], nb), dim3(1024), 0, stream, V, bs, 0, 0, 0);
+        if (G.la2[lv] > 0 && !prof_on) {
+            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.la1[lv], nb), dim3(1024), 0, stream, V, bs, 1, 0, 0);
+            HIPCHK(hipEventRecord(G.evA[lv], stream));
+            HIPCHK(hipStreamWaitEvent(stream2, G.evA[lv], 0));
+            hipLaunchKernelGGL(k_big_schur, dim3(std::min(G.la2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, bs, 2, G.la2[lv], 0);
+            HIPCHK(hipEventRecord(G.evB[lv], stream2));
+            la_last = G.evB[lv]; la_pending = true;
+        } else if (G.tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.tiles[lv], nb), dim3(1024), 0, stream, V, bs, 0, 0, 0);
         return true;
     }
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
