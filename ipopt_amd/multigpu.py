@@ -144,6 +144,24 @@ class CommKKT:
             self.s.set_comm_callback(gloo_allreduce_callback(torch, dist))
 
 
+def partition_model(s, I, own, world):
+    """What the partition itself allows (work only, no latency, no communication): flops of the replicated top (every rank repeats them)
+    and of the most loaded rank's subtrees; predicted_speedup_bound = total / (top + heaviest rank).  The measured speed-up of the line
+    can be compared with it: the gap is latency of the replicated separator chains + the all-reduce."""
+    colptr = s.symbolic(1, I.num_sn + 1).astype(np.int64); rowptr = s.symbolic(2, I.num_sn + 1).astype(np.int64)
+    k = np.diff(colptr); m = np.diff(rowptr)
+    # sum_{j<k} (c_j - 1)(c_j + 2), c_j = m - j
+    j = np.arange(int(k.max()) + 1)
+    f = np.array([(((mm - j[:kk]) - 1) * ((mm - j[:kk]) + 2)).sum() for kk, mm in zip(k, m)], dtype=np.float64)
+    top = float(f[own < 0].sum())
+    local = [float(f[own == r].sum()) for r in range(world)]
+    total = float(f.sum())
+    return {"flops_total": total, "flops_replicated_top": top, "flops_heaviest_rank": max(local) if local else 0.0,
+            "replicated_fraction": top / total if total else 0.0,
+            "predicted_speedup_bound": total / (top + (max(local) if local else 0.0)) if total else 1.0,
+            "what": "work-only bound of the subtree-to-rank partition with a replicated top; latency of the replicated separator chains and the all-reduce come on top"}
+
+
 def bench_main(args, rank, world, local):
     """bench.py --gpus N (N > 1): launched by torch.distributed.run, one rank per GPU."""
     import torch
@@ -228,6 +246,7 @@ def bench_main(args, rank, world, local):
                        "RCCL all-reduce of the top arena per factorisation inside libmi355x_kkt (no Python collective on the data path)",
                        "supernodes": I.num_sn, "replicated_top_supernodes": int((own < 0).sum()), "num_neg": nneg, "scaled_residual": res},
             "same_workload_1gpu": {"ms_per_step": dt1 * 1e3, "value": flops_step / dt1 / 1e9, "speedup": dt1 / dt},
+            "partition_model": partition_model(s, I, own, world),
             "roofline": roof,
         }
     dist.barrier()
