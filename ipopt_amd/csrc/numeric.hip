@@ -71,9 +71,14 @@ struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp,
 // (+ one per 64 rows beyond the chain in the forward sweep); a link's workgroup waits on a flag for each earlier (forward) / later
 // (backward) link, applies that link's 64 x 64 block of the panel to its own rows, then solves with its pivot block and raises its
 // own flag -- the point-to-point pipeline of a "synchronisation-free" sparse triangular solve (Liu et al., Euro-Par 2016).
-struct ChainLink { long long panel_off, minv_off; int c0, k, ldp, s, r0, koff, pad0, pad1; };      // links of all chains, chain by chain, bottom link first
-struct ChainDesc { long long cvb; int link0, nlinks, tail, ktot, wg0f, wg0b, pad0, pad1; };         // cvb: chain vector base, ktot: columns of the chain
+struct ChainLink { long long panel_off, minv_off; int c0, k, ldp, s, r0, koff, fi, pad1; };      // links of all chains, chain by chain, bottom link first; fi: slot of the link's flags
+constexpr int FLAG_STRIDE = 32;      // ints between two flags of the sweeps: one 128-byte line each (hundreds of workgroups poll them; side by side they would all queue at one L2 channel)
+struct ChainDesc { long long cvb; int link0, nlinks, tail, ktot, wg0f, wg0b;       // cvb: chain vector base, ktot: columns of the chain, wg0*: first workgroup (within the segment's launch)
+                   int ch0, ch1, alias0, s0, init, gw0, gw1, tf0, pw0, pw1; };         // first link: children (cmeta range), in place on a child's vector, supernode; init: see setup;
+                                                                                       // gw0..gw1: tail flags (chwait) awaited before the first link's children are gathered; tf0: own tail flags;
+                                                                                       // pw0..pw1: backward, link flags (chwait) of the parent's chain
 
+typedef double v2d __attribute__((ext_vector_type(2)));      // {value, tag}: the 16-byte messages of the solve sweeps
 struct DevView {
     // symbolic
     const int* sn_colptr; const int* sn_rowptr; const int* sn_rows; const int* rel;
@@ -117,10 +122,13 @@ struct DevView {
     int* qstat;             // [0]: some pivot decision of this factorisation would differ at u = pivtol2
     double* cnorm;          // inf-norm of every column of the (scaled) INPUT matrix, permuted numbering: scale of the zero-pivot test
     const ChainLink* chlink; const ChainDesc* chdesc;     // chain solve tables
+    int strace_b;                    // (first backward workgroup's slot)
+    unsigned long long* strace;      // development aid (MI355X_KKT_SOLVE_TRACE=file): 4 wall-clock stamps per workgroup of the data-flow sweeps
+    const int* chwg_f; const int* chwg_b; const int* chwait; int* sflag_t; v2d* ytag; v2d* xtag;     // workgroup -> chain (forward / backward launch), wait lists, tail / gather flags
     int* tcnt;                                                  // per front: panel-solve workgroups finished (fused pivot block + panel solve + narrow update launch), zeroed by the prologue
     double* isg; int* hasis;      // per big front: the four 16 x 16 diagonal-block inverses of L11 left by the blocked factorisation (hasis: valid), for the panel solves
     int* sflag_s;           // [4 * link + q]: rows of the group's link q have stored their W / L against this link (k_grp_fused)
-    int* sflag_f; int* sflag_b; int* sflag_d; int* sepoch;     // (sflag_d / sepoch[2]: pivot block done, fused pivot-block + panel-solve launch)              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
+    int* sflag_b; int* sflag_d; int* sepoch;     // (sflag_d / sepoch[2]: pivot block done, fused pivot-block + panel-solve launch)              // per-supernode 'done' flags of the chain sweeps (value = epoch of the solve)
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
     int fastpiv;            // pivot blocks of the big fronts: blocked LDL^T accepted a posteriori first, the strict loop as fall-back (ldlt_blocked_static)
@@ -1020,7 +1028,7 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
 // alive mask) for the 128-column panels of the wide_panels option (19 ms against 28 ms with 8x8 tiles on 256 threads, but
 // still slower per column than two 64-column blocks: option off by default)
 __device__ __forceinline__ void chain_signal(int* flag, const int epoch);
-__device__ __forceinline__ void chain_wait(const int* flag, const int epoch, int* err);
+template <int NAP = 2> __device__ __forceinline__ void chain_wait(const int* flag, const int epoch, int* err);
 // PRE: the caller has left the assembled, fully updated block in Lb (lower triangle) AND in the panel storage; late_*: a row block's L21 the
 // caller kept back in LDS, stored once the flag is up (off the critical chain)
 __device__ __forceinline__ void trsm_store_l(const DevView& V, const FrontMeta& M, const double* Lr, const int ibase, const int rlim);
@@ -1881,13 +1889,16 @@ __global__ __launch_bounds__(256) void k_bwd_grp(DevView V, int list_off)
 // sync-free chain sweeps (see ChainLink / ChainDesc)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_bump_epoch(int* e) { if (threadIdx.x == 0 && blockIdx.x == 0) *e += 1; }
+template <int NAP>
 __device__ __forceinline__ void chain_wait(const int* flag, const int epoch, int* err)
 {
     if (threadIdx.x == 0) {
-        // bounded: a producer that never shows up (it cannot, all workgroups of the launch are resident) must not hang the GPU
+        // bounded: a producer that never shows up (it cannot: it has a lower workgroup index, so it was dispatched before) must not hang the GPU
+        // NAP: 64-cycle units between two polls -- long where the flag is not the last one the workgroup waits for (fewer requests in the
+        // L2 queues the critical hop goes through)
         int spins = 0;
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(NAP);
             if (++spins > (1 << 24)) { *err = 1; break; }
         }
     }
@@ -1900,173 +1911,285 @@ __device__ __forceinline__ void chain_signal(int* flag, const int epoch)
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-// One hop of the pipeline costs a flag round trip through memory plus every DEPENDENT global access behind it (~1.5-2 us each
-// on this part): so everything that does not depend on the incoming vector -- the link's inverse, pivot order and D, and the panel
-// block of the NEXT predecessor -- is fetched BEFORE the wait (measured: 13 us per hop without).
-__global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int desc0, int ndesc)
+// ---- the messages of the sweeps ----
+// The 8 XCDs of the part have an L2 each; what one workgroup stores becomes visible to another XCD only through the fabric.  A release
+// fence at agent scope writes the WHOLE L2 back (buffer_wbl2) and an acquire invalidates it: measured 1.6-2.1 us per one-way message of
+// 64 doubles with "data, fence, flag / poll, fence, load" (tools/micro/pingpong.hip).  So nothing here uses fences:
+//   * a link's solution travels as 64 {value, tag} pairs, each ONE 16-byte agent-coherent store (sc1: through the L2 to the fabric) that the
+//     consumers poll with 16-byte agent-coherent loads -- value and tag arrive together, no flag, no fence: 0.4-0.5 us per message;
+//   * everything else a workgroup hands to another one inside a launch (rows of a chain vector, solution entries) is stored and loaded
+//     agent-coherently too, and the flag that announces it goes out after the stores have been acknowledged (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ v2d ld_tag(const v2d* p) { v2d r; asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(p) : "memory"); return r; }
+__device__ __forceinline__ void st_tag(v2d* p, v2d v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// the whole wavefront waits until the (first k of the) 64 tagged entries at p carry this solve's tag; returns lane's value (0 beyond k).
+// Dozens of workgroups wait for the same message, and every poll is a request to the ONE memory channel that holds it: polls of all 64
+// entries from every waiter queue up there and the message the next link is waiting for arrives 1.7 us late instead of 0.45 (measured).  So a
+// waiter polls the first entry only (one request per wavefront), and the further it is from needing the message -- dist: hops between this
+// message and the last one it waits for -- the longer it sleeps between polls; then one load of all entries (repeated if the producer's other
+// wavefronts have not landed yet).  There is ALWAYS an s_sleep between two polls: re-issued back to back (~100 ns apart) by the same wavefront,
+// the agent-coherent load of the same line kept returning the value of the first poll -- for seconds -- on this part.
+__device__ __forceinline__ double tag_await(const v2d* p, const int lane, const int k, const double ep, const int dist, int* err)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* Ms = reinterpret_cast<double*>(smem_raw);           // 64 x 65: the link's stored inverse
-    __shared__ double acc[64], ys[64], bp[64], part[4][64], dv[64], dof[64];
-    __shared__ int lp[64], pts[64];
-    const int tid = threadIdx.x;
-    ChainDesc C = V.chdesc[desc0];
-    for (int q = 1; q < ndesc; ++q) { const ChainDesc Cn = V.chdesc[desc0 + q]; if ((int)blockIdx.x >= Cn.wg0f) C = Cn; }
+    int spins = 0;
+    const int ehi = __double2hiint(ep), elo = __double2loint(ep);
+    while (dist > 0) {          // (the message the workgroup needs next is polled in full straight away: one round trip less)
+        const v2d h = ld_tag(p);
+        if (__builtin_amdgcn_readfirstlane(__double2hiint(h.y)) == ehi && __builtin_amdgcn_readfirstlane(__double2loint(h.y)) == elo) break;      // (scalar branch)
+        __builtin_amdgcn_s_sleep(1);
+        for (int d = 0; d < min(dist, 6); ++d) __builtin_amdgcn_s_sleep(10);
+        if (++spins > (1 << 22)) { *err = 1; break; }       // (cannot happen: the producer has a lower workgroup index, it was dispatched first)
+    }
+    const v2d* q = p + (lane < k ? lane : 0);
+    v2d v;
+    while (true) {
+        v = ld_tag(q);
+        if (__all(v.y == ep)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 22)) { *err = 1; break; }
+    }
+    return lane < k ? v.x : 0.0;
+}
+// flags of the sweeps (FLAG_STRIDE ints apart): raised after this workgroup's coherent stores are acknowledged; awaited side by side, one per lane
+__device__ __forceinline__ void flag_raise(int* flag, const int epoch)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flags_await(const int* flags, const int* list, const int f0, const int f1, const int epoch, int* err)
+{
+    if (threadIdx.x < 64)
+        for (int f = f0 + (int)threadIdx.x; f < f1; f += 64) {
+            const int* flag = flags + (size_t)list[f] * FLAG_STRIDE;
+            int spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1 << 22)) { *err = 1; break; }
+            }
+        }
+    __syncthreads();
+}
+
+// Forward sweep of a segment.  Workgroup = one link of a chain (64 pivot rows of the chain vector) or 64 rows beyond the chain; it OWNS its rows:
+// their running value sits in registers (4 lanes per row, each with 16 of the 64 columns of a panel block) until every earlier link of the
+// chain has been applied.  Per earlier link: await its tagged y, 16 FMAs per lane, two DPP adds.  A link then permutes (LDS, the one barrier
+// of a hop), applies its stored inverse from registers and publishes y.  Everything that does not depend on the incoming vectors -- inverse,
+// pivot data, the next panel block, the children's inverse row maps -- is in registers before the first wait.
+__global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int wg0)
+{
+    __shared__ double ysw[4][64], bps[64], yss[64];
+    __shared__ int ipos[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = tid >> 2, part = tid & 3;
+    const int di = V.chwg_f[wg0 + (int)blockIdx.x];
+    const ChainDesc C = V.chdesc[di];
+    unsigned long long* tr = V.strace ? V.strace + 4 * (size_t)(wg0 + (int)blockIdx.x) : nullptr;
+    if (tr && tid == 0) tr[0] = wall_clock64();
     const int w = (int)blockIdx.x - C.wg0f;
     const int epoch = *V.sepoch;
+    const double ep = (double)epoch;
+    int* err = V.sepoch + 1;
     const bool is_link = w < C.nlinks;
     const ChainLink Me = V.chlink[C.link0 + (is_link ? w : C.nlinks - 1)];
     const int roff = is_link ? Me.koff : C.ktot + 64 * (w - C.nlinks);       // my rows inside the chain vector
     const int rows = is_link ? Me.k : min(64, C.tail - 64 * (w - C.nlinks));
+    const bool rok = row < rows;
     double* cvp = V.cvec + C.cvb;
-    if (tid < 64) acc[tid] = (tid < rows) ? cvp[roff + tid] + (is_link ? V.xw[Me.c0 + tid] : 0.0) : 0.0;
+    const int k = Me.k, c0 = Me.c0;
+    double mreg[16];
+    int pt = 1; double dq = 0.0, oq = 0.0, oq1 = 0.0;
     if (is_link) {
-        const int k = Me.k, c0 = Me.c0;
         const double* Mg = V.minv + Me.minv_off;
-        for (int idx = tid; idx < k * k; idx += 256) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
-        if (tid < k) { lp[tid] = V.lperm[c0 + tid]; pts[tid] = V.ptype[c0 + tid]; dv[tid] = V.dinv[c0 + tid]; dof[tid] = V.doff[c0 + tid]; }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int pp = part + 4 * u; mreg[u] = (row < k && pp <= row) ? Mg[row + (size_t)pp * k] : 0.0; }      // Minv(row, pp)
+        if (tid < k) ipos[V.lperm[c0 + tid]] = tid;
+        if (part == 0 && row < k) { pt = V.ptype[c0 + row]; dq = V.dinv[c0 + row]; oq = V.doff[c0 + row]; oq1 = row > 0 ? V.doff[c0 + row - 1] : 0.0; }
     }
+    const double xb = (is_link && rok) ? V.xw[c0 + row] : 0.0;
     const int nprev = is_link ? w : C.nlinks;
-    const int p = tid & 63, qq = tid >> 6;
     double lreg[16];
     ChainLink Li = V.chlink[C.link0];
     auto fetch_block = [&](const ChainLink& L) {
-        const double* Lb = V.L + L.panel_off + (roff - L.koff) + p;              // my rows of that link's panel
+        const double* Lb = V.L + L.panel_off + (roff - L.koff) + (rok ? row : 0);              // my rows of that link's panel
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int q = qq + 4 * u; lreg[u] = (p < rows && q < L.k) ? Lb[(size_t)q * L.ldp] : 0.0; }
+        for (int u = 0; u < 16; ++u) { const int q = part + 4 * u; lreg[u] = (rok && q < L.k) ? Lb[(size_t)q * L.ldp] : 0.0; }
     };
     if (nprev > 0) fetch_block(Li);
-    __syncthreads();
+    // ---- the value my rows start from ----
+    double acc;
+    if (C.init == 2) {
+        // rows of the children's fronts that land on mine (inverse row maps: static), then the children's chains must be complete
+        int inv[4]; long long cvb[4]; int nc = 0, cp = C.ch0;
+        for (; cp < C.ch1 && nc < 4; ++cp) {
+            const ChildMeta Cm = V.cmeta[cp];
+            if (Cm.aliased) continue;
+            inv[nc] = rok ? V.relinv[Cm.inv + roff + row] : -1; cvb[nc] = Cm.cvbase; ++nc;
+        }
+        flags_await(V.sflag_t, V.chwait, C.gw0, C.gw1, epoch, err);
+        double t = (C.alias0 && rok) ? ld_coh(&cvp[roff + row]) : 0.0;
+        for (int c = 0; c < nc; ++c) if (inv[c] >= 0) t += ld_coh(V.cvec + cvb[c] + inv[c]);
+        for (; cp < C.ch1; ++cp) {          // (more than 4 gathered children: not a nested-dissection tree)
+            const ChildMeta Cm = V.cmeta[cp];
+            if (Cm.aliased) continue;
+            const int iv = rok ? V.relinv[Cm.inv + roff + row] : -1;
+            if (iv >= 0) t += ld_coh(V.cvec + Cm.cvbase + iv);
+        }
+        acc = xb + t;
+    } else {
+        __syncthreads();                    // (ipos)
+        acc = (C.init == 0 && rok) ? xb + cvp[roff + row] : xb;
+    }
+    const int myipos = (is_link && row < k) ? ipos[row] : 0;
+    if (tr && tid == 0) tr[1] = wall_clock64();
     for (int i = 0; i < nprev; ++i) {
-        chain_wait(&V.sflag_f[Li.s], epoch, V.sepoch + 1);
-        if (tid < 64) ys[tid] = (tid < Li.k) ? V.ybuf[Li.c0 + tid] : 0.0;
-        __syncthreads();
+        const double yv = tag_await(V.ytag + Li.c0, lane, Li.k, ep, nprev - 1 - i, err);
+        if (tr && tid == 0 && i + 1 == nprev) tr[2] = wall_clock64();
+        ysw[wave][lane] = yv;
+        __builtin_amdgcn_wave_barrier();
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; u += 2) { a0 += lreg[u] * ys[qq + 4 * u]; a1 += lreg[u + 1] * ys[qq + 4 * u + 4]; }
-        part[qq][p] = a0 + a1;
-        if (i + 1 < nprev) { Li = V.chlink[C.link0 + i + 1]; fetch_block(Li); }        // in flight while the next flag is awaited
-        __syncthreads();
-        if (tid < 64) acc[tid] -= (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        __syncthreads();
+        for (int u = 0; u < 16; u += 2) { a0 += lreg[u] * ysw[wave][part + 4 * u]; a1 += lreg[u + 1] * ysw[wave][part + 4 * u + 4]; }
+        __builtin_amdgcn_wave_barrier();
+        if (i + 1 < nprev) { Li = V.chlink[C.link0 + i + 1]; fetch_block(Li); }        // in flight while the next y is awaited
+        double t = a0 + a1;
+        t += dpp_f64<0xB1>(t); t += dpp_f64<0x4E>(t);               // the 4 lanes of a row are a DPP quad
+        acc -= t;
     }
-    if (!is_link) { if (tid < rows) cvp[roff + tid] = acc[tid]; return; }
-    const int k = Me.k, c0 = Me.c0;
-    if (tid < k) bp[tid] = acc[lp[tid]];
-    __syncthreads();
-    {   // y = Minv (P b): 4 threads per row, inverse from LDS
-        const int part4 = tid & 3;
-        for (int q = tid >> 2; q < k; q += 64) {
-            double a = 0.0;
-            for (int pp = part4; pp <= q; pp += 4) a += Ms[q + pp * 65] * bp[pp];
-            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
-            if (part4 == 0) ys[q] = a;
-        }
+    if (!is_link) {          // rows beyond the chain: complete, the parent's chain may take them
+        if (rok && part == 0) st_coh(&cvp[roff + row], acc);
+        flag_raise(&V.sflag_t[(size_t)(C.tf0 + (w - C.nlinks)) * FLAG_STRIDE], epoch);
+        if (tr && tid == 0) tr[3] = wall_clock64();
+        return;
     }
+    if (part == 0 && row < k) bps[myipos] = acc;              // P b
     __syncthreads();
-    if (tid < k) {
-        const int pt = pts[tid];
+    double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u += 2) { a0 += mreg[u] * bps[part + 4 * u]; a1 += mreg[u + 1] * bps[part + 4 * u + 4]; }      // (mreg is zero beyond the row)
+    double y = a0 + a1;
+    y += dpp_f64<0xB1>(y); y += dpp_f64<0x4E>(y);
+    if (part == 0 && row < k) { v2d m; m.x = y; m.y = ep; st_tag(V.ytag + c0 + row, m); }
+    if (tr && tid == 0) tr[3] = wall_clock64();
+    // off the chain's critical path: z = D^{-1} y for the backward sweep
+    if (part == 0) yss[row] = y;
+    __syncthreads();
+    if (part == 0 && row < k) {
         double z;
-        if (pt == 1) z = ys[tid] * dv[tid];
-        else if (pt == 2) z = dv[tid] * ys[tid] + dof[tid] * ys[tid + 1];
-        else z = dof[tid - 1] * ys[tid - 1] + dv[tid] * ys[tid];
-        V.ybuf[c0 + tid] = ys[tid];
-        V.zb[c0 + tid] = z;
+        if (pt == 1) z = y * dq;
+        else if (pt == 2) z = dq * y + oq * yss[row + 1];
+        else z = oq1 * yss[row - 1] + dq * y;
+        V.ybuf[c0 + row] = y;
+        V.zb[c0 + row] = z;
     }
-    chain_signal(&V.sflag_f[Me.s], epoch);
 }
+// Backward sweep of a segment: one workgroup per link, the parents' chains first.  The rows beyond the chain (their solution is complete once
+// every link of the parent's chain has raised its flag) are streamed by the whole workgroup -- NT = 1024 where that part is long: 16 wavefronts x
+// 16 loads in flight -- then 4 wavefronts walk the chain: per later link, await its tagged x, 16 FMAs per lane on the 64 x 64 block of my panel
+// that meets its rows, two DPP adds; finally L11^{-T} from registers, x published tagged (for the chain) and plain (for everything below).
 template <int NT>
-__global__ __launch_bounds__(NT) void k_bwd_chain(DevView V, int desc0, int ndesc)
+__global__ __launch_bounds__(NT) void k_bwd_chain(DevView V, int wg0)
 {
-    constexpr int NW = NT / 64, CPW = 64 / NW;                 // wavefronts, columns per wavefront
-    // NT = 1024 where many rows BEYOND the chain exist: that part of the panel (up to a few thousand rows x 64 columns) is streamed by this
-    // one workgroup, so it needs memory-level parallelism (4 columns per wavefront, 4 row strips of 64 in flight per lane);
-    // NT = 256 for a chain that ends (almost) at a root: cheaper barriers on the flag pipeline
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* Ms = reinterpret_cast<double*>(smem_raw);           // 64 x 65: the link's stored inverse
-    __shared__ double ws[64], xs[NT];
-    __shared__ int lp[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    ChainDesc C = V.chdesc[desc0];
-    for (int q = 1; q < ndesc; ++q) { const ChainDesc Cn = V.chdesc[desc0 + q]; if ((int)blockIdx.x >= Cn.wg0b) C = Cn; }
+    constexpr int NW = NT / 64, CPW = 64 / NW;                 // wavefronts, columns per wavefront (streaming part)
+    __shared__ double ws[64], xs[NT], xsw[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = (tid >> 2) & 63, part = tid & 3;
+    const ChainDesc C = V.chdesc[V.chwg_b[wg0 + (int)blockIdx.x]];
+    unsigned long long* tr = V.strace ? V.strace + 4 * (size_t)(V.strace_b + wg0 + (int)blockIdx.x) : nullptr;
+    if (tr && tid == 0) tr[0] = wall_clock64();
     // the TOP link gets the first workgroup of its chain: it is the head of the dependency chain
     const int j = C.nlinks - 1 - ((int)blockIdx.x - C.wg0b);
     const int epoch = *V.sepoch;
+    const double ep = (double)epoch;
+    int* err = V.sepoch + 1;
     const ChainLink Me = V.chlink[C.link0 + j];
     const int k = Me.k, c0 = Me.c0;
     if (tid < 64) ws[tid] = (tid < k) ? V.zb[c0 + tid] : 0.0;
-    {
-        const double* Mg = V.minv + Me.minv_off;
-        for (int idx = tid; idx < k * k; idx += NT) { const int q = idx % k, pp = idx / k; Ms[q + pp * 65] = Mg[idx]; }
-        if (tid < k) lp[tid] = V.lperm[c0 + tid];
-    }
-    // later links of the chain, top first: the block of my panel that meets link r's rows is fetched before r's flag is awaited
-    double lreg[CPW];                                          // lane = row t of the block, columns wave, wave + NW, ...
+    double mreg[16], lreg[16];
+    int lpv = 0;
     ChainLink Lr = V.chlink[C.link0 + C.nlinks - 1];
-    auto fetch_block = [&](const ChainLink& L) {
-        const double* Lb = V.L + Me.panel_off + (L.koff - Me.koff) + lane;
+    auto fetch_block = [&](const ChainLink& L) {      // rows of link L's pivots in my panel, my column; lane part has rows part, part + 4, ...
+        const double* Lb = V.L + Me.panel_off + (L.koff - Me.koff) + (size_t)(col < k ? col : 0) * Me.ldp;
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) { const int q = wave + NW * u; lreg[u] = (lane < L.k && q < k) ? Lb[(size_t)q * Me.ldp] : 0.0; }
+        for (int u = 0; u < 16; ++u) { const int t = part + 4 * u; lreg[u] = (col < k && t < L.k) ? Lb[t] : 0.0; }
     };
-    if (j < C.nlinks - 1) fetch_block(Lr);
-    __syncthreads();
-    // rows beyond the chain: their solution is known since the levels above
-    const int toff = C.ktot - Me.koff;
-    const double* Lt = V.L + Me.panel_off + toff;
-    double t[CPW];                                             // columns CPW wave .. CPW wave + CPW - 1
+    if (C.tail > 0) {
+        flags_await(V.sflag_b, V.chwait, C.pw0, C.pw1, epoch, err);        // (barrier inside)
+        if (tr && tid == 0) tr[1] = wall_clock64();
+        const int toff = C.ktot - Me.koff;
+        const double* Lt = V.L + Me.panel_off + toff;
+        double t[CPW];                                             // columns CPW wave .. CPW wave + CPW - 1
 #pragma unroll
-    for (int u = 0; u < CPW; ++u) t[u] = 0.0;
-    for (int base = 0; base < C.tail; base += NT) {
-        const int nrow = min(NT, C.tail - base);
-        xs[tid] = (tid < nrow) ? V.xw[V.sn_rows[Me.r0 + toff + base + tid]] : 0.0;
-        __syncthreads();
-        if (CPW * wave < k) {
-            constexpr int RS = (CPW <= 4) ? 4 : 1;               // row strips of 64 in flight per lane (16 loads per lane either way)
-            for (int i0 = 0; i0 < nrow; i0 += 64 * RS) {
-                double lv[RS][CPW];
+        for (int u = 0; u < CPW; ++u) t[u] = 0.0;
+        for (int base = 0; base < C.tail; base += NT) {
+            const int nrow = min(NT, C.tail - base);
+            xs[tid] = (tid < nrow) ? ld_coh(&V.xw[V.sn_rows[Me.r0 + toff + base + tid]]) : 0.0;
+            __syncthreads();
+            if (CPW * wave < k) {
+                constexpr int RS = (CPW <= 4) ? 4 : 1;               // row strips of 64 in flight per lane (16 loads per lane either way)
+                for (int i0 = 0; i0 < nrow; i0 += 64 * RS) {
+                    double lv[RS][CPW];
 #pragma unroll
-                for (int a = 0; a < RS; ++a)
+                    for (int a = 0; a < RS; ++a)
 #pragma unroll
-                    for (int u = 0; u < CPW; ++u) {
-                        const int i = i0 + 64 * a + lane, q = CPW * wave + u;
-                        lv[a][u] = (i < nrow && q < k) ? Lt[base + i + (size_t)q * Me.ldp] : 0.0;
+                        for (int u = 0; u < CPW; ++u) {
+                            const int i = i0 + 64 * a + lane, q = CPW * wave + u;
+                            lv[a][u] = (i < nrow && q < k) ? Lt[base + i + (size_t)q * Me.ldp] : 0.0;
+                        }
+#pragma unroll
+                    for (int a = 0; a < RS; ++a) {
+                        const double x = xs[min(i0 + 64 * a + lane, NT - 1)];
+#pragma unroll
+                        for (int u = 0; u < CPW; ++u) t[u] += lv[a][u] * x;
                     }
-#pragma unroll
-                for (int a = 0; a < RS; ++a) {
-                    const double x = xs[min(i0 + 64 * a + lane, NT - 1)];
-#pragma unroll
-                    for (int u = 0; u < CPW; ++u) t[u] += lv[a][u] * x;
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
-    }
-    if (C.tail > 0 && CPW * wave < k) {
+        if (CPW * wave < k) {
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) { const double sv = wave_sum_dpp(t[u]); if (lane == 0 && CPW * wave + u < k) ws[CPW * wave + u] -= sv; }
+            for (int u = 0; u < CPW; ++u) { const double sv = wave_sum_dpp(t[u]); if (lane == 0 && CPW * wave + u < k) ws[CPW * wave + u] -= sv; }
+        }
     }
     __syncthreads();
+    if (tid >= 256) return;                                    // (NT = 1024: the other 12 wavefronts were only here to stream)
+    {   // what the walk along the chain needs, in registers before the first wait (not earlier: the streaming part needs the registers, and
+        // every link but the top one has hops to wait for anyway)
+        const double* Mg = V.minv + Me.minv_off;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { const int q = col + part + 4 * u; mreg[u] = (col < k && q < k) ? Mg[q + (size_t)col * k] : 0.0; }      // Minv(q, col), q >= col
+        if (col < k) lpv = V.lperm[c0 + col];
+        if (j < C.nlinks - 1) fetch_block(Lr);
+    }
+    double wv = ws[col];
+    __syncthreads();                                           // (everybody has read ws)
+    if (tr && tid == 0) tr[2] = wall_clock64();
     for (int r = C.nlinks - 1; r > j; --r) {
-        chain_wait(&V.sflag_b[Lr.s], epoch, V.sepoch + 1);
-        const double xv = (lane < Lr.k) ? V.xw[Lr.c0 + lane] : 0.0;
-        double v[CPW];
+        const double xv = tag_await(V.xtag + Lr.c0, lane, Lr.k, ep, r - 1 - j, err);
+        xsw[wave][lane] = xv;
+        __builtin_amdgcn_wave_barrier();
+        double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) v[u] = lreg[u] * xv;
+        for (int u = 0; u < 16; u += 2) { a0 += lreg[u] * xsw[wave][part + 4 * u]; a1 += lreg[u + 1] * xsw[wave][part + 4 * u + 4]; }
+        __builtin_amdgcn_wave_barrier();
         if (r - 1 > j) { Lr = V.chlink[C.link0 + r - 1]; fetch_block(Lr); }
+        double t = a0 + a1;
+        t += dpp_f64<0xB1>(t); t += dpp_f64<0x4E>(t);               // the 4 lanes of a row are a DPP quad
+        wv -= t;
+    }
+    if (part == 0) ws[col] = wv;
+    __syncthreads();
+    double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) { const double sv = wave_sum_dpp(v[u]); if (lane == 0 && wave + NW * u < k) ws[wave + NW * u] -= sv; }
-        __syncthreads();
+    for (int u = 0; u < 16; u += 2) { a0 += mreg[u] * ws[(col + part + 4 * u) & 63]; a1 += mreg[u + 1] * ws[(col + part + 4 * u + 4) & 63]; }     // (mreg is zero beyond k)
+    double x = a0 + a1;
+    x += dpp_f64<0xB1>(x); x += dpp_f64<0x4E>(x);
+    if (part == 0 && col < k) {
+        v2d m; m.x = x; m.y = ep;
+        st_tag(V.xtag + c0 + lpv, m);
+        st_coh(&V.xw[c0 + lpv], x);
     }
-    if (tid < 256) {   // x_p = sum_{q >= p} Minv(q,p) w_q : 4 threads per column, inverse from LDS
-        const int part4 = tid & 3;
-        for (int pp = tid >> 2; pp < k; pp += 64) {
-            double a = 0.0;
-            for (int q = pp + part4; q < k; q += 4) a += Ms[q + pp * 65] * ws[q];
-            a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
-            if (part4 == 0) V.xw[c0 + lp[pp]] = a;
-        }
-    }
-    chain_signal(&V.sflag_b[Me.s], epoch);
+    flag_raise(&V.sflag_b[(size_t)Me.fi * FLAG_STRIDE], epoch);
+    if (tr && tid == 0) tr[3] = wall_clock64();
 }
 
 // ================================================================================================
@@ -3569,7 +3692,9 @@ public:
     std::vector<int> lv_narrow_tiles;   // > 0: every big front of the level is a chain link with a narrow update; the 64 x 64 tiles of the largest one
     std::vector<char> lv_asm_skip;      // every big front of the level is a pure in-place chain link: no assembly launch at all
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
-    struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail; };
+    int dbg_c0 = 0, dbg_k = 0;
+    size_t strace_n = 0; struct TraceDesc { int chain, w, nlinks, tail; }; std::vector<TraceDesc> strace_desc;
+    struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail, wgf0, wgb0; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
     bool pair_solve = true; std::vector<int> wave_kmax;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
     bool fuse_dt = true;                               // pivot block + panel solve in one launch where a level has few fronts
@@ -3919,8 +4044,12 @@ public:
                 }
                 lv_allsolo[lv] = all ? 1 : 0;
             }
-        // ---- sync-free chain sweeps: segments of >= 4 consecutive levels whose fronts are all pure in-place chain links ----
-        std::vector<ChainLink> chl; std::vector<ChainDesc> chd;
+        // ---- sync-free (data-flow) sweeps over the latency-bound top of the tree: a SEGMENT is a run of consecutive levels whose fronts are
+        // all BIG with <= 64 pivots and of which there are at most chain_maxc per level; its fronts are cut into CHAINS (maximal runs of
+        // in-place links: every link after the first has the previous link as its only child and shares its vector), and ONE launch per
+        // sweep runs the whole segment: workgroups wait on flags for exactly what they consume (see k_fwd_chain / k_bwd_chain) ----
+        std::vector<ChainLink> chl; std::vector<ChainDesc> chd; std::vector<int> chwait, wgf, wgb;
+        int ntailflags = 0;
         chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
@@ -3930,51 +4059,117 @@ public:
         wave_kmax.assign(Sy.num_levels, 0);
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
         if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
-        if (!Sy.solve_group && chain_solve) {      // (multi-GPU: only runs of levels that belong entirely to the replicated top)
+        if (!Sy.solve_group && chain_solve) {
             auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
             auto Mr = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
-            auto pure = [&](int sn) { return Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] == 1 && Kc(sn) <= 64; };
+            auto nchild = [&](int sn) { return Sy.child_ptr[sn + 1] - Sy.child_ptr[sn]; };
+            auto cnt = [&](int l) { return Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)l * FC_COUNT]; };
+            // multi-GPU: only runs of >= 4 levels made of pure links of the replicated top (nothing to gather inside the launch: the
+            // distributed sweeps exchange the joins between launches)
+            auto pure = [&](int sn) { return Sy.sn_class[sn] == FC_BIG && Sy.alias_child[sn] >= 0 && nchild(sn) == 1 && Kc(sn) <= 64; };
             std::vector<char> lvok(Sy.num_levels, 0);
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
                 const int a = Sy.level_ptr[(size_t)lv * FC_COUNT], b = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT];
-                bool ok = b > a;
-                for (int q = a; q < b && ok; ++q) { const int sn = Sy.level_sn[q]; ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1 && (!multi || Sy.sn_owner[sn] < 0); }
+                bool ok = b > a && b - a <= chain_maxc;
+                for (int q = a; q < b && ok; ++q) {
+                    const int sn = Sy.level_sn[q];
+                    if (multi) ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1 && Sy.sn_owner[sn] < 0;
+                    else       ok = Sy.sn_class[sn] == FC_BIG && Kc(sn) <= 64;
+                }
                 lvok[lv] = ok ? 1 : 0;
             }
-            std::vector<int> alias_parent(Sy.num_sn, -1);
-            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0) alias_parent[Sy.alias_child[sn]] = sn;
+            std::vector<int> chain_of(Sy.num_sn, -1);
             for (int lv = 0; lv < Sy.num_levels; ) {
                 if (!lvok[lv]) { ++lv; continue; }
                 int e = lv;
-                auto cnt = [&](int l) { return Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)l * FC_COUNT]; };
-                while (e + 1 < Sy.num_levels && lvok[e + 1] && cnt(e + 1) == cnt(lv)) ++e;
-                if (e - lv + 1 >= 4 && cnt(lv) <= chain_maxc) {
-                    ChainSeg sg{lv, e, (int)chd.size(), 0, 0, 0, 0};
-                    bool good = true;
-                    const size_t chl0 = chl.size(), chd0 = chd.size();
-                    for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT] && good; ++q) {
-                        ChainDesc D{}; D.link0 = (int)chl.size(); D.cvb = Sy.cv_off[Sy.level_sn[q]]; D.wg0f = sg.nwg_f; D.wg0b = sg.nwg_b;
-                        int koff = 0, sn = Sy.level_sn[q], last = sn;
-                        for (int l = lv; l <= e && sn >= 0; ++l, sn = alias_parent[sn]) {
-                            if (Sy.sn_level[sn] != l || Sy.cv_off[sn] != D.cvb + koff) { good = false; break; }
+                while (e + 1 < Sy.num_levels && lvok[e + 1] && (!multi || cnt(e + 1) == cnt(lv))) ++e;
+                if (e - lv + 1 >= (multi ? 4 : 2)) {
+                    ChainSeg sg{lv, e, (int)chd.size(), 0, 0, 0, 0, (int)wgf.size(), (int)wgb.size()};
+                    // chains, in the order of their first links' levels
+                    const size_t chl0 = chl.size();
+                    for (int l = lv; l <= e; ++l)
+                        for (int q = Sy.level_ptr[(size_t)l * FC_COUNT]; q < Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT]; ++q) {
+                            const int sn = Sy.level_sn[q], ac = Sy.alias_child[sn];
                             ChainLink L{}; L.panel_off = Sy.panel_off[sn]; L.minv_off = Sy.minv_off[sn]; L.c0 = Sy.sn_colptr[sn]; L.k = Kc(sn); L.ldp = Sy.sn_ldp[sn];
-                            L.s = sn; L.r0 = Sy.sn_rowptr[sn]; L.koff = koff;
-                            chl.push_back(L); koff += L.k; last = sn; D.nlinks++;
+                            L.s = sn; L.r0 = Sy.sn_rowptr[sn];
+                            const int cprev = (ac >= 0 && nchild(sn) == 1 && Sy.sn_level[ac] >= lv) ? chain_of[ac] : -1;
+                            if (cprev >= 0) {          // next link of its child's chain (the child is that chain's last link so far)
+                                ChainDesc& D = chd[cprev];
+                                L.koff = D.ktot; D.ktot += L.k; D.nlinks++; D.tail = Mr(sn) - L.k; L.fi = cprev;
+                                chain_of[sn] = cprev;
+                            } else {
+                                ChainDesc D{}; D.cvb = Sy.cv_off[sn]; D.nlinks = 1; D.ktot = L.k; D.tail = Mr(sn) - L.k; D.ch0 = Sy.child_ptr[sn]; D.ch1 = Sy.child_ptr[sn + 1];
+                                D.alias0 = ac >= 0 ? 1 : 0; D.s0 = sn;
+                                L.koff = 0; L.fi = (int)chd.size();
+                                chain_of[sn] = (int)chd.size(); chd.push_back(D);
+                            }
+                            chl.push_back(L);
                         }
-                        if (D.nlinks != e - lv + 1) good = false;
-                        D.ktot = koff; D.tail = Mr(last) - Kc(last);
-                        // in-place construction: every link's rows = its columns + the later links' columns + the common tail
-                        for (int t = 0; t < D.nlinks && good; ++t) { const ChainLink& L = chl[D.link0 + t]; if (Mr(L.s) != D.ktot - L.koff + D.tail) good = false; }
-                        sg.nwg_f += D.nlinks + (D.tail + 63) / 64; sg.nwg_b += D.nlinks; sg.maxtail = std::max(sg.maxtail, D.tail);
-                        chd.push_back(D);
-                    }
                     sg.ndesc = (int)chd.size() - sg.desc0;
-                    if (good && sg.nwg_f <= 1024) { seg_at_lv0[lv] = seg_at_lv1[e] = (int)chain_segs.size(); chain_segs.push_back(sg); }
-                    else { chl.resize(chl0); chd.resize(chd0); }
+                    {   // flatten: links chain by chain, bottom link first
+                        const size_t first = chl0;
+                        std::vector<ChainLink> part(chl.begin() + first, chl.end());
+                        std::stable_sort(part.begin(), part.end(), [](const ChainLink& x, const ChainLink& y) { return x.fi < y.fi; });
+                        std::copy(part.begin(), part.end(), chl.begin() + first);
+                        int cur = -1;
+                        for (size_t t = first; t < chl.size(); ++t) { if (chl[t].fi != cur) { cur = chl[t].fi; chd[cur].link0 = (int)t; } }
+                        for (size_t t = first; t < chl.size(); ++t) chl[t].fi = (int)t;
+                    }
+                    // workgroups: forward in chain order (children's chains first), backward in reverse (parents first)
+                    for (int d = sg.desc0; d < sg.desc0 + sg.ndesc; ++d) {
+                        ChainDesc& D = chd[d];
+                        const int nt = (D.tail + 63) / 64;
+                        D.wg0f = sg.nwg_f; D.tf0 = ntailflags; ntailflags += nt;
+                        for (int w = 0; w < D.nlinks + nt; ++w) wgf.push_back(d);
+                        sg.nwg_f += D.nlinks + nt; sg.maxtail = std::max(sg.maxtail, D.tail);
+                    }
+                    for (int d = sg.desc0 + sg.ndesc - 1; d >= sg.desc0; --d) {
+                        ChainDesc& D = chd[d];
+                        D.wg0b = sg.nwg_b; sg.nwg_b += D.nlinks;
+                        for (int w = 0; w < D.nlinks; ++w) wgb.push_back(d);
+                    }
+                    // what a chain waits for: forward, the rows beyond each child chain of its first link (all of them before anything is
+                    // gathered); backward, the bottom link of the chain its parent lives in
+                    for (int d = sg.desc0; d < sg.desc0 + sg.ndesc; ++d) {
+                        ChainDesc& D = chd[d];
+                        D.gw0 = (int)chwait.size();
+                        bool gathers = false;
+                        for (int q = D.ch0; q < D.ch1; ++q) {
+                            const int c = Sy.child_idx[q];
+                            if (c != Sy.alias_child[D.s0]) gathers = true;
+                            if (Sy.sn_level[c] < lv || chain_of[c] < 0) continue;
+                            const ChainDesc& X = chd[chain_of[c]];
+                            for (int b = 0; b < (X.tail + 63) / 64; ++b) chwait.push_back(X.tf0 + b);
+                        }
+                        D.gw1 = (int)chwait.size();
+                        // 0: the vector is in place (in-place link of a front below the segment), 1: fresh vector, nothing to gather, 2: gather step
+                        D.init = (gathers || D.gw1 > D.gw0) ? 2 : (D.alias0 ? 0 : 1);
+                        if (multi && D.init != 0) { fprintf(stderr, "[mi355x_kkt] internal: chain segment with a gather in a distributed schedule\n"); return false; }
+                        const int last = chl[D.link0 + D.nlinks - 1].s, par = Sy.sn_parent[last];
+                        D.pw0 = (int)chwait.size();
+                        if (par >= 0 && Sy.sn_level[par] <= e && chain_of[par] >= 0) { const ChainDesc& P = chd[chain_of[par]]; for (int t = 0; t < P.nlinks; ++t) chwait.push_back(P.link0 + t); }
+                        D.pw1 = (int)chwait.size();
+                    }
+                    seg_at_lv0[lv] = seg_at_lv1[e] = (int)chain_segs.size(); chain_segs.push_back(sg);
                 }
                 lv = e + 1;
             }
-            if (opt.verbose) { int nl = 0; for (auto& sg : chain_segs) nl += sg.lv1 - sg.lv0 + 1; fprintf(stderr, "[mi355x_kkt] sync-free chain sweeps: %d segments covering %d of %d levels\n", (int)chain_segs.size(), nl, Sy.num_levels); }
+            if (opt.verbose) { int nl = 0; for (auto& sg : chain_segs) nl += sg.lv1 - sg.lv0 + 1; fprintf(stderr, "[mi355x_kkt] data-flow solve sweeps: %d segments covering %d of %d levels, %d chains, %d links\n", (int)chain_segs.size(), nl, Sy.num_levels, (int)chd.size(), (int)chl.size()); }
+        }
+        if (!chl.empty()) { dbg_c0 = chl.back().c0; dbg_k = chl.back().k; }
+        if (!upload(wgf, &V.chwg_f) || !upload(wgb, &V.chwg_b) || !upload(chwait, &V.chwait)) return false;
+        V.strace = nullptr; V.strace_b = (int)wgf.size(); strace_n = 0;
+        if (getenv("MI355X_KKT_SOLVE_TRACE") && !wgf.empty()) {
+            strace_n = 4 * (wgf.size() + wgb.size());
+            if (!dalloc(&V.strace, strace_n)) return false;
+            strace_desc.clear();
+            for (size_t i = 0; i < wgf.size(); ++i) { const ChainDesc& D = chd[wgf[i]]; strace_desc.push_back({wgf[i], (int)i - D.wg0f - chain_segs[0].wgf0 * 0, D.nlinks, D.tail}); }
+            for (size_t i = 0; i < wgb.size(); ++i) { const ChainDesc& D = chd[wgb[i]]; strace_desc.push_back({wgb[i], (int)i - D.wg0b, D.nlinks, D.tail}); }
+        }
+        if (!dalloc(&V.sflag_t, (size_t)std::max(ntailflags, 1) * FLAG_STRIDE) || !dalloc(&V.sflag_b, std::max<size_t>(chl.size(), 1) * FLAG_STRIDE)) return false;
+        {   // tagged solution entries of the segments' columns (indexed by column; + 64: a wavefront polls 64 entries from a link's first column)
+            const size_t nt = chl.empty() ? 1 : (size_t)Sy.n + 64;
+            if (!dalloc(&V.ytag, nt) || !dalloc(&V.xtag, nt)) return false;
         }
         if (!upload(chl, &V.chlink) || !upload(chd, &V.chdesc)) return false;
         std::vector<int> bigidx_of(Sy.num_sn, 0);
@@ -4232,7 +4427,7 @@ public:
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
-            !dalloc(&V.sflag_f, Sy.num_sn) || !dalloc(&V.sflag_b, Sy.num_sn) || !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
+            !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         if (opt.scaling == 3) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
@@ -4535,7 +4730,7 @@ public:
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
                 if (seg_at_lv0[lv] >= 0) {      // a run of pure chain levels: one sync-free launch for all of them
                     const ChainSeg& sg = chain_segs[seg_at_lv0[lv]];
-                    LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(256), 0, stream, V, sg.wgf0);
                     lv = sg.lv1; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -4557,8 +4752,8 @@ public:
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
-                    if (sg.maxtail > 256) LAUNCH(KK_BWD_BIG, (k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
-                    else                LAUNCH(KK_BWD_BIG, (k_bwd_chain<256>),  dim3(sg.nwg_b), dim3(256),  64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    if (sg.maxtail > 256) LAUNCH(KK_BWD_BIG, (k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 0, stream, V, sg.wgb0);
+                    else                LAUNCH(KK_BWD_BIG, (k_bwd_chain<256>),  dim3(sg.nwg_b), dim3(256),  0, stream, V, sg.wgb0);
                     lv = sg.lv0; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -4615,6 +4810,26 @@ public:
             if (!chain_segs.empty()) HIPCHK(hipMemcpyAsync(h_stats + 6, V.sepoch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
             float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms;
+            if (V.strace) {
+                std::vector<unsigned long long> h(strace_n);
+                HIPCHK(hipMemcpy(h.data(), V.strace, strace_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+                if (FILE* f = fopen(getenv("MI355X_KKT_SOLVE_TRACE"), "w")) {
+                    for (size_t i = 0; i < strace_desc.size(); ++i)
+                        fprintf(f, "%c %d %d %d %d %llu %llu %llu %llu\n", i < (size_t)V.strace_b ? 'F' : 'B', strace_desc[i].chain, strace_desc[i].w, strace_desc[i].nlinks, strace_desc[i].tail,
+                                h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
+                    fclose(f);
+                }
+            }
+            if (!chain_segs.empty() && h_stats[6] != 0 && getenv("MI355X_KKT_DEBUG_TAGS")) {
+                std::vector<double> h(2 * 64); int ep[4];
+                HIPCHK(hipMemcpy(ep, V.sepoch, sizeof(ep), hipMemcpyDeviceToHost));
+                for (int which = 0; which < 2; ++which) {
+                    HIPCHK(hipMemcpy(h.data(), (which ? V.xtag : V.ytag) + dbg_c0, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+                    fprintf(stderr, "%s tags of the top link (c0 %d, k %d), epoch %d:", which ? "x" : "y", dbg_c0, dbg_k, ep[0]);
+                    for (int i = 0; i < 64; ++i) fprintf(stderr, " %g", h[2 * i + 1]);
+                    fprintf(stderr, "\n");
+                }
+            }
             if (!chain_segs.empty() && h_stats[6] != 0) { err_ = "solve: a chain sweep timed out waiting for its predecessor (workgroups not co-resident?)"; return false; }
         }
         return true;
@@ -4794,9 +5009,9 @@ public:
                 const int sgi = forward ? seg_at_lv0[lv] : seg_at_lv1[lv];
                 if (sgi >= 0) {
                     const ChainSeg& sg = chain_segs[sgi];
-                    if (forward) hipLaunchKernelGGL(k_fwd_chain, dim3(sg.nwg_f), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
-                    else if (sg.maxtail > 256) hipLaunchKernelGGL((k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
-                    else hipLaunchKernelGGL((k_bwd_chain<256>), dim3(sg.nwg_b), dim3(256), 64 * 65 * sizeof(double), stream, V, sg.desc0, sg.ndesc);
+                    if (forward) hipLaunchKernelGGL(k_fwd_chain, dim3(sg.nwg_f), dim3(256), 0, stream, V, sg.wgf0);
+                    else if (sg.maxtail > 256) hipLaunchKernelGGL((k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 0, stream, V, sg.wgb0);
+                    else hipLaunchKernelGGL((k_bwd_chain<256>), dim3(sg.nwg_b), dim3(256), 0, stream, V, sg.wgb0);
                     q += sg.lv1 - sg.lv0; continue;
                 }
             }
