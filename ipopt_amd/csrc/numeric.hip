@@ -74,9 +74,9 @@ struct GroupLink { long long panel_off, wb, minv_off, cv, tr; int c0, k, m, ldp,
 struct ChainLink { long long panel_off, minv_off; int c0, k, ldp, s, r0, koff, fi, pad1; };      // links of all chains, chain by chain, bottom link first; fi: slot of the link's flags
 constexpr int FLAG_STRIDE = 32;      // ints between two flags of the sweeps: one 128-byte line each (hundreds of workgroups poll them; side by side they would all queue at one L2 channel)
 struct ChainDesc { long long cvb; int link0, nlinks, tail, ktot, wg0f, wg0b;       // cvb: chain vector base, ktot: columns of the chain, wg0*: first workgroup (within the segment's launch)
-                   int ch0, ch1, alias0, s0, init, gw0, gw1, tf0, pw0, pw1; };         // first link: children (cmeta range), in place on a child's vector, supernode; init: see setup;
+                   int ch0, ch1, alias0, s0, init, gw0, gw1, tf0, pw0, pw1, dot0, pad0; };         // first link: children (cmeta range), in place on a child's vector, supernode; init: see setup;
                                                                                        // gw0..gw1: tail flags (chwait) awaited before the first link's children are gathered; tf0: own tail flags;
-                                                                                       // pw0..pw1: backward, link flags (chwait) of the parent's chain
+                                                                                       // pw0..pw1: backward, link flags (chwait) of the parent's chain; dot0: first dot workgroup (flags, partial sums)
 
 typedef double v2d __attribute__((ext_vector_type(2)));      // {value, tag}: the 16-byte messages of the solve sweeps
 struct DevView {
@@ -124,7 +124,7 @@ struct DevView {
     const ChainLink* chlink; const ChainDesc* chdesc;     // chain solve tables
     int strace_b;                    // (first backward workgroup's slot)
     unsigned long long* strace;      // development aid (MI355X_KKT_SOLVE_TRACE=file): 4 wall-clock stamps per workgroup of the data-flow sweeps
-    const int* chwg_f; const int* chwg_b; const int* chwait; int* sflag_t; v2d* ytag; v2d* xtag;     // workgroup -> chain (forward / backward launch), wait lists, tail / gather flags
+    const int* chwg_f; const int* chwg_b; const int* chwait; int* sflag_t; int* sflag_dot; double* dpart; v2d* ytag; v2d* xtag;     // workgroup -> chain (forward / backward launch), wait lists, tail / gather flags
     int* tcnt;                                                  // per front: panel-solve workgroups finished (fused pivot block + panel solve + narrow update launch), zeroed by the prologue
     double* isg; int* hasis;      // per big front: the four 16 x 16 diagonal-block inverses of L11 left by the blocked factorisation (hasis: valid), for the panel solves
     int* sflag_s;           // [4 * link + q]: rows of the group's link q have stored their W / L against this link (k_grp_fused)
@@ -1923,6 +1923,21 @@ __device__ __forceinline__ v2d ld_tag(const v2d* p) { v2d r; asm volatile("globa
 __device__ __forceinline__ void st_tag(v2d* p, v2d v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(p), "v"(v) : "memory"); }
 __device__ __forceinline__ double ld_coh(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a value every lane holds identically, moved to scalar registers (the compiler cannot see that what a vector load of a per-workgroup record returns is uniform)
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ long long uni(long long x) { return ((long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(x >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)x); }
+__device__ __forceinline__ ChainLink uni(const ChainLink& a)
+{
+    ChainLink r; r.panel_off = uni(a.panel_off); r.minv_off = uni(a.minv_off); r.c0 = uni(a.c0); r.k = uni(a.k); r.ldp = uni(a.ldp); r.s = uni(a.s); r.r0 = uni(a.r0); r.koff = uni(a.koff); r.fi = uni(a.fi); r.pad1 = 0;
+    return r;
+}
+__device__ __forceinline__ ChainDesc uni(const ChainDesc& a)
+{
+    ChainDesc r; r.cvb = uni(a.cvb); r.link0 = uni(a.link0); r.nlinks = uni(a.nlinks); r.tail = uni(a.tail); r.ktot = uni(a.ktot); r.wg0f = uni(a.wg0f); r.wg0b = uni(a.wg0b);
+    r.ch0 = uni(a.ch0); r.ch1 = uni(a.ch1); r.alias0 = uni(a.alias0); r.s0 = uni(a.s0); r.init = uni(a.init); r.gw0 = uni(a.gw0); r.gw1 = uni(a.gw1); r.tf0 = uni(a.tf0);
+    r.pw0 = uni(a.pw0); r.pw1 = uni(a.pw1); r.dot0 = uni(a.dot0); r.pad0 = 0;
+    return r;
+}
 // the whole wavefront waits until the (first k of the) 64 tagged entries at p carry this solve's tag; returns lane's value (0 beyond k).
 // Dozens of workgroups wait for the same message, and every poll is a request to the ONE memory channel that holds it: polls of all 64
 // entries from every waiter queue up there and the message the next link is waiting for arrives 1.7 us late instead of 0.45 (measured).  So a
@@ -1962,7 +1977,7 @@ __device__ __forceinline__ void flags_await(const int* flags, const int* list, c
 {
     if (threadIdx.x < 64)
         for (int f = f0 + (int)threadIdx.x; f < f1; f += 64) {
-            const int* flag = flags + (size_t)list[f] * FLAG_STRIDE;
+            const int* flag = flags + (size_t)(list ? list[f] : f) * FLAG_STRIDE;
             int spins = 0;
             while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                 __builtin_amdgcn_s_sleep(4);
@@ -1974,88 +1989,115 @@ __device__ __forceinline__ void flags_await(const int* flags, const int* list, c
 
 // Forward sweep of a segment.  Workgroup = one link of a chain (64 pivot rows of the chain vector) or 64 rows beyond the chain; it OWNS its rows:
 // their running value sits in registers (4 lanes per row, each with 16 of the 64 columns of a panel block) until every earlier link of the
-// chain has been applied.  Per earlier link: await its tagged y, 16 FMAs per lane, two DPP adds.  A link then permutes (LDS, the one barrier
-// of a hop), applies its stored inverse from registers and publishes y.  Everything that does not depend on the incoming vectors -- inverse,
-// pivot data, the next panel block, the children's inverse row maps -- is in registers before the first wait.
-__global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int wg0)
+// chain has been applied.  Five wavefronts:
+//   * wavefront 4 is the POLLER: it waits for the tagged y of one earlier link after the other and puts it into LDS -- it has no other memory
+//     operation in flight, ever: loads return to a wavefront in order, so a poll issued behind the prefetch of a panel block (HBM, ~2 us) would
+//     see the message that much late (measured: 2.4 us per hop that way, 0.9 us for the bare message, tools/micro/chain_hop.hip);
+//   * wavefronts 0-3 apply a message as soon as the barrier says it is there: 16 FMAs per lane, two DPP adds.  The panel blocks of the NEXT TWO
+//     links are in registers or on their way (a block is requested two hops before it is needed).
+// A link then permutes (LDS, one barrier), applies its stored inverse from registers and publishes y.  Everything that does not depend on the
+// incoming vectors -- inverse, pivot data, panel blocks, the children's inverse row maps -- is requested before the first wait.
+__global__ __launch_bounds__(320) void k_fwd_chain(DevView V, int wg0)
 {
-    __shared__ double ysw[4][64], bps[64], yss[64];
-    __shared__ int ipos[64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = tid >> 2, part = tid & 3;
+    __shared__ double ymsg[2][64], bps[64], yss[64];
+    __shared__ int ipos[64], lc0[64], lkk[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, row = (tid >> 2) & 63, part = tid & 3;
+    const bool poller = wave == 4;
     const int di = V.chwg_f[wg0 + (int)blockIdx.x];
-    const ChainDesc C = V.chdesc[di];
+    const ChainDesc C = uni(V.chdesc[di]);
     unsigned long long* tr = V.strace ? V.strace + 4 * (size_t)(wg0 + (int)blockIdx.x) : nullptr;
     if (tr && tid == 0) tr[0] = wall_clock64();
     const int w = (int)blockIdx.x - C.wg0f;
-    const int epoch = *V.sepoch;
+    const int epoch = uni(*V.sepoch);
     const double ep = (double)epoch;
     int* err = V.sepoch + 1;
     const bool is_link = w < C.nlinks;
-    const ChainLink Me = V.chlink[C.link0 + (is_link ? w : C.nlinks - 1)];
+    const ChainLink Me = uni(V.chlink[C.link0 + (is_link ? w : C.nlinks - 1)]);
     const int roff = is_link ? Me.koff : C.ktot + 64 * (w - C.nlinks);       // my rows inside the chain vector
     const int rows = is_link ? Me.k : min(64, C.tail - 64 * (w - C.nlinks));
-    const bool rok = row < rows;
+    const bool rok = !poller && row < rows;
     double* cvp = V.cvec + C.cvb;
     const int k = Me.k, c0 = Me.c0;
-    double mreg[16];
-    int pt = 1; double dq = 0.0, oq = 0.0, oq1 = 0.0;
-    if (is_link) {
-        const double* Mg = V.minv + Me.minv_off;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) { const int pp = part + 4 * u; mreg[u] = (row < k && pp <= row) ? Mg[row + (size_t)pp * k] : 0.0; }      // Minv(row, pp)
-        if (tid < k) ipos[V.lperm[c0 + tid]] = tid;
-        if (part == 0 && row < k) { pt = V.ptype[c0 + row]; dq = V.dinv[c0 + row]; oq = V.doff[c0 + row]; oq1 = row > 0 ? V.doff[c0 + row - 1] : 0.0; }
-    }
-    const double xb = (is_link && rok) ? V.xw[c0 + row] : 0.0;
     const int nprev = is_link ? w : C.nlinks;
-    double lreg[16];
-    ChainLink Li = V.chlink[C.link0];
-    auto fetch_block = [&](const ChainLink& L) {
-        const double* Lb = V.L + L.panel_off + (roff - L.koff) + (rok ? row : 0);              // my rows of that link's panel
+    double mreg[16], lrA[16], lrB[16];
+    int pt = 1; double dq = 0.0, oq = 0.0, oq1 = 0.0;
+    auto fetch_block = [&](double (&lr)[16], const int i) {      // my rows of link i's panel
+        const ChainLink L = V.chlink[C.link0 + i];
+        const double* Lb = V.L + uni(L.panel_off) + (roff - uni(L.koff));      // (uniform base + 32-bit lane offsets: one address register pair, not 16)
+        const int ldl = uni(L.ldp), kl = uni(L.k);
+        const int off = (rok ? row : 0) + part * ldl;
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int q = part + 4 * u; lreg[u] = (rok && q < L.k) ? Lb[(size_t)q * L.ldp] : 0.0; }
+        for (int u = 0; u < 16; ++u) lr[u] = (rok && part + 4 * u < kl) ? Lb[off + 4 * u * ldl] : 0.0;
     };
-    if (nprev > 0) fetch_block(Li);
+    double xb = 0.0;
+    if (!poller) {
+        if (is_link) {
+            const double* Mg = V.minv + Me.minv_off;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int pp = part + 4 * u; mreg[u] = (row < k && pp <= row) ? Mg[row + (size_t)pp * k] : 0.0; }      // Minv(row, pp)
+            if (tid < k) ipos[V.lperm[c0 + tid]] = tid;
+            if (part == 0 && row < k) { pt = V.ptype[c0 + row]; dq = V.dinv[c0 + row]; oq = V.doff[c0 + row]; oq1 = row > 0 ? V.doff[c0 + row - 1] : 0.0; }
+            if (rok) xb = V.xw[c0 + row];
+        }
+        if (nprev > 0) fetch_block(lrA, 0);
+        if (nprev > 1) fetch_block(lrB, 1);
+    } else {
+        for (int i = lane; i < min(nprev, 64); i += 64) { const ChainLink L = V.chlink[C.link0 + i]; lc0[i] = L.c0; lkk[i] = L.k; }
+    }
     // ---- the value my rows start from ----
-    double acc;
+    double acc = 0.0;
     if (C.init == 2) {
         // rows of the children's fronts that land on mine (inverse row maps: static), then the children's chains must be complete
         int inv[4]; long long cvb[4]; int nc = 0, cp = C.ch0;
-        for (; cp < C.ch1 && nc < 4; ++cp) {
-            const ChildMeta Cm = V.cmeta[cp];
-            if (Cm.aliased) continue;
-            inv[nc] = rok ? V.relinv[Cm.inv + roff + row] : -1; cvb[nc] = Cm.cvbase; ++nc;
-        }
+        if (!poller)
+            for (; cp < C.ch1 && nc < 4; ++cp) {
+                const ChildMeta Cm = V.cmeta[cp];
+                if (Cm.aliased) continue;
+                inv[nc] = rok ? V.relinv[Cm.inv + roff + row] : -1; cvb[nc] = Cm.cvbase; ++nc;
+            }
         flags_await(V.sflag_t, V.chwait, C.gw0, C.gw1, epoch, err);
-        double t = (C.alias0 && rok) ? ld_coh(&cvp[roff + row]) : 0.0;
-        for (int c = 0; c < nc; ++c) if (inv[c] >= 0) t += ld_coh(V.cvec + cvb[c] + inv[c]);
-        for (; cp < C.ch1; ++cp) {          // (more than 4 gathered children: not a nested-dissection tree)
-            const ChildMeta Cm = V.cmeta[cp];
-            if (Cm.aliased) continue;
-            const int iv = rok ? V.relinv[Cm.inv + roff + row] : -1;
-            if (iv >= 0) t += ld_coh(V.cvec + Cm.cvbase + iv);
+        if (!poller) {
+            double t = (C.alias0 && rok) ? ld_coh(&cvp[roff + row]) : 0.0;
+            for (int c = 0; c < nc; ++c) if (inv[c] >= 0) t += ld_coh(V.cvec + cvb[c] + inv[c]);
+            for (; cp < C.ch1; ++cp) {          // (more than 4 gathered children: not a nested-dissection tree)
+                const ChildMeta Cm = V.cmeta[cp];
+                if (Cm.aliased) continue;
+                const int iv = rok ? V.relinv[Cm.inv + roff + row] : -1;
+                if (iv >= 0) t += ld_coh(V.cvec + Cm.cvbase + iv);
+            }
+            acc = xb + t;
         }
-        acc = xb + t;
     } else {
         __syncthreads();                    // (ipos)
-        acc = (C.init == 0 && rok) ? xb + cvp[roff + row] : xb;
+        if (!poller) acc = (C.init == 0 && rok) ? xb + cvp[roff + row] : xb;
     }
-    const int myipos = (is_link && row < k) ? ipos[row] : 0;
+    const int myipos = (!poller && is_link && row < k) ? ipos[row] : 0;
     if (tr && tid == 0) tr[1] = wall_clock64();
-    for (int i = 0; i < nprev; ++i) {
-        const double yv = tag_await(V.ytag + Li.c0, lane, Li.k, ep, nprev - 1 - i, err);
-        if (tr && tid == 0 && i + 1 == nprev) tr[2] = wall_clock64();
-        ysw[wave][lane] = yv;
-        __builtin_amdgcn_wave_barrier();
+    auto poll = [&](const int i, double* dst) {
+        if ((i & 63) == 0 && i > 0) { for (int q = lane; q < min(nprev - i, 64); q += 64) { const ChainLink L = V.chlink[C.link0 + i + q]; lc0[q] = L.c0; lkk[q] = L.k; } __builtin_amdgcn_wave_barrier(); }
+        dst[lane] = tag_await(V.ytag + lc0[i & 63], lane, lkk[i & 63], ep, nprev - 1 - i, err);
+    };
+    auto step = [&](double (&lr)[16], const double* ym, const int i) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; u += 2) { a0 += lreg[u] * ysw[wave][part + 4 * u]; a1 += lreg[u + 1] * ysw[wave][part + 4 * u + 4]; }
-        __builtin_amdgcn_wave_barrier();
-        if (i + 1 < nprev) { Li = V.chlink[C.link0 + i + 1]; fetch_block(Li); }        // in flight while the next y is awaited
+        for (int u = 0; u < 16; u += 2) { a0 += lr[u] * ym[part + 4 * u]; a1 += lr[u + 1] * ym[part + 4 * u + 4]; }
+        if (i + 2 < nprev) fetch_block(lr, i + 2);          // two hops ahead
         double t = a0 + a1;
-        t += dpp_f64<0xB1>(t); t += dpp_f64<0x4E>(t);               // the 4 lanes of a row are a DPP quad
+        t += dpp_f64<0xB1>(t); t += dpp_f64<0x4E>(t);       // the 4 lanes of a row are a DPP quad
         acc -= t;
+    };
+    for (int i = 0; i < nprev; i += 2) {
+        if (poller) poll(i, ymsg[0]);
+        __syncthreads();
+        if (!poller) step(lrA, ymsg[0], i);
+        if (i + 1 < nprev) {
+            if (poller) poll(i + 1, ymsg[1]);
+            __syncthreads();
+            if (!poller) step(lrB, ymsg[1], i + 1);
+        }
     }
+    if (poller) return;
+    if (tr && tid == 0) tr[2] = wall_clock64();
     if (!is_link) {          // rows beyond the chain: complete, the parent's chain may take them
         if (rok && part == 0) st_coh(&cvp[roff + row], acc);
         flag_raise(&V.sflag_t[(size_t)(C.tf0 + (w - C.nlinks)) * FLAG_STRIDE], epoch);
@@ -2083,99 +2125,133 @@ __global__ __launch_bounds__(256) void k_fwd_chain(DevView V, int wg0)
         V.zb[c0 + row] = z;
     }
 }
-// Backward sweep of a segment: one workgroup per link, the parents' chains first.  The rows beyond the chain (their solution is complete once
-// every link of the parent's chain has raised its flag) are streamed by the whole workgroup -- NT = 1024 where that part is long: 16 wavefronts x
-// 16 loads in flight -- then 4 wavefronts walk the chain: per later link, await its tagged x, 16 FMAs per lane on the 64 x 64 block of my panel
-// that meets its rows, two DPP adds; finally L11^{-T} from registers, x published tagged (for the chain) and plain (for everything below).
-template <int NT>
-__global__ __launch_bounds__(NT) void k_bwd_chain(DevView V, int wg0)
+// Backward sweep of a segment, the parents' chains first.  Per chain, two kinds of workgroups:
+//   * DOT workgroups, one per (link, 256 rows beyond the chain): the 256 x 64 block of the link's panel goes into registers BEFORE anything is awaited
+//     (it does not depend on the solution), then -- once every link of the parent's chain has raised its flag -- the rows' solution entries, 64 FMAs per
+//     lane, a DPP sum per column, 64 partial sums stored coherently, flag.  The streaming of a chain's panels is spread over the whole machine and is
+//     over when the parent finishes; up to round 2 one workgroup per link streamed its own rows after the wait (18-30 us per tree level);
+//   * LINK workgroups, top link first, walk the chain as in the forward sweep: wavefront 4 polls the tagged x of the later links, wavefronts 0-3 apply the
+//     64 x 64 block of MY panel that meets a later link's rows (16 FMAs per lane, two DPP adds; blocks requested two hops ahead); finally L11^{-T} from
+//     registers, x published tagged (for the chain) and plain (for everything below), flag for the children's chains.
+__global__ __launch_bounds__(320) void k_bwd_chain(DevView V, int wg0)
 {
-    constexpr int NW = NT / 64, CPW = 64 / NW;                 // wavefronts, columns per wavefront (streaming part)
-    __shared__ double ws[64], xs[NT], xsw[4][64];
+    __shared__ double ws[64], xmsg[2][64];
+    __shared__ int lc0[64], lkk[64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, col = (tid >> 2) & 63, part = tid & 3;
-    const ChainDesc C = V.chdesc[V.chwg_b[wg0 + (int)blockIdx.x]];
+    const bool poller = wave == 4;
+    const ChainDesc C = uni(V.chdesc[V.chwg_b[wg0 + (int)blockIdx.x]]);
     unsigned long long* tr = V.strace ? V.strace + 4 * (size_t)(V.strace_b + wg0 + (int)blockIdx.x) : nullptr;
     if (tr && tid == 0) tr[0] = wall_clock64();
-    // the TOP link gets the first workgroup of its chain: it is the head of the dependency chain
-    const int j = C.nlinks - 1 - ((int)blockIdx.x - C.wg0b);
-    const int epoch = *V.sepoch;
+    const int r = (int)blockIdx.x - C.wg0b;
+    const int nbk = (C.tail + 255) >> 8, ndots = C.nlinks * nbk;
+    const int epoch = uni(*V.sepoch);
     const double ep = (double)epoch;
     int* err = V.sepoch + 1;
-    const ChainLink Me = V.chlink[C.link0 + j];
-    const int k = Me.k, c0 = Me.c0;
-    if (tid < 64) ws[tid] = (tid < k) ? V.zb[c0 + tid] : 0.0;
-    double mreg[16], lreg[16];
-    int lpv = 0;
-    ChainLink Lr = V.chlink[C.link0 + C.nlinks - 1];
-    auto fetch_block = [&](const ChainLink& L) {      // rows of link L's pivots in my panel, my column; lane part has rows part, part + 4, ...
-        const double* Lb = V.L + Me.panel_off + (L.koff - Me.koff) + (size_t)(col < k ? col : 0) * Me.ldp;
+    if (r < ndots) {
+        // ---------------- dot workgroup ----------------
+        if (poller) return;
+        const int jj = r / nbk, b = r - jj * nbk;                // (jj = 0: the top link)
+        const ChainLink Me = uni(V.chlink[C.link0 + C.nlinks - 1 - jj]);
+        const int k = Me.k, toff = C.ktot - Me.koff, ibase = b * 256, nrow = min(256, C.tail - ibase);
+        const bool v0 = lane < nrow, v1 = lane + 64 < nrow, v2 = lane + 128 < nrow, v3 = lane + 192 < nrow;
+        const double* Lg = V.L + Me.panel_off + toff + ibase + lane;
+        double lv[4][4][4];                                      // [pass][column of the pass][row strip]
 #pragma unroll
-        for (int u = 0; u < 16; ++u) { const int t = part + 4 * u; lreg[u] = (col < k && t < L.k) ? Lb[t] : 0.0; }
-    };
-    if (C.tail > 0) {
-        flags_await(V.sflag_b, V.chwait, C.pw0, C.pw1, epoch, err);        // (barrier inside)
-        if (tr && tid == 0) tr[1] = wall_clock64();
-        const int toff = C.ktot - Me.koff;
-        const double* Lt = V.L + Me.panel_off + toff;
-        double t[CPW];                                             // columns CPW wave .. CPW wave + CPW - 1
+        for (int ps = 0; ps < 4; ++ps)
 #pragma unroll
-        for (int u = 0; u < CPW; ++u) t[u] = 0.0;
-        for (int base = 0; base < C.tail; base += NT) {
-            const int nrow = min(NT, C.tail - base);
-            xs[tid] = (tid < nrow) ? ld_coh(&V.xw[V.sn_rows[Me.r0 + toff + base + tid]]) : 0.0;
-            __syncthreads();
-            if (CPW * wave < k) {
-                constexpr int RS = (CPW <= 4) ? 4 : 1;               // row strips of 64 in flight per lane (16 loads per lane either way)
-                for (int i0 = 0; i0 < nrow; i0 += 64 * RS) {
-                    double lv[RS][CPW];
-#pragma unroll
-                    for (int a = 0; a < RS; ++a)
-#pragma unroll
-                        for (int u = 0; u < CPW; ++u) {
-                            const int i = i0 + 64 * a + lane, q = CPW * wave + u;
-                            lv[a][u] = (i < nrow && q < k) ? Lt[base + i + (size_t)q * Me.ldp] : 0.0;
-                        }
-#pragma unroll
-                    for (int a = 0; a < RS; ++a) {
-                        const double x = xs[min(i0 + 64 * a + lane, NT - 1)];
-#pragma unroll
-                        for (int u = 0; u < CPW; ++u) t[u] += lv[a][u] * x;
-                    }
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int cc = wave * 4 + 16 * ps + u;
+                const bool cv = cc < k;
+                const double* c = Lg + (size_t)(cv ? cc : 0) * Me.ldp;
+                lv[ps][u][0] = (cv && v0) ? c[0] : 0.0; lv[ps][u][1] = (cv && v1) ? c[64] : 0.0;
+                lv[ps][u][2] = (cv && v2) ? c[128] : 0.0; lv[ps][u][3] = (cv && v3) ? c[192] : 0.0;
             }
-            __syncthreads();
-        }
-        if (CPW * wave < k) {
+        const int r0i = Me.r0 + toff + ibase + lane;
+        const int i0 = v0 ? V.sn_rows[r0i] : 0, i1 = v1 ? V.sn_rows[r0i + 64] : 0, i2 = v2 ? V.sn_rows[r0i + 128] : 0, i3 = v3 ? V.sn_rows[r0i + 192] : 0;
+        flags_await(V.sflag_b, V.chwait, C.pw0, C.pw1, epoch, err);
+        if (tr && tid == 0) tr[1] = wall_clock64();
+        const double x0 = v0 ? ld_coh(&V.xw[i0]) : 0.0, x1 = v1 ? ld_coh(&V.xw[i1]) : 0.0, x2 = v2 ? ld_coh(&V.xw[i2]) : 0.0, x3 = v3 ? ld_coh(&V.xw[i3]) : 0.0;
+        double* dp = V.dpart + (size_t)(C.dot0 + r) * 64;
 #pragma unroll
-            for (int u = 0; u < CPW; ++u) { const double sv = wave_sum_dpp(t[u]); if (lane == 0 && CPW * wave + u < k) ws[CPW * wave + u] -= sv; }
-        }
+        for (int ps = 0; ps < 4; ++ps)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int cc = wave * 4 + 16 * ps + u;
+                double t = (lv[ps][u][0] * x0 + lv[ps][u][1] * x1) + (lv[ps][u][2] * x2 + lv[ps][u][3] * x3);
+                t = wave_sum_dpp(t);
+                if (lane == 0 && cc < k) st_coh(&dp[cc], t);
+            }
+        if (tr && tid == 0) tr[2] = wall_clock64();
+        flag_raise(&V.sflag_dot[(size_t)(C.dot0 + r) * FLAG_STRIDE], epoch);
+        if (tr && tid == 0) tr[3] = wall_clock64();
+        return;
     }
-    __syncthreads();
-    if (tid >= 256) return;                                    // (NT = 1024: the other 12 wavefronts were only here to stream)
-    {   // what the walk along the chain needs, in registers before the first wait (not earlier: the streaming part needs the registers, and
-        // every link but the top one has hops to wait for anyway)
+    // ---------------- link workgroup ----------------
+    const int jt = r - ndots;                                  // 0: the top link, the head of the dependency chain
+    const int j = C.nlinks - 1 - jt;
+    const int nlater = jt;                                     // links whose x I wait for, top first: link nlinks - 1 - i is message i
+    const ChainLink Me = uni(V.chlink[C.link0 + j]);
+    const int k = Me.k, c0 = Me.c0;
+    double mreg[16], lrA[16], lrB[16];
+    int lpv = 0;
+    auto fetch_block = [&](double (&lr)[16], const int i) {      // rows of the pivots of link nlinks - 1 - i in my panel, my column; lane part has rows part, part + 4, ...
+        const ChainLink L = V.chlink[C.link0 + C.nlinks - 1 - i];
+        const double* Lb = V.L + uni(Me.panel_off) + (uni(L.koff) - uni(Me.koff));
+        const int kl = uni(L.k);
+        const int off = (col < k ? col : 0) * uni(Me.ldp) + part;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) lr[u] = (col < k && part + 4 * u < kl) ? Lb[off + 4 * u] : 0.0;
+    };
+    if (!poller) {
         const double* Mg = V.minv + Me.minv_off;
 #pragma unroll
         for (int u = 0; u < 16; ++u) { const int q = col + part + 4 * u; mreg[u] = (col < k && q < k) ? Mg[q + (size_t)col * k] : 0.0; }      // Minv(q, col), q >= col
         if (col < k) lpv = V.lperm[c0 + col];
-        if (j < C.nlinks - 1) fetch_block(Lr);
+        if (nlater > 0) fetch_block(lrA, 0);
+        if (nlater > 1) fetch_block(lrB, 1);
+    } else {
+        for (int i = lane; i < min(nlater, 64); i += 64) { const ChainLink L = V.chlink[C.link0 + C.nlinks - 1 - i]; lc0[i] = L.c0; lkk[i] = L.k; }
     }
-    double wv = ws[col];
+    const double zv = (tid < k) ? V.zb[c0 + tid] : 0.0;
+    if (C.tail > 0) {
+        // the partial sums of my dot workgroups, added in block order
+        flags_await(V.sflag_dot, nullptr, C.dot0 + jt * nbk, C.dot0 + (jt + 1) * nbk, epoch, err);
+        if (tr && tid == 0) tr[1] = wall_clock64();
+        if (tid < 64) {
+            double t = 0.0;
+            const double* dp = V.dpart + (size_t)(C.dot0 + jt * nbk) * 64 + tid;
+            for (int b = 0; b < nbk; ++b) t += (tid < k) ? ld_coh(dp + (size_t)b * 64) : 0.0;
+            ws[tid] = zv - t;
+        }
+    } else if (tid < 64) ws[tid] = zv;
+    __syncthreads();
+    double wv = poller ? 0.0 : ws[col];
     __syncthreads();                                           // (everybody has read ws)
     if (tr && tid == 0) tr[2] = wall_clock64();
-    for (int r = C.nlinks - 1; r > j; --r) {
-        const double xv = tag_await(V.xtag + Lr.c0, lane, Lr.k, ep, r - 1 - j, err);
-        xsw[wave][lane] = xv;
-        __builtin_amdgcn_wave_barrier();
+    auto poll = [&](const int i, double* dst) {
+        if ((i & 63) == 0 && i > 0) { for (int q = lane; q < min(nlater - i, 64); q += 64) { const ChainLink L = V.chlink[C.link0 + C.nlinks - 1 - i - q]; lc0[q] = L.c0; lkk[q] = L.k; } __builtin_amdgcn_wave_barrier(); }
+        dst[lane] = tag_await(V.xtag + lc0[i & 63], lane, lkk[i & 63], ep, nlater - 1 - i, err);
+    };
+    auto step = [&](double (&lr)[16], const double* xm, const int i) {
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
-        for (int u = 0; u < 16; u += 2) { a0 += lreg[u] * xsw[wave][part + 4 * u]; a1 += lreg[u + 1] * xsw[wave][part + 4 * u + 4]; }
-        __builtin_amdgcn_wave_barrier();
-        if (r - 1 > j) { Lr = V.chlink[C.link0 + r - 1]; fetch_block(Lr); }
+        for (int u = 0; u < 16; u += 2) { a0 += lr[u] * xm[part + 4 * u]; a1 += lr[u + 1] * xm[part + 4 * u + 4]; }
+        if (i + 2 < nlater) fetch_block(lr, i + 2);
         double t = a0 + a1;
-        t += dpp_f64<0xB1>(t); t += dpp_f64<0x4E>(t);               // the 4 lanes of a row are a DPP quad
+        t += dpp_f64<0xB1>(t); t += dpp_f64<0x4E>(t);
         wv -= t;
+    };
+    for (int i = 0; i < nlater; i += 2) {
+        if (poller) poll(i, xmsg[0]);
+        __syncthreads();
+        if (!poller) step(lrA, xmsg[0], i);
+        if (i + 1 < nlater) {
+            if (poller) poll(i + 1, xmsg[1]);
+            __syncthreads();
+            if (!poller) step(lrB, xmsg[1], i + 1);
+        }
     }
+    if (poller) return;
     if (part == 0) ws[col] = wv;
     __syncthreads();
     double a0 = 0.0, a1 = 0.0;
@@ -3694,12 +3770,13 @@ public:
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
     int dbg_c0 = 0, dbg_k = 0;
     size_t strace_n = 0; struct TraceDesc { int chain, w, nlinks, tail; }; std::vector<TraceDesc> strace_desc;
+    std::vector<char> in_seg;         // fronts handled by the data-flow sweeps
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail, wgf0, wgb0; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
     bool pair_solve = true; std::vector<int> wave_kmax;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
     bool fuse_dt = true;                               // pivot block + panel solve in one launch where a level has few fronts
     int fuse_dt_maxwg = 448;                           // ... few = this many workgroups (pivot blocks + 64-row panel blocks) at most
-    bool chain_solve = true; int chain_maxc = 8;       // only where few chains run side by side (the latency-bound top of the tree)
+    bool chain_solve = true; int chain_maxc = 128;       // only where few chains run side by side (the latency-bound top of the tree)
     std::vector<char> lv_allsolo;       // every big solve unit of the level is one link with nothing to gather (fused forward kernel)
     std::vector<int> big_split, part_mm[2], part_kk[2], part_tiles[2];   // single-GPU schedule: BIG buckets split at 1024 rows
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
@@ -4049,7 +4126,7 @@ public:
         // in-place links: every link after the first has the previous link as its only child and shares its vector), and ONE launch per
         // sweep runs the whole segment: workgroups wait on flags for exactly what they consume (see k_fwd_chain / k_bwd_chain) ----
         std::vector<ChainLink> chl; std::vector<ChainDesc> chd; std::vector<int> chwait, wgf, wgb;
-        int ntailflags = 0;
+        int ntailflags = 0, ndots = 0;
         chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
@@ -4074,11 +4151,12 @@ public:
                 for (int q = a; q < b && ok; ++q) {
                     const int sn = Sy.level_sn[q];
                     if (multi) ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1 && Sy.sn_owner[sn] < 0;
-                    else       ok = Sy.sn_class[sn] == FC_BIG && Kc(sn) <= 64;
+                    else       ok = Kc(sn) <= 64;          // (any class: to the sweeps a small front is a one-link chain like any other)
                 }
                 lvok[lv] = ok ? 1 : 0;
             }
             std::vector<int> chain_of(Sy.num_sn, -1);
+            in_seg.assign(Sy.num_sn, 0);
             for (int lv = 0; lv < Sy.num_levels; ) {
                 if (!lvok[lv]) { ++lv; continue; }
                 int e = lv;
@@ -4090,6 +4168,7 @@ public:
                     for (int l = lv; l <= e; ++l)
                         for (int q = Sy.level_ptr[(size_t)l * FC_COUNT]; q < Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT]; ++q) {
                             const int sn = Sy.level_sn[q], ac = Sy.alias_child[sn];
+                            in_seg[sn] = 1;
                             ChainLink L{}; L.panel_off = Sy.panel_off[sn]; L.minv_off = Sy.minv_off[sn]; L.c0 = Sy.sn_colptr[sn]; L.k = Kc(sn); L.ldp = Sy.sn_ldp[sn];
                             L.s = sn; L.r0 = Sy.sn_rowptr[sn];
                             const int cprev = (ac >= 0 && nchild(sn) == 1 && Sy.sn_level[ac] >= lv) ? chain_of[ac] : -1;
@@ -4123,10 +4202,12 @@ public:
                         for (int w = 0; w < D.nlinks + nt; ++w) wgf.push_back(d);
                         sg.nwg_f += D.nlinks + nt; sg.maxtail = std::max(sg.maxtail, D.tail);
                     }
-                    for (int d = sg.desc0 + sg.ndesc - 1; d >= sg.desc0; --d) {
+                    for (int d = sg.desc0 + sg.ndesc - 1; d >= sg.desc0; --d) {      // per chain: its dot workgroups (256 rows beyond the chain x one link each), then its links
                         ChainDesc& D = chd[d];
-                        D.wg0b = sg.nwg_b; sg.nwg_b += D.nlinks;
-                        for (int w = 0; w < D.nlinks; ++w) wgb.push_back(d);
+                        const int nw = D.nlinks * ((D.tail + 255) / 256 + 1);
+                        D.wg0b = sg.nwg_b; sg.nwg_b += nw;
+                        D.dot0 = ndots; ndots += D.nlinks * ((D.tail + 255) / 256);
+                        for (int w = 0; w < nw; ++w) wgb.push_back(d);
                     }
                     // what a chain waits for: forward, the rows beyond each child chain of its first link (all of them before anything is
                     // gathered); backward, the bottom link of the chain its parent lives in
@@ -4164,9 +4245,10 @@ public:
             if (!dalloc(&V.strace, strace_n)) return false;
             strace_desc.clear();
             for (size_t i = 0; i < wgf.size(); ++i) { const ChainDesc& D = chd[wgf[i]]; strace_desc.push_back({wgf[i], (int)i - D.wg0f - chain_segs[0].wgf0 * 0, D.nlinks, D.tail}); }
-            for (size_t i = 0; i < wgb.size(); ++i) { const ChainDesc& D = chd[wgb[i]]; strace_desc.push_back({wgb[i], (int)i - D.wg0b, D.nlinks, D.tail}); }
+            for (size_t i = 0; i < wgb.size(); ++i) { const ChainDesc& D = chd[wgb[i]]; strace_desc.push_back({wgb[i], (int)i - D.wg0b - D.nlinks * ((D.tail + 255) / 256), D.nlinks, D.tail}); }      // (dot workgroups: negative)
         }
-        if (!dalloc(&V.sflag_t, (size_t)std::max(ntailflags, 1) * FLAG_STRIDE) || !dalloc(&V.sflag_b, std::max<size_t>(chl.size(), 1) * FLAG_STRIDE)) return false;
+        if (!dalloc(&V.sflag_dot, (size_t)std::max(ndots, 1) * FLAG_STRIDE) || !dalloc(&V.dpart, (size_t)std::max(ndots, 1) * 64) ||
+            !dalloc(&V.sflag_t, (size_t)std::max(ntailflags, 1) * FLAG_STRIDE) || !dalloc(&V.sflag_b, std::max<size_t>(chl.size(), 1) * FLAG_STRIDE)) return false;
         {   // tagged solution entries of the segments' columns (indexed by column; + 64: a wavefront polls 64 entries from a link's first column)
             const size_t nt = chl.empty() ? 1 : (size_t)Sy.n + 64;
             if (!dalloc(&V.ytag, nt) || !dalloc(&V.xtag, nt)) return false;
@@ -4393,7 +4475,7 @@ public:
         std::vector<int> relinv;
         for (int sn = 0; sn < Sy.num_sn; ++sn) {
             for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) cm[q].inv = 0;
-            if (Sy.sn_class[sn] != FC_BIG) continue;
+            if (Sy.sn_class[sn] != FC_BIG && !(sn < (int)in_seg.size() && in_seg[sn])) continue;
             const int mp = Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn];
             for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) {
                 if (cm[q].aliased) continue;
@@ -4730,7 +4812,7 @@ public:
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
                 if (seg_at_lv0[lv] >= 0) {      // a run of pure chain levels: one sync-free launch for all of them
                     const ChainSeg& sg = chain_segs[seg_at_lv0[lv]];
-                    LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(256), 0, stream, V, sg.wgf0);
+                    LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(320), 0, stream, V, sg.wgf0);
                     lv = sg.lv1; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -4752,8 +4834,7 @@ public:
             for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
-                    if (sg.maxtail > 256) LAUNCH(KK_BWD_BIG, (k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 0, stream, V, sg.wgb0);
-                    else                LAUNCH(KK_BWD_BIG, (k_bwd_chain<256>),  dim3(sg.nwg_b), dim3(256),  0, stream, V, sg.wgb0);
+                    LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(320), 0, stream, V, sg.wgb0);
                     lv = sg.lv0; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -5009,9 +5090,8 @@ public:
                 const int sgi = forward ? seg_at_lv0[lv] : seg_at_lv1[lv];
                 if (sgi >= 0) {
                     const ChainSeg& sg = chain_segs[sgi];
-                    if (forward) hipLaunchKernelGGL(k_fwd_chain, dim3(sg.nwg_f), dim3(256), 0, stream, V, sg.wgf0);
-                    else if (sg.maxtail > 256) hipLaunchKernelGGL((k_bwd_chain<1024>), dim3(sg.nwg_b), dim3(1024), 0, stream, V, sg.wgb0);
-                    else hipLaunchKernelGGL((k_bwd_chain<256>), dim3(sg.nwg_b), dim3(256), 0, stream, V, sg.wgb0);
+                    if (forward) hipLaunchKernelGGL(k_fwd_chain, dim3(sg.nwg_f), dim3(320), 0, stream, V, sg.wgf0);
+                    else hipLaunchKernelGGL(k_bwd_chain, dim3(sg.nwg_b), dim3(320), 0, stream, V, sg.wgb0);
                     q += sg.lv1 - sg.lv0; continue;
                 }
             }

@@ -13,8 +13,9 @@ for d in "FB":
     print("  chain links tail | first wg in   start value   first link out   last link out   tails out | us per hop")
     order = sorted(ch, reverse=True)
     for c in order[: int(sys.argv[2]) if len(sys.argv) > 2 else 16]:
-        L = sorted(ch[c], key=lambda r: r[1]); nl = L[0][2]
+        L = sorted([r for r in ch[c] if r[1] >= 0], key=lambda r: r[1]); nl = L[0][2]
         links, tails = L[:nl], L[nl:]
+        if d == "B": tails = [r for r in ch[c] if r[1] < 0]          # (the dot workgroups: partial sums over the rows beyond the chain)
         first, last = (links[0], links[-1]) if d == "F" else (links[0], links[-1])
         print(f"  {c:5d} {nl:5d} {L[0][3]:5d} | {f(min(x[4][0] for x in L)):8.1f} {f(first[4][1]):10.1f} {f(first[4][3]):12.1f} {f(last[4][3]):14.1f} "
               f"{(max(f(t[4][3]) for t in tails) if tails else float('nan')):12.1f} | {(f(last[4][3]) - f(first[4][3])) / max(nl - 1, 1):6.2f}")
