@@ -1,4 +1,4 @@
-"""-m 'not gpu': the N > 1 path on CPU -- world_size 2 (and 4) over gloo.  The product's collective sequence
+"""-m 'not gpu': the N > 1 path on CPU -- world_size 2, 4 and 8 (the driver's scaling run) over gloo.  The product's collective sequence
 (ipopt_amd.multigpu.DistributedKKT: all-reduce of the top arena at the subtree joins, replicated top, mirrored solve)
 runs unchanged; the per-rank numeric engine is the numpy walk of the same symbolic structures
 (tests/support/mirror_mg.py), because there is no GPU here.  The HIP engine is exercised by test_multigpu_gpu.py."""
@@ -50,8 +50,8 @@ def _case_band():
     return kktgen.lukvl_like(1500, seed=6)
 
 
-@pytest.mark.parametrize("world", [2, 4])
-@pytest.mark.parametrize("case", [_case_grid, _case_band], ids=["grid", "band"])
+@pytest.mark.parametrize("world,case", [(2, _case_grid), (2, _case_band), (4, _case_grid), (4, _case_band), (8, _case_grid)],
+                         ids=["2-grid", "2-band", "4-grid", "4-band", "8-grid"])
 def test_subtree_sharded_factor_solve_over_gloo(world, case):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
