@@ -135,3 +135,19 @@ def nearly_dependent_rows(delta=1e-15, nx=6):
     H = (np.arange(nx), np.arange(nx), np.full(nx, 2.0))
     ji = np.array([0, 0, 1, 1, 2, 2]); jj = np.array([0, 1, 0, 1, 3, 4]); jv = np.array([1.0, 2.0, 1.0, 2.0 * (1.0 + delta), 1.0, 1.0])
     return kkt_from_blocks(H, np.zeros(nx), (ji, jj, jv), np.zeros(m), nx, m)
+
+
+def hostile_grid_kkt(nx_grid, ny_grid, dof=3, ncon=2, seed=0, frac=0.35, tiny=1e-6):
+    """grid_kkt made hostile to static pivoting: a fraction `frac` of the Hessian diagonal entries (Sigma included) is replaced by
+    +-tiny * U(0.1, 1) while the couplings stay O(1), delta_c = 0 -- the 1x1 candidates of those columns fail the threshold test at any
+    practical u, 2x2 pivots are needed inside the pivot blocks, and in the separator fronts the rows below a pivot block see
+    multipliers > 1/u (the a-posteriori check of the big fronts).  The inertia is whatever it is: the tests take it from the oracle
+    (which delays) and from LAPACK on a dense copy."""
+    n, r, c, v, m = grid_kkt(nx_grid, ny_grid, dof=dof, ncon=ncon, seed=seed, sigma_exp=0.0)
+    rng = np.random.default_rng(seed + 1000)
+    nxv = nx_grid * ny_grid * dof
+    v = v.copy()
+    diag = np.nonzero((r == c) & (r <= nxv))[0]            # (1-based triplets: Hessian diagonal)
+    hit = diag[rng.random(diag.shape[0]) < frac]
+    v[hit] = tiny * rng.uniform(0.1, 1.0, hit.shape[0]) * rng.choice([-1.0, 1.0], hit.shape[0])
+    return n, r, c, v

@@ -133,3 +133,23 @@ def test_zero_pivot_list_names_the_dependent_rows():
     assert st == kkt.SINGULAR and len(z) == 2
     keep = [i for i in range(nrow) if i not in set(z.tolist())]
     assert np.linalg.matrix_rank(J[keep]) == nrow - 2 == np.linalg.matrix_rank(J)      # what is left has full row rank
+
+
+@pytest.mark.parametrize("u", [1e-8, 0.01])
+def test_hostile_grid_hip_equals_the_specification(u):
+    """the hostile system of tests/test_pivoting_spec.py (fronts of up to ~300 rows whose pivot blocks leave the blocked a-posteriori path,
+    2x2 pivots, forced pivots, a-posteriori failures in the rows below the pivot blocks): every statistic of the HIP factorisation
+    equals the specification's, the inertia is the delaying oracle's, and the solve is as accurate as the specification's."""
+    n, r, c, v = kktgen.hostile_grid_kkt(16, 16, seed=3)
+    K = kktgen.to_scipy(n, r, c, v)
+    xt = np.ones(n); b = K @ xt
+    s, st, x = hip_run(n, r, c, v, b, u, scaling=0, pivtolmax=max(u, 1e-4))
+    xs, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=max(u, 1e-4))
+    _, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=u)
+    I = s.info()
+    assert st == kkt.SUCCESS
+    assert (I.num_neg, I.num_zero, I.num_two, I.num_small, I.u_sensitive, I.num_fast_blocks) == \
+           (spec["num_neg"], spec["num_zero"], spec["num_two"], spec["num_delay"], spec["u_sensitive"], spec["num_fast"]), (I, spec)
+    assert I.num_neg == oneg and ozero == 0
+    assert spec["num_two"] >= 20 and (u < 0.01 or spec["num_delay"] >= 50)
+    assert np.abs(x - xt).max() <= 1e-6 and np.abs(x - xs).max() <= 1e-6
