@@ -132,6 +132,7 @@ struct DevView {
     int* zpiv;              // per column (permuted numbering): 1 if its pivot was a zero pivot (DetermineDependentRows)
     int n, nnz_a, nsn, rank;
     int fastpiv;            // pivot blocks of the big fronts: blocked LDL^T accepted a posteriori first, the strict loop as fall-back (ldlt_blocked_static)
+    double fastu;           // ... accepted iff every multiplier <= 1 / max(u, u2, fastu)
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
 };
 
@@ -841,7 +842,7 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
 //     factor the same way;
 //   * the rows below and the remaining columns follow by v_mfma_f64_16x16x4_f64 (ldlt_blocked_static below);
 //   * nothing is decided per pivot.  The block is ACCEPTED afterwards iff every pivot is clear of the zero threshold and every
-//     multiplier of the block is <= gmax = 1 / max(u, u2, 0.01) -- the threshold test of MA57/MA97 at their default u = 0.01, far
+//     multiplier of the block is <= gmax = 1 / max(u, u2, 1e-4) -- the threshold test at the LARGEST u Ipopt raises its solvers to (pivtolmax = 1e-4), far
 //     tighter than the 1e-8 Ipopt asks for, so an accepted block satisfies the strict rule's tests at u AND at u2 (no u-sensitive
 //     decision).  Otherwise nothing has been written and the caller runs the strict loop on the untouched block.
 // Returns (workgroup-uniform) true when accepted: Lb = unit-lower L (strictly lower part, natural order), dinv_s = 1 / d.
@@ -1097,7 +1098,7 @@ __device__ __forceinline__ void big_diag_body(const DevView& V, const FrontMeta&
                 cmx = fmax(fmax(colbuf[0], colbuf[1]), fmax(colbuf[2], colbuf[3]));
             }
             const double zmax = fmax(V.small, ZERO_REL * cmx);
-            const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), 0.01);
+            const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), V.fastu);
             DBGT(2);
             if (ts) ts[9] = clock64();
             fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Isb, shflag, zmax, gmax, nneg, V.dbg, ts);
@@ -3063,7 +3064,7 @@ __global__ __launch_bounds__(512) void k_grp_diag(const DevView* __restrict__ Vp
                 for (int w = 0; w < NW; ++w) cmx = fmax(cmx, colbuf[w]);
             }
             const double zmax = fmax(V.small, ZERO_REL * cmx);
-            const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), 0.01);
+            const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), V.fastu);
             fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Is, shflag, zmax, gmax, nneg);
             if (fast) {
 #pragma unroll
@@ -4131,6 +4132,7 @@ public:
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
         V.fastpiv = getenv("MI355X_KKT_NO_FASTPIV") == nullptr ? 1 : 0;
+        V.fastu = 1e-4; if (const char* e = getenv("MI355X_KKT_FASTPIV_FLOOR")) V.fastu = atof(e);      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
         if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
         pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
         wave_kmax.assign(Sy.num_levels, 0);

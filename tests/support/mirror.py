@@ -206,7 +206,7 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True, cnorm=None):
 
 
 BIG_FRONT = 128      # fronts above this order take the blocked path: in-block test + a posteriori test on the rows below
-FAST_U = 0.01        # a pivot block taken in natural order is accepted iff every multiplier is <= 1 / max(u, u2, FAST_U)
+FAST_U = 1e-4        # a pivot block taken in natural order is accepted iff every multiplier is <= 1 / max(u, u2, FAST_U)
 
 
 def ldlt_block_static(A, k, u, u2, small=1e-20, cnorm=None):

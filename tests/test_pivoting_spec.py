@@ -156,7 +156,8 @@ def test_hostile_grid_specification_against_the_delaying_oracle(u):
     assert st["num_neg"] == oneg == true_neg and st["num_zero"] == ozero == 0
     assert np.abs(xo - xt).max() <= 1e-6 and np.abs(x - xt).max() <= 1e-6
     nbig = int((np.diff(sym["rowptr"]) > mirror.BIG_FRONT).sum())
-    assert nbig >= 10 and st["num_fast"] < nbig / 2          # most pivot blocks of the big fronts need the strict rule
+    assert nbig >= 10 and st["num_fast"] < nbig              # some pivot blocks of the big fronts need the strict rule at either u
     assert st["num_two"] >= 20 and st["u_sensitive"] == 1
     if u == 0.01:
+        assert st["num_fast"] < nbig / 2                      # ... most of them at the tight threshold
         assert st["num_delay"] >= 50                          # forced pivots + a-posteriori failures below the pivot blocks
