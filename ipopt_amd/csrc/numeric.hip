@@ -679,11 +679,18 @@ __device__ __forceinline__ double front_colmax(const double (&t)[TS][TS], double
     return wave_max_all(fmax(lane < k ? cm0[lane] : 0.0, lane + 64 < k ? cm0[lane + 64] : 0.0));
 }
 
+// fronts of order 65 .. 128 with <= 16 pivots: static-order blocked elimination accepted a posteriori (defined behind the DPP helpers below)
+__device__ __forceinline__ bool front_fast16(double* F, const int m, const int k, double* scratch, double* dinv_s, const double* cnorm, const double small, const double gmax, int& nneg);
+
 // front kernel on the register-tiled core: LDS assembly (A scatter + children extend-add), tiles -> VGPRs, LDL^T,
 // write-back of the pivot-ordered panel, the contribution block (straight from registers), pivot data and L11^{-1}.
-template <int NT, int TS>
-__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS == 2) ? 6 : ((NT == 256 && TS == 6) ? 3 : 1))) void k_front_reg(DevView V, int list_off, int top_mode)
+// FAST (256 threads only): the fronts of the bucket with <= 16 pivots are assembled and eliminated on the static-order path (front_fast16) and
+// marked done (hasis[s] = 2) when it accepts them; the ordinary instantiation is launched behind it with flags & 2 and leaves those alone.  Two
+// kernels, not one with a branch: inlined into the strict kernel the fast path's 100 registers pushed <256, 6> from 134 to 459 spilled VGPRs.
+template <int NT, int TS, bool FAST = false>
+__global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS == 2) ? 6 : ((NT == 256 && TS == 6) ? 3 : 1))) void k_front_reg(DevView V, int list_off, int flags)
 {
+    const int top_mode = flags & 1;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int G = (NT == 64) ? 8 : 16;
     constexpr int MAXM = G * TS;
@@ -691,6 +698,8 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
     constexpr int NW = NT / 64;
     const FrontMeta M = V.fmeta[list_off + blockIdx.x];
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
+    if (FAST) { if (k > 16) { if (tid == 0) V.hasis[s] = 0; return; } }
+    else if ((flags & 2) && V.hasis[s] == 2) return;
     const int ld = m | 1, ldi = k | 1;
     DBGSTAMP(4);
 #ifdef MI355X_PIVSTAT
@@ -767,6 +776,30 @@ __global__ __launch_bounds__(NT, (NT == 64 && TS == 4) ? 4 : ((NT == 64 && TS ==
 #ifdef MI355X_PIVSTAT
     ph1 = clock64();
 #endif
+    // ---- fast path: <= 16 pivots eliminated in natural order by ONE wavefront (DPP), the rest of the front by MFMA; accepted a posteriori ----
+    if constexpr (FAST) {
+        int fneg = 0;
+        const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), V.fastu);
+        if (!front_fast16(F, m, k, colbuf, dinv_s, V.cnorm + c0, V.small, gmax, fneg)) { if (tid == 0) V.hasis[s] = 0; return; }
+        {
+            // F(i, c), c < k: W = L d (i > c);  F(i, c), i >= c >= k: the Schur complement;  colbuf: L11^{-1} (X(i, p) at [i + 17 p])
+            double* Lg = V.L + M.panel_off;
+            for (int c = wave; c < k; c += NW) {
+                const double di = dinv_s[c];
+                for (int i = lane; i < m; i += 64) Lg[i + (size_t)c * m] = (i > c) ? F[pk(i, c)] * di : 0.0;
+            }
+            for (int jj = tid; jj < k; jj += NT) { V.dinv[c0 + jj] = dinv_s[jj]; V.doff[c0 + jj] = 0.0; V.ptype[c0 + jj] = 1; V.lperm[c0 + jj] = jj; }
+            const int mu = m - k;
+            double* Cg = V.cb + M.cb_off;
+            for (int c = k + wave; c < m; c += NW)
+                for (int i = c + lane; i < m; i += 64) Cg[(i - k) + (size_t)(c - k) * mu] = F[pk(i, c)];
+            if (tid == 0) V.fstat[s] = make_int4(fneg, 0, 0, 0);
+            double* Mg = V.minv + M.minv_off;
+            for (int idx = tid; idx < k * k; idx += NT) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? colbuf[i + 17 * c] : (i == c ? 1.0 : 0.0); }
+            if (tid == 0) V.hasis[s] = 2;
+            return;
+        }
+    }
     // ---- tiles -> registers (full symmetric) ----
     const int ti = tid % G, tj = tid / G, row0 = ti * TS, col0 = tj * TS;
     double t[TS][TS];
@@ -1022,6 +1055,160 @@ __device__ __forceinline__ bool ldlt_blocked_static(double* Lb, const int ld, co
     }
 #undef PSTAMP
     nneg += neg;
+    return true;
+}
+
+// ================================================================================================
+// Fronts of order 65 .. 128 with k <= 16 pivots (the bulk of the 256-thread front kernel's work on 2-D problems: 33 000 fronts per
+// factorisation of synth_1e6, mean k = 15): the strict loop costs ~2 700 cycles per pivot there (three workgroups share a CU).  Same idea as
+// the pivot blocks of the big fronts: natural order, 1x1 pivots, nothing decided per pivot, accepted A POSTERIORI --
+//   A  wavefront 0: rows 0..15 of the front in registers, the k pivots eliminated by DPP (fast16_step; the non-pivot rows k..15 ride along and
+//      come out holding their Schur complement entries), X = L11^{-1} by the same DPP substitution;
+//   B  the rows below, 16 per wavefront and pass: W21 = A21 X^T by 4 MFMAs, multipliers W21 D^{-1} checked;
+//   -- acceptance: every multiplier of the WHOLE front column (a front of this size sees all its rows) <= gmax, every pivot clear of the zero
+//      threshold; on rejection NOTHING has been written into F and the caller runs the strict loop --
+//   C  the trailing 16 x 16 tiles: S(i, c) -= sum_p L(i, p) W(c, p) (4 MFMAs each) on the packed lower triangle.
+// F: the assembled front, lower triangle packed by columns.  On acceptance F(i, c) = W(i, c) = L(i, c) d_c for c < k < = i..., the Schur
+// complement for i >= c >= k; dinv_s = 1 / d; scratch[i + 17 p] = X(i, p) (the inverse the triangular solves use).
+// ================================================================================================
+template <int J> __device__ __forceinline__ void fast16_step(double (&a)[16], double (&w)[16], double& rsave, const int l15)
+{
+    const double t = a[J];
+    w[J] = t;
+    const double d = bcast16<J>(t);
+    const double ri = fast_rcp(d);
+    rsave = (l15 == J) ? ri : rsave;
+    const double l = t * ri;
+    rank1_dpp16<J>(a, t, l);
+    a[J] = l;
+}
+template <int J> __device__ __forceinline__ void fast16_inv(const double (&a)[16], double (&x)[4], const int l15, const int k)
+{
+    const double m = (l15 > J && l15 < k) ? -a[J] : 0.0;         // rows up to J are finished; rows from k on are not part of L11
+    subst_dpp16<J>(x[0], m);
+    if constexpr (J >= 4) subst_dpp16<J>(x[1], m);
+    if constexpr (J >= 8) subst_dpp16<J>(x[2], m);
+    if constexpr (J >= 12) subst_dpp16<J>(x[3], m);
+}
+__device__ __forceinline__ bool front_fast16(double* F, const int m, const int k, double* scratch, double* dinv_s, const double* cnorm, const double small, const double gmax, int& nneg)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    auto pk = [m](int i, int c) { return c * m - ((c * (c - 1)) >> 1) + (i - c); };      // i >= c
+    double* Xs = scratch;                                        // 16 x 17
+    int* shflag = reinterpret_cast<int*>(scratch + 280);         // [0] rejected, [1] negative pivots
+    double* cmv = scratch + 288;                                 // 16 column maxima
+    // zero threshold of the front: largest |entry| of the assembled pivot columns / of the input columns
+    {
+        const int c = tid >> 4, part = tid & 15;
+        double mx = 0.0;
+        if (c < k) for (int i = part; i < m; i += 16) mx = fmax(mx, fabs(F[pk(max(i, c), min(i, c))]));
+        mx = fmax(mx, dpp_f64<0xB1>(mx)); mx = fmax(mx, dpp_f64<0x4E>(mx)); mx = fmax(mx, dpp_f64<0x141>(mx)); mx = fmax(mx, dpp_f64<0x140>(mx));
+        if (part == 0) cmv[c] = (c < k) ? fmax(mx, cnorm[c]) : 0.0;
+        if (tid == 0) { shflag[0] = 0; shflag[1] = 0; }
+    }
+    __syncthreads();
+    double cmx = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) cmx = fmax(cmx, cmv[c]);
+    const double zmax = fmax(small, ZERO_REL * cmx);
+    // ---- A ----
+    double a[16], w[16], rsave = 1.0;
+    if (wave == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { a[c] = F[pk(max(l15, c), min(l15, c))]; w[c] = 0.0; }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#define MI_STEP(j) if (j < k) fast16_step<j>(a, w, rsave, l15);
+        MI_STEP(0) MI_STEP(1) MI_STEP(2) MI_STEP(3) MI_STEP(4) MI_STEP(5) MI_STEP(6) MI_STEP(7)
+        MI_STEP(8) MI_STEP(9) MI_STEP(10) MI_STEP(11) MI_STEP(12) MI_STEP(13) MI_STEP(14) MI_STEP(15)
+#undef MI_STEP
+        double gm = 0.0;
+#pragma unroll
+        for (int c = 0; c < 15; ++c) gm = fmax(gm, (c < k && l15 > c) ? fabs(a[c]) : 0.0);
+        const bool mine = l15 < k;
+        bool bad = __ballot(gm > gmax) != 0ull;
+        bad |= __ballot(mine && !(fabs(rsave) * zmax < 1.0)) != 0ull;
+        const int neg = __popcll(__ballot(mine && l4 == 0 && rsave < 0.0));
+        double x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x[q] = (l15 == 4 * q + l4) ? 1.0 : 0.0;
+#define MI_INV(j) if (j + 1 < k) fast16_inv<j>(a, x, l15, k);
+        MI_INV(0) MI_INV(1) MI_INV(2) MI_INV(3) MI_INV(4) MI_INV(5) MI_INV(6) MI_INV(7) MI_INV(8) MI_INV(9) MI_INV(10) MI_INV(11) MI_INV(12) MI_INV(13) MI_INV(14)
+#undef MI_INV
+        if (bad) { if (lane == 0) shflag[0] = 1; }
+        else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Xs[l15 + (4 * q + l4) * 17] = x[q];      // X(i = l15, p = 4 q + l4)
+            if (l4 == 0 && mine) dinv_s[l15] = rsave;
+            if (lane == 0) shflag[1] = neg;
+        }
+    }
+    __syncthreads();
+    if (shflag[0]) return false;
+    // ---- B: rows 16 .. m-1, W21 = A21 X^T (kept in registers until the front is accepted) ----
+    const int ntl = (m + 15) >> 4;                               // 16-row tiles of the front (tile 0 = wavefront 0's rows)
+    v4f64_ wacc[2];
+    int wrow[2] = {-1, -1};
+    {
+        bool big = false;
+        int slot = 0;
+        for (int t = 1 + wave; t < ntl; t += 4, ++slot) {        // (m <= 128: at most 2 tiles per wavefront)
+            const int r = 16 * t + l15;
+            v4f64_ acc = (v4f64_){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int p = 4 * u + l4;
+                const double av = (p < k) ? Xs[l15 + p * 17] : 0.0;                  // X(c = l15, p)   (zero beyond k: columns >= k are not pivots)
+                const double bv = (r < m && p < k) ? F[pk(min(r, m - 1), p)] : 0.0;   // A21(r, p)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64((l15 < k) ? av : 0.0, bv, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const int c = l4 + 4 * g; if (c < k && r < m) big |= fabs(acc[g] * dinv_s[c]) > gmax; }      // acc[g] = W21(r, c)
+            if (slot == 0) { wacc[0] = acc; wrow[0] = r; } else { wacc[1] = acc; wrow[1] = r; }
+        }
+        if (__ballot(big) != 0ull && lane == 0) shflag[0] = 1;
+    }
+    __syncthreads();
+    if (shflag[0]) return false;
+    // ---- accepted: W into the first k columns of F, the Schur complement of rows k..15 ----
+    nneg = shflag[1];
+    if (wave == 0 && l4 == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            if (c < k) { if (l15 > c) F[pk(l15, c)] = w[c]; }
+            else if (l15 >= c) F[pk(l15, c)] = a[c];
+        }
+    }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int r = wrow[sl];
+        if (r >= 0 && r < m) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const int c = l4 + 4 * g; if (c < k) F[pk(r, c)] = wacc[sl][g]; }
+        }
+    }
+    __syncthreads();
+    // ---- C: S(i, c) -= sum_p L(i, p) W(c, p),  i >= 16, i >= c >= k ----
+    {
+        int q = 0;
+        for (int tc = 0; tc < ntl; ++tc)
+            for (int ti = max(tc, 1); ti < ntl; ++ti, ++q) {
+                if ((q & 3) != wave) continue;
+                v4f64_ acc = (v4f64_){0.0, 0.0, 0.0, 0.0};
+                const int ri = 16 * ti + l15, rc = 16 * tc + l15;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int p = 4 * t + l4;
+                    const double av = (ri < m && p < k) ? F[pk(min(ri, m - 1), p)] * dinv_s[min(p, 15)] : 0.0;       // L(ri, p)
+                    const double bv = (rc < m && rc >= k && p < k) ? F[pk(min(max(rc, p), m - 1), p)] : 0.0;        // W(rc, p)   (rc >= k > p)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+                }
+                const int cc = 16 * tc + l15;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) { const int rr = 16 * ti + l4 + 4 * g; if (rr < m && cc >= k && rr >= cc) F[pk(rr, cc)] -= acc[g]; }
+            }
+    }
+    __syncthreads();
     return true;
 }
 
@@ -4528,6 +4715,8 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // exact LDS need of the register-tiled front kernel per (level, class) bucket
         reg_lds.assign((size_t)Sy.num_levels * FC_COUNT, 0);
         for (int s = 0; s < Sy.num_sn; ++s) {
@@ -4588,8 +4777,13 @@ public:
             LAUNCH(KK_FRONT_LDS64, (k_front_reg<64, 8>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
         } else if (fc == FC_LDS128) {
             const int nm = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_LDS128]) ? mid_split[lv] : 0;    // single-GPU schedule only
-            if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
-            if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
+            const int fl = top_mode | (V.fastpiv ? 2 : 0);
+            if (V.fastpiv) {      // fronts with <= 16 pivots: static-order path first; what it accepts is skipped by the launch behind it
+                if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
+                if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
+            }
+            if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, fl);
+            if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, fl);
         } else {
             const bool single = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_BIG]) && !multi;       // the single-GPU schedule
             if ((single || multi) && grouped && lv >= S->grp_cut_level) {

@@ -236,6 +236,39 @@ def ldlt_block_static(A, k, u, u2, small=1e-20, cnorm=None):
     return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0)
 
 
+FAST16_MIN_M = 65    # fronts of order 65 .. 128 (the 256-thread front kernel) with <= 16 pivots try the static path first
+
+
+def ldlt_front_static(F, k, u, u2, small=1e-20, cnorm=None):
+    """The fast path of a front of order 65 .. 128 with k <= 16 pivots (numeric.hip: front_fast16): the k fully-summed columns are
+    eliminated in NATURAL order with 1x1 pivots, nothing decided per pivot, and the result is accepted A POSTERIORI iff every pivot is
+    clear of the front's zero threshold and every multiplier -- update rows included: a front of this size sees its whole column -- is
+    <= 1 / max(u, u2, FAST_U).  On acceptance F holds the Schur complement in F[k:, k:] and the same dict as ldlt_front is returned;
+    on rejection F is untouched and None is returned (the strict rule then runs)."""
+    m = F.shape[0]
+    A = F.copy()
+    cm = np.abs(A[:, :k]).max(axis=0) if k else np.zeros(0)
+    if cnorm is not None:
+        cm = np.maximum(cm, cnorm)
+    zmax = max(small, ZERO_REL * (cm.max() if k else 0.0))
+    gmax = 1.0 / max(u, u2, FAST_U)
+    L = np.zeros((m, k)); dinv = np.zeros(k); nneg = 0
+    for j in range(k):
+        d = A[j, j]
+        if not abs(d) > zmax:
+            return None
+        w = A[j + 1:, j].copy()
+        l = w / d
+        if l.size and np.abs(l).max() > gmax:
+            return None
+        L[j + 1:, j] = l
+        A[j + 1:, j + 1:] -= np.outer(l, w)
+        dinv[j] = 1.0 / d
+        nneg += int(d < 0)
+    F[:, :] = A
+    return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0)
+
+
 def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_blocks=True):
     """multifrontal LDL^T with the pivoting rules of the HIP kernels (no scaling: use scaling=0 on the GPU side).
     Returns (x, dict(num_neg, num_zero, num_two, num_delay, u_sensitive, num_fast)); num_fast = pivot blocks of big fronts
@@ -276,7 +309,9 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_bloc
             bs[rl] += cvec[ch]
             cbs[ch] = None
         if m <= BIG_FRONT:
-            st = ldlt_front(F, k, u, u2, small, cnorm=cn[c0:c1])
+            st = ldlt_front_static(F, k, u, u2, small, cnorm=cn[c0:c1]) if (fast_blocks and m >= FAST16_MIN_M and k <= 16) else None
+            if st is None:
+                st = ldlt_front(F, k, u, u2, small, cnorm=cn[c0:c1])
             P = st["ord"]
             L11 = np.tril(st["L"][P, :], -1) + np.eye(k)
             L21 = st["L"][k:, :]
