@@ -133,6 +133,7 @@ struct DevView {
     int n, nnz_a, nsn, rank;
     int fastpiv;            // pivot blocks of the big fronts: blocked LDL^T accepted a posteriori first, the strict loop as fall-back (ldlt_blocked_static)
     double fastu;           // ... accepted iff every multiplier <= 1 / max(u, u2, fastu)
+    int asm_pull;           // k_big_assemble: entries summed through the inverse row maps and written once (default) / scatter-added child by child
     unsigned long long* dbg;   // optional phase time stamps of block 0 (development aid), may be null
 };
 
@@ -2485,6 +2486,35 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
         else        col = V.cb + M.cb_off + (size_t)(fc - k) * M.ldt - k;
         if (M.alias) {          // the front already sits in its chain child's contribution block: nothing to clear or copy
             if (from_arena) for (int i = fc + lane; i < m; i += 64) col[i] += Ar[i];
+        } else if (V.asm_pull) {
+            // PULL: every entry of the column is the sum of what the children hold for it -- looked up through the inverse row maps -- and is
+            // written ONCE: no zero fill, no read-modify-write chain per child (the scatter form costs three stores and two dependent loads per
+            // entry).  Children are added in their fixed order; up to 4 of them here, the others (rare) by the scatter loop below.
+            const double* Cc[4]; const int* Iv[4]; int nc = 0;
+            for (int cp = M.ch0; cp < M.ch1 && nc < 4; ++cp) {
+                const ChildMeta Cm = V.cmeta[cp];
+                if (Cm.aliased || (skip_owned && Cm.owner >= 0)) continue;
+                const int lo = V.relinv[Cm.inv + fc];
+                if (lo < 0) continue;
+                Cc[nc] = V.cb + Cm.cb_off + (size_t)lo * Cm.ldt; Iv[nc] = V.relinv + Cm.inv; ++nc;
+            }
+            if (fc < k) for (int i = lane; i < fc; i += 64) col[i] = 0.0;
+            for (int i0 = fc + lane; i0 < m; i0 += 256) {
+                int av[4][4]; double t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 64 * u;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) av[c][u] = (c < nc && i < m) ? Iv[c][i] : -1;
+                    t[u] = (from_arena && i < m) ? Ar[i] : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (av[c][u] >= 0) t[u] += Cc[c][av[c][u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + 64 * u; if (i < m) col[i] = t[u]; }
+            }
         } else if (fc < k) {
             for (int i = lane; i < m; i += 64) col[i] = (from_arena && i >= fc) ? Ar[i] : 0.0;
         } else {
@@ -2497,6 +2527,7 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
         for (int q = q0 + lane; q < q1; q += 64) col[V.apos[q] - fc * m] += V.aval[q];
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // each wavefront owns its column: ordering of its own stores/loads is all that is needed
+    int npulled = 0;                                           // contributing children the pull loop has dealt with
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
         const ChildMeta Cm = V.cmeta[cp];
         const int ch = Cm.ch; (void)ch;
@@ -2504,6 +2535,7 @@ __global__ __launch_bounds__(256) void k_big_assemble(DevView V, int list_off, i
             const int mc = Cm.mc;
             const int* relc = V.rel + Cm.relbase;
             const int lo = V.relinv[Cm.inv + fc];          // index of parent column fc among the child's update rows (one load, no search)
+            if (lo >= 0 && V.asm_pull && !M.alias && npulled < 4) { ++npulled; continue; }
             if (lo >= 0) {
                 const double* C = V.cb + Cm.cb_off + (size_t)lo * Cm.ldt;
                 int a = lo + lane;
@@ -4319,6 +4351,7 @@ public:
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
         V.fastpiv = getenv("MI355X_KKT_NO_FASTPIV") == nullptr ? 1 : 0;
+        V.asm_pull = getenv("MI355X_KKT_NO_ASM_PULL") == nullptr ? 1 : 0;
         V.fastu = 1e-4; if (const char* e = getenv("MI355X_KKT_FASTPIV_FLOOR")) V.fastu = atof(e);      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
         if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
         pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
