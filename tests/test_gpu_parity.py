@@ -329,6 +329,46 @@ def test_sync_free_chain_sweeps_match_the_level_by_level_solves(monkeypatch):
         assert np.array_equal(x, x2)
 
 
+@pytest.mark.parametrize("gen", ["grid", "band", "hostile", "uneven"])
+def test_data_flow_solve_sweeps_at_every_extent(monkeypatch, gen):
+    """the data-flow solve sweeps (k_fwd_chain / k_bwd_chain: tagged messages, poller wavefront, dot workgroups, children pulled through the
+    inverse row maps) with the segment reaching down to levels of 1 / 8 / 128 / every number of fronts -- small fronts ride as one-link chains,
+    far more workgroups than fit on the chip (in-order dispatch is what keeps the waits deadlock-free) -- against the launch-per-level solves:
+    same solution to rounding, bitwise reproducible, several right-hand sides through one factorisation, with and without device refinement."""
+    if gen == "grid":
+        n, r, c, v, neg = kktgen.grid_kkt(60, 52, dof=3, ncon=2, seed=41)
+    elif gen == "band":
+        n, r, c, v, neg = kktgen.lukvl_like(30000, seed=7)
+    elif gen == "uneven":
+        n, r, c, v, neg = kktgen.grid_kkt(150, 9, dof=4, ncon=1, seed=43)         # long thin domain: unbalanced tree, chains of very different lengths
+    else:
+        n, r, c, v = kktgen.hostile_grid_kkt(24, 20, seed=5); neg = None
+    K = kktgen.to_scipy(n, r, c, v)
+    rng = np.random.default_rng(9)
+    B = [K @ np.ones(n), rng.standard_normal(n), K @ rng.standard_normal(n)]
+    for refine in (0, 2):
+        monkeypatch.setenv("MI355X_KKT_NO_CHAIN_SOLVE", "1")
+        s0, st0, _ = gpu_factor_solve(n, r, c, v, B[0], refine_steps=refine)
+        assert st0 == kkt.SUCCESS
+        X0 = []
+        for b in B:
+            x = b.copy(); s0.multi_solve(False, x); X0.append(x)
+        monkeypatch.delenv("MI355X_KKT_NO_CHAIN_SOLVE")
+        for maxc in ("1", "8", "128", "1000000"):
+            monkeypatch.setenv("MI355X_KKT_CHAIN_SOLVE_MAXC", maxc)
+            s1, st1, _ = gpu_factor_solve(n, r, c, v, B[0], refine_steps=refine)
+            assert st1 == kkt.SUCCESS and s1.number_of_neg_evals() == s0.number_of_neg_evals()
+            for b, x0 in zip(B, X0):
+                x = b.copy(); s1.multi_solve(False, x)
+                assert np.abs(x - x0).max() <= 1e-9 * max(1.0, np.abs(x0).max()), (gen, maxc, refine)
+                x2 = b.copy(); s1.multi_solve(False, x2)
+                assert np.array_equal(x, x2)
+            Xm = np.stack(B, axis=0).copy()                   # three right-hand sides in one call
+            s1.multi_solve(False, Xm)
+            for j, x0 in enumerate(X0):
+                assert np.abs(Xm[j] - x0).max() <= 1e-9 * max(1.0, np.abs(x0).max())
+        monkeypatch.delenv("MI355X_KKT_CHAIN_SOLVE_MAXC")
+
 def test_fused_pivot_block_and_panel_solve_is_bitwise_identical(monkeypatch):
     """k_big_diag_trsm (pivot block + panel solve of a front in one flag-synchronised launch, used where a level has few
     fronts) against the two separate launches: the same arithmetic, so the same bits"""
