@@ -3178,340 +3178,13 @@ __global__ __launch_bounds__(256) void k_big_schur64(DevView V, int list_off, in
 
 
 // ================================================================================================
-// CHAIN GROUPS FACTORED AS ONE UNIT (the single-GPU schedule).  A chain group = up to 4 consecutive links of an in-place separator
-// chain (<= 256 columns); every link after the first has the chain child as its ONLY child, so the whole group can be factored at
-// the tree level of its first link: no launch per link, no flags between workgroups.  Three launches per level:
-//   k_grp_diag   ONE 512-thread workgroup per group walks the group's leading (<= 256)^2 block link by link: pivot block (blocked
-//                a-posteriori LDL^T, strict threshold pivoting as fall-back), the rows of the group's LATER pivots solved against it
-//                (blocked substitution, fp64 MFMA), their rank-k update of the rest of the leading block -- the serial spine of a
-//                separator chain, 8 wavefronts on one CU, everything between two pivot blocks staged through LDS / L2;
-//   k_grp_rows   the rows BELOW the group's columns, 64 per workgroup, right-looking over the group's links: solve against link p
-//                (k_big_trsm's arithmetic), then update the own rows' entries in the columns of the later links -- a workgroup
-//                depends on k_grp_diag's results only, never on another row block;
-//   k_big_schur  the rank-(<= 256) update of the contribution block by all the group's panels (unchanged).
-// (k_big_inverse builds the L11^{-1} the triangular solves use, for all big fronts in one launch at the end of the factorisation.)
+// CHAIN GROUPS FACTORED AS ONE UNIT.  A chain group = up to 4 consecutive links of an in-place separator chain (<= 256 columns); every
+// link after the first has the chain child as its ONLY child, so the whole group can be factored at the tree level of its first link:
+// one launch for the group's leading block and all its panel rows (k_grp_fused), then the rank-(<= 256) update of the contribution block
+// by all the group's panels (k_big_schur, unchanged).  (A two-launch variant -- one 512-thread workgroup walking the leading block link by
+// link, row blocks behind it -- was built first and measured slower: 210 us per group, a lone wavefront issues one fp64 MFMA per ~150
+// cycles; removed.)
 // ================================================================================================
-constexpr int GX_ROWS = 192, GX_LD = 208;      // staged rows of the later pivots; GX_LD = 16 mod 32 doubles: the 16 x 2 (row, column) operand reads of a half wave hit 32 banks
-static size_t grp_lds_bytes() { return (size_t)(64 * 65 + 256 + 3 * 64 + 4 * 272 + 16 * 65 + 64 * GX_LD) * sizeof(double) + (size_t)(4 * 64 + 8) * sizeof(int) + 64; }
-
-__global__ __launch_bounds__(512) void k_grp_diag(const DevView* __restrict__ Vp, int list_off)
-{
-    const DevView& V = *Vp;          // (by reference: the 90-pointer view by value costs ~200 spilled SGPRs in this kernel)
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NT = 512, NW = NT / 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const FrontMeta M = V.fmeta[list_off + blockIdx.x];              // the LAST link of the group
-    const int g = M.gpos + 1;
-    double* Lb     = reinterpret_cast<double*>(smem_raw);            // pivot block, 64 x 65
-    double* colbuf = Lb + 64 * 65;                                   // 4 x 64 (strict loop: published pivot columns)
-    double* dinv_s = colbuf + 256; double* doff_s = dinv_s + 64; double* cm0 = doff_s + 64;
-    double* Is     = cm0 + 64;                                       // inverses of the 16 x 16 diagonal blocks of L11: Is[b*272 + i + p*17]
-    double* Wp     = Is + 4 * 272;                                   // 64 x 16 (ld 65): W panel of the blocked factorisation
-    double* Xs     = Wp + 16 * 65;                                   // rows of the later pivots (R x k, ld GX_LD): A21 P -> W21
-    int* ord = reinterpret_cast<int*>(Xs + 64 * GX_LD); int* pt_s = ord + 64; int* iord = pt_s + 64; int* shflag = iord + 64;
-    int done = 0;
-    for (int j = 0; j < g; ++j) {
-        const GroupLink G = V.gtab[M.gbase + j];
-        const int k = G.k, m = G.m, c0 = G.c0, s = G.s;
-        const int R = M.gcols - done - k;                            // the group's later pivots = the first R rows below this link's pivot block
-        done += k;
-        constexpr int ld = 65;                                       // (fixed: rows / columns beyond k are kept zero)
-        const int kp16 = (k + 15) & ~15;
-        double* P = V.L + G.panel_off;
-        const size_t ldp = (size_t)G.ldp;
-        // ---- loads: pivot block, rows of the later pivots (kept in registers until the pivot order is known), the link's own A entries ----
-        const int bi = tid & 63, bq = tid >> 6;                      // pivot block: row bi, columns bq + 8 e
-        auto load_block = [&]() {
-            double pv[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; pv[e] = (bi < k && c < k && bi >= c) ? P[bi + (size_t)c * ldp] : 0.0; }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi >= c) { Lb[bi + c * ld] = pv[e]; Lb[c + bi * ld] = pv[e]; } }
-        };
-        // rows of the later pivots -> Xs, column p of Xs = column ord[p] of the panel (identity until the strict loop says otherwise)
-        auto load_rows = [&](const bool permuted) {                   // thread (bi, bq): rows bi + 64 h, columns bq + 8 e
-#pragma unroll 1
-            for (int h = 0; h < 3; ++h) {
-                const int r = bi + 64 * h;
-                if (64 * h >= R) break;
-                double xr[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; xr[e] = (r < R && c < k) ? P[(k + r) + (size_t)c * ldp] : 0.0; }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (c < k) Xs[r + (permuted ? iord[c] : c) * GX_LD] = xr[e]; else if (c < kp16) Xs[r + c * GX_LD] = 0.0; }
-            }
-        };
-        constexpr int NA = 4;                                        // A entries kept in registers per thread (the others are re-read)
-        int apos_[NA]; double aval_[NA]; int na = 0;
-        if (G.selfasm) {
-#pragma unroll
-            for (int e = 0; e < NA; ++e) { const int q = G.aq0 + tid + e * NT; if (q < G.aq1) { apos_[e] = V.apos[q]; aval_[e] = V.aval[q]; na = e + 1; } }
-        }
-        // mode 0: pivot block + rows (natural column order), 1: pivot block only, 2: rows only (column order iord)
-        auto add_a = [&](const int pos, const double v, const int mode) {
-            const int ii = pos % m, cc = pos / m;
-            if (ii < k) { if (mode != 2) { Lb[ii + cc * ld] += v; if (ii != cc) Lb[cc + ii * ld] += v; } }
-            else if (ii < k + R && mode != 1) Xs[(ii - k) + (mode == 2 ? iord[cc] : cc) * GX_LD] += v;
-        };
-        auto a_entries = [&](const int mode) {
-            if (!G.selfasm) return;
-#pragma unroll
-            for (int e = 0; e < NA; ++e) if (e < na) add_a(apos_[e], aval_[e], mode);
-            for (int q = G.aq0 + tid + NA * NT; q < G.aq1; q += NT) add_a(V.apos[q], V.aval[q], mode);
-            __syncthreads();
-        };
-        load_block();
-        if (R > 0) load_rows(false);
-        __syncthreads();
-        a_entries(0);
-        // ---- pivot block ----
-        int nneg = 0, nzero = 0, ntwo = 0, nsmall = 0, chg = 0;
-        bool fast = false;
-        if (V.fastpiv) {
-            double cmx;
-            {
-                const int c = tid >> 3, part = tid & 7;
-                double mx = 0.0;
-                if (c < k) for (int r = part; r < k; r += 8) mx = fmax(mx, fabs(Lb[r + c * ld]));
-                if (c < k && part == 0) mx = fmax(mx, V.cnorm[c0 + c]);
-                cmx = wave_max_all(mx);
-                if (lane == 0) colbuf[wave] = cmx;
-                __syncthreads();
-                cmx = 0.0;
-#pragma unroll
-                for (int w = 0; w < NW; ++w) cmx = fmax(cmx, colbuf[w]);
-            }
-            const double zmax = fmax(V.small, ZERO_REL * cmx);
-            const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), V.fastu);
-            fast = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Is, shflag, zmax, gmax, nneg);
-            if (fast) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi < k && c < k && bi <= c) Lb[bi + c * ld] = 0.0; }
-                for (int q = tid; q < k; q += NT) { doff_s[q] = 0.0; pt_s[q] = 1; ord[q] = q; iord[q] = q; }
-                if (tid == 0) atomicAdd(&V.qstat[3], 1);
-            } else {
-                if (tid == 0) atomicAdd(&V.qstat[2], 1);
-                __syncthreads();
-                load_block();
-                __syncthreads();
-                a_entries(1);
-            }
-        }
-        if (!fast) {
-            // strict threshold pivoting (ldlt_reg) on 16 x 16 threads with 4 x 4 register tiles, exactly as in k_big_diag_reg: the other
-            // 256 threads of the workgroup ride along on empty tiles beyond column 64 (they keep the barriers matched)
-            constexpr int TS = 4, GG = 16;
-            const int ti = tid % GG, tj = tid / GG, row0 = ti * TS, col0 = tj * TS;
-            double t[TS][TS];
-#pragma unroll
-            for (int x = 0; x < TS; ++x)
-#pragma unroll
-                for (int y = 0; y < TS; ++y) { const int i = row0 + x, c = col0 + y; t[x][y] = (i < k && c < k) ? Lb[i + c * ld] : 0.0; }
-            __syncthreads();
-            nneg = 0;
-            const double cmx = front_colmax<256, TS>(t, cm0, k, V.cnorm + c0);
-            ldlt_reg<256, TS, false>(t, k, k, Lb, ld, colbuf, dinv_s, doff_s, pt_s, ord, V.pivtol, V.pivtol2, V.small, cm0, cmx, V.zpiv + c0, nneg, nzero, ntwo, nsmall, chg);
-            if (chg && tid == 0) V.qstat[0] = 1;
-            __syncthreads();
-            double tmp[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; tmp[e] = (bi < k && c < k && bi > c) ? Lb[ord[bi] + c * ld] : 0.0; }
-            __syncthreads();
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi < k && c < k) Lb[bi + c * ld] = tmp[e]; }
-            for (int q = tid; q < k; q += NT) iord[ord[q]] = q;
-        }
-        __syncthreads();
-        // ---- L11, D, pivot order -> global (the triangular solves, k_grp_rows, k_big_inverse) ----
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const int c = bq + 8 * e; if (bi < k && c < k) P[bi + (size_t)c * ldp] = Lb[bi + c * ld]; }
-        for (int q = tid; q < k; q += NT) { V.dinv[c0 + q] = dinv_s[q]; V.doff[c0 + q] = doff_s[q]; V.ptype[c0 + q] = pt_s[q]; V.lperm[c0 + q] = ord[q]; }
-        if (tid == 0) V.fstat[s] = make_int4(nneg, nzero, ntwo, nsmall);
-        if (R <= 0) continue;                                        // (last link: the rows below are k_grp_rows' business)
-        // ---- rows of the later pivots:  W = (A21 P) L11^{-T},  L21 = W D^{-1} ----
-        if (!fast) {                                                 // the strict loop permuted the pivots: stage the rows again in pivot order
-            load_rows(true);
-            __syncthreads();
-            a_entries(2);
-        }
-        auto Lat = [&](const int i, const int c) -> double { return Lb[i + c * ld]; };      // (strictly lower part; zero on and above the diagonal and beyond k)
-        if (!fast && wave < 4 && 16 * wave < kp16 && lane < 16) {    // inverses of the unit-lower 16 x 16 diagonal blocks (column `lane` by lane; the blocked factorisation left them in Is)
-            const int o = 16 * wave;
-            double x[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) x[i] = (i == lane) ? 1.0 : 0.0;
-#pragma unroll
-            for (int pp = 0; pp < 15; ++pp) {
-                const double xp = (pp >= lane) ? x[pp] : 0.0;
-                double lc[15];
-#pragma unroll
-                for (int i = pp + 1; i < 16; ++i) lc[i - 1] = Lat(o + i, o + pp);
-#pragma unroll
-                for (int i = pp + 1; i < 16; ++i) x[i] = fma(-lc[i - 1], xp, x[i]);
-                asm volatile("" ::: "memory");                       // one column of L in flight at a time (hoisting all 120 loads spills)
-            }
-#pragma unroll
-            for (int i = 0; i < 16; ++i) Is[wave * 272 + i + lane * 17] = x[i];
-        }
-        __syncthreads();
-        const int nrt = (R + 15) >> 4;
-        for (int rt = wave; rt < nrt; rt += NW) {
-            const int r16 = rt * 16;
-            for (int c16 = 0; c16 < kp16; c16 += 16) {
-                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
-                for (int p = 0; p < c16; p += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Lat(c16 + l15, p + l4), Xs[r16 + l15 + (p + l4) * GX_LD], acc, 0, 0, 0);
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) Xs[r16 + l15 + (c16 + l4 + 4 * gg) * GX_LD] -= acc[gg];
-                double bv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) bv[u] = Xs[r16 + l15 + (c16 + 4 * u + l4) * GX_LD];
-                const double* Ib = Is + (c16 >> 4) * 272;
-                v4f64 w = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) w = __builtin_amdgcn_mfma_f64_16x16x4f64(Ib[l15 + (4 * u + l4) * 17], bv[u], w, 0, 0, 0);
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) Xs[r16 + l15 + (c16 + l4 + 4 * gg) * GX_LD] = w[gg];
-            }
-        }
-        __syncthreads();
-        // L21 = W D^{-1} of one row: 1x1 pivots scale, a 2x2 pivot mixes its two columns
-        auto lval = [&](const int r, const int q) -> double {
-            const int pt = pt_s[q];
-            const double wq = Xs[r + q * GX_LD];
-            if (pt == 1) return wq * dinv_s[q];
-            if (pt == 2) return dinv_s[q] * wq + doff_s[q] * Xs[r + (q + 1) * GX_LD];
-            return doff_s[q - 1] * Xs[r + (q - 1) * GX_LD] + dinv_s[q] * wq;
-        };
-        {
-            double* W = V.wbuf + G.wb;
-#pragma unroll 1
-            for (int h = 0; h < 3; ++h) {
-                const int r = bi + 64 * h;
-                if (r >= R) continue;
-#pragma unroll 2
-                for (int q = bq; q < k; q += 8) {
-                    const double l = lval(r, q);
-                    W[(k + r) + (size_t)q * m] = Xs[r + q * GX_LD]; P[(k + r) + (size_t)q * ldp] = l;
-                    if (fabs(l) * V.pivtol > 1.0 && atomicExch(&V.colfail[c0 + q], 1) == 0) atomicAdd(&V.fstat[s].w, 1);      // a posteriori threshold test (see k_big_trsm)
-                }
-            }
-        }
-        // ---- rank-k update of the rest of the leading block: T(i, c) -= sum_q L21(i, q) W21(c, q), i >= c, 16 x 16 tiles ----
-        {
-            double* T = V.cb + G.t_off;
-            const size_t ldt = (size_t)G.ldt;
-            const int ntile = nrt * (nrt + 1) / 2;
-            for (int t = wave; t < ntile; t += NT / 64) {
-                int ti = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-                while (ti * (ti + 1) / 2 > t) --ti;
-                while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-                const int tc = t - ti * (ti + 1) / 2;
-                const int ra = 16 * tc + l15, rb = 16 * ti + l15;      // W row (-> T column), L row (-> T row) of this lane's operands
-                v4f64 acc = (v4f64){0.0, 0.0, 0.0, 0.0};
-                for (int q = 0; q < kp16; q += 4) {
-                    const int qq = q + l4;
-                    const double av = (ra < R) ? Xs[ra + qq * GX_LD] : 0.0;
-                    const double bv = (rb < R && qq < k) ? lval(rb, qq) : 0.0;
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-                }
-                double tv[4];
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) { const int c = 16 * tc + l4 + 4 * gg; tv[gg] = (rb < R && c < R && rb >= c) ? T[rb + (size_t)c * ldt] : 0.0; }
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) { const int c = 16 * tc + l4 + 4 * gg; if (rb < R && c < R && rb >= c) T[rb + (size_t)c * ldt] = tv[gg] - acc[gg]; }
-            }
-        }
-        __syncthreads();              // the next link reads its pivot block and rows out of what was just updated
-    }
-}
-
-// Rows below a chain group's columns, 64 per workgroup, right-looking over the links of the group (see above).
-__global__ __launch_bounds__(256) void k_grp_rows(DevView V, int list_off)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const FrontMeta M = V.fmeta[list_off + blockIdx.y];              // the LAST link of the group
-    const int tail = M.m - M.k;                                      // rows below the group's columns (the same rows in every link)
-    const int e0 = 64 * (int)blockIdx.x;
-    if (e0 >= tail) return;
-    const int g = M.gpos + 1;
-    int done = 0;
-    for (int p = 0; p < g; ++p) {
-        const GroupLink G = V.gtab[M.gbase + p];
-        const int k = G.k, m = G.m;
-        const int R = M.gcols - done - k;
-        done += k;
-        const int ibase = k + R + e0;                                // my first row in this link's front
-        double* P = V.L + G.panel_off;
-        const size_t ldp = (size_t)G.ldp;
-        if (G.selfasm) {
-            for (int q = G.aq0 + tid; q < G.aq1; q += 256) { const int pos = V.apos[q]; const int i = pos % m, c = pos / m; if (i >= ibase && i < ibase + 64) P[i + (size_t)c * ldp] += V.aval[q]; }
-            __syncthreads();
-        }
-        FrontMeta Mp = M;
-        Mp.s = G.s; Mp.c0 = G.c0; Mp.k = k; Mp.m = m; Mp.panel_off = G.panel_off; Mp.ldp = G.ldp; Mp.wb = G.wb;
-        const TrsmLds T = trsm_layout(smem_raw, k, false);
-        trsm_rows_impl<true>(V, Mp, T, ibase);
-        if (R <= 0) break;
-        __syncthreads();
-        // my rows' entries in the columns of the later links:  T(i, c) -= sum_q L21(i, q) W21(c, q),  c < R  (W21 of those rows: k_grp_diag)
-        {
-            const double* Ds = T.Ds; const int* Ts = T.Ts; const double* As = T.As;
-            auto lval = [&](const int r, const int q) -> double {
-                const int pt = Ts[q];
-                const double wq = As[r + q * 65];
-                if (pt == 1) return wq * Ds[q];
-                if (pt == 2) return Ds[q] * wq + Ds[k + q] * As[r + (q + 1) * 65];
-                return Ds[k + q - 1] * As[r + (q - 1) * 65] + Ds[q] * wq;
-            };
-            const int kp16 = T.kp16;
-            double bv[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) { const int qq = 4 * u + l4; bv[u] = (qq < k) ? lval(16 * wave + l15, qq) : 0.0; }
-            const double* Wg = V.wbuf + G.wb + k;                    // W21 rows of the later pivots
-            double* Tt = V.cb + G.t_off;
-            const size_t ldt = (size_t)G.ldt;
-            const int irow = R + e0 + 16 * wave + l15;               // my row in T
-            const bool rowok = e0 + 16 * wave + l15 < tail;
-            const int nct = (R + 15) >> 4;
-            for (int tc = 0; tc < nct; tc += 2) {
-                double a0[16], a1[16];
-                const int ra = 16 * tc + l15, rb = ra + 16;
-#pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    const int qq = 4 * u + l4;
-                    a0[u] = (ra < R && qq < k) ? Wg[ra + (size_t)qq * m] : 0.0;
-                    a1[u] = (rb < R && qq < k) ? Wg[rb + (size_t)qq * m] : 0.0;
-                }
-                double t0[4], t1[4];
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const int c = 16 * tc + l4 + 4 * gg;
-                    t0[gg] = (rowok && c < R) ? Tt[irow + (size_t)c * ldt] : 0.0;
-                    t1[gg] = (rowok && c + 16 < R) ? Tt[irow + (size_t)(c + 16) * ldt] : 0.0;
-                }
-                v4f64 c0v = (v4f64){0.0, 0.0, 0.0, 0.0}, c1v = (v4f64){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (4 * u < kp16) {
-                        c0v = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bv[u], c0v, 0, 0, 0);
-                        c1v = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bv[u], c1v, 0, 0, 0);
-                    }
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) {
-                    const int c = 16 * tc + l4 + 4 * gg;
-                    if (rowok && c < R) Tt[irow + (size_t)c * ldt] = t0[gg] - c0v[gg];
-                    if (rowok && c + 16 < R) Tt[irow + (size_t)(c + 16) * ldt] = t1[gg] - c1v[gg];
-                }
-            }
-        }
-        __syncthreads();
-    }
-}
-
 // A chain group as ONE launch of row-block workgroups (the default of the grouped schedule): grid = (groups, 4 + row blocks below the
 // group).  Role q < 4 owns the pivot rows of the group's link q, role 4 + b the b-th block of 64 rows below the group's columns.  A
 // row block walks the links p before its own (all of them for the rows below): rows staged in LDS, wait for link p's pivot block
@@ -3724,20 +3397,6 @@ __global__ __launch_bounds__(256) void k_grp_fused(DevView V, int list_off, int 
 #undef GSTAMP
 }
 
-// L11^{-1} of the big fronts (the triangular solves multiply by it): one workgroup per front, L11 as stored by the pivot-block kernels
-__global__ __launch_bounds__(256) void k_big_inverse(DevView V, int list_off)
-{
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    const FrontMeta M = V.fmeta[list_off + blockIdx.x];
-    const int tid = threadIdx.x, k = M.k, ld = k | 1;
-    double* Lb = reinterpret_cast<double*>(smem_raw);
-    const double* P = V.L + M.panel_off;
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Lb[i + c * ld] = (i > c) ? P[i + (size_t)c * M.ldp] : 0.0; }
-    __syncthreads();
-    invert_unit_lower<256>(Lb, ld, k);
-    double* Mg = V.minv + M.minv_off;
-    for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Mg[idx] = (i > c) ? Lb[i + c * ld] : (i == c ? 1.0 : 0.0); }
-}
 
 
 // ================================================================================================
@@ -4002,20 +3661,10 @@ public:
     // look-ahead of the group-end trailing updates (single-GPU schedule): per level the grids of the two parts, second stream
     std::vector<int> la_tiles1, la_tiles2; std::vector<char> la_full;     // la_full: the level has a full (group-last) update
     // grouped schedule (single GPU): per level the chain groups whose FIRST link sits there (entries = FrontMeta of the LAST link, sorted by
-    // order, split at 1024 rows like the BIG buckets), launch geometry, look-ahead tiles; all big fronts once more for k_big_inverse
-    bool grouped = false, grp_fused = true;
-    DevView* d_view = nullptr; bool view_dirty = true; double sv_u = -1.0, sv_u2 = -1.0, sv_small = -1.0;     // device copy of V for the kernels that take the view by reference
-    bool sync_view() {
-        if (!d_view) return true;
-        if (view_dirty || sv_u != V.pivtol || sv_u2 != V.pivtol2 || sv_small != V.small) {
-            HIPCHK(hipMemcpyAsync(d_view, &V, sizeof(DevView), hipMemcpyHostToDevice, stream)); HIPCHK(hipStreamSynchronize(stream));
-            view_dirty = false; sv_u = V.pivtol; sv_u2 = V.pivtol2; sv_small = V.small;
-        }
-        return true;
-    }
+    // order, split at 1024 rows like the BIG buckets), launch geometry, look-ahead tiles
+    bool grouped = false;
     struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2; std::vector<hipEvent_t> evA, evB; };
     GrpSched gs_single, gs_local, gs_top;      // one-GPU schedule; multi-GPU: the rank's own subtrees / the replicated top
-    int allbig_base = 0, allbig_count = 0, allbig_maxk = 0;
     std::vector<hipEvent_t> la_evA, la_evB;
     // chain look-ahead (single-GPU schedule, levels whose fronts are all pure in-place chain links): the critical path
     //   pivot block (k_big_diag_reg) -> first row block of the panel (k_big_trsm, 1 workgroup) -> the NEXT link's 64 x 64 pivot
@@ -4162,7 +3811,7 @@ public:
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
         for (void* p : allocs) (void)hipFree(p);
-        allocs.clear(); d_view = nullptr;
+        allocs.clear();
         if (d_rhs) { (void)hipFree(d_rhs); d_rhs = nullptr; d_rhs_cap = 0; }
         if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
         if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
@@ -4616,9 +4265,8 @@ public:
                 for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) HIPCHK(hipEventCreateWithFlags(&(*v)[lv], hipEventDisableTiming));
             if (opt.verbose) fprintf(stderr, "[mi355x_kkt] chain look-ahead on %d of %d levels\n", nchain >= 8 ? nchain : 0, Sy.num_levels);
         }
-        // ---- grouped schedule: every chain group is factored at the level of its first link (k_grp_diag / k_grp_rows / update) ----
+        // ---- grouped schedule: every chain group is factored at the level of its first link (k_grp_fused + update) ----
         grouped = Sy.maxsupernode <= 64 && selfasm_on && getenv("MI355X_KKT_NO_GROUPED") == nullptr;
-        grp_fused = getenv("MI355X_KKT_GRP_SPLIT") == nullptr || multi;      // (the split variant is a one-GPU development path)
         {
             auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
             auto cols_of = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
@@ -4660,10 +4308,6 @@ public:
             };
             if (!multi) { if (!build_groups(gs_single, 0)) return false; }
             else { if (!build_groups(gs_local, 1) || !build_groups(gs_top, 2)) return false; }
-            allbig_base = (int)lvl_list.size();
-            if (grouped && !grp_fused)
-                for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG) { lvl_list.push_back(sn); allbig_maxk = std::max(allbig_maxk, cols_of(sn)); }
-            allbig_count = (int)lvl_list.size() - allbig_base;
         }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
@@ -4763,10 +4407,7 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_grp_diag, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_grp_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_grp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_big_inverse, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
@@ -4776,7 +4417,6 @@ public:
             big_tiles[lv] = std::max(big_tiles[lv], schur_tiles(Sy, s));
             big_tiles64[lv] = std::max(big_tiles64[lv], schur_tiles64(Sy, s));
         }
-        { DevView* dv = nullptr; if (!dalloc(&dv, 1)) return false; d_view = dv; view_dirty = true; }
         ready = true; return true;
     }
 
@@ -4875,12 +4515,9 @@ public:
     bool launch_groups(int lv, GrpSched& G) {
         const int b0 = G.g0[lv], b1 = G.g1[lv], bs = b0 + G.split[lv];
         if (b1 == b0) return true;
-        if (grp_fused) {
+        {
             const int st = (b1 - b0) * (4 + G.nrb[lv]) <= 256 ? 1 : 0;
             LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + G.nrb[lv]), dim3(256), std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0)), stream, V, b0, st);
-        } else {
-            LAUNCH(KK_BIG_DIAG, k_grp_diag, dim3(b1 - b0), dim3(512), grp_lds_bytes(), stream, (const DevView*)d_view, b0);
-            if (G.nrb[lv] > 0) LAUNCH(KK_BIG_TRSM, k_grp_rows, dim3(G.nrb[lv], b1 - b0), dim3(256), trsm_lds_bytes(64, false), stream, V, b0);
         }
         if (bs > b0 && G.tiles64[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(G.tiles64[lv], bs - b0), dim3(256), 0, stream, V, b0, 0);
         if (b1 == bs) return true;
@@ -4964,7 +4601,6 @@ public:
         }
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
         if (!drain_chain()) return false;
-        if (grouped && !grp_fused && allbig_count > 0) LAUNCH(KK_BIG_DIAG, k_big_inverse, dim3(allbig_count), dim3(256), (size_t)allbig_maxk * (allbig_maxk | 1) * sizeof(double) + 64, stream, V, allbig_base);
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
         LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());
@@ -4977,7 +4613,6 @@ public:
         if (multi) return factor_dist(dvals, reuse, st);          // needs a communicator (set_comm_*), fails loudly otherwise
         const Symbolic& Sy = *S;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
-        if (!sync_view()) return false;
         if (!reuse) {
             if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -5363,7 +4998,6 @@ public:
         if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
         const Symbolic& Sy = *S; const int n = Sy.n;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
-        if (!sync_view()) return false;
         if (!reuse) {
             if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
@@ -5511,7 +5145,7 @@ public:
                                         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
         prof_on = true;
         for (int r = 0; r < reps; ++r) {
-            if (!sync_view() || !enqueue_factor() || !enqueue_solve(d_rhs, d_rhs)) { prof_on = false; return false; }
+            if (!enqueue_factor() || !enqueue_solve(d_rhs, d_rhs)) { prof_on = false; return false; }
             prof_collect();
         }
         prof_on = false;

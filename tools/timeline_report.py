@@ -28,7 +28,7 @@ for t, d in ev:
     cur += d; last = t
 print(f"  idle {idle / 1e6:.2f} ms, exactly one kernel {one / 1e6:.2f} ms, two or more {multi / 1e6:.2f} ms")
 # the critical chain: consecutive pivot-block launches
-D = [r for r in F if r["k"].startswith("k_big_diag_reg") or r["k"].startswith("k_grp_diag")]
+D = [r for r in F if r["k"].startswith("k_big_diag_reg")]
 gaps = [(D[i + 1]["s"] - D[i]["e"]) / 1e3 for i in range(len(D) - 1)]
 tail = gaps[-60:]
 if len(D) > 1: print(f"  pivot blocks: {len(D)} launches, mean duration {sum((r['e'] - r['s']) for r in D) / len(D) / 1e3:.1f} us; gap between consecutive pivot blocks over the last 60 levels: "
