@@ -3647,7 +3647,6 @@ public:
     std::vector<int> lv_narrow_tiles;   // > 0: every big front of the level is a chain link with a narrow update; the 64 x 64 tiles of the largest one
     std::vector<char> lv_asm_skip;      // every big front of the level is a pure in-place chain link: no assembly launch at all
     // sync-free chain sweeps: runs of consecutive levels made of pure chain links (single-GPU schedule, per-link solves)
-    int dbg_c0 = 0, dbg_k = 0;
     size_t strace_n = 0; struct TraceDesc { int chain, w, nlinks, tail; }; std::vector<TraceDesc> strace_desc;
     std::vector<char> in_seg;         // fronts handled by the data-flow sweeps
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail, wgf0, wgb0; };
@@ -4108,7 +4107,6 @@ public:
             }
             if (opt.verbose) { int nl = 0; for (auto& sg : chain_segs) nl += sg.lv1 - sg.lv0 + 1; fprintf(stderr, "[mi355x_kkt] data-flow solve sweeps: %d segments covering %d of %d levels, %d chains, %d links\n", (int)chain_segs.size(), nl, Sy.num_levels, (int)chd.size(), (int)chl.size()); }
         }
-        if (!chl.empty()) { dbg_c0 = chl.back().c0; dbg_k = chl.back().k; }
         if (!upload(wgf, &V.chwg_f) || !upload(wgb, &V.chwg_b) || !upload(chwait, &V.chwait)) return false;
         V.strace = nullptr; V.strace_b = (int)wgf.size(); strace_n = 0;
         if (getenv("MI355X_KKT_SOLVE_TRACE") && !wgf.empty()) {
@@ -4763,16 +4761,6 @@ public:
                         fprintf(f, "%c %d %d %d %d %llu %llu %llu %llu\n", i < (size_t)V.strace_b ? 'F' : 'B', strace_desc[i].chain, strace_desc[i].w, strace_desc[i].nlinks, strace_desc[i].tail,
                                 h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);
                     fclose(f);
-                }
-            }
-            if (!chain_segs.empty() && h_stats[6] != 0 && getenv("MI355X_KKT_DEBUG_TAGS")) {
-                std::vector<double> h(2 * 64); int ep[4];
-                HIPCHK(hipMemcpy(ep, V.sepoch, sizeof(ep), hipMemcpyDeviceToHost));
-                for (int which = 0; which < 2; ++which) {
-                    HIPCHK(hipMemcpy(h.data(), (which ? V.xtag : V.ytag) + dbg_c0, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-                    fprintf(stderr, "%s tags of the top link (c0 %d, k %d), epoch %d:", which ? "x" : "y", dbg_c0, dbg_k, ep[0]);
-                    for (int i = 0; i < 64; ++i) fprintf(stderr, " %g", h[2 * i + 1]);
-                    fprintf(stderr, "\n");
                 }
             }
             if (!chain_segs.empty() && h_stats[6] != 0) { err_ = "solve: a chain sweep timed out waiting for its predecessor (workgroups not co-resident?)"; return false; }
