@@ -1554,12 +1554,13 @@ __global__ __launch_bounds__(NT) void k_bwd(DevView V, int list_off)
 // then the children's contributions (forward) or the ancestors' solution entries (backward), then arithmetic.  The sweeps are
 // bound by (dependent round trips) x (fronts / resident wavefronts), not by bytes.  KP = compile-time bound on the pivot count.
 // ------------------------------------------------------------------------------------------------
-template <int KP>
+template <int KP, int LPF = 32>      // LPF lanes per front: 32 (order <= 32, two fronts per wavefront) or 16 (levels whose fronts all have order <= 16: four)
 __global__ __launch_bounds__(64) void k_fwd_pair(DevView V, int list_off, int nfronts)
 {
-    __shared__ double xs[2][32], bp[2][32], ys[2][33];
-    const int lane = threadIdx.x, h = lane >> 5, li = lane & 31;
-    const int f = 2 * (int)blockIdx.x + h;
+    constexpr int FPW = 64 / LPF;
+    __shared__ double xs[FPW][LPF], bp[FPW][LPF], ys[FPW][LPF + 1];
+    const int lane = threadIdx.x, h = lane / LPF, li = lane % LPF;
+    const int f = FPW * (int)blockIdx.x + h;
     const bool act = f < nfronts;
     const FrontMeta* Mp = V.fmeta + list_off + (act ? f : 0);
     const int c0 = Mp->c0, k = act ? Mp->k : 0, m = act ? Mp->m : 0, ch0 = Mp->ch0, ch1 = act ? Mp->ch1 : Mp->ch0, ldp = Mp->ldp;
@@ -1605,7 +1606,7 @@ __global__ __launch_bounds__(64) void k_fwd_pair(DevView V, int list_off, int nf
 #pragma unroll
     for (int p = 0; p < KP; ++p) y += mrow[p] * bp[h][p];
     ys[h][li] = piv ? y : 0.0;
-    if (li == 0) ys[h][32] = 0.0;
+    if (li == 0) ys[h][LPF] = 0.0;
     __syncthreads();
     if (upd) {
         double t = 0.0;
@@ -1621,12 +1622,13 @@ __global__ __launch_bounds__(64) void k_fwd_pair(DevView V, int list_off, int nf
         V.zb[c0 + li] = z;
     }
 }
-template <int KP>
+template <int KP, int LPF = 32>
 __global__ __launch_bounds__(64) void k_bwd_pair(DevView V, int list_off, int nfronts)
 {
-    __shared__ double xus[2][32], w[2][32];
-    const int lane = threadIdx.x, h = lane >> 5, li = lane & 31;
-    const int f = 2 * (int)blockIdx.x + h;
+    constexpr int FPW = 64 / LPF;
+    __shared__ double xus[FPW][LPF], w[FPW][LPF];
+    const int lane = threadIdx.x, h = lane / LPF, li = lane % LPF;
+    const int f = FPW * (int)blockIdx.x + h;
     const bool act = f < nfronts;
     const FrontMeta* Mp = V.fmeta + list_off + (act ? f : 0);
     const int c0 = Mp->c0, k = act ? Mp->k : 0, m = act ? Mp->m : 0, r0 = Mp->r0, ldp = Mp->ldp;
@@ -1637,24 +1639,24 @@ __global__ __launch_bounds__(64) void k_bwd_pair(DevView V, int list_off, int nf
     const int ridx = upd ? V.sn_rows[r0 + li] : 0;
     const double* Mg = V.minv + Mp->minv_off;
     const double* Lg = V.L + Mp->panel_off;
-    double mcol[KP], lcol[32];
+    double mcol[KP], lcol[LPF];
 #pragma unroll
     for (int q = 0; q < KP; ++q) mcol[q] = (piv && li + q < k) ? Mg[li + q + (size_t)li * k] : 0.0;      // Minv(li + q, li)
 #pragma unroll
-    for (int i = 0; i < 32; ++i) lcol[i] = (piv && k + i < m) ? Lg[k + i + (size_t)li * ldp] : 0.0;        // L(k + i, li)
+    for (int i = 0; i < LPF; ++i) lcol[i] = (piv && k + i < m) ? Lg[k + i + (size_t)li * ldp] : 0.0;        // L(k + i, li)
     // ---- phase 2: the ancestors' solution entries ----
     xus[h][li] = upd ? V.xw[ridx] : 0.0;
     __syncthreads();
     // ---- phase 3 ----
     double t = 0.0;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) t += lcol[i] * xus[h][(k + i) & 31];
+    for (int i = 0; i < LPF; ++i) t += lcol[i] * xus[h][(k + i) & (LPF - 1)];
     w[h][li] = piv ? zbv - t : 0.0;
     __syncthreads();
     if (piv) {
         double a = 0.0;
 #pragma unroll
-        for (int q = 0; q < KP; ++q) a += mcol[q] * w[h][(li + q) & 31];
+        for (int q = 0; q < KP; ++q) a += mcol[q] * w[h][(li + q) & (LPF - 1)];
         V.xw[c0 + lpv] = a;
     }
 }
@@ -3651,7 +3653,7 @@ public:
     std::vector<char> in_seg;         // fronts handled by the data-flow sweeps
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail, wgf0, wgb0; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
-    bool pair_solve = true; std::vector<int> wave_kmax;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
+    bool pair_solve = true; std::vector<int> wave_kmax, wave_mmax;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
     bool fuse_dt = true;                               // pivot block + panel solve in one launch where a level has few fronts
     int fuse_dt_maxwg = 448;                           // ... few = this many workgroups (pivot blocks + 64-row panel blocks) at most
     bool chain_solve = true; int chain_maxc = 128;       // only where few chains run side by side (the latency-bound top of the tree)
@@ -4003,8 +4005,11 @@ public:
         V.fastu = 1e-4; if (const char* e = getenv("MI355X_KKT_FASTPIV_FLOOR")) V.fastu = atof(e);      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
         if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
         pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
-        wave_kmax.assign(Sy.num_levels, 0);
-        for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+        wave_kmax.assign(Sy.num_levels, 0); wave_mmax.assign(Sy.num_levels, 0);
+        for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) {
+            wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+            wave_mmax[Sy.sn_level[sn]] = std::max(wave_mmax[Sy.sn_level[sn]], Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]);
+        }
         if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
         if (!Sy.solve_group && chain_solve) {
             auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
@@ -4680,7 +4685,8 @@ public:
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
-                    if (fc == FC_WAVE && pair_solve && wave_kmax[lv] <= 16) LAUNCH(KK_FWD_WAVE, (k_fwd_pair<16>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
+                    if (fc == FC_WAVE && pair_solve && wave_mmax[lv] <= 16) LAUNCH(KK_FWD_WAVE, (k_fwd_pair<16, 16>), dim3((b1 - b0 + 3) / 4), dim3(64), 0, stream, V, b0, b1 - b0);
+                    else if (fc == FC_WAVE && pair_solve && wave_kmax[lv] <= 16) LAUNCH(KK_FWD_WAVE, (k_fwd_pair<16>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
                     else if (fc == FC_WAVE && pair_solve)                   LAUNCH(KK_FWD_WAVE, (k_fwd_pair<32>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
                     else if (fc == FC_WAVE)   LAUNCH(KK_FWD_WAVE, (k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0, 0);
                     else if (fc == FC_LDS64)  LAUNCH(KK_FWD_LDS,  (k_fwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0, 0);
@@ -4702,7 +4708,8 @@ public:
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
                     const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                     if (b1 == b0) continue;
-                    if (fc == FC_WAVE && pair_solve && wave_kmax[lv] <= 16) LAUNCH(KK_BWD_WAVE, (k_bwd_pair<16>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
+                    if (fc == FC_WAVE && pair_solve && wave_mmax[lv] <= 16) LAUNCH(KK_BWD_WAVE, (k_bwd_pair<16, 16>), dim3((b1 - b0 + 3) / 4), dim3(64), 0, stream, V, b0, b1 - b0);
+                    else if (fc == FC_WAVE && pair_solve && wave_kmax[lv] <= 16) LAUNCH(KK_BWD_WAVE, (k_bwd_pair<16>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
                     else if (fc == FC_WAVE && pair_solve)                   LAUNCH(KK_BWD_WAVE, (k_bwd_pair<32>), dim3((b1 - b0 + 1) / 2), dim3(64), 0, stream, V, b0, b1 - b0);
                     else if (fc == FC_WAVE)   LAUNCH(KK_BWD_WAVE, (k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(32, 32),   stream, V, b0);
                     else if (fc == FC_LDS64)  LAUNCH(KK_BWD_LDS,  (k_bwd<64>),  dim3(b1 - b0), dim3(64),  lds_solve(64, 64),   stream, V, b0);
