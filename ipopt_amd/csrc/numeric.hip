@@ -1213,6 +1213,119 @@ __device__ __forceinline__ bool front_fast16(double* F, const int m, const int k
     return true;
 }
 
+// ================================================================================================
+// Fronts of order <= 16 (the LukVl regime: 10^5 of them per tree level): FOUR fronts per wavefront, one per 16-lane DPP row, on the static-order
+// path -- lane i of a row holds row i of its front in 16 registers, the pivots are eliminated by DPP (masked per front by its own pivot
+// count), L11^{-1} by the same DPP substitution, everything accepted A POSTERIORI (every multiplier of the front <= gmax, every pivot clear
+// of the zero threshold); a front that fails is left to the strict kernel launched behind (hasis[s] != 2).  The register-tiled kernel gives
+// such a front a whole wavefront (8 x 8 threads with 2 x 2 tiles) and ~20 us of mostly latency; here four fronts share the latency and
+// the instruction stream.
+// ================================================================================================
+template <int J> __device__ __forceinline__ void fast16_step_masked(double (&a)[16], double& rsave, const int l15, const bool on)
+{
+    const double t = a[J];
+    const double d = bcast16<J>(t);
+    const double ri = on ? fast_rcp(d) : 0.0;
+    rsave = (on && l15 == J) ? ri : rsave;
+    const double l = on ? t * ri : 0.0;
+    rank1_dpp16<J>(a, t, l);
+    a[J] = on ? l : t;
+}
+__global__ __launch_bounds__(64) void k_front_dpp16(DevView V, int list_off, int nfronts, int top_mode)
+{
+    __shared__ double Fs[4][16 * 17];
+    __shared__ int relS[4][16];
+    const int lane = threadIdx.x, g = lane >> 4, li = lane & 15;
+    const int f = 4 * (int)blockIdx.x + g;
+    const FrontMeta* Mp = V.fmeta + list_off + min(f, nfronts - 1);
+    const int s = Mp->s, c0 = Mp->c0;
+    const int m0 = Mp->m;
+    const bool act = f < nfronts && m0 <= 16;                    // (larger fronts of the bucket: the strict kernel's)
+    const int k = act ? Mp->k : 0, m = act ? m0 : 1;
+    double* F = Fs[g];
+    // ---- assembly: full symmetric 16 x 17 square per front ----
+    const bool from_arena = act && top_mode && V.arena && V.arena_off[s] >= 0;
+    const bool skip_owned = top_mode && V.arena;
+    for (int idx = li; idx < 16 * 17; idx += 16) F[idx] = 0.0;
+    if (from_arena) {
+        const double* Ar = V.arena + V.arena_off[s];
+        for (int idx = li; idx < m * m; idx += 16) { const int i = idx % m, c = idx / m; if (i >= c) { const double v = Ar[idx]; F[i + 17 * c] = v; F[c + 17 * i] = v; } }
+    }
+    if (act) {
+        for (int q = Mp->aq0 + li; q < Mp->aq1; q += 16) {
+            const int pos = V.apos[q]; const int i = pos % m, c = pos / m; const double v = V.aval[q];
+            F[i + 17 * c] += v; if (i != c) F[c + 17 * i] += v;
+        }
+        for (int cp = Mp->ch0; cp < Mp->ch1; ++cp) {
+            const ChildMeta* Cp = V.cmeta + cp;
+            if (skip_owned && Cp->owner >= 0) continue;
+            const int mc = Cp->mc, ldt = Cp->ldt;                  // (mc <= m <= 16: lane li owns row li of the child's lower triangle)
+            const double* C = V.cb + Cp->cb_off;
+            const bool mine = li < mc;
+            if (mine) relS[g][li] = V.rel[Cp->relbase + li];
+            double cv[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) cv[b] = (mine && b <= li) ? C[li + (size_t)b * ldt] : 0.0;
+            const int ra = relS[g][li];
+#pragma unroll
+            for (int b = 0; b < 16; ++b)
+                if (mine && b <= li) { const int rb = relS[g][b]; F[ra + 17 * rb] += cv[b]; if (ra != rb) F[rb + 17 * ra] += cv[b]; }
+        }
+    }
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = F[li + 17 * c];
+    // ---- zero threshold of the front: largest |entry| of its assembled pivot columns / of the input columns ----
+    double cmine = 0.0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        double mx = fabs(a[c]);
+        mx = fmax(mx, dpp_f64<0xB1>(mx)); mx = fmax(mx, dpp_f64<0x4E>(mx)); mx = fmax(mx, dpp_f64<0x141>(mx)); mx = fmax(mx, dpp_f64<0x140>(mx));
+        cmine = (li == c) ? mx : cmine;
+    }
+    double cmx = (li < k) ? fmax(cmine, V.cnorm[c0 + li]) : 0.0;
+    cmx = fmax(cmx, dpp_f64<0xB1>(cmx)); cmx = fmax(cmx, dpp_f64<0x4E>(cmx)); cmx = fmax(cmx, dpp_f64<0x141>(cmx)); cmx = fmax(cmx, dpp_f64<0x140>(cmx));
+    const double zmax = fmax(V.small, ZERO_REL * cmx);
+    const double gmax = 1.0 / fmax(fmax(V.pivtol, V.pivtol2), V.fastu);
+    // ---- elimination (every front of the wavefront walks the same steps, masked by its own pivot count) ----
+    double rsave = 1.0;
+    const int kw = max(max(__builtin_amdgcn_readlane(k, 0), __builtin_amdgcn_readlane(k, 16)), max(__builtin_amdgcn_readlane(k, 32), __builtin_amdgcn_readlane(k, 48)));
+#define MI_STEP(j) if (j < kw) fast16_step_masked<j>(a, rsave, li, j < k);
+    MI_STEP(0) MI_STEP(1) MI_STEP(2) MI_STEP(3) MI_STEP(4) MI_STEP(5) MI_STEP(6) MI_STEP(7)
+    MI_STEP(8) MI_STEP(9) MI_STEP(10) MI_STEP(11) MI_STEP(12) MI_STEP(13) MI_STEP(14) MI_STEP(15)
+#undef MI_STEP
+    double gm = 0.0;
+#pragma unroll
+    for (int c = 0; c < 15; ++c) gm = fmax(gm, (c < k && li > c) ? fabs(a[c]) : 0.0);
+    const bool pv = li < k;
+    const unsigned long long badm = __ballot(gm > gmax) | __ballot(pv && !(fabs(rsave) * zmax < 1.0));
+    const unsigned long long negm = __ballot(pv && rsave < 0.0);
+    const bool ok = act && ((badm >> (16 * g)) & 0xffffull) == 0ull;
+    if (act && li == 0) V.hasis[s] = ok ? 2 : 0;
+    // ---- L11^{-1}: row li of X in 16 registers, DPP substitution ----
+    double x[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) x[p] = (p == li) ? 1.0 : 0.0;
+#define MI_INV(j) if (j + 1 < kw) { const double mj = (li > j && li < k) ? -a[j] : 0.0; _Pragma("unroll") for (int p = 0; p <= j; ++p) subst_dpp16<j>(x[p], mj); }
+    MI_INV(0) MI_INV(1) MI_INV(2) MI_INV(3) MI_INV(4) MI_INV(5) MI_INV(6) MI_INV(7) MI_INV(8) MI_INV(9) MI_INV(10) MI_INV(11) MI_INV(12) MI_INV(13) MI_INV(14)
+#undef MI_INV
+    if (!ok) return;
+    // ---- results ----
+    double* Lg = V.L + Mp->panel_off;
+    double* Cg = V.cb + Mp->cb_off;
+    double* Mg = V.minv + Mp->minv_off;
+    const int mu = m - k;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        if (c < k) {
+            if (li < m) Lg[li + (size_t)c * m] = (li > c) ? a[c] : 0.0;
+            if (li < k) Mg[li + (size_t)c * k] = (li > c) ? x[c] : (li == c ? 1.0 : 0.0);
+        } else if (li >= c && li < m) Cg[(li - k) + (size_t)(c - k) * mu] = a[c];
+    }
+    if (pv) { V.dinv[c0 + li] = rsave; V.doff[c0 + li] = 0.0; V.ptype[c0 + li] = 1; V.lperm[c0 + li] = li; }
+    if (li == 0) V.fstat[s] = make_int4(__popcll((negm >> (16 * g)) & 0xffffull), 0, 0, 0);
+}
+
 // pivot block of a BIG front on the register-tiled core: 4x4 tiles on 16x16 threads for k <= 64, on 32x32 threads (two-word
 // alive mask) for the 128-column panels of the wide_panels option (19 ms against 28 ms with 8x8 tiles on 256 threads, but
 // still slower per column than two 64-column blocks: option off by default)
@@ -3653,7 +3766,7 @@ public:
     std::vector<char> in_seg;         // fronts handled by the data-flow sweeps
     struct ChainSeg { int lv0, lv1, desc0, ndesc, nwg_f, nwg_b, maxtail, wgf0, wgb0; };
     std::vector<ChainSeg> chain_segs; std::vector<int> seg_at_lv0, seg_at_lv1;      // level -> segment index (or -1)
-    bool pair_solve = true; std::vector<int> wave_kmax, wave_mmax;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
+    bool pair_solve = true; std::vector<int> wave_kmax, wave_mmax, wave_mmin;   // solves of the order <= 32 fronts: two fronts per wavefront (k_fwd_pair / k_bwd_pair); largest pivot count per level
     bool fuse_dt = true;                               // pivot block + panel solve in one launch where a level has few fronts
     int fuse_dt_maxwg = 448;                           // ... few = this many workgroups (pivot blocks + 64-row panel blocks) at most
     bool chain_solve = true; int chain_maxc = 128;       // only where few chains run side by side (the latency-bound top of the tree)
@@ -3680,6 +3793,7 @@ public:
     std::vector<size_t> reg_lds;
     std::vector<int> mid_split; std::vector<size_t> mid_lds;   // per level: leading FC_LDS128 fronts of order <= 96 (6x6-tile kernel, 2 workgroups per CU) and their LDS need
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
+    std::vector<int> tiny16;          // per level: leading FC_WAVE fronts of order <= 16 (the four-per-wavefront static-order kernel takes them first)
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
     struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk, tiles, tiles64, last0, last1; std::vector<char> allsolo; };   // last0/1: per level, the group-last BIG fronts (solve units)
@@ -3931,13 +4045,14 @@ public:
         // inside every (level, FC_WAVE) bucket of the single-GPU schedule: fronts of order <= 16 first.  When there are many of
         // them (throughput regime) they run on the 2x2-tile instantiation, whose small register footprint doubles the
         // number of resident wavefronts.
-        tiny_split.assign(Sy.num_levels, 0);
+        tiny_split.assign(Sy.num_levels, 0); tiny16.assign(Sy.num_levels, 0);
         for (int lv = 0; lv < Sy.num_levels; ++lv) {
             const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE + 1];
             auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
             std::stable_sort(lvl_list.begin() + b0, lvl_list.begin() + b1, [&](int a, int b) { return order_of(a) < order_of(b); });
             int q = b0; while (q < b1 && order_of(lvl_list[q]) <= 16) ++q;
             tiny_split[lv] = (q - b0 >= 2048) ? q - b0 : 0;
+            tiny16[lv] = q - b0;
         }
         // same for the (level, FC_LDS128) buckets: fronts of order <= 96 first; they run on the 6x6-tile instantiation (half the
         // registers and LDS of the 8x8 one => two workgroups per CU)
@@ -4005,10 +4120,11 @@ public:
         V.fastu = 1e-4; if (const char* e = getenv("MI355X_KKT_FASTPIV_FLOOR")) V.fastu = atof(e);      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
         if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
         pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
-        wave_kmax.assign(Sy.num_levels, 0); wave_mmax.assign(Sy.num_levels, 0);
+        wave_kmax.assign(Sy.num_levels, 0); wave_mmax.assign(Sy.num_levels, 0); wave_mmin.assign(Sy.num_levels, 1 << 30);
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) {
             wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
             wave_mmax[Sy.sn_level[sn]] = std::max(wave_mmax[Sy.sn_level[sn]], Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]);
+            wave_mmin[Sy.sn_level[sn]] = std::min(wave_mmin[Sy.sn_level[sn]], Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]);
         }
         if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
         if (!Sy.solve_group && chain_solve) {
@@ -4446,9 +4562,15 @@ public:
         if (fc != FC_BIG && !drain_chain()) return false;        // (a level with small fronts is never a chain level)
         const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
         if (fc == FC_WAVE) {
-            const int nt = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_WAVE]) ? tiny_split[lv] : 0;     // single-GPU schedule only
-            if (nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 2>), dim3(nt), dim3(64), rl, stream, V, b0, top_mode);
-            if (nb - nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb - nt), dim3(64), rl, stream, V, b0 + nt, top_mode);
+            const bool sg = b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_WAVE];                            // single-GPU schedule: the bucket is sorted by order
+            const int nt = sg ? tiny_split[lv] : 0;
+            int fl = top_mode;
+            if (V.fastpiv && wave_mmin[lv] <= 16) {      // fronts of order <= 16: four per wavefront on the static-order path first; what it accepts is skipped below
+                const int n16 = sg ? tiny16[lv] : nb;
+                if (n16 > 0) { LAUNCH(KK_FRONT_WAVE, k_front_dpp16, dim3((n16 + 3) / 4), dim3(64), 0, stream, V, b0, n16, top_mode); fl |= 2; }
+            }
+            if (nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 2>), dim3(nt), dim3(64), rl, stream, V, b0, fl);
+            if (nb - nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb - nt), dim3(64), rl, stream, V, b0 + nt, fl);
         } else if (fc == FC_LDS64) {
             LAUNCH(KK_FRONT_LDS64, (k_front_reg<64, 8>), dim3(nb), dim3(64), rl, stream, V, b0, top_mode);
         } else if (fc == FC_LDS128) {

@@ -309,7 +309,8 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_bloc
             bs[rl] += cvec[ch]
             cbs[ch] = None
         if m <= BIG_FRONT:
-            st = ldlt_front_static(F, k, u, u2, small, cnorm=cn[c0:c1]) if (fast_blocks and m >= FAST16_MIN_M and k <= 16) else None
+            # static-order path first: fronts of order <= 16 (k_front_dpp16) and of order 65 .. 128 with <= 16 pivots (front_fast16)
+            st = ldlt_front_static(F, k, u, u2, small, cnorm=cn[c0:c1]) if (fast_blocks and (m <= 16 or (m >= FAST16_MIN_M and k <= 16))) else None
             if st is None:
                 st = ldlt_front(F, k, u, u2, small, cnorm=cn[c0:c1])
             P = st["ord"]
