@@ -279,7 +279,7 @@ def main():
                     peak_sustained_measured=MFMA_F64_SUSTAINED_TFLOPS, frac_of_sustained=ach / MFMA_F64_SUSTAINED_TFLOPS)
     else:
         ach = w["bytes"] / (dms * 1e-3) / 1e9
-        kn = {"front_wave": "k_front_reg<64,4>", "front_lds64": "k_front_reg<64,8>", "front_lds128": "k_front_reg<256,6|8>", "big_diag": "k_big_diag_reg<4>",
+        kn = {"front_wave": "k_front_dpp16 + k_front_reg<64,2|4>", "front_lds64": "k_front_reg<64,8>", "front_lds128": "k_front_reg<256,6|8>(fast + strict)", "big_diag": "k_big_diag_reg<4> / k_grp_fused / k_big_diag_trsm",
               "fwd_wave": "k_fwd<64,false>", "bwd_wave": "k_bwd<64,false>", "fwd_lds": "k_fwd<*,false>", "bwd_lds": "k_bwd<*,false>",
               "fwd_big": "k_fwd_grp", "bwd_big": "k_bwd_grp", "fwd_big_upd": "k_fwd_grp_upd", "bwd_big_dot": "k_bwd_grp_dot"}.get(dom, "k_" + dom)
         roof = dict(bound="hbm", kernel=kn, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
