@@ -328,18 +328,21 @@ public:
             // one connected component: level structure from a pseudo-peripheral node
             vector<int>& comp = comps[0];
             int root = comp[0]; int nlev = 0;
+            bool fresh = false;                                  // queue / lev hold the level structure of `root`
             for (int it = 0; it < 4; ++it) {
                 int nl = bfs_levels(root, cstamp, ++stamp, queue); cstamp = stamp;
+                fresh = true;
                 // candidate: min-degree node of last level
                 int best = -1, bd = 1 << 30;
                 for (int q = (int)queue.size() - 1; q >= 0 && lev[queue[q]] == nl - 1; --q) {
                     int v = queue[q], d = G.xadj[v + 1] - G.xadj[v]; if (d < bd) { bd = d; best = v; } }
-                if (nl <= nlev) { break; }
-                nlev = nl; if (best == root) break; root = best;
+                if (nl <= nlev) { nlev = nl; break; }
+                nlev = nl; if (best == root) break; root = best; fresh = false;
             }
-            nlev = bfs_levels(root, cstamp, ++stamp, queue); cstamp = stamp;
+            if (!fresh) { nlev = bfs_levels(root, cstamp, ++stamp, queue); cstamp = stamp; }      // (otherwise the pass just made IS the structure of root)
             if (nlev < 3) { md.order(t.nodes, order.data() + t.start); return; }
             // choose the separator level: small and balanced
+            int bestsz = 0;                                  // size of the chosen level
             auto best_level = [&](int nl, int& bestl, double& bests) {
                 vector<int> lsize(nl, 0);
                 for (int v : queue) lsize[lev[v]]++;
@@ -349,16 +352,19 @@ public:
                     if (a == 0 || b == 0) break;
                     double imb = std::fabs((double)a - b) / (double)(a + b);
                     double score = (double)s * (1.0 + 4.0 * imb * imb) + 0.05 * m * imb;
-                    if (score < bests) { bests = score; bestl = l; }
+                    if (score < bests) { bests = score; bestl = l; bestsz = s; }
                 }
             };
             int bestl = -1; double bests = 1e300;
             best_level(nlev, bestl, bests);
+            // a separator of a handful of nodes that already halves the piece (banded / chain-like graphs: the LukVl family) cannot be beaten by
+            // the two alternative level structures below: skip their breadth-first passes (3 of the ~8 per bisection)
+            const bool tiny_sep = bestl >= 0 && bestsz <= std::max(4, m / 2000) && bests <= 1.2 * bestsz;
             // Second level structure, rooted at the whole LAST LEVEL of the first one.  On stencil-like graphs whose BFS balls
             // are boxes (9-point / block couplings, i.e. every PDE-constrained KKT) the levels from a corner are L-shaped, but
             // the last level is an entire side of the domain, and the levels grown from a side are straight lines: separators
             // up to 2.7x smaller at the top of the tree.  Keep whichever structure has the better separator.
-            {
+            if (!tiny_sep) {
                 vector<int> src;
                 for (int q = (int)queue.size() - 1; q >= 0 && lev[queue[q]] == nlev - 1; --q) src.push_back(queue[q]);
                 // second candidate source: HALF of that last level (on a square domain the last level is two sides meeting in
