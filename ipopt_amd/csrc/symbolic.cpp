@@ -15,6 +15,8 @@
 #include <set>
 #include <cstdio>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
 #include <atomic>
 #include <functional>
 
@@ -507,21 +509,36 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         std::fill(corder.begin(), corder.end(), -1);
         if (T <= 1 || nc < 50000) nd.drain(st, corder);
         else {
-            const size_t budget = (size_t)8 * T;
-            while (st.size() < budget) {
-                size_t big = 0; for (size_t q = 1; q < st.size(); ++q) if (st[q].nodes.size() > st[big].nodes.size()) big = q;
-                if ((int)st[big].nodes.size() <= std::max(nd.leaf(), nc / (int)(4 * budget))) break;
-                NestedDissection::Task t = std::move(st[big]); st.erase(st.begin() + big);
-                nd.step(std::move(t), st, corder);
-                if (st.empty()) break;
-            }
-            std::sort(st.begin(), st.end(), [](const NestedDissection::Task& a, const NestedDissection::Task& b) { return a.nodes.size() > b.nodes.size(); });
-            std::atomic<size_t> next(0);
+            // a shared pool of pieces: a worker takes the largest pending piece, bisects it (step) and puts the parts back, or -- once a piece is
+            // small -- finishes it on its own (drain).  The top bisections therefore overlap as soon as there are two pieces; up to round 2 the
+            // main thread made the first 8 T pieces alone, i.e. walked the whole graph ~8 times serially (0.5 of the 0.7 s of this phase at
+            // n = 10^6).  What a piece becomes depends on the piece only, not on who handles it: the ordering does not depend on T.
+            const int small_piece = std::max(nd.leaf(), std::max(20000, nc / (32 * T)));
+            std::mutex mu; std::condition_variable cv;
+            size_t outstanding = st.size();
             std::vector<std::thread> th;
             for (int w = 0; w < T; ++w) th.emplace_back([&] {
                 NestedDissection local(CG, opt.nd_leaf);
                 vector<NestedDissection::Task> mine;
-                for (;;) { size_t q = next.fetch_add(1); if (q >= st.size()) break; mine.clear(); mine.push_back(std::move(st[q])); local.drain(mine, corder); }
+                for (;;) {
+                    NestedDissection::Task t;
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return !st.empty() || outstanding == 0; });
+                        if (st.empty()) return;
+                        size_t big = 0; for (size_t q = 1; q < st.size(); ++q) if (st[q].nodes.size() > st[big].nodes.size()) big = q;
+                        t = std::move(st[big]); st.erase(st.begin() + big);
+                    }
+                    mine.clear();
+                    if ((int)t.nodes.size() <= small_piece) { mine.push_back(std::move(t)); local.drain(mine, corder); }
+                    else local.step(std::move(t), mine, corder);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        outstanding += mine.size(); --outstanding;
+                        for (auto& c : mine) st.push_back(std::move(c));
+                    }
+                    cv.notify_all();
+                }
             });
             for (auto& x : th) x.join();
         }
