@@ -9,6 +9,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace mi355x;
@@ -65,7 +66,12 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
         so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 64 ? 64 : h->opts.max_sn_cols) : 64;   // 64: LDS budget of k_big_trsm (104 KiB at k = 65)
         so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose; so.leaf_cols = h->opts.leaf_cols; so.tree_merge = h->opts.tree_merge; so.wide_panels = h->opts.wide_panels; so.chain_group = h->opts.chain_group > 0 ? h->opts.chain_group : 4; so.solve_group = h->opts.solve_group;
-        if (!analyse(h->sym, so, n, nnz, row, col, format, vals)) { h->err = h->sym.error; return MI355X_KKT_FATAL; }
+        // the device's first touch and the pinned staging buffer do not depend on the analysis: made on a thread next to it
+        void* pre = nullptr;
+        std::thread warm([&] { try { pre = Numeric::prewarm(h->opts.device, (size_t)(nnz > 0 ? nnz : 1)); } catch (...) { pre = nullptr; } });
+        const bool aok = analyse(h->sym, so, n, nnz, row, col, format, vals);
+        warm.join();
+        if (!aok) { Numeric::prewarm_discard(pre); h->err = h->sym.error; return MI355X_KKT_FATAL; }
         h->analysed = true;
         // device setup is attempted right away so that values_buffer() can hand out pinned memory;
         // without a GPU the symbolic result stays queryable and factor()/solve() fail loudly.
@@ -75,6 +81,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         no.pivtolmax = h->opts.pivtolmax > h->opts.pivtol ? h->opts.pivtolmax : h->opts.pivtol;
         no.refine_steps = h->opts.refine_steps; no.use_graph = h->opts.use_graph; no.rank = h->opts.rank; no.nranks = so.nranks;
         no.verbose = h->opts.verbose;
+        no.prewarmed_vals = pre; no.prewarmed_count = (size_t)(nnz > 0 ? nnz : 1);
         h->numeric_ready = h->num->setup(h->sym, no);
         if (!h->numeric_ready) h->err = h->num->error();
         return MI355X_KKT_SUCCESS;

@@ -18,6 +18,8 @@ struct NumericOptions {
     int    use_graph = 1;
     int    rank = 0, nranks = 1;
     int    verbose = 0;
+    void*  prewarmed_vals = nullptr;   // pinned staging buffer of prewarmed_count doubles made by Numeric::prewarm while the analysis ran (setup takes ownership)
+    size_t prewarmed_count = 0;
 };
 
 // num_small = failed pivots (num_delay of MA97/SSIDS): eliminated although they failed the threshold test, because the static
@@ -55,6 +57,10 @@ public:
     bool   solve_top_and_bwd(double* drhs);
     bool   set_scaling(int mode, const double* user_factors_orig_numbering);   // 0 none, 1 Ruiz (device), 2 the caller's factors
     bool   get_scaling(double* out_orig_numbering);                             // factors of the last factorisation
+    // first touch of the device (context, code objects) and the pinned staging buffer: independent of the analysis, so the C API runs it on a
+    // thread next to it (0.1-0.3 s of an Ipopt run's LinearSystemSymbolicFactorization otherwise).  Returns the buffer or nullptr.
+    static void* prewarm(int device, size_t count);
+    static void prewarm_discard(void* p);
     static bool ruiz_triplet(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int base, int sweeps, double* out, std::string& err);
     bool   zero_pivots(std::vector<int>& idx0);           // columns (original numbering, 0-based) with a zero pivot in the last factorisation
     // device-side value assembly: triplet values = concatenated segments, each  scale * src + shift  from a device-resident source

@@ -3982,7 +3982,12 @@ public:
         if (const char* e = getenv("MI355X_KKT_LA_WGS")) la_wgs = std::max(1, atoi(e));          // development knobs
         if (const char* e = getenv("MI355X_KKT_LA_MIN_NT")) la_min_nt = std::max(3, atoi(e));
         HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
-        HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
+        if (opt.prewarmed_vals && opt.prewarmed_count >= std::max<size_t>(Sy.nnz_in, 1)) h_vals = (double*)opt.prewarmed_vals;       // (made while the analysis ran)
+        else {
+            if (opt.prewarmed_vals) (void)hipHostFree(opt.prewarmed_vals);
+            HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
+        }
+        opt.prewarmed_vals = nullptr;
         HIPCHK(hipHostMalloc((void**)&h_stats, 8 * sizeof(int), hipHostMallocDefault));
         lap("device, streams, pinned buffer");
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
@@ -5292,6 +5297,22 @@ Numeric::Numeric() : p_(new NumericImpl) {}
 Numeric::~Numeric() { delete p_; }
 bool Numeric::setup(const Symbolic& S, const NumericOptions& opt) { return p_->setup(S, opt); }
 double* Numeric::values_buffer() { return p_->h_vals; }
+void* Numeric::prewarm(int device, size_t count)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return nullptr;
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return nullptr;
+    int prev = 0; (void)hipGetDevice(&prev);
+    if (hipSetDevice(dev) != hipSuccess) return nullptr;
+    (void)hipFree(nullptr);                                   // context
+    hipFuncAttributes fa; (void)hipFuncGetAttributes(&fa, (const void*)k_bump_epoch);      // code object of this library
+    void* p = nullptr;
+    if (hipHostMalloc(&p, std::max<size_t>(count, 1) * sizeof(double), hipHostMallocDefault) != hipSuccess) p = nullptr;
+    (void)hipSetDevice(prev);
+    return p;
+}
+void Numeric::prewarm_discard(void* p) { if (p) (void)hipHostFree(p); }
 bool Numeric::factor(const double* dvals, bool reuse, FactorStats& st) { return p_->factor(dvals, reuse, st); }
 bool Numeric::solve_host(int nrhs, double* rhs, int ld) { return p_->solve_host(nrhs, rhs, ld); }
 bool Numeric::solve_device(int nrhs, double* drhs, int ld) { return p_->solve_device(nrhs, drhs, ld, drhs, ld, true); }
