@@ -53,6 +53,7 @@ template <class KeyFn> void parallel_bucket(long long N, int nb, int T, KeyFn ke
 struct Pattern {
     vector<int> colptr, row;   // lower CSC, rows sorted, diagonal present
     vector<int> t2slot;        // triplet -> slot
+    vector<int> tcnt, tsorted; // triplets grouped by column (tcnt: n + 1 offsets), inside a column by (row, triplet index)
 };
 
 bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int format, Pattern& P,
@@ -112,6 +113,7 @@ bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int f
         }
     });
     P.colptr[n] = (int)P.row.size();
+    P.tcnt = std::move(cnt); P.tsorted = std::move(sorted_t);
     return true;
 }
 
@@ -152,7 +154,14 @@ void zero_diag_matching(int n, const Pattern& P, const vector<int>& xadj, const 
     if (!vals) return;
     // summed slot values
     vector<double> sval(P.row.size(), 0.0);
-    for (int t = 0; t < nnz; ++t) sval[P.t2slot[t]] += vals[t];
+    const int T0 = analysis_threads();
+    if ((int)P.tcnt.size() == n + 1 && (int)P.tsorted.size() == nnz) {
+        // column by column on threads: the triplets of a column only touch that column's slots, and inside a slot they come in ascending triplet
+        // index -- the order of the serial loop, so the sums are bit for bit the same
+        parallel_chunks(n, T0, [&](long long jb, long long je, int) {
+            for (long long p = P.tcnt[jb]; p < P.tcnt[je]; ++p) { const int t = P.tsorted[p]; sval[P.t2slot[t]] += vals[t]; }
+        });
+    } else for (int t = 0; t < nnz; ++t) sval[P.t2slot[t]] += vals[t];
     // per-node edge weights |a_ij| aligned with the (sorted) adjacency lists, by binary search in the lower pattern; row maxima from them
     const int T = analysis_threads();
     vector<double> diag(n, 0.0), rowmax(n, 0.0), w(adj.size(), 0.0);
