@@ -165,14 +165,16 @@ def test_nested_dissection_finds_straight_separators_on_stencil_kkt(nx, ny, limi
     assert s.info().maxfront <= limit
 
 
-def test_analysis_is_independent_of_the_thread_count(monkeypatch):
-    """the task-parallel nested dissection must give the same permutation whatever the number of host threads (Ipopt runs
-    must be reproducible from one machine to the next)"""
-    n, r, c, v, neg = kktgen.grid_kkt(60, 44, dof=3, ncon=2, seed=9)
+@pytest.mark.parametrize("shape", [(60, 44), (160, 130)], ids=["serial-dissection", "task-pool"])
+def test_analysis_is_independent_of_the_thread_count(monkeypatch, shape):
+    """the task-parallel nested dissection must give the same permutation whatever the number of host threads and however the pool
+    happens to schedule the pieces (Ipopt runs must be reproducible from one machine to the next).  The larger grid has more than
+    50 000 compressed nodes: there the bisections run on the shared task pool from the second piece on."""
+    n, r, c, v, neg = kktgen.grid_kkt(shape[0], shape[1], dof=3, ncon=2, seed=9)
     perms = []
-    for th in ("1", "3", "8"):
+    for th in ("1", "3", "8", "8"):
         monkeypatch.setenv("MI355X_KKT_THREADS", th)
         s = ipopt_amd.KKTSolver(device=-1)
         s.initialize_structure(n, r, c, vals=v)
         perms.append(s.symbolic(0, n).copy())
-    assert np.array_equal(perms[0], perms[1]) and np.array_equal(perms[0], perms[2])
+    assert all(np.array_equal(perms[0], q) for q in perms[1:])
