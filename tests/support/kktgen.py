@@ -151,3 +151,16 @@ def hostile_grid_kkt(nx_grid, ny_grid, dof=3, ncon=2, seed=0, frac=0.35, tiny=1e
     hit = diag[rng.random(diag.shape[0]) < frac]
     v[hit] = tiny * rng.uniform(0.1, 1.0, hit.shape[0]) * rng.choice([-1.0, 1.0], hit.shape[0])
     return n, r, c, v
+
+
+def hostile_band_kkt(n, seed=0, frac=0.3, tiny=1e-6):
+    """lukvl_like made hostile to static pivoting: no Sigma, a fraction `frac` of the Hessian diagonal at +-tiny * U(0.1, 1) against O(1)
+    couplings.  All fronts have order <= ~20: the four-fronts-per-wavefront kernel (k_front_dpp16) must reject some of them and leave them to
+    the strict kernel behind it.  Inertia from the oracle / LAPACK."""
+    nn, r, c, v, m = lukvl_like(n, seed=seed, sigma_scale=0.0)
+    rng = np.random.default_rng(seed + 2000)
+    v = v.copy()
+    diag = np.nonzero((r == c) & (r <= n))[0]
+    hit = diag[rng.random(diag.shape[0]) < frac]
+    v[hit] = tiny * rng.uniform(0.1, 1.0, hit.shape[0]) * rng.choice([-1.0, 1.0], hit.shape[0])
+    return nn, r, c, v

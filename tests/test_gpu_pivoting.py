@@ -153,3 +153,21 @@ def test_hostile_grid_hip_equals_the_specification(u):
     assert I.num_neg == oneg and ozero == 0
     assert spec["num_two"] >= 20 and (u < 0.01 or spec["num_delay"] >= 50)
     assert np.abs(x - xt).max() <= 1e-6 and np.abs(x - xs).max() <= 1e-6
+
+
+@pytest.mark.parametrize("u", [1e-8, 0.01])
+def test_small_fronts_static_path_and_its_fallback_equal_the_specification(u):
+    """k_front_dpp16 (four fronts of order <= 16 per wavefront, static order, accepted a posteriori) with the strict kernel behind it on a
+    banded system whose small diagonals make it reject a part of the fronts at u = 0.01: statistics equal to the specification, inertia the oracle's."""
+    n, r, c, v = kktgen.hostile_band_kkt(2000, frac=0.15, tiny=1e-2, seed=4)
+    K = kktgen.to_scipy(n, r, c, v)
+    xt = np.ones(n); b = K @ xt
+    s, st, x = hip_run(n, r, c, v, b, u, scaling=0, pivtolmax=max(u, 1e-4))
+    xs, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=max(u, 1e-4))
+    _, oneg, _, _ = ko.factor_solve(n, r, c, v, b, u=u)
+    I = s.info()
+    assert st == kkt.SUCCESS
+    assert (I.num_neg, I.num_zero, I.num_two, I.num_small, I.u_sensitive) == \
+           (spec["num_neg"], spec["num_zero"], spec["num_two"], spec["num_delay"], spec["u_sensitive"]), (I, spec)
+    assert I.num_neg == oneg and (spec["num_two"] == 0 if u == 1e-8 else spec["num_two"] >= 20)
+    assert np.abs(x - xt).max() <= 1e-9 and np.abs(x - xs).max() <= 1e-9

@@ -161,3 +161,19 @@ def test_hostile_grid_specification_against_the_delaying_oracle(u):
     if u == 0.01:
         assert st["num_fast"] < nbig / 2                      # ... most of them at the tight threshold
         assert st["num_delay"] >= 50                          # forced pivots + a-posteriori failures below the pivot blocks
+
+
+@pytest.mark.parametrize("u", [1e-8, 0.01])
+def test_band_with_small_diagonals_static_order_first_then_strict(u):
+    """kktgen.hostile_band_kkt (fronts of order <= ~20, 15 % of the Hessian diagonal at 1e-2): the static-order path of the small fronts accepts
+    everything at u = 1e-8 and must hand a part of the fronts to the strict rule (2x2 pivots) at u = 0.01; either way the inertia is the oracle's."""
+    n, r, c, v = kktgen.hostile_band_kkt(2000, frac=0.15, tiny=1e-2, seed=4)
+    K = kktgen.to_scipy(n, r, c, v)
+    xt = np.ones(n); b = K @ xt
+    sym, x, st = spec_run(n, r, c, v, b, u, u2=max(u, 1e-4), scaling=0)
+    _, st_strict = mirror.factor_solve_pivoted(sym, v, b, u=u, u2=max(u, 1e-4), fast_blocks=False)
+    xo, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=u)
+    assert st["num_neg"] == oneg == st_strict["num_neg"] and st["num_zero"] == ozero == 0 and st["num_delay"] == 0
+    assert np.abs(x - xt).max() <= 1e-10 and np.abs(xo - xt).max() <= 1e-7
+    assert st_strict["num_two"] >= 100                        # what the strict rule alone would do
+    assert (st["num_two"] == 0) if u == 1e-8 else (20 <= st["num_two"] < st_strict["num_two"])
