@@ -3818,6 +3818,7 @@ public:
         if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
         HIPCHK(hipMalloc((void**)&asm_pool, std::max<long long>(total, 1) * sizeof(double)));
         HIPCHK(hipMemset(asm_pool, 0, std::max<long long>(total, 1) * sizeof(double)));
+        HIPCHK(hipDeviceSynchronize());
         HIPCHK(hipHostMalloc((void**)&asm_hpool, std::max<long long>(total, 1) * sizeof(double), hipHostMallocDefault));
         asm_.nseg = nseg; asm_host.assign(nseg, nullptr);
         for (int q = 0; q < nseg; ++q) { asm_.off[q] = off[q]; asm_.len[q] = len[q]; asm_.src[q] = asm_pool + off[q]; asm_host[q] = asm_hpool + off[q]; asm_.scale[q] = 0.0; asm_.shift[q] = 0.0; }
@@ -4541,6 +4542,10 @@ public:
             big_tiles[lv] = std::max(big_tiles[lv], schur_tiles(Sy, s));
             big_tiles64[lv] = std::max(big_tiles64[lv], schur_tiles64(Sy, s));
         }
+        // hipMemset runs on the legacy default stream; the solver's streams are non-blocking, i.e. NOT ordered behind it: without this the first
+        // sweeps could meet flags / tagged messages left in recycled device memory by an earlier handle (or process) before the zero fill landed
+        // (seen as all-NaN solutions of the second and third handle of a process, and never with the level-by-level solves)
+        HIPCHK(hipDeviceSynchronize());
         ready = true; return true;
     }
 
@@ -4992,6 +4997,7 @@ public:
         HIPCHK(hipMalloc((void**)&pd_norms_d, 4 * sizeof(unsigned long long)));
         HIPCHK(hipHostMalloc((void**)&pd_norms_h, 4 * sizeof(unsigned long long), hipHostMallocDefault));
         P.norms = pd_norms_d; P.tvals = V.tvals;
+        HIPCHK(hipDeviceSynchronize());          // (the zero fills above ran on the default stream)
         pd_ready = true;
         return true;
     }
@@ -5263,7 +5269,7 @@ public:
         DeviceGuard guard(dev);
         if (!ready || !have_values) { err_ = "profile: factor() must have been called once"; return false; }
         for (int q = 0; q < KK_COUNT; ++q) { prof_ms[q] = 0; prof_launches[q] = 0; }
-        if (d_rhs_cap < (size_t)S->n) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(S->n, 1) * sizeof(double))); d_rhs_cap = S->n; HIPCHK(hipMemset(d_rhs, 0, S->n * sizeof(double)));
+        if (d_rhs_cap < (size_t)S->n) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(S->n, 1) * sizeof(double))); d_rhs_cap = S->n; HIPCHK(hipMemset(d_rhs, 0, S->n * sizeof(double))); HIPCHK(hipDeviceSynchronize());
                                         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
         prof_on = true;
         for (int r = 0; r < reps; ++r) {

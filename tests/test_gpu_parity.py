@@ -369,6 +369,23 @@ def test_data_flow_solve_sweeps_at_every_extent(monkeypatch, gen):
                 assert np.abs(Xm[j] - x0).max() <= 1e-9 * max(1.0, np.abs(x0).max())
         monkeypatch.delenv("MI355X_KKT_CHAIN_SOLVE_MAXC")
 
+def test_short_lived_handles_on_recycled_device_memory():
+    """many handles set up, used for a factorisation and two solves, and dropped in one process: each new handle is given device memory the
+    previous one left full of flags and tagged messages of ITS solves.  (Regression: the zero fills of the set-up run on the default stream,
+    the solver's streams are non-blocking -- a first solve racing those fills returned all-NaN vectors; tools/stress_handles.py is the long form.)"""
+    for it in range(24):
+        nn = [100, 400, 2000, 5000][it % 4]
+        n, r, c, v, neg = kktgen.lukvl_like(nn, seed=it)
+        K = kktgen.to_scipy(n, r, c, v)
+        b = K @ np.ones(n)
+        s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
+        assert st == kkt.SUCCESS and s.number_of_neg_evals() == neg
+        x2 = b.copy(); s.multi_solve(False, x2)
+        assert np.isfinite(x).all() and np.isfinite(x2).all(), it
+        assert np.abs(x - 1.0).max() <= 1e-8 and np.abs(x - x2).max() <= 1e-12, it
+        del s
+
+
 def test_fused_pivot_block_and_panel_solve_is_bitwise_identical(monkeypatch):
     """k_big_diag_trsm (pivot block + panel solve of a front in one flag-synchronised launch, used where a level has few
     fronts) against the two separate launches: the same arithmetic, so the same bits"""
