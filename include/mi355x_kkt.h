@@ -79,7 +79,9 @@ typedef struct mi355x_kkt_options {
     int    wide_panels;     /* 1: 128-column panels on separator fronts of order >= 512 (default 0)      */
     int    chain_group;     /* links of an in-place separator chain per update/solve unit, 1..4 (default 4) */
     int    solve_group;     /* 1: triangular solves per chain group instead of per link (default 0)       */
-    int    reserved[3];
+    int    subcube;         /* multi-GPU: 1 = subtree-to-subcube mapping -- a front of the top of the tree is replicated only */
+                            /* on the ranks whose subtrees lie beneath it; 0 (default) = one top replicated on all ranks      */
+    int    reserved[2];
 } mi355x_kkt_options;
 
 typedef struct mi355x_kkt_info {

@@ -34,7 +34,7 @@ void mi355x_kkt_default_options(mi355x_kkt_options* o)
     o->device = -1; o->index_base = 1; o->ordering = 0; o->matching = 1; o->scaling = 1;
     o->nd_leaf = 32; o->nemin = 8; o->max_sn_cols = 64;
     o->pivtol = 1e-8; o->pivtolmax = 1e-4; o->small = 1e-20;
-    o->refine_steps = 0; o->use_graph = 1; o->nranks = 1; o->rank = 0; o->verbose = 0; o->leaf_cols = 0; o->tree_merge = 0; o->wide_panels = 0; o->chain_group = 4; o->solve_group = 0;
+    o->refine_steps = 0; o->use_graph = 1; o->nranks = 1; o->rank = 0; o->verbose = 0; o->leaf_cols = 0; o->tree_merge = 0; o->wide_panels = 0; o->chain_group = 4; o->solve_group = 0; o->subcube = 0;
 }
 
 int mi355x_kkt_create(mi355x_kkt_handle* h, const mi355x_kkt_options* opts)
@@ -65,7 +65,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
         so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 64 ? 64 : h->opts.max_sn_cols) : 64;   // 64: LDS budget of k_big_trsm (104 KiB at k = 65)
-        so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose; so.leaf_cols = h->opts.leaf_cols; so.tree_merge = h->opts.tree_merge; so.wide_panels = h->opts.wide_panels; so.chain_group = h->opts.chain_group > 0 ? h->opts.chain_group : 4; so.solve_group = h->opts.solve_group;
+        so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose; so.leaf_cols = h->opts.leaf_cols; so.tree_merge = h->opts.tree_merge; so.wide_panels = h->opts.wide_panels; so.chain_group = h->opts.chain_group > 0 ? h->opts.chain_group : 4; so.solve_group = h->opts.solve_group; so.subcube = h->opts.subcube;
         // the device's first touch and the pinned staging buffer do not depend on the analysis: made on a thread next to it
         void* pre = nullptr;
         std::thread warm([&] { try { pre = Numeric::prewarm(h->opts.device, (size_t)(nnz > 0 ? nnz : 1)); } catch (...) { pre = nullptr; } });
@@ -331,6 +331,7 @@ int mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t cap
         case 9: v = &S.trip2slot; break;   case 10: v = &S.pair_of; break;   case 11: v = &S.sn_owner; break;
         case 12: v = &S.apos; break;       case 13: v = &S.level_ptr; break; case 14: v = &S.level_sn; break;
         case 15: v = &S.grp_pos; break;    case 16: v = &S.grp_rem; break;   case 17: v = &S.alias_child; break;
+        case 18: v = &S.sn_glo; break;     case 19: v = &S.sn_gsz; break;    case 20: v = &S.sn_gdepth; break;
         default: h->err = "get_symbolic: unknown selector"; return MI355X_KKT_FATAL;
     }
     if ((int64_t)v->size() > cap) { h->err = "get_symbolic: buffer too small"; return MI355X_KKT_FATAL; }

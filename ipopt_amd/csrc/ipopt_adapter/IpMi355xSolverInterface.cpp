@@ -62,6 +62,10 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
                                           "0: take WORLD_SIZE / OMPI_COMM_WORLD_SIZE from the environment (1 if unset).");
    roptions->AddLowerBoundedIntegerOption("mi355x_rank", "Rank of this process among mi355x_nranks.", -1, -1,
                                           "-1: take RANK / OMPI_COMM_WORLD_RANK from the environment.");
+   roptions->AddStringOption2("mi355x_subcube", "Fronts above the ranks' subtrees are replicated only on the ranks beneath them.", "no",
+                              "no", "one top of the elimination tree replicated on every rank, one exchange step per factorisation",
+                              "yes", "subtree-to-subcube mapping: one exchange step per bisection of the machine (more than two ranks)",
+                              "Multi-GPU partition of the KKT factorisation (load-balance knob; cf. IpSpralSolverInterface.cpp:55-67).");
    roptions->AddStringOption1("mi355x_comm_file", "File through which rank 0 hands the RCCL unique id to the other ranks.", "",
                               "*", "any path on a file system all ranks see (default: $MI355X_KKT_COMM_FILE)");
 }
@@ -165,6 +169,10 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
       if( options.GetStringValue("mi355x_comm_file", sv, prefix) )
       {
          comm_file_ = sv;
+      }
+      if( options.GetStringValue("mi355x_subcube", sv, prefix) )
+      {
+         kopts_.subcube = sv == "yes" ? 1 : 0;
       }
    }
    catch( ... )

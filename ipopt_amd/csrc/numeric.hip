@@ -3633,7 +3633,7 @@ __global__ void k_pd_norms(PdView P, const double* rhs, const double* res, const
 // Every rank adds what IT knows about each replicated (top) front into that front's m x m arena square: rank 0 the
 // A entries, every rank the contribution blocks of its own subtree roots.  One wavefront per front column, children
 // in fixed order => deterministic.  The arena is then summed over ranks (RCCL all-reduce) by the caller.
-__global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off)
+__global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off, int who)
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.y];
     const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
@@ -3644,7 +3644,7 @@ __global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off)
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
         const ChildMeta Cm = V.cmeta[cp];
         const int ch = Cm.ch; (void)ch;
-        if (active && Cm.owner == V.rank) {
+        if (active && Cm.owner == who) {
             const int mc = Cm.mc;
             const int* relc = V.rel + Cm.relbase;
             int lo = 0, hi = mc;
@@ -3657,31 +3657,30 @@ __global__ __launch_bounds__(256) void k_arena_assemble(DevView V, int list_off)
         __syncthreads();
     }
 }
-// forward-solve contributions of this rank's subtree roots to the replicated fronts (summed over ranks by the caller)
-__global__ __launch_bounds__(256) void k_top_rhs_assemble(DevView V, int list_off)
+// forward-solve contributions of the children this rank reports (code `who`, see setup) to the replicated fronts above them, ADDED to the
+// accumulators the caller zeroed at the start of the solve (and sums over the ranks afterwards)
+__global__ __launch_bounds__(256) void k_top_rhs_assemble(DevView V, int list_off, int who)
 {
     const FrontMeta M = V.fmeta[list_off + blockIdx.x];
-    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k;
+    const int s = M.s, c0 = M.c0, k = M.k, r0 = M.r0, m = M.m; (void)s; (void)c0; (void)r0; (void)k; (void)m;
     double* tr = V.top_rhs + V.top_rhs_off[s];
-    for (int i = threadIdx.x; i < m; i += 256) tr[i] = 0.0;
-    __syncthreads();
     for (int cp = M.ch0; cp < M.ch1; ++cp) {
         const ChildMeta Cm = V.cmeta[cp];
         const int ch = Cm.ch; (void)ch;
-        if (Cm.owner == V.rank) {
+        if (Cm.owner == who) {
             const int base = Cm.relbase, mc = Cm.mc;
             for (int t = threadIdx.x; t < mc; t += 256) tr[V.rel[base + t]] += V.cvec[Cm.cvbase + t];
         }
         __syncthreads();
     }
 }
-// this rank's part of the solution (own subtrees; rank 0 also the replicated columns), zero elsewhere => the
-// caller's all-reduce(sum) assembles the full vector on every rank
+// this rank's part of the solution (own subtrees + the replicated columns it reports: col_owner is this rank's view, setup), zero
+// elsewhere => the caller's all-reduce(sum) assembles the full vector on every rank
 __global__ void k_store_sol_mg(DevView V, double* b)
 {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < V.n; i += gridDim.x * blockDim.x) {
         const int o = V.col_owner[i];
-        b[V.perm[i]] = (o == V.rank || (o < 0 && V.rank == 0)) ? V.scale[i] * V.xw[i] : 0.0;
+        b[V.perm[i]] = o == V.rank ? V.scale[i] * V.xw[i] : 0.0;
     }
 }
 
@@ -3778,7 +3777,9 @@ public:
     // order, split at 1024 rows like the BIG buckets), launch geometry, look-ahead tiles
     bool grouped = false;
     struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2; std::vector<hipEvent_t> evA, evB; };
-    GrpSched gs_single, gs_local, gs_top;      // one-GPU schedule; multi-GPU: the rank's own subtrees / the replicated top
+    GrpSched gs_single, gs_local;              // one-GPU schedule; multi-GPU: the rank's own subtrees
+    std::vector<GrpSched> gs_stage;            // multi-GPU: the replicated fronts this rank holds, per exchange step (sn_gdepth)
+    GrpSched* gs_cur = nullptr;                // ... the step launch_fronts is working on
     std::vector<hipEvent_t> la_evA, la_evB;
     // chain look-ahead (single-GPU schedule, levels whose fronts are all pure in-place chain links): the critical path
     //   pivot block (k_big_diag_reg) -> first row block of the panel (k_big_trsm, 1 workgroup) -> the NEXT link's 64 x 64 pivot
@@ -3797,9 +3798,16 @@ public:
     // multi-GPU schedules: buckets (level, class) of the fronts this rank owns / of the replicated top, stored behind
     // the single-GPU list in the same device array
     struct Sched { std::vector<int> ptr; int base = 0; std::vector<int> maxm, maxk, tiles, tiles64, last0, last1; std::vector<char> allsolo; };   // last0/1: per level, the group-last BIG fronts (solve units)
-    Sched sch_local, sch_top;
-    int top_list_base = 0, top_count = 0, top_maxm = 0;      // all replicated fronts (top-rhs assembly)
-    int join_list_base = 0, join_count = 0, join_maxm = 0;   // replicated fronts with a rank-owned child (arena squares)
+    Sched sch_local; std::vector<Sched> sch_stage;      // sch_stage[d]: replicated fronts of exchange step d (ranges of ranks d bisections below the whole machine) that this rank holds
+    // Exchange steps (subtree-to-subcube mapping; the classic replicated top is the case of ONE step): a replicated front is held by a range of
+    // ranks; what its children OUTSIDE that range -- subtrees owned by one rank, fronts of a sub-range -- contribute travels through the front's
+    // arena square / top-rhs accumulator, written by ONE reporting rank per child (its owner; the first rank of its range) and summed over the
+    // ranks, all ranges of one depth in one collective, deepest first.  join[c]: the fronts this rank reports a child of kind c to
+    // (c = 0: own subtree roots, c = 1 + d: fronts of its depth-d range) and the code those children carry in ChildMeta::owner.
+    struct JoinList { int base = 0, count = 0, maxm = 0, who = -1; };
+    std::vector<JoinList> join;
+    int ndepth = 1;
+    std::vector<long long> abeg, aend, tbeg, tend;            // per step: its part of the arena / of the top right-hand sides
     long long arena_doubles = 0, toprhs_doubles = 0;
     bool multi = false;
 
@@ -3940,7 +3948,8 @@ public:
         for (auto e : la_evA) if (e) (void)hipEventDestroy(e);
         for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
         la_evA.clear(); la_evB.clear();
-        for (GrpSched* g : {&gs_single, &gs_local, &gs_top}) { for (auto e : g->evA) if (e) (void)hipEventDestroy(e); for (auto e : g->evB) if (e) (void)hipEventDestroy(e); g->evA.clear(); g->evB.clear(); }
+        { std::vector<GrpSched*> all{&gs_single, &gs_local}; for (auto& g : gs_stage) all.push_back(&g);
+          for (GrpSched* g : all) { for (auto e : g->evA) if (e) (void)hipEventDestroy(e); for (auto e : g->evB) if (e) (void)hipEventDestroy(e); g->evA.clear(); g->evB.clear(); } }
         for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
         if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
         if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
@@ -3998,12 +4007,15 @@ public:
         std::vector<long long> aoff(Sy.num_sn, -1), troff(Sy.num_sn, -1);
         std::vector<int> colown(Sy.n, 0);
         if (multi) {
-            auto build = [&](Sched& sc, bool top) {
+            const int P = std::max(1, opt.nranks);
+            ndepth = std::max(1, Sy.num_gdepths);
+            auto held = [&](int s) { return Sy.sn_owner[s] < 0 && Sy.sn_glo[s] <= opt.rank && opt.rank < Sy.sn_glo[s] + Sy.sn_gsz[s]; };      // replicated front on this rank
+            auto build = [&](Sched& sc, int depth) {      // depth < 0: the rank's own subtrees
                 sc.ptr.assign((size_t)Sy.num_levels * FC_COUNT + 1, 0); sc.base = (int)lvl_list.size();
                 sc.maxm.assign(Sy.num_levels, 0); sc.maxk.assign(Sy.num_levels, 0); sc.tiles.assign(Sy.num_levels, 0); sc.tiles64.assign(Sy.num_levels, 0);
                 std::vector<std::vector<int>> bucket((size_t)Sy.num_levels * FC_COUNT);
                 for (int s = 0; s < Sy.num_sn; ++s) {
-                    const bool mine = top ? (Sy.sn_owner[s] < 0) : (Sy.sn_owner[s] == opt.rank);
+                    const bool mine = depth >= 0 ? (held(s) && Sy.sn_gdepth[s] == depth) : (Sy.sn_owner[s] == opt.rank);
                     if (!mine) continue;
                     bucket[(size_t)Sy.sn_level[s] * FC_COUNT + Sy.sn_class[s]].push_back(s);
                     if (Sy.sn_class[s] == FC_BIG) { sc.maxm[Sy.sn_level[s]] = std::max(sc.maxm[Sy.sn_level[s]], Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]);
@@ -4029,24 +4041,43 @@ public:
                         sc.allsolo[lv] = all ? 1 : 0;
                     }
             };
-            build(sch_local, false); build(sch_top, true);
-            // top-rhs accumulators for every replicated front; arena squares only for those that have a child owned by some
-            // rank (the subtree joins): that is all the all-reduce has to carry (A is replicated input, not reduced)
-            std::vector<char> has_local_child(Sy.num_sn, 0);
-            for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] >= 0 && Sy.sn_parent[s] >= 0 && Sy.sn_owner[Sy.sn_parent[s]] < 0) has_local_child[Sy.sn_parent[s]] = 1;
-            top_list_base = (int)lvl_list.size();
-            for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0) {
-                const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
-                lvl_list.push_back(s); ++top_count; top_maxm = std::max<int>(top_maxm, (int)m);
-                troff[s] = toprhs_doubles; toprhs_doubles += m;
+            build(sch_local, -1);
+            sch_stage.assign(ndepth, Sched());
+            for (int d = 0; d < ndepth; ++d) build(sch_stage[d], d);
+            // a child goes through the arena / the top-rhs accumulators when its parent is a replicated front of ANOTHER range of ranks
+            auto same_range = [&](int a, int b) { return Sy.sn_owner[a] < 0 && Sy.sn_owner[b] < 0 && Sy.sn_glo[a] == Sy.sn_glo[b] && Sy.sn_gsz[a] == Sy.sn_gsz[b]; };
+            auto crosses = [&](int c) { const int pa = Sy.sn_parent[c]; return pa >= 0 && Sy.sn_owner[pa] < 0 && !same_range(c, pa); };
+            // top-rhs accumulators for every replicated front; arena squares only for those with a child from outside their range (the joins):
+            // that is all the all-reduce has to carry (A is replicated input, not reduced).  Both laid out step by step, the same on every rank.
+            std::vector<char> is_join(Sy.num_sn, 0);
+            for (int c = 0; c < Sy.num_sn; ++c) if (crosses(c)) is_join[Sy.sn_parent[c]] = 1;
+            abeg.assign(ndepth, 0); aend.assign(ndepth, 0); tbeg.assign(ndepth, 0); tend.assign(ndepth, 0);
+            for (int d = 0; d < ndepth; ++d) {
+                abeg[d] = arena_doubles; tbeg[d] = toprhs_doubles;
+                for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && Sy.sn_gdepth[s] == d) {
+                    const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
+                    troff[s] = toprhs_doubles; toprhs_doubles += m;
+                    if (is_join[s]) { aoff[s] = arena_doubles; arena_doubles += m * m; }
+                }
+                aend[d] = arena_doubles; tend[d] = toprhs_doubles;
             }
-            join_list_base = (int)lvl_list.size();
-            for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && has_local_child[s]) {
-                const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
-                lvl_list.push_back(s); ++join_count; join_maxm = std::max<int>(join_maxm, (int)m);
-                aoff[s] = arena_doubles; arena_doubles += m * m;
+            // what this rank reports: its own subtree roots (kind 0), and -- as the first rank of its depth-d range -- that range's fronts (kind 1 + d)
+            join.assign(ndepth + 1, JoinList());
+            for (int c = 0; c <= ndepth; ++c) {
+                JoinList& J = join[c]; J.base = (int)lvl_list.size(); J.who = opt.rank + P * c;
+                std::vector<char> listed(Sy.num_sn, 0);
+                for (int ch = 0; ch < Sy.num_sn; ++ch) {
+                    if (!crosses(ch)) continue;
+                    const bool rep = c == 0 ? Sy.sn_owner[ch] == opt.rank : (Sy.sn_owner[ch] < 0 && Sy.sn_gdepth[ch] == c - 1 && Sy.sn_glo[ch] == opt.rank);
+                    if (rep) listed[Sy.sn_parent[ch]] = 1;
+                }
+                for (int s = 0; s < Sy.num_sn; ++s) if (listed[s]) { lvl_list.push_back(s); ++J.count; J.maxm = std::max(J.maxm, Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s]); }
             }
-            for (int s = 0; s < Sy.num_sn; ++s) for (int j = Sy.sn_colptr[s]; j < Sy.sn_colptr[s + 1]; ++j) colown[j] = Sy.sn_owner[s];
+            // the solution pieces are summed over the ranks: a column is reported by its owner / by the first rank of its front's range
+            for (int s = 0; s < Sy.num_sn; ++s) {
+                const int o = Sy.sn_owner[s] >= 0 ? Sy.sn_owner[s] : (Sy.sn_glo[s] == opt.rank ? opt.rank : P);
+                for (int j = Sy.sn_colptr[s]; j < Sy.sn_colptr[s + 1]; ++j) colown[j] = o;
+            }
         }
         // inside every (level, FC_WAVE) bucket of the single-GPU schedule: fronts of order <= 16 first.  When there are many of
         // them (throughput regime) they run on the 2x2-tile instantiation, whose small register footprint doubles the
@@ -4147,7 +4178,7 @@ public:
                 bool ok = b > a && b - a <= chain_maxc;
                 for (int q = a; q < b && ok; ++q) {
                     const int sn = Sy.level_sn[q];
-                    if (multi) ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1 && Sy.sn_owner[sn] < 0;
+                    if (multi) ok = pure(sn) && Sy.sn_level[Sy.alias_child[sn]] == lv - 1 && Sy.sn_owner[sn] < 0 && Sy.sn_gdepth[sn] == 0 && Sy.sn_gsz[sn] >= opt.nranks;
                     else       ok = Kc(sn) <= 64;          // (any class: to the sweeps a small front is a one-link chain like any other)
                 }
                 lvok[lv] = ok ? 1 : 0;
@@ -4395,15 +4426,16 @@ public:
         {
             auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
             auto cols_of = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
-            // which: 0 = every front (one GPU), 1 = the rank's own subtrees, 2 = the replicated top (an in-place chain never crosses the
-            // ownership boundary -- symbolic.cpp only aliases fronts of one owner -- so neither does a group)
+            // which: 0 = every front (one GPU), 1 = the rank's own subtrees, 2 + d = the replicated fronts of exchange step d held by this rank (an
+            // in-place chain never crosses an ownership boundary -- symbolic.cpp only aliases fronts of one owner and one range of ranks -- so neither does a group)
             auto build_groups = [&](GrpSched& G, int which) -> bool {
                 for (auto* v : {&G.g0, &G.g1, &G.split, &G.nrb, &G.tiles64, &G.tiles, &G.la1, &G.la2}) v->assign(Sy.num_levels, 0);
                 G.evA.assign(Sy.num_levels, nullptr); G.evB.assign(Sy.num_levels, nullptr);
                 if (!grouped) return true;
                 std::vector<std::vector<int>> at(Sy.num_levels);
                 for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
-                    if ((which == 1 && Sy.sn_owner[sn] != opt.rank) || (which == 2 && Sy.sn_owner[sn] >= 0)) continue;
+                    if (which == 1 && Sy.sn_owner[sn] != opt.rank) continue;
+                    if (which >= 2 && !(Sy.sn_owner[sn] < 0 && Sy.sn_glo[sn] <= opt.rank && opt.rank < Sy.sn_glo[sn] + Sy.sn_gsz[sn] && Sy.sn_gdepth[sn] == which - 2)) continue;
                     int first = sn;
                     for (int j = Sy.grp_pos[sn]; j > 0; --j) first = Sy.alias_child[first];
                     if (Sy.sn_level[first] >= Sy.grp_cut_level) at[Sy.sn_level[first]].push_back(sn);      // (groups do not straddle the cut: symbolic.cpp)
@@ -4428,11 +4460,13 @@ public:
                     if (G.la2[lv] > 0) { HIPCHK(hipEventCreateWithFlags(&G.evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&G.evB[lv], hipEventDisableTiming)); }
                 }
                 if (opt.verbose) fprintf(stderr, "[mi355x_kkt] grouped schedule%s: %d chain groups factored in one launch each (tree levels >= %d)\n",
-                                         which == 0 ? "" : (which == 1 ? " (own subtrees)" : " (replicated top)"), ng, Sy.grp_cut_level);
+                                         which == 0 ? "" : (which == 1 ? " (own subtrees)" : " (replicated fronts of one exchange step)"), ng, Sy.grp_cut_level);
                 return true;
             };
             if (!multi) { if (!build_groups(gs_single, 0)) return false; }
-            else { if (!build_groups(gs_local, 1) || !build_groups(gs_top, 2)) return false; }
+            else { if (!build_groups(gs_local, 1)) return false;
+                   gs_stage.assign(ndepth, GrpSched());
+                   for (int d = 0; d < ndepth; ++d) if (!build_groups(gs_stage[d], 2 + d)) return false; }
         }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
@@ -4454,11 +4488,21 @@ public:
                 M.gbase += M.gpos; M.gpos = 0; M.grem = 0; M.gcols = M.k;
             }
         }
+        // ChildMeta::owner as the kernels read it: -1 = assembled directly by the parent (same owner / same range of ranks); otherwise the child
+        // reaches its (replicated) parent through the arena and the value says who reports it and in which exchange step: reporting rank
+        // + nranks * (0 for an owned subtree root, 1 + depth for a front of a sub-range) -- the `who` of k_arena_assemble / k_top_rhs_assemble
+        auto child_code = [&](int ch) {
+            const int pa = Sy.sn_parent[ch], P = std::max(1, opt.nranks);
+            if (!multi || pa < 0 || Sy.sn_owner[pa] >= 0) return Sy.sn_owner[ch];
+            if (Sy.sn_owner[ch] >= 0) return Sy.sn_owner[ch];
+            if (Sy.sn_glo[ch] == Sy.sn_glo[pa] && Sy.sn_gsz[ch] == Sy.sn_gsz[pa]) return -1;
+            return Sy.sn_glo[ch] + P * (1 + Sy.sn_gdepth[ch]);
+        };
         std::vector<ChildMeta> cm(Sy.child_idx.size());
         for (size_t q = 0; q < cm.size(); ++q) {
             const int ch = Sy.child_idx[q]; const int kc = Sy.sn_colptr[ch + 1] - Sy.sn_colptr[ch];
             cm[q].ch = ch; cm[q].relbase = Sy.sn_rowptr[ch] + kc; cm[q].mc = Sy.sn_rowptr[ch + 1] - cm[q].relbase;
-            cm[q].owner = Sy.sn_owner[ch]; cm[q].cb_off = Sy.cb_off[ch]; cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0; cm[q].cvbase = Sy.cv_off[ch] + kc;
+            cm[q].owner = child_code(ch); cm[q].cb_off = Sy.cb_off[ch]; cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0; cm[q].cvbase = Sy.cv_off[ch] + kc;
         }
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0)
             for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) if (Sy.child_idx[q] == Sy.alias_child[sn]) cm[q].aliased = 1;
@@ -4484,9 +4528,12 @@ public:
         }
         lap("host-side schedules and tables");
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
+        // the inertia / pivot counts are summed over the ranks: a replicated front is counted by the first rank of its range (-1 in this rank's view), -3 = not here
+        std::vector<int> stat_owner(Sy.sn_owner);
+        if (multi) for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_owner[sn] < 0) stat_owner[sn] = Sy.sn_glo[sn] == opt.rank ? -1 : -3;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||
-            !upload(Sy.sn_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(moff, &V.minv_off) ||
+            !upload(stat_owner, &V.sn_owner) || !upload(poff, &V.panel_off) || !upload(coff, &V.cb_off) || !upload(moff, &V.minv_off) ||
             !upload(Sy.acolptr, &V.acolptr) || !upload(Sy.apos, &V.apos) || !upload(Sy.arow, &V.arow) || !upload(Sy.acol, &V.acol) ||
             !upload(Sy.dup_ptr, &V.dup_ptr) || !upload(Sy.dup_src, &V.dup_src) || !upload(Sy.rslot_ptr, &V.rslot_ptr) || !upload(Sy.rslot_idx, &V.rslot_idx) || !upload(Sy.rslot_col, &V.rslot_col) || !upload(lvl_list, &V.level_sn) ||
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
@@ -4598,7 +4645,7 @@ public:
                 // the chain groups whose first link sits on this level, one launch each (the multi-GPU schedules have their own group lists)
                 if (!drain_chain()) return false;
                 if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
-                return launch_groups(lv, single ? gs_single : (top_mode ? gs_top : gs_local));
+                return launch_groups(lv, single ? gs_single : (top_mode ? *gs_cur : gs_local));
             }
             if (!single) { const bool sm = mm <= 640; return launch_big(lv, b0, sm ? b1 : b0, b1, top_mode, mm, kk, sm ? tiles64 : 0, sm ? 0 : tiles, false); }
             return launch_big(lv, b0, b0 + big_split[lv], b1, top_mode, mm, kk, part_tiles[0][lv], part_tiles[1][lv], true);
@@ -5073,12 +5120,12 @@ public:
         HIPCHK(hipGetLastError());
         return true;
     }
-    bool launch_solve_sweep(const Sched& sc, bool forward, int top_mode) {
+    bool launch_solve_sweep(const Sched& sc, bool forward, int top_mode, bool use_segs = true) {
         const Symbolic& Sy = *S;
         auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
         for (int q = 0; q < Sy.num_levels; ++q) {
             const int lv = forward ? q : Sy.num_levels - 1 - q;
-            if (top_mode && !chain_segs.empty()) {      // runs of pure chain levels of the replicated top: the sync-free sweeps (pure links have no rank-owned children)
+            if (top_mode && use_segs && !chain_segs.empty()) {      // runs of pure chain levels of the fronts every rank holds: the sync-free sweeps (pure links have no child from outside)
                 const int sgi = forward ? seg_at_lv0[lv] : seg_at_lv1[lv];
                 if (sgi >= 0) {
                     const ChainSeg& sg = chain_segs[sgi];
@@ -5113,15 +5160,31 @@ public:
         HIPCHK(hipGetLastError());
         return true;
     }
+    // the phase entry points (the caller runs the collectives between them: ipopt_amd.multigpu.DistributedKKT) exist for the classic mapping,
+    // ONE exchange step; with the subtree-to-subcube mapping the sequence runs behind the ordinary entry points (factor_dist / solve_dist)
+    bool one_step(const char* who) { if (ndepth != 1) { err_ = std::string(who) + ": the phase entry points serve one exchange step (subcube = 0); set a communicator and use factor / solve"; return false; } return true; }
     bool factor_local(const double* dvals) {
         DeviceGuard guard(dev);
+        if (!one_step("factor_local")) return false;
         if (!enqueue_factor_local(dvals, false)) return false;
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipStreamSynchronize(stream));       // the caller's collective runs on another stream
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
         return true;
     }
-    // own subtrees + own contributions to the top arena, enqueued on the solver's stream (no host synchronisation)
+    bool report_to_arena(int kind) {
+        const JoinList& J = join[kind];
+        if (J.count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((J.maxm + 3) / 4, J.count), dim3(256), 0, stream, V, J.base, J.who);
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+    bool report_to_top_rhs(int kind) {
+        const JoinList& J = join[kind];
+        if (J.count > 0) hipLaunchKernelGGL(k_top_rhs_assemble, dim3(J.count), dim3(256), 0, stream, V, J.base, J.who);
+        HIPCHK(hipGetLastError());
+        return true;
+    }
+    // own subtrees + own contributions to the arena squares above them, enqueued on the solver's stream (no host synchronisation)
     bool enqueue_factor_local(const double* dvals, bool reuse) {
         if (!ready || !multi) { err_ = "factor_local: not a multi-GPU handle (nranks must be > 1 at create)"; return false; }
         const Symbolic& Sy = *S; const int n = Sy.n;
@@ -5138,22 +5201,35 @@ public:
         enqueue_scaling();
         if (!launch_fronts(sch_local, 0)) return false;
         HIPCHK(hipMemsetAsync(V.arena, 0, (size_t)arena_doubles * sizeof(double), stream));
-        if (join_count > 0) hipLaunchKernelGGL(k_arena_assemble, dim3((join_maxm + 3) / 4, join_count), dim3(256), 0, stream, V, join_list_base);
+        return report_to_arena(0);
+    }
+    // replicated fronts of exchange step d held by this rank (their arena squares have been summed); afterwards the first rank of the range
+    // reports what they contribute to the fronts of the wider ranges above
+    bool enqueue_factor_step(int d) {
+        gs_cur = &gs_stage[d];
+        if (!launch_fronts(sch_stage[d], 1)) return false;
+        return d > 0 ? report_to_arena(1 + d) : true;
+    }
+    bool enqueue_stats() {
+        // this rank counts its own subtrees and the replicated fronts whose range it is the first rank of => the sum over ranks is the inertia
+        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
         HIPCHK(hipGetLastError());
         return true;
     }
     // The whole distributed factorisation behind the ordinary factor() entry point (a communicator has been set):
-    //   own subtrees -> all-reduce(top arena) -> replicated top -> all-reduce(inertia / pivot statistics),
-    // everything stream-ordered on the solver's stream, ONE host synchronisation at the end.
+    //   own subtrees -> per exchange step, deepest ranges of ranks first: all-reduce(that step's arena squares) -> the step's replicated
+    //   fronts -> ... -> all-reduce(inertia / pivot statistics),
+    // everything stream-ordered on the solver's stream, ONE host synchronisation at the end.  Every rank takes part in every collective
+    // (with zeros for the squares of ranges it is not in), in the same order: no sub-communicators, nothing to deadlock.
     bool factor_dist(const double* dvals, bool reuse, FactorStats& st) {
         if (!enqueue_factor_local(dvals, reuse)) return false;
-        if (!allreduce(V.arena, arena_doubles, 0)) return false;
-        if (!launch_fronts(sch_top, 1)) return false;
-        // this rank contributes its own subtrees; rank 0 also the replicated top => the sum over ranks is the inertia
-        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
-        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
-        if (opt.rank == 0) hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
-        HIPCHK(hipGetLastError());
+        for (int d = ndepth - 1; d >= 0; --d) {
+            if (aend[d] > abeg[d] && !allreduce(V.arena + abeg[d], aend[d] - abeg[d], 0)) return false;
+            if (!enqueue_factor_step(d)) return false;
+        }
+        if (!enqueue_stats()) return false;
         if (!allreduce(d_stats, 8, 1)) return false;
         HIPCHK(hipEventRecord(ev1, stream));
         HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -5162,20 +5238,28 @@ public:
         st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4] != 0; st.num_fast = h_stats[7];
         return true;
     }
+    bool enqueue_fwd_local(const double* src) {
+        hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, src);
+        if (!chain_segs.empty()) hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
+        if (toprhs_doubles > 0) HIPCHK(hipMemsetAsync(V.top_rhs, 0, (size_t)toprhs_doubles * sizeof(double), stream));
+        if (!launch_solve_sweep(sch_local, true, 0)) return false;
+        return report_to_top_rhs(0);
+    }
     // distributed solve of one right-hand side (identical on every rank), solution on every rank:
-    //   local forward -> all-reduce(top right-hand sides) -> replicated top forward + backward -> local backward ->
-    //   all-reduce of the solution pieces
+    //   local forward -> per exchange step, deepest first: all-reduce(that step's top right-hand sides) -> forward on the step's fronts ->
+    //   backward on the replicated fronts, widest range first (a front's ancestors are all held by its ranks: nothing to exchange) ->
+    //   local backward -> all-reduce of the solution pieces
     bool solve_dist(int nrhs, const double* dsrc, int lds_, double* drhs, int ld) {
         HIPCHK(hipEventRecord(ev0, stream));
         for (int r = 0; r < nrhs; ++r) {
             const double* src = dsrc + (size_t)r * lds_; double* col = drhs + (size_t)r * ld;
-            hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, src);
-            if (!chain_segs.empty()) hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
-            if (!launch_solve_sweep(sch_local, true, 0)) return false;
-            if (top_count > 0) hipLaunchKernelGGL(k_top_rhs_assemble, dim3(top_count), dim3(256), 0, stream, V, top_list_base);
-            if (!allreduce(V.top_rhs, toprhs_doubles, 0)) return false;
-            if (!launch_solve_sweep(sch_top, true, 1)) return false;
-            if (!launch_solve_sweep(sch_top, false, 1)) return false;
+            if (!enqueue_fwd_local(src)) return false;
+            for (int d = ndepth - 1; d >= 0; --d) {
+                if (tend[d] > tbeg[d] && !allreduce(V.top_rhs + tbeg[d], tend[d] - tbeg[d], 0)) return false;
+                if (!launch_solve_sweep(sch_stage[d], true, 1, d == 0)) return false;
+                if (d > 0 && !report_to_top_rhs(1 + d)) return false;
+            }
+            for (int d = 0; d < ndepth; ++d) if (!launch_solve_sweep(sch_stage[d], false, 1, d == 0)) return false;
             if (!launch_solve_sweep(sch_local, false, 0)) return false;
             hipLaunchKernelGGL(k_store_sol_mg, dim3(grid1d(S->n)), dim3(256), 0, stream, V, col);
             HIPCHK(hipGetLastError());
@@ -5188,34 +5272,21 @@ public:
     bool factor_top(FactorStats& st) {
         DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "factor_top: not a multi-GPU handle"; return false; }
+        if (!one_step("factor_top")) return false;
         HIPCHK(hipEventRecord(ev0, stream));
-        if (!launch_fronts(sch_top, 1)) return false;
-        // this rank reports its own subtrees; rank 0 also the replicated top => the sum over ranks is the inertia
-        hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
-        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
+        if (!enqueue_factor_step(0) || !enqueue_stats()) return false;
         HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4]; st.num_fast = h_stats[7];
-        if (opt.rank == 0) {
-            hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
-            hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
-            HIPCHK(hipMemcpyAsync(h_stats, d_stats, 4 * sizeof(int), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            st.num_neg += h_stats[0]; st.num_zero += h_stats[1]; st.num_two += h_stats[2]; st.num_small += h_stats[3];
-        }
         HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream));
+        st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4]; st.num_fast = h_stats[7];
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms += ms;
         return true;
     }
     bool solve_fwd_local(double* drhs) {
         DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "solve_fwd_local: not a multi-GPU handle"; return false; }
+        if (!one_step("solve_fwd_local")) return false;
         HIPCHK(hipEventRecord(ev0, stream));
-        hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, (const double*)drhs);
-        if (!chain_segs.empty()) hipLaunchKernelGGL(k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
-        if (!launch_solve_sweep(sch_local, true, 0)) return false;
-        if (top_count > 0) hipLaunchKernelGGL(k_top_rhs_assemble, dim3(top_count), dim3(256), 0, stream, V, top_list_base);
-        HIPCHK(hipGetLastError());
+        if (!enqueue_fwd_local((const double*)drhs)) return false;
         HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms;
         return true;
@@ -5223,9 +5294,10 @@ public:
     bool solve_top_and_bwd(double* drhs) {
         DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "solve_top_and_bwd: not a multi-GPU handle"; return false; }
+        if (!one_step("solve_top_and_bwd")) return false;
         HIPCHK(hipEventRecord(ev0, stream));
-        if (!launch_solve_sweep(sch_top, true, 1)) return false;
-        if (!launch_solve_sweep(sch_top, false, 1)) return false;
+        if (!launch_solve_sweep(sch_stage[0], true, 1)) return false;
+        if (!launch_solve_sweep(sch_stage[0], false, 1)) return false;
         if (!launch_solve_sweep(sch_local, false, 0)) return false;
         hipLaunchKernelGGL(k_store_sol_mg, dim3(grid1d(S->n)), dim3(256), 0, stream, V, drhs);
         HIPCHK(hipGetLastError());

@@ -937,7 +937,72 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     lap("rel/apos/levels");
     // ---- 11. multi-GPU ownership: proportional subtree-to-rank mapping ----
     S.sn_owner.assign(nsn, opt.nranks > 1 ? -1 : 0);
-    if (opt.nranks > 1) {
+    S.sn_glo.assign(nsn, 0); S.sn_gsz.assign(nsn, std::max(1, opt.nranks)); S.sn_gdepth.assign(nsn, 0); S.num_gdepths = 1;
+    if (opt.nranks > 1 && opt.subcube) {
+        // SUBTREE-TO-SUBCUBE mapping: a front of the top of the tree is needed only by the ranks whose subtrees lie beneath it, so it is
+        // replicated on THAT range of ranks [glo, glo + gsz) instead of on all of them.  Recursive bisection of (set of sibling subtrees,
+        // range of ranks): a set is split into two bins of about equal work (LPT), the range in proportion; the heaviest member of a set is
+        // OPENED -- its front joins the replicated part of the range, its children join the set -- while that shortens the critical rank's
+        // work (a lone member is always opened: that is how a separator chain stays with its range).  A range of one rank owns what is left.
+        // gdepth = number of bisections above the range: the exchange steps run deepest ranges first, all ranges of one depth in ONE
+        // collective (every rank takes part in every step, which is what keeps the sequence deadlock-free by construction).
+        vector<double> work(nsn, 0.0), own(nsn, 0.0);
+        for (int s = 0; s < nsn; ++s) {
+            double k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+            own[s] = k * m * m + 64.0; work[s] += own[s];
+            if (S.sn_parent[s] >= 0) work[S.sn_parent[s]] += work[s];
+        }
+        struct Split { vector<int> bin[2]; double load[2]; int g[2]; double crit; };
+        auto split_set = [&](const vector<int>& set, int g) {
+            vector<int> order(set);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
+            Split best; best.crit = -1;
+            for (int g0 = 1; g0 < g; ++g0) {              // every way of sharing the range out; the members go, heaviest first, where the load per rank stays lowest
+                if (g > 4 && g0 != g / 2 && g0 != g - g / 2 && g0 != 1 && g0 != g - 1) continue;
+                Split sp; sp.load[0] = sp.load[1] = 0; sp.g[0] = g0; sp.g[1] = g - g0;
+                for (int c : order) { const int b = (sp.load[0] + work[c]) / sp.g[0] <= (sp.load[1] + work[c]) / sp.g[1] ? 0 : 1; sp.bin[b].push_back(c); sp.load[b] += work[c]; }
+                sp.crit = std::max(sp.load[0] / sp.g[0], sp.load[1] / sp.g[1]);
+                if (best.crit < 0 || sp.crit < best.crit * (1.0 - 1e-12)) best = sp;
+            }
+            return best;
+        };
+        std::function<void(int, int)> own_subtree = [&](int root, int r) {
+            vector<int> st(1, root);
+            while (!st.empty()) { const int s = st.back(); st.pop_back(); S.sn_owner[s] = r; S.sn_glo[s] = r; S.sn_gsz[s] = 1; S.sn_gdepth[s] = 0;
+                                  for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) st.push_back(S.child_idx[q]); }
+        };
+        int maxdepth = 0;
+        std::function<void(vector<int>, int, int, int)> assign = [&](vector<int> set, int a, int g, int depth) {
+            if (set.empty()) return;
+            if (g == 1) { for (int c : set) own_subtree(c, a); return; }
+            for (int guard = 0; guard < nsn; ++guard) {
+                int heavy = set[0];
+                for (int c : set) if (work[c] > work[heavy] || (work[c] == work[heavy] && c < heavy)) heavy = c;
+                const bool can_open = S.child_ptr[heavy + 1] > S.child_ptr[heavy];
+                bool open = false;
+                if (set.size() == 1) open = can_open;
+                else if (can_open) {
+                    vector<int> set2;
+                    for (int c : set) if (c != heavy) set2.push_back(c);
+                    for (int q = S.child_ptr[heavy]; q < S.child_ptr[heavy + 1]; ++q) set2.push_back(S.child_idx[q]);
+                    open = own[heavy] + split_set(set2, g).crit < 0.98 * split_set(set, g).crit;
+                }
+                if (!open) break;
+                S.sn_owner[heavy] = -1; S.sn_glo[heavy] = a; S.sn_gsz[heavy] = g; S.sn_gdepth[heavy] = depth; maxdepth = std::max(maxdepth, depth);
+                set.erase(std::find(set.begin(), set.end(), heavy));
+                for (int q = S.child_ptr[heavy]; q < S.child_ptr[heavy + 1]; ++q) set.push_back(S.child_idx[q]);
+                if (set.empty()) return;
+            }
+            if (set.size() == 1) { own_subtree(set[0], a); return; }      // a leaf front nobody can split: one rank takes it
+            Split sp = split_set(set, g);
+            assign(sp.bin[0], a, sp.g[0], depth + 1);
+            assign(sp.bin[1], a + sp.g[0], sp.g[1], depth + 1);
+        };
+        vector<int> roots;
+        for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] < 0) roots.push_back(s);
+        assign(roots, 0, opt.nranks, 0);
+        S.num_gdepths = maxdepth + 1;
+    } else if (opt.nranks > 1) {
         // subtree work estimates
         vector<double> work(nsn, 0.0);
         for (int s = 0; s < nsn; ++s) {
@@ -977,6 +1042,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             else if (S.sn_parent[s] >= 0 && S.sn_owner[S.sn_parent[s]] >= 0) S.sn_owner[s] = S.sn_owner[S.sn_parent[s]];
             else S.sn_owner[s] = -1;
         }
+        for (int s = 0; s < nsn; ++s) if (S.sn_owner[s] >= 0) { S.sn_glo[s] = S.sn_owner[s]; S.sn_gsz[s] = 1; }
     }
     lap("ownership");
     // ---- 12. storage: panels, contribution blocks, in-place separator chains (needs the ownership map) ----
@@ -987,7 +1053,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG)
             for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
                 const int c = S.child_idx[q];
-                if (S.sn_class[c] == FC_BIG && Mf(c) - K(c) == Mf(s) && S.sn_owner[c] == S.sn_owner[s]) { S.alias_child[s] = c; break; }
+                if (S.sn_class[c] == FC_BIG && Mf(c) - K(c) == Mf(s) && S.sn_owner[c] == S.sn_owner[s] && S.sn_glo[c] == S.sn_glo[s] && S.sn_gsz[c] == S.sn_gsz[s]) { S.alias_child[s] = c; break; }
             }
         int64_t loff = 0, coff = 0;
         for (int s = 0; s < nsn; ++s) if (S.alias_child[s] < 0) loff += Mf(s) * K(s);

@@ -28,6 +28,7 @@ struct SymbolicOptions {
     int    chain_group = 4;    // links of an in-place separator chain handled as one unit (1 = off, max 4)
     int    wide_panels = 0;    // 1: separator fronts of order >= 512 get 128-column panels (kernels support it; default off)
     int    nranks      = 1;
+    int    subcube     = 0;    // multi-GPU: 1 = subtree-to-subcube mapping (a top front is replicated on the ranks beneath it only), 0 = one replicated top
     int    verbose     = 0;
 };
 
@@ -93,6 +94,10 @@ struct Symbolic {
     std::vector<int> level_sn;             // [num_sn]
     // multi-GPU ownership: rank owning the supernode (subtree sharding) or -1 = replicated top
     std::vector<int> sn_owner;
+    // ... and the range of ranks [sn_glo, sn_glo + sn_gsz) that holds the front (one rank for an owned front, all ranks for the classic replicated
+    // top, the ranks beneath it with the subtree-to-subcube mapping); sn_gdepth: bisections above that range = exchange step the front belongs to
+    std::vector<int> sn_glo, sn_gsz, sn_gdepth;
+    int num_gdepths = 1;
     // statistics
     int64_t nnz_l = 0, flops_factor = 0, sum_sn_rows = 0, cb_doubles = 0, l_doubles = 0;
     int maxfront = 0, maxsupernode = 0, num_big = 0;

@@ -1,15 +1,17 @@
-"""Multi-GPU driver: one process per GPU, elimination-tree subtrees sharded over the ranks, the top of
-the tree replicated, Schur contributions combined by ONE all-reduce per factorisation (RCCL over xGMI;
-`torch.distributed` backend "nccl" is RCCL on ROCm).  See DESIGN.md (e).
+"""Multi-GPU driver: one process per GPU, elimination-tree subtrees sharded over the ranks, the fronts above them replicated --
+on every rank (classic mapping: ONE exchange step) or only on the range of ranks beneath each front (subtree-to-subcube mapping, option
+`subcube`: one exchange step per bisection of the machine) -- and the Schur contributions that cross a range boundary combined by one
+all-reduce per step (RCCL over xGMI; `torch.distributed` backend "nccl" is RCCL on ROCm).  See DESIGN.md (e).
 
-The collective SEQUENCE lives here (host logic, covered by world_size-2 gloo tests on CPU with a numpy
-engine from tests/support); the numeric work is the C ABI's factor_local / factor_top / solve_* entry
-points.  torch is plumbing only: device tensors, streams, process group.
+The collective SEQUENCE is stated here (DistributedKKT: host logic, covered by world_size 2-8 gloo tests on CPU with a numpy engine from
+tests/support) and implemented inside the C library behind the ordinary entry points once a communicator is set (CommKKT: what bench.py
+--gpus N and the Ipopt adapter use).  torch is plumbing only: device tensors, streams, process group.
 
-    factor:  engine.factor_local(vals)                      # own subtrees + own part of the top arena
-             all_reduce(arena, SUM)                          # <- the exchange step at the subtree joins
-             neg, zero = engine.factor_top()                 # replicated; + all_reduce of the two counters
-    solve :  engine.fwd_local(rhs);  all_reduce(top_rhs);  engine.top_and_bwd(rhs);  all_reduce(rhs)
+    factor:  engine.factor_local(vals)                      # own subtrees + what they contribute to the replicated fronts above them
+             for step in deepest ... 0:  all_reduce(arena[step], SUM);  engine.factor_step(step)
+             all_reduce(counters)
+    solve :  engine.fwd_local(rhs);  for step in deepest ... 0:  all_reduce(top_rhs[step]);  engine.fwd_step(step)
+             engine.bwd(rhs);  all_reduce(rhs)
 """
 from __future__ import annotations
 
@@ -51,27 +53,36 @@ class HipEngine:
             return self.torch.zeros(0, dtype=self.torch.float64, device="cuda")
         return self.torch.as_tensor(_DevArray(p.value, nd.value), device="cuda")
 
+    def num_steps(self):
+        return 1                                         # the phase entry points serve the classic mapping (one replicated top)
+
     def factor_local(self, dvals):
         if self.s.lib.mi355x_kkt_factor_local(self.s._h, C.c_void_p(dvals.data_ptr())) != 0:
             raise _kkt.KKTError("factor_local: " + self.s.last_error())
 
-    def arena(self):
+    def arena(self, d=0):
         return self._view(self.s.lib.mi355x_kkt_top_arena)
 
-    def factor_top(self):
+    def factor_step(self, d):
         neg, zero = C.c_int(0), C.c_int(0)
         if self.s.lib.mi355x_kkt_factor_top(self.s._h, C.byref(neg), C.byref(zero)) != 0:
             raise _kkt.KKTError("factor_top: " + self.s.last_error())
-        return neg.value, zero.value
+        self._cnt = (neg.value, zero.value)
+
+    def counters(self):
+        return self._cnt
 
     def fwd_local(self, drhs):
         if self.s.lib.mi355x_kkt_solve_fwd_local(self.s._h, C.c_void_p(drhs.data_ptr())) != 0:
             raise _kkt.KKTError("solve_fwd_local: " + self.s.last_error())
 
-    def top_rhs(self):
+    def top_rhs(self, d=0):
         return self._view(self.s.lib.mi355x_kkt_top_rhs)
 
-    def top_and_bwd(self, drhs):
+    def fwd_step(self, d):
+        pass                                             # (solve_top_and_bwd runs the replicated forward sweep too)
+
+    def bwd(self, drhs):
         if self.s.lib.mi355x_kkt_solve_top_and_bwd(self.s._h, C.c_void_p(drhs.data_ptr())) != 0:
             raise _kkt.KKTError("solve_top_and_bwd: " + self.s.last_error())
 
@@ -83,19 +94,24 @@ class HipEngine:
 
 
 class DistributedKKT:
-    """Collective sequence around an engine (HipEngine on GPUs; a numpy engine in the CPU tests)."""
+    """Collective sequence around an engine (HipEngine on GPUs; a numpy engine in the CPU tests): own subtrees, then per exchange step --
+    deepest ranges of ranks first -- all-reduce of that step's arena squares and the step's replicated fronts.  Every rank takes part in
+    every collective in the same order (ranges it is not in contribute zeros).  The classic replicated top is ONE step; the
+    subtree-to-subcube mapping (option subcube) has one per bisection of the machine.  Mirrors numeric.hip: factor_dist / solve_dist."""
 
     def __init__(self, engine, dist):
         self.e, self.dist = engine, dist
 
     def factor(self, vals):
         e, dist = self.e, self.dist
-        e.factor_local(vals)
-        arena = e.arena()
-        if arena.numel() > 0:
-            dist.all_reduce(arena)                       # sum of the subtree roots' Schur contributions (+ A of the top fronts)
-            e.sync()
-        neg, zero = e.factor_top()
+        e.factor_local(vals)                             # own subtrees + what they contribute to the replicated fronts above them
+        for d in reversed(range(e.num_steps())):
+            arena = e.arena(d)
+            if arena.numel() > 0:
+                dist.all_reduce(arena)                   # sum of the contributions from outside each front's range of ranks
+                e.sync()
+            e.factor_step(d)
+        neg, zero = e.counters()
         cnt = e.counters_tensor(neg, zero)
         dist.all_reduce(cnt)
         e.sync()
@@ -106,11 +122,13 @@ class DistributedKKT:
         """rhs: full right-hand side, identical on every rank; overwritten by the full solution on every rank."""
         e, dist = self.e, self.dist
         e.fwd_local(rhs)
-        tr = e.top_rhs()
-        if tr.numel() > 0:
-            dist.all_reduce(tr)
-            e.sync()
-        e.top_and_bwd(rhs)
+        for d in reversed(range(e.num_steps())):
+            tr = e.top_rhs(d)
+            if tr.numel() > 0:
+                dist.all_reduce(tr)
+                e.sync()
+            e.fwd_step(d)
+        e.bwd(rhs)                                       # replicated fronts (nothing to exchange on the way down), own subtrees, own solution pieces
         dist.all_reduce(rhs)
         e.sync()
         return rhs
@@ -145,21 +163,27 @@ class CommKKT:
 
 
 def partition_model(s, I, own, world):
-    """What the partition itself allows (work only, no latency, no communication): flops of the replicated top (every rank repeats them)
-    and of the most loaded rank's subtrees; predicted_speedup_bound = total / (top + heaviest rank).  The measured speed-up of the line
-    can be compared with it: the gap is latency of the replicated separator chains + the all-reduce."""
+    """What the partition itself allows (work only, no latency, no communication): every rank does the flops of its own subtrees and of the
+    replicated fronts it holds (all of them with the classic mapping, those above its subtrees with the subtree-to-subcube mapping);
+    predicted_speedup_bound = total / most loaded rank.  The measured speed-up of the line can be compared with it: the gap is latency of
+    the replicated separator chains + the all-reduces."""
     colptr = s.symbolic(1, I.num_sn + 1).astype(np.int64); rowptr = s.symbolic(2, I.num_sn + 1).astype(np.int64)
+    glo, gsz, gd = s.symbolic(18, I.num_sn), s.symbolic(19, I.num_sn), s.symbolic(20, I.num_sn)
     k = np.diff(colptr); m = np.diff(rowptr)
     # sum_{j<k} (c_j - 1)(c_j + 2), c_j = m - j
     j = np.arange(int(k.max()) + 1)
     f = np.array([(((mm - j[:kk]) - 1) * ((mm - j[:kk]) + 2)).sum() for kk, mm in zip(k, m)], dtype=np.float64)
-    top = float(f[own < 0].sum())
-    local = [float(f[own == r].sum()) for r in range(world)]
+    top = own < 0
+    held = [top & (glo <= r) & (r < glo + gsz) for r in range(world)]
+    per_rank = [float(f[own == r].sum() + f[held[r]].sum()) for r in range(world)]
     total = float(f.sum())
-    return {"flops_total": total, "flops_replicated_top": top, "flops_heaviest_rank": max(local) if local else 0.0,
-            "replicated_fraction": top / total if total else 0.0,
-            "predicted_speedup_bound": total / (top + (max(local) if local else 0.0)) if total else 1.0,
-            "what": "work-only bound of the subtree-to-rank partition with a replicated top; latency of the replicated separator chains and the all-reduce come on top"}
+    crit = max(per_rank) if per_rank else total
+    steps = int(gd[top].max()) + 1 if top.any() else 1
+    return {"flops_total": total, "flops_replicated_fronts": float(f[top].sum()), "flops_replicated_on_the_most_loaded_rank": float(max(f[h].sum() for h in held)) if held else 0.0,
+            "flops_most_loaded_rank": crit, "flops_least_loaded_rank": min(per_rank) if per_rank else total,
+            "replicated_fronts": int(top.sum()), "replicated_fronts_held_per_rank": [int(h.sum()) for h in held], "exchange_steps": steps,
+            "predicted_speedup_bound": total / crit if crit else 1.0,
+            "what": "work-only bound of the partition (own subtrees + the replicated fronts a rank holds); latency of the replicated separator chains and the all-reduces come on top"}
 
 
 def bench_main(args, rank, world, local):
@@ -176,7 +200,8 @@ def bench_main(args, rank, world, local):
     K = kktgen.to_scipy(n, r, c, v)
     b = K @ np.ones(n)
     # the collectives (all-reduce of the top arena / top right-hand sides / solution, RCCL over xGMI) run inside the C library
-    ck = CommKKT(rank, world, local, n, r, c, v, dist, use_rccl=not os.environ.get("MI355X_KKT_BENCH_GLOO"))
+    subcube = int(os.environ.get("MI355X_KKT_SUBCUBE", "1" if world > 2 else "0"))      # (two ranks: the two mappings coincide)
+    ck = CommKKT(rank, world, local, n, r, c, v, dist, use_rccl=not os.environ.get("MI355X_KKT_BENCH_GLOO"), subcube=subcube)
     s = ck.s
     I = s.info()
     dv = torch.tensor(v, dtype=torch.float64, device="cuda")
@@ -242,8 +267,10 @@ def bench_main(args, rank, world, local):
             "value": flops_step / dt / 1e9, "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl, "kkt_dim": n, "triplet_nnz": int(len(v)), "nnz_L": I.nnz_l, "flops_per_factor": I.flops_factor,
-                       "flops_per_solve": I.flops_solve, "solves_per_step": NSOLVE, "parallelism": f"etree subtrees over {world} ranks, replicated top, "
-                       "RCCL all-reduce of the top arena per factorisation inside libmi355x_kkt (no Python collective on the data path)",
+                       "flops_per_solve": I.flops_solve, "solves_per_step": NSOLVE, "parallelism": f"etree subtrees over {world} ranks, "
+                       + ("top fronts replicated on the ranks beneath them (subtree-to-subcube), one RCCL all-reduce of the arena squares per bisection level"
+                          if subcube else "one top replicated on every rank, one RCCL all-reduce of the top arena per factorisation")
+                       + " inside libmi355x_kkt (no Python collective on the data path)", "subcube": subcube,
                        "supernodes": I.num_sn, "replicated_top_supernodes": int((own < 0).sum()), "num_neg": nneg, "scaled_residual": res},
             "same_workload_1gpu": {"ms_per_step": dt1 * 1e3, "value": flops_step / dt1 / 1e9, "speedup": dt1 / dt},
             "partition_model": partition_model(s, I, own, world),

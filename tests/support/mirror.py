@@ -13,7 +13,8 @@ def fetch(solver):
     g = solver.symbolic
     return dict(info=I, perm=g(0, I.n), colptr=g(1, I.num_sn + 1), rowptr=g(2, I.num_sn + 1), rows=g(3, I.sum_sn_rows),
                 parent=g(4, I.num_sn), level=g(5, I.num_sn), rel=g(6, I.sum_sn_rows), acolptr=g(7, I.n + 1),
-                arow=g(8, I.nnz_a), t2s=g(9, I.nnz_in), pair=g(10, I.n), owner=g(11, I.num_sn), apos=g(12, I.nnz_a))
+                arow=g(8, I.nnz_a), t2s=g(9, I.nnz_in), pair=g(10, I.n), owner=g(11, I.num_sn), apos=g(12, I.nnz_a),
+                glo=g(18, I.num_sn), gsz=g(19, I.num_sn), gdepth=g(20, I.num_sn))
 
 
 def factor_solve(sym, vals, rhs, only=None):

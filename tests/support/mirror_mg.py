@@ -1,6 +1,9 @@
 """numpy stand-in for ipopt_amd.multigpu.HipEngine -- TEST SUPPORT ONLY (CPU, gloo).  Walks the symbolic structures
-exported by the C ABI exactly as the HIP multi-GPU path does: own subtrees first, own contributions to the replicated
-top fronts into an arena that the driver all-reduces, replicated top factorisation, mirrored solve."""
+exported by the C ABI exactly as the HIP multi-GPU path does (numeric.hip: factor_dist / solve_dist): own subtrees first;
+then, per exchange step (deepest ranges of ranks first), what the children OUTSIDE a replicated front's range contribute
+is written into the front's arena square by ONE reporting rank per child, the driver all-reduces that step's part of the
+arena, and the ranks of the range factor the front.  The classic replicated top is the case of one step; with the
+subtree-to-subcube mapping (option subcube) a front is held only by the ranks beneath it.  Mirrored solve."""
 from __future__ import annotations
 
 import numpy as np
@@ -21,20 +24,36 @@ class MirrorEngine:
         sy = self.sym
         I = sy["info"]
         self.n, self.nsn = I.n, I.num_sn
+        own, glo, gsz, gd, par = sy["owner"], sy["glo"], sy["gsz"], sy["gdepth"], sy["parent"]
         self.children = [[] for _ in range(self.nsn)]
         for s in range(self.nsn):
-            if sy["parent"][s] >= 0:
-                self.children[sy["parent"][s]].append(s)
-        self.top = [s for s in range(self.nsn) if sy["owner"][s] < 0]
-        # arena squares only for replicated fronts with a rank-owned child (the subtree joins), as in numeric.hip
-        self.join = [s for s in self.top if any(sy["owner"][ch] >= 0 for ch in self.children[s])]
-        self.aoff, self.toff, a, t = {}, {}, 0, 0
-        for s in self.top:
-            self.toff[s] = t; t += sy["rowptr"][s + 1] - sy["rowptr"][s]
-        for s in self.join:
-            m = sy["rowptr"][s + 1] - sy["rowptr"][s]
-            self.aoff[s] = a; a += m * m
+            if par[s] >= 0:
+                self.children[par[s]].append(s)
+        self.nsteps = int(gd[own < 0].max()) + 1 if (own < 0).any() else 1
+        self.held = lambda s: own[s] < 0 and glo[s] <= self.rank < glo[s] + gsz[s]
+        self.same = lambda a, b: own[a] < 0 and own[b] < 0 and glo[a] == glo[b] and gsz[a] == gsz[b]
+        # a child reaches its replicated parent through the arena when the parent belongs to another range of ranks
+        self.crosses = lambda c: par[c] >= 0 and own[par[c]] < 0 and not self.same(c, par[c])
+        # ... and is reported by its owner / by the first rank of its range, after its own step (kind 0 = owned subtree root)
+        self.reporter = lambda c: own[c] if own[c] >= 0 else glo[c]
+        self.kind = lambda c: 0 if own[c] >= 0 else 1 + gd[c]
+        self.step = [[s for s in range(self.nsn) if self.held(s) and gd[s] == d] for d in range(self.nsteps)]
+        join = set(par[c] for c in range(self.nsn) if self.crosses(c))
+        # layout: step by step, the same on every rank (fronts of ranges this rank is not in stay zero here)
+        self.aoff, self.toff, self.abounds, self.tbounds, a, t = {}, {}, [], [], 0, 0
+        for d in range(self.nsteps):
+            a0, t0 = a, t
+            for s in range(self.nsn):
+                if own[s] < 0 and gd[s] == d:
+                    m = sy["rowptr"][s + 1] - sy["rowptr"][s]
+                    self.toff[s] = t; t += m
+                    if s in join:
+                        self.aoff[s] = a; a += m * m
+            self.abounds.append((a0, a)); self.tbounds.append((t0, t))
         self._arena = np.zeros(a); self._toprhs = np.zeros(t)
+
+    def num_steps(self):
+        return self.nsteps
 
     def _front_dims(self, s):
         sy = self.sym
@@ -65,6 +84,14 @@ class MirrorEngine:
         self.F11i[s], self.F21[s] = inv, A21.copy()
         self.cb[s] = A22 - A21 @ inv @ A21.T
 
+    def _report_arena(self, kind):
+        sy = self.sym
+        for ch in range(self.nsn):
+            if self.crosses(ch) and self.kind(ch) == kind and self.reporter(ch) == self.rank:
+                p = sy["parent"][ch]; m = self._front_dims(p)[3]
+                F = self._arena[self.aoff[p]:self.aoff[p] + m * m].reshape(m, m)
+                rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
+
     def factor_local(self, vals):
         sy = self.sym
         vals = np.asarray(vals)
@@ -79,30 +106,27 @@ class MirrorEngine:
                 rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
             self._eliminate(s, F)
         self._arena[:] = 0.0
-        for s in self.join:
-            c0, k, r, m = self._front_dims(s)
-            F = np.zeros((m, m))
-            for ch in self.children[s]:
-                if sy["owner"][ch] == self.rank:
-                    rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
-            self._arena[self.aoff[s]:self.aoff[s] + m * m] = F.ravel()
+        self._report_arena(0)
 
-    def arena(self):
-        return torch.from_numpy(self._arena)
+    def arena(self, d=0):
+        a0, a1 = self.abounds[d]
+        return torch.from_numpy(self._arena[a0:a1])
 
-    def factor_top(self):
-        sy = self.sym
-        for s in self.top:
+    def factor_step(self, d):
+        for s in self.step[d]:
             c0, k, r, m = self._front_dims(s)
             F = self._arena[self.aoff[s]:self.aoff[s] + m * m].reshape(m, m).copy() if s in self.aoff else np.zeros((m, m))
             self._a_entries(s, F)                      # A is replicated input: every rank adds it itself
             for ch in self.children[s]:
-                if sy["owner"][ch] < 0:
+                if self.same(ch, s):
                     rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
             self._eliminate(s, F)
-        neg = sum(self.neg[s] for s in range(self.nsn) if sy["owner"][s] == self.rank)
-        if self.rank == 0:
-            neg += sum(self.neg[s] for s in self.top)
+        if d > 0:
+            self._report_arena(1 + d)
+
+    def counters(self):
+        sy = self.sym
+        neg = sum(self.neg[s] for s in range(self.nsn) if sy["owner"][s] == self.rank or (sy["owner"][s] < 0 and sy["glo"][s] == self.rank))
         return neg, 0
 
     def _fwd_front(self, s, extra):
@@ -113,10 +137,17 @@ class MirrorEngine:
         self.cvec[s] = bs[k:] - self.F21[s] @ (self.F11i[s] @ y)
         self.b[c0:c0 + k] = y
 
+    def _report_rhs(self, kind):
+        sy = self.sym
+        for ch in range(self.nsn):
+            if self.crosses(ch) and self.kind(ch) == kind and self.reporter(ch) == self.rank:
+                self._toprhs[self.toff[sy["parent"][ch]] + self._rel(ch)] += self.cvec[ch]
+
     def fwd_local(self, rhs):
         sy = self.sym
         self.b = rhs.numpy()[sy["perm"]].astype(float).copy()
         self.cvec = [None] * self.nsn
+        self._toprhs[:] = 0.0
         for s in range(self.nsn):
             if sy["owner"][s] != self.rank:
                 continue
@@ -125,27 +156,27 @@ class MirrorEngine:
             for ch in self.children[s]:
                 extra[self._rel(ch)] += self.cvec[ch]
             self._fwd_front(s, extra)
-        self._toprhs[:] = 0.0
-        for s in self.top:
-            m = self._front_dims(s)[3]
-            for ch in self.children[s]:
-                if sy["owner"][ch] == self.rank:
-                    self._toprhs[self.toff[s] + self._rel(ch)] += self.cvec[ch]
+        self._report_rhs(0)
 
-    def top_rhs(self):
-        return torch.from_numpy(self._toprhs)
+    def top_rhs(self, d=0):
+        t0, t1 = self.tbounds[d]
+        return torch.from_numpy(self._toprhs[t0:t1])
 
-    def top_and_bwd(self, rhs):
-        sy = self.sym
-        for s in self.top:
+    def fwd_step(self, d):
+        for s in self.step[d]:
             c0, k, r, m = self._front_dims(s)
             extra = self._toprhs[self.toff[s]:self.toff[s] + m].copy()
             for ch in self.children[s]:
-                if sy["owner"][ch] < 0:
+                if self.same(ch, s):
                     extra[self._rel(ch)] += self.cvec[ch]
             self._fwd_front(s, extra)
+        if d > 0:
+            self._report_rhs(1 + d)
+
+    def bwd(self, rhs):
+        sy = self.sym
         x = np.zeros(self.n)
-        mine = lambda s: sy["owner"][s] == self.rank or sy["owner"][s] < 0
+        mine = lambda s: sy["owner"][s] == self.rank or self.held(s)
         for s in range(self.nsn - 1, -1, -1):
             if not mine(s):
                 continue
@@ -153,7 +184,7 @@ class MirrorEngine:
             x[c0:c0 + k] = self.F11i[s] @ (self.b[c0:c0 + k] - self.F21[s].T @ x[r[k:]])
         out = np.zeros(self.n)
         for s in range(self.nsn):
-            if sy["owner"][s] == self.rank or (sy["owner"][s] < 0 and self.rank == 0):
+            if sy["owner"][s] == self.rank or (sy["owner"][s] < 0 and sy["glo"][s] == self.rank):
                 c0, k = sy["colptr"][s], sy["colptr"][s + 1] - sy["colptr"][s]
                 out[sy["perm"][c0:c0 + k]] = x[c0:c0 + k]
         rhs.numpy()[:] = out

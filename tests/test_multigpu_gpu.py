@@ -81,7 +81,7 @@ def test_hip_multigpu_path_matches_single_gpu(world, case):
 # ---------------------------------------------------------------------------------------------------------------
 # collectives INSIDE the C library (mi355x_kkt_set_comm_*): the ordinary entry points run the distributed sequence
 # ---------------------------------------------------------------------------------------------------------------
-def _worker_comm(rank, world, port, case, ret):
+def _worker_comm(rank, world, port, case, subcube, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -89,7 +89,7 @@ def _worker_comm(rank, world, port, case, ret):
     n, r, c, v, neg = case()
     K = kktgen.to_scipy(n, r, c, v)
     # RCCL refuses several ranks on one device, so the library gets the one collective it needs as a callback (gloo)
-    s = CommKKT(rank, world, 0, n, r, c, v, dist, use_rccl=False).s
+    s = CommKKT(rank, world, 0, n, r, c, v, dist, use_rccl=False, subcube=subcube).s
     out = []
     for rep in range(2):
         s.values()[:] = v
@@ -102,28 +102,40 @@ def _worker_comm(rank, world, port, case, ret):
         out.append((st, st2, s.number_of_neg_evals(), res, float(np.abs(x2 - 2.0 * x).max()), s.info().num_two, s.info().num_small, x.copy()))
     gathered = [None] * world
     dist.all_gather_object(gathered, [o[-1] for o in out])
+    I = s.info()
+    own, glo, gsz, gd = (s.symbolic(w, I.num_sn) for w in (11, 18, 19, 20))
+    held = int(((own < 0) & (glo <= rank) & (rank < glo + gsz)).sum())
+    allheld = [None] * world
+    dist.all_gather_object(allheld, held)
     if rank == 0:
         same = all(np.array_equal(gathered[0][k], g[k]) for g in gathered for k in range(2))     # every rank holds the same solution
-        ret.put(([o[:-1] for o in out], neg, same))
+        ret.put(([o[:-1] for o in out], neg, same, int(gd[own < 0].max()) + 1, int((own < 0).sum()), allheld))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
-def test_c_level_collectives_through_the_ordinary_entry_points(world):
+@pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (4, 0, _case_grid), (4, 1, _case_grid), (3, 1, _case_grid), (4, 1, _case_band)],
+                         ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band"])
+def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, case):
+    """... with the classic mapping (one top replicated on every rank) and with the subtree-to-subcube mapping: replicated fronts held by the
+    ranks beneath them only, one exchange step per bisection of the machine, the fronts of a sub-range reported upwards by its first rank"""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_comm, args=(rk, world, port, _case_grid, ret)) for rk in range(world)]
+    procs = [ctx.Process(target=_worker_comm, args=(rk, world, port, case, subcube, ret)) for rk in range(world)]
     for p in procs:
         p.start()
-    out, neg, same = ret.get(timeout=600)
+    out, neg, same, nsteps, ntop, held = ret.get(timeout=600)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     assert same
     for st, st2, nneg, res, lin, ntwo, nsmall in out:
         assert st == 0 and st2 == 0 and nneg == neg and res <= 1e-12 and lin <= 1e-9
+    if subcube:
+        assert nsteps >= 2 and min(held) < ntop
+    else:
+        assert nsteps == 1 and held == [ntop] * world
 
 
 def test_rccl_communicator_of_one_rank(monkeypatch):

@@ -121,6 +121,59 @@ def test_multigpu_ownership_is_a_subtree_partition(nranks):
     assert len(set(own[own >= 0].tolist())) == nranks
 
 
+@pytest.mark.parametrize("nranks", [2, 3, 4, 6, 8])
+def test_subtree_to_subcube_mapping_is_a_nested_partition(nranks):
+    """option subcube: a replicated front is held by a RANGE of ranks [glo, glo + gsz): the ranks beneath it.  Ranges are nested along the
+    tree (a child's range lies inside its parent's), a range is cut deeper (gdepth) exactly when it shrinks, owned subtrees hang below
+    the range that contains their rank, in-place chains stay inside one range -- and the most loaded rank carries less than with one top
+    replicated on every rank."""
+    n, r, c, v, _ = kktgen.grid_kkt(40, 36, dof=2, ncon=1, seed=7)
+
+    def load(sym, P):
+        k = np.diff(sym["colptr"]).astype(float); m = np.diff(sym["rowptr"]).astype(float)
+        w = k * m * m
+        return max(w[(sym["glo"] <= rk) & (rk < sym["glo"] + sym["gsz"])].sum() for rk in range(P)), w.sum()
+
+    syms = {}
+    for sub in (0, 1):
+        s = ipopt_amd.KKTSolver(nranks=nranks, subcube=sub)
+        s.initialize_structure(n, r, c, vals=v)
+        syms[sub] = mirror.fetch(s)
+        syms[sub]["alias"] = s.symbolic(17, syms[sub]["info"].num_sn)
+    sym = syms[1]
+    own, par, glo, gsz, gd, alias = sym["owner"], sym["parent"], sym["glo"], sym["gsz"], sym["gdepth"], sym["alias"]
+    assert len(set(own[own >= 0].tolist())) == nranks and (own < 0).any()
+    for sn in range(sym["info"].num_sn):
+        p = par[sn]
+        assert 0 <= glo[sn] and glo[sn] + gsz[sn] <= nranks and gsz[sn] >= 1
+        if own[sn] >= 0:
+            assert (glo[sn], gsz[sn]) == (own[sn], 1)
+            assert p < 0 or own[p] == own[sn] or (own[p] < 0 and glo[p] <= own[sn] < glo[p] + gsz[p])
+        else:
+            assert gsz[sn] >= 2
+            if p >= 0:
+                assert own[p] < 0 and glo[p] <= glo[sn] and glo[sn] + gsz[sn] <= glo[p] + gsz[p]
+                same = (glo[p], gsz[p]) == (glo[sn], gsz[sn])
+                assert gd[p] == gd[sn] if same else gd[p] < gd[sn]
+            else:
+                assert (glo[sn], gsz[sn], gd[sn]) == (0, nranks, 0)
+        if alias[sn] >= 0:
+            a = alias[sn]
+            assert own[a] == own[sn] and (glo[a], gsz[a]) == (glo[sn], gsz[sn])
+    # ranges of one depth are disjoint or equal
+    rng = sorted(set((int(gd[sn]), int(glo[sn]), int(gsz[sn])) for sn in range(sym["info"].num_sn) if own[sn] < 0))
+    for d, a, g in rng:
+        for d2, a2, g2 in rng:
+            if d2 == d and (a2, g2) != (a, g):
+                assert a + g <= a2 or a2 + g2 <= a
+    # the classic mapping reports every replicated front on every rank
+    s0 = syms[0]
+    assert ((s0["glo"][s0["owner"] < 0] == 0) & (s0["gsz"][s0["owner"] < 0] == nranks) & (s0["gdepth"][s0["owner"] < 0] == 0)).all()
+    if nranks >= 4:
+        (l1, tot), (l0, _) = load(sym, nranks), load(s0, nranks)
+        assert l1 < l0 and tot / l1 > 0.4 * nranks
+
+
 def test_chain_groups_are_consistent():
     """in-place chains and chain groups (numeric.hip relies on these invariants): an in-place front has exactly its chain
     child's update rows; a group is <= 4 consecutive links on consecutive levels with <= 256 columns; grp_rem = columns
