@@ -293,6 +293,10 @@ def main():
             if tj.get("workload") == wl and tj.get("kernel") == roof["kernel"] and tj.get("source_hash") == source_hash():
                 roof["traffic"] = tj["hbm_bytes_per_factorisation"] / max(dlaunch, 1)     # per launch, like `achieved`
                 roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources: hash %s)" % tj["source_hash"]
+            elif tj.get("workload") == wl and tj.get("kernel") == roof["kernel"]:
+                # not emitted as `traffic`: the sources have changed since the PMC passes; reported beside it so that the reader can judge
+                roof["traffic_stale"] = {"value": tj["hbm_bytes_per_factorisation"] / max(dlaunch, 1), "measured_with_source_hash": tj.get("source_hash"),
+                                         "current_source_hash": source_hash(), "note": "PMC figure of tools/prof.sh for an earlier state of ipopt_amd/csrc; rerun tools/prof.sh"}
         except Exception:
             pass
     kernel_ms = {kname: round(ms * weight[kname], 4) for kname, (ms, _) in per_rep.items()}

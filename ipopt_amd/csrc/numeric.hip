@@ -1953,7 +1953,7 @@ __global__ __launch_bounds__(256) void k_fwd_solo64(DevView V, int list_off)
     int pt = 1; double dq = 0.0, oq = 0.0, oq1 = 0.0;
     if (rb < 0 && tid < k) { pt = V.ptype[c0 + tid]; dq = V.dinv[c0 + tid]; oq = V.doff[c0 + tid]; oq1 = tid > 0 ? V.doff[c0 + tid - 1] : 0.0; }
     // ---- dependent on the pivot order ----
-    if (tid < k) bp[tid] = V.xw[c0 + lpv] + (M.solo == 1 ? cv[lpv] : 0.0);
+    if (tid < 64) bp[tid] = tid < k ? V.xw[c0 + lpv] + (M.solo == 1 ? cv[lpv] : 0.0) : 0.0;      // (ALL 64 entries: the product below runs over them with zeros of mreg, and 0 x a NaN left in LDS by an earlier kernel is NaN)
     __syncthreads();
     {
         double a = 0.0;
@@ -2339,6 +2339,7 @@ __global__ __launch_bounds__(320) void k_fwd_chain(DevView V, int wg0)
             const double* Mg = V.minv + Me.minv_off;
 #pragma unroll
             for (int u = 0; u < 16; ++u) { const int pp = part + 4 * u; mreg[u] = (row < k && pp <= row) ? Mg[row + (size_t)pp * k] : 0.0; }      // Minv(row, pp)
+            if (tid < 64) bps[tid] = 0.0;          // (entries beyond k meet zeros of mreg below: they must not be whatever an earlier kernel left in LDS -- 0 x NaN)
             if (tid < k) ipos[V.lperm[c0 + tid]] = tid;
             if (part == 0 && row < k) { pt = V.ptype[c0 + row]; dq = V.dinv[c0 + row]; oq = V.doff[c0 + row]; oq1 = row > 0 ? V.doff[c0 + row - 1] : 0.0; }
             if (rok) xb = V.xw[c0 + row];
