@@ -4591,8 +4591,8 @@ public:
             big_tiles64[lv] = std::max(big_tiles64[lv], schur_tiles64(Sy, s));
         }
         // hipMemset runs on the legacy default stream; the solver's streams are non-blocking, i.e. NOT ordered behind it: without this the first
-        // sweeps could meet flags / tagged messages left in recycled device memory by an earlier handle (or process) before the zero fill landed
-        // (seen as all-NaN solutions of the second and third handle of a process, and never with the level-by-level solves)
+        // sweeps of a small system could meet flags / tagged messages left in recycled device memory by an earlier handle (or process) before
+        // the zero fill has landed
         HIPCHK(hipDeviceSynchronize());
         ready = true; return true;
     }

@@ -370,9 +370,10 @@ def test_data_flow_solve_sweeps_at_every_extent(monkeypatch, gen):
         monkeypatch.delenv("MI355X_KKT_CHAIN_SOLVE_MAXC")
 
 def test_short_lived_handles_on_recycled_device_memory():
-    """many handles set up, used for a factorisation and two solves, and dropped in one process: each new handle is given device memory the
-    previous one left full of flags and tagged messages of ITS solves.  (Regression: the zero fills of the set-up run on the default stream,
-    the solver's streams are non-blocking -- a first solve racing those fills returned all-NaN vectors; tools/stress_handles.py is the long form.)"""
+    """many handles set up, used for a factorisation and two solves, and dropped in one process: each new handle is given device memory (and
+    finds LDS contents) the previous ones left behind.  Regression for the intermittent all-NaN first solves of round 3: the forward chain
+    sweep multiplied zero-padded inverse rows with LDS words it had not written (0 x NaN); and the zero fills of the set-up run on the
+    default stream while the solver's streams are non-blocking.  tools/stress_handles.py is the long form."""
     for it in range(24):
         nn = [100, 400, 2000, 5000][it % 4]
         n, r, c, v, neg = kktgen.lukvl_like(nn, seed=it)
