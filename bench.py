@@ -89,7 +89,7 @@ def source_hash():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "ipopt_amd", "csrc")
     for f in sorted(os.listdir(d)):
-        if f.endswith((".hip", ".cpp", ".h")):
+        if f.endswith((".hip", ".hip.inc", ".cpp", ".h")):
             h.update(open(os.path.join(d, f), "rb").read())
     return h.hexdigest()[:16]
 

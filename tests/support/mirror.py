@@ -75,7 +75,7 @@ def factor_solve(sym, vals, rhs, only=None):
 
 
 # ------------------------------------------------------------------------------------------------------
-# Executable SPECIFICATION of the pivoting rules of ipopt_amd/csrc/numeric.hip (ldlt_reg / k_big_trsm), in
+# Executable SPECIFICATION of the pivoting rules of ipopt_amd/csrc/kernels_fronts.hip.inc / kernels_big.hip.inc (ldlt_reg / k_big_trsm; parts of the numeric.hip translation unit), in
 # plain numpy: same candidate order, same Bunch-Kaufman preference, same MA27/MA57 threshold tests against
 # the whole front column, same pass-over / forced-pivot / zero-pivot rules.  The CPU tests pin it against
 # the oracle (inertia, solution) at several u; the GPU tests compare the HIP kernels' pivot statistics
@@ -211,7 +211,7 @@ FAST_U = 1e-4        # a pivot block taken in natural order is accepted iff ever
 
 
 def ldlt_block_static(A, k, u, u2, small=1e-20, cnorm=None):
-    """The fast path of a big front's pivot block (numeric.hip: ldlt_blocked_static): the k x k block is eliminated in NATURAL
+    """The fast path of a big front's pivot block (kernels_fronts.hip.inc: ldlt_blocked_static): the k x k block is eliminated in NATURAL
     order with 1x1 pivots, nothing is decided per pivot, and the result is accepted A POSTERIORI iff every pivot is clear of the
     zero threshold of the block and every multiplier inside the block is <= 1 / max(u, u2, FAST_U).  Returns the same dict as
     ldlt_front, or None when the block is rejected (the caller then runs the strict rule on the untouched block)."""
@@ -241,7 +241,7 @@ FAST16_MIN_M = 65    # fronts of order 65 .. 128 (the 256-thread front kernel) w
 
 
 def ldlt_front_static(F, k, u, u2, small=1e-20, cnorm=None):
-    """The fast path of a front of order 65 .. 128 with k <= 16 pivots (numeric.hip: front_fast16): the k fully-summed columns are
+    """The fast path of a front of order 65 .. 128 with k <= 16 pivots (kernels_fronts.hip.inc: front_fast16): the k fully-summed columns are
     eliminated in NATURAL order with 1x1 pivots, nothing decided per pivot, and the result is accepted A POSTERIORI iff every pivot is
     clear of the front's zero threshold and every multiplier -- update rows included: a front of this size sees its whole column -- is
     <= 1 / max(u, u2, FAST_U).  On acceptance F holds the Schur complement in F[k:, k:] and the same dict as ldlt_front is returned;

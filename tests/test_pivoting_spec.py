@@ -110,7 +110,7 @@ def test_benign_kkt_systems_do_not_depend_on_u():
 
 
 def test_blocked_a_posteriori_rule_of_the_big_pivot_blocks():
-    """The fast path of a big front's pivot block (numeric.hip ldlt_blocked_static, mirror.ldlt_block_static): natural order, 1x1 pivots,
+    """The fast path of a big front's pivot block (kernels_fronts.hip.inc ldlt_blocked_static, mirror.ldlt_block_static): natural order, 1x1 pivots,
     accepted a posteriori iff every multiplier of the block is <= 1 / max(u, u2, 0.01) and no pivot is at the zero threshold -- otherwise
     the strict rule runs on the untouched block.  Either way: inertia as constructed, converged solve; a benign system takes the fast
     path on (nearly) all blocks, a block with a tiny leading diagonal is rejected."""
