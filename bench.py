@@ -94,6 +94,43 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+def kernel_code_hash(kernel, lib=None):
+    """sha256 over the MACHINE CODE of every gfx950 kernel of the built library whose name contains `kernel` (function bytes + kernel
+    descriptors, from the code object inside libmi355x_kkt.so): the second key under which a cached PMC traffic figure stays valid -- the
+    same kernel binary launched on the same workload moves the same bytes, whatever else changed in the sources.  None if the LLVM tools
+    are missing (the figure is then only accepted on an equal source hash)."""
+    import hashlib, re, subprocess, tempfile
+    lib = lib or os.path.join(ROOT, "ipopt_amd", "lib", "libmi355x_kkt.so")
+    llvm = "/opt/rocm/lib/llvm/bin"
+    try:
+        with tempfile.TemporaryDirectory() as td:
+            fat, co = os.path.join(td, "fat.bin"), os.path.join(td, "dev.co")
+            subprocess.run([f"{llvm}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", lib, os.path.join(td, "copy.so")], check=True, capture_output=True)
+            subprocess.run([f"{llvm}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={fat}", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"],
+                           check=True, capture_output=True)
+            sec = subprocess.run([f"{llvm}/llvm-readelf", "-S", "-W", co], check=True, capture_output=True, text=True).stdout
+            sym = subprocess.run([f"{llvm}/llvm-readelf", "-s", "-W", co], check=True, capture_output=True, text=True).stdout
+            blob = open(co, "rb").read()
+        secs = {}
+        for m in re.finditer(r"\[\s*(\d+)\]\s+(\S+)\s+\S+\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", sec):
+            secs[int(m.group(1))] = (int(m.group(3), 16), int(m.group(4), 16))          # address, file offset
+        items = []
+        for ln in sym.splitlines():
+            f = ln.split()
+            if len(f) >= 8 and f[3] in ("FUNC", "OBJECT") and kernel in f[7] and f[6].isdigit():
+                addr, size, ndx = int(f[1], 16), int(f[2]), int(f[6])
+                a0, off = secs[ndx]
+                items.append((f[7], blob[off + addr - a0: off + addr - a0 + size]))
+        if not items:
+            return None
+        h = hashlib.sha256()
+        for name, code in sorted(items):
+            h.update(name.encode()); h.update(code)
+        return h.hexdigest()[:16]
+    except Exception:
+        return None
+
+
 def cpu_baseline(n, r, c, v, b, x_gpu, neg_gpu, nsolve):
     """the reference's own CPU path (TripletToCSRConverter + PardisoMKLSolverInterface, oneMKL PARDISO), prebuilt in
     oracle/_ref by oracle/ref_build.mk, timed on this box's host cores (one process per MKL thread count: the analysis fixes
@@ -290,9 +327,13 @@ def main():
         try:
             tj = json.load(open(tfile))
             # a cached PMC figure (tools/prof.sh, separate --pmc passes): only valid for the sources it was measured with
-            if tj.get("workload") == wl and tj.get("kernel") == roof["kernel"] and tj.get("source_hash") == source_hash():
+            same_src = tj.get("source_hash") == source_hash()
+            kch = None if same_src else kernel_code_hash(roof["kernel"])
+            if tj.get("workload") == wl and tj.get("kernel") == roof["kernel"] and (same_src or (kch is not None and kch == tj.get("kernel_code_hash"))):
                 roof["traffic"] = tj["hbm_bytes_per_factorisation"] / max(dlaunch, 1)     # per launch, like `achieved`
-                roof["traffic_source"] = "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources: hash %s)" % tj["source_hash"]
+                roof["traffic_source"] = ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, same sources: hash %s)" % tj["source_hash"]) if same_src else \
+                    ("profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE; other sources have changed since, the machine code of %s in the built library "
+                     "is the one measured: kernel_code_hash %s)" % (roof["kernel"], kch))
             elif tj.get("workload") == wl and tj.get("kernel") == roof["kernel"]:
                 # not emitted as `traffic`: the sources have changed since the PMC passes; reported beside it so that the reader can judge
                 roof["traffic_stale"] = {"value": tj["hbm_bytes_per_factorisation"] / max(dlaunch, 1), "measured_with_source_hash": tj.get("source_hash"),
