@@ -44,6 +44,8 @@ def test_option_struct_layout_matches_header():
     assert (o.nd_leaf, o.nemin, o.max_sn_cols) == (32, 8, 64)
     assert (o.pivtol, o.pivtolmax, o.small) == (1e-8, 1e-4, 1e-20)
     assert (o.use_graph, o.nranks, o.rank) == (1, 1, 0)
+    assert (o.chain_group, o.solve_group, o.subcube) == (4, 0, 0)      # (subcube took the first of the reserved ints: same struct size)
+    assert ctypes.sizeof(o) == ctypes.sizeof(kkt._Options) and list(o.reserved) == [0, 0]
 
 
 def _has_gpu():
@@ -95,3 +97,18 @@ def test_matching_scaling_is_a_maximum_product_scaling():
         assert un.value == 0 and np.all(s > 0)
         assert K.max() <= 1.0 + 1e-10
         assert np.allclose(K.max(axis=1).toarray().ravel(), 1.0, rtol=1e-10)
+
+
+def test_kernel_code_hash_and_the_cached_traffic_record():
+    """bench.py emits a cached PMC traffic figure only for the sources or -- second key -- the kernel machine code it was measured with:
+    the hash of a kernel's gfx950 code in the built library is well defined and stable, differs between kernels, is None for a name that
+    matches nothing, and the committed record carries both keys."""
+    import json
+    import bench
+    h1, h2 = bench.kernel_code_hash("k_big_schur"), bench.kernel_code_hash("k_big_schur")
+    assert h1 is not None and re.fullmatch(r"[0-9a-f]{16}", h1) and h1 == h2
+    assert bench.kernel_code_hash("k_fwd_chain") not in (None, h1)
+    assert bench.kernel_code_hash("no_such_kernel") is None
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")))
+    assert rec["workload"] == "synth_1e6" and rec["kernel"] == "k_big_schur" and rec["hbm_bytes_per_factorisation"] > 0
+    assert re.fullmatch(r"[0-9a-f]{16}", rec["source_hash"]) and re.fullmatch(r"[0-9a-f]{16}", rec["kernel_code_hash"])
