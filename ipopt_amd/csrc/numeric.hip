@@ -333,7 +333,7 @@ public:
         if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
         ready = false;
     }
-    template <class T> bool upload(const std::vector<T>& h, const T** d) {
+    template <class T, class A> bool upload(const std::vector<T, A>& h, const T** d) {
         T* p = nullptr; size_t bytes = std::max<size_t>(h.size(), 1) * sizeof(T);
         HIPCHK(hipMalloc((void**)&p, bytes)); allocs.push_back(p);
         if (!h.empty()) HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -379,7 +379,7 @@ public:
         lap("device, streams, pinned buffer");
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
-        std::vector<int> lvl_list(Sy.level_sn);
+        std::vector<int> lvl_list(Sy.level_sn.begin(), Sy.level_sn.end());
         std::vector<char> solve_entry;      // parallel to lvl_list: 1 = entry of a solve-unit list
         std::vector<long long> aoff(Sy.num_sn, -1), troff(Sy.num_sn, -1);
         std::vector<int> colown(Sy.n, 0);
@@ -906,7 +906,7 @@ public:
         lap("host-side schedules and tables");
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
         // the inertia / pivot counts are summed over the ranks: a replicated front is counted by the first rank of its range (-1 in this rank's view), -3 = not here
-        std::vector<int> stat_owner(Sy.sn_owner);
+        std::vector<int> stat_owner(Sy.sn_owner.begin(), Sy.sn_owner.end());
         if (multi) for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_owner[sn] < 0) stat_owner[sn] = Sy.sn_glo[sn] == opt.rank ? -1 : -3;
         if (!upload(Sy.sn_colptr, &V.sn_colptr) || !upload(Sy.sn_rowptr, &V.sn_rowptr) || !upload(Sy.sn_rows, &V.sn_rows) ||
             !upload(Sy.rel, &V.rel) || !upload(Sy.child_ptr, &V.child_ptr) || !upload(Sy.child_idx, &V.child_idx) ||

@@ -10,10 +10,15 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <new>
 #include <numeric>
+#include <map>
 #include <set>
 #include <cstdio>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <thread>
 #include <mutex>
 #include <condition_variable>
@@ -21,9 +26,104 @@
 #include <functional>
 
 namespace mi355x {
+
+// ---- BlockCache: one reserved range of address space; big blocks are carved out of it first-fit with coalescing, pages stay resident
+//      while an analysis runs (that is the point: no page faults for the 2nd .. n-th array), free ranges are given back to the kernel
+//      (MADV_DONTNEED) when the last running analysis returns.  Everything else -- small blocks, blocks when the range is exhausted or
+//      could not be reserved -- is malloc.
+namespace {
+struct CacheState {
+    std::mutex mu;
+    int scopes = 0;
+    char* base = nullptr; size_t size = 0;        // the reservation (lazily made, kept for the life of the process: address space only)
+    size_t top = 0;                               // allocation frontier: everything in use or on the free list lies below it
+    size_t hwm = 0;                               // highest frontier since pages were last given back: [top, hwm) is resident but unused
+    std::map<size_t, size_t> free_at;             // offset -> length of the free ranges below top, coalesced
+    std::map<size_t, size_t> live;                // offset -> length of the blocks in use
+    bool tried = false;
+};
+CacheState& cache_state() { static CacheState* st = new CacheState; return *st; }      // (never destroyed: vectors may be freed during static destruction)
+constexpr size_t CACHE_MIN_BYTES = 256u << 10, CACHE_ALIGN = 4096;
+void cache_release_range(CacheState& C, size_t off, size_t len)      // physical pages of a free range back to the kernel (whole pages inside it)
+{
+    const size_t a = (off + CACHE_ALIGN - 1) & ~(CACHE_ALIGN - 1), b = (off + len) & ~(CACHE_ALIGN - 1);
+    if (b > a) (void)madvise(C.base + a, b - a, MADV_DONTNEED);
+}
+}
+void* BlockCache::get(size_t bytes)
+{
+    if (bytes >= CACHE_MIN_BYTES) {
+        CacheState& C = cache_state();
+        std::lock_guard<std::mutex> lk(C.mu);
+        if (C.scopes > 0) {
+            if (!C.tried) {
+                C.tried = true;
+                const long pages = sysconf(_SC_PHYS_PAGES), psz = sysconf(_SC_PAGESIZE);
+                size_t want = (pages > 0 && psz > 0) ? (size_t)pages * (size_t)psz / 2 : ((size_t)16 << 30);
+                want = std::min(want, (size_t)256 << 30);
+                void* p = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+                if (p != MAP_FAILED) { C.base = static_cast<char*>(p); C.size = want; }
+            }
+            if (C.base) {
+                const size_t len = (bytes + CACHE_ALIGN - 1) & ~(CACHE_ALIGN - 1);
+                // best fit among the free ranges (pages already resident); otherwise fresh space at the top
+                auto best = C.free_at.end();
+                for (auto it = C.free_at.begin(); it != C.free_at.end(); ++it)
+                    if (it->second >= len && (best == C.free_at.end() || it->second < best->second)) best = it;
+                if (best != C.free_at.end()) {
+                    const size_t off = best->first, flen = best->second;
+                    C.free_at.erase(best);
+                    if (flen > len) C.free_at.emplace(off + len, flen - len);
+                    C.live[off] = len;
+                    return C.base + off;
+                }
+                if (C.top + len <= C.size) { const size_t off = C.top; C.top += len; C.hwm = std::max(C.hwm, C.top); C.live[off] = len; return C.base + off; }
+            }
+        }
+    }
+    void* p = std::malloc(bytes ? bytes : 1);
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+void BlockCache::put(void* p, size_t) noexcept
+{
+    if (!p) return;
+    CacheState& C = cache_state();
+    char* q = static_cast<char*>(p);
+    if (!C.base || q < C.base || q >= C.base + C.size) { std::free(p); return; }      // (base / size are written once, before any block of the range exists)
+    std::lock_guard<std::mutex> lk(C.mu);
+    size_t off = (size_t)(q - C.base);
+    auto it = C.live.find(off);
+    if (it == C.live.end()) return;               // (cannot happen)
+    size_t len = it->second;
+    C.live.erase(it);
+    // coalesce with the free neighbours
+    auto nx = C.free_at.lower_bound(off);
+    if (nx != C.free_at.end() && nx->first == off + len) { len += nx->second; nx = C.free_at.erase(nx); }
+    if (nx != C.free_at.begin()) { auto pv = std::prev(nx); if (pv->first + pv->second == off) { off = pv->first; len += pv->second; C.free_at.erase(pv); } }
+    if (off + len == C.top) C.top = off;          // the frontier moves down (its pages stay resident while an analysis runs)
+    else C.free_at.emplace(off, len);
+    if (C.scopes == 0) {                          // a block that outlived its analysis (the Symbolic arrays): its pages go back at once
+        if (C.top == off) { cache_release_range(C, C.top, C.hwm - C.top); C.hwm = C.top; }
+        else cache_release_range(C, off, len);
+    }
+}
+BlockCache::Scope::Scope() { CacheState& C = cache_state(); std::lock_guard<std::mutex> lk(C.mu); ++C.scopes; }
+BlockCache::Scope::~Scope()
+{
+    CacheState& C = cache_state();
+    std::lock_guard<std::mutex> lk(C.mu);
+    if (--C.scopes > 0 || !C.base) return;
+    // nothing is being analysed any more: the free ranges (and what lies between the last block and the high-water mark) go back to the kernel
+    for (auto& e : C.free_at) cache_release_range(C, e.first, e.second);
+    if (C.hwm > C.top) cache_release_range(C, C.top, C.hwm - C.top);
+    C.hwm = C.top;
+}
+
 namespace {
 
-using std::vector;
+template <class T> using vector = avec<T>;       // every array of the analysis comes from the recycling allocator (symbolic.h); small ones fall through to malloc
+
 
 // static-chunk parallel loop on std::thread (the analysis is the only multi-threaded host code; T <= 16)
 int analysis_threads() { unsigned h = std::thread::hardware_concurrency(); int t = h ? std::min((int)h, 32) : 1; const char* e = getenv("MI355X_KKT_THREADS"); if (e) t = atoi(e); return std::max(1, std::min(t, 256)); }      // default: up to 32 (measured on the 2 x 64-core host of the GPU box); MI355X_KKT_THREADS overrides
@@ -54,43 +154,49 @@ struct Pattern {
     vector<int> colptr, row;   // lower CSC, rows sorted, diagonal present
     vector<int> t2slot;        // triplet -> slot
     vector<int> tcnt, tsorted; // triplets grouped by column (tcnt: n + 1 offsets), inside a column by (row, triplet index)
+    vector<int> sfirst, scnt;  // per slot: where its triplets start in tsorted and how many there are (0: a diagonal nobody supplied) -- ascending triplet index
 };
 
 bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int format, Pattern& P,
                    std::string& err)
 {
-    vector<int> lo(nnz), hi(nnz);
     const int T = analysis_threads();
+    vector<int> crow;                      // CSR input only: the row of every entry
     if (format == 0) {
         std::atomic<int> bad(0);
         parallel_chunks(nnz, T, [&](long long tb, long long te, int) {
             for (long long t = tb; t < te; ++t) {
-                int r = ri[t] - base, c = ci[t] - base;
-                if (r < 0 || r >= n || c < 0 || c >= n) { bad.store(1, std::memory_order_relaxed); r = c = 0; }
-                lo[t] = std::min(r, c); hi[t] = std::max(r, c);
+                const int r = ri[t] - base, c = ci[t] - base;
+                if (r < 0 || r >= n || c < 0 || c >= n) bad.store(1, std::memory_order_relaxed);
             }
         });
         if (bad.load()) { err = "analyse: index out of range"; return false; }
     } else {  // CSR upper: ri = ia[n+1], ci = ja[nnz]
         if (ri[n] - base != nnz) { err = "analyse: ia[n] does not match nnz"; return false; }
+        crow.resize(nnz);
         for (int i = 0; i < n; ++i)
             for (int p = ri[i] - base; p < ri[i + 1] - base; ++p) {
                 int c = ci[p] - base;
                 if (c < 0 || c >= n) { err = "analyse: index out of range"; return false; }
-                lo[p] = std::min(i, c); hi[p] = std::max(i, c);
+                crow[p] = i;
             }
     }
+    // (col = min, row = max) of an entry, computed where it is needed: two arrays of the size of the input less to fault in
+    const int* rowp = format == 0 ? ri : crow.data();
+    const int rbase = format == 0 ? base : 0;
+    auto LO = [&](long long t) { return std::min(rowp[t] - rbase, ci[t] - base); };
+    auto HI = [&](long long t) { return std::max(rowp[t] - rbase, ci[t] - base); };
     // bucket by column (lo), then sort rows inside each column
-    vector<int> cnt, order;
-    parallel_bucket(nnz, n, T, [&](long long t) { return lo[t]; }, cnt, order);
+    vector<int> cnt, sorted_t;
+    parallel_bucket(nnz, n, T, LO, cnt, sorted_t);
     // per column: sort the (row, triplet) pairs, count distinct rows (+ the always-present diagonal) -- columns are
     // independent, so both passes run on threads; the prefix sum in between is sequential
-    vector<int> sorted_hi(nnz), sorted_t(nnz), ndist(n, 0);
+    vector<int> sorted_hi(nnz), ndist(n, 0);
     parallel_chunks(n, T, [&](long long jb, long long je, int) {
         vector<std::pair<int,int>> tmp;
         for (int j = (int)jb; j < (int)je; ++j) {
             tmp.clear();
-            for (int p = cnt[j]; p < cnt[j + 1]; ++p) tmp.emplace_back(hi[order[p]], order[p]);
+            for (int p = cnt[j]; p < cnt[j + 1]; ++p) tmp.emplace_back(HI(sorted_t[p]), sorted_t[p]);
             if (tmp.size() > 1) std::sort(tmp.begin(), tmp.end());
             int last = j, d = 1;
             for (size_t q = 0; q < tmp.size(); ++q) { sorted_hi[cnt[j] + q] = tmp[q].first; sorted_t[cnt[j] + q] = tmp[q].second; if (tmp[q].first != last) { ++d; last = tmp[q].first; } }
@@ -101,14 +207,16 @@ bool build_pattern(int n, int nnz, const int* ri, const int* ci, int base, int f
     for (int j = 0; j < n; ++j) P.colptr[j + 1] = P.colptr[j] + ndist[j];
     P.row.assign(P.colptr[n], 0);
     P.t2slot.assign(nnz, -1);
+    P.sfirst.assign(P.colptr[n], 0); P.scnt.assign(P.colptr[n], 0);
     parallel_chunks(n, T, [&](long long jb, long long je, int) {
         for (int j = (int)jb; j < (int)je; ++j) {
             int w = P.colptr[j];
             P.row[w] = j;                       // diagonal first, always present
+            P.sfirst[w] = cnt[j];
             int last = j;
             for (int p = cnt[j]; p < cnt[j + 1]; ++p) {
-                if (sorted_hi[p] != last) { P.row[++w] = sorted_hi[p]; last = sorted_hi[p]; }
-                P.t2slot[sorted_t[p]] = w;
+                if (sorted_hi[p] != last) { P.row[++w] = sorted_hi[p]; last = sorted_hi[p]; P.sfirst[w] = p; }
+                P.t2slot[sorted_t[p]] = w; ++P.scnt[w];
             }
         }
     });
@@ -462,6 +570,7 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int* ri, const int* ci,
              int format, const double* vals)
 {
+    BlockCache::Scope recycle;          // (declared first: destroyed last, after every array of the analysis has been returned)
     double t0 = now_s(), tl = t0;
     auto lap = [&](const char* what) { if (opt.verbose >= 2) { double t = now_s(); fprintf(stderr, "[mi355x_kkt]   %-28s %.3f s\n", what, t - tl); tl = t; } };
     S = Symbolic();
@@ -635,7 +744,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
         vector<int> cnt, src;
         parallel_bucket(nnzA, n, T, [&](long long p) { return pc[p]; }, cnt, src);
         S.acolptr = cnt;
-        vector<int> old2new(nnzA); S.arow.resize(nnzA); S.acol.resize(nnzA);
+        vector<int> old2new(nnzA), new2old(nnzA); S.arow.resize(nnzA); S.acol.resize(nnzA);
         parallel_chunks(n, T, [&](long long jb, long long je, int) {
             vector<std::pair<int,int>> tmp;
             for (int j = (int)jb; j < (int)je; ++j) {
@@ -643,17 +752,29 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
                 tmp.clear();
                 for (int q = q0; q < q1; ++q) tmp.emplace_back(pr[src[q]], src[q]);
                 if (q1 - q0 > 1) std::sort(tmp.begin(), tmp.end());
-                for (int q = q0; q < q1; ++q) { S.arow[q] = tmp[q - q0].first; S.acol[q] = j; old2new[tmp[q - q0].second] = q; }
+                for (int q = q0; q < q1; ++q) { S.arow[q] = tmp[q - q0].first; S.acol[q] = j; old2new[tmp[q - q0].second] = q; new2old[q] = tmp[q - q0].second; }
             }
         });
         S.nnz_a = nnzA;
         S.trip2slot.resize(nnz);
         parallel_chunks(nnz, T, [&](long long tb, long long te, int) { for (long long t = tb; t < te; ++t) S.trip2slot[t] = old2new[P.t2slot[t]]; });
-        // duplicate lists: the triplets of every slot in ascending order (the device sums them in this order => bitwise reproducible)
-        parallel_bucket(nnz, nnzA, T, [&](long long t) { return S.trip2slot[t]; }, S.dup_ptr, S.dup_src);
-        parallel_chunks(nnzA, T, [&](long long qb, long long qe, int) {
-            for (long long q = qb; q < qe; ++q) if (S.dup_ptr[q + 1] - S.dup_ptr[q] > 1) std::sort(S.dup_src.begin() + S.dup_ptr[q], S.dup_src.begin() + S.dup_ptr[q + 1]);
-        });
+        // duplicate lists: the triplets of every slot in ascending order (the device sums them in this order => bitwise reproducible).  The
+        // pattern pass left them as runs of its (column, row, triplet)-sorted list: a prefix sum over the slots in their new order and a copy
+        // (no second bucketing of the triplets, no sort)
+        S.dup_ptr.assign((size_t)nnzA + 1, 0);
+        if ((int)P.scnt.size() == nnzA && (int)P.tsorted.size() == nnz) {
+            for (int q = 0; q < nnzA; ++q) S.dup_ptr[q + 1] = S.dup_ptr[q] + P.scnt[new2old[q]];
+            S.dup_src.resize((size_t)nnz);
+            parallel_chunks(nnzA, T, [&](long long qb, long long qe, int) {
+                for (long long q = qb; q < qe; ++q) { const int o = new2old[q]; const int* src = P.tsorted.data() + P.sfirst[o]; int* dst = S.dup_src.data() + S.dup_ptr[q];
+                                                      for (int e = 0; e < P.scnt[o]; ++e) dst[e] = src[e]; }
+            });
+        } else {
+            parallel_bucket(nnz, nnzA, T, [&](long long t) { return S.trip2slot[t]; }, S.dup_ptr, S.dup_src);
+            parallel_chunks(nnzA, T, [&](long long qb, long long qe, int) {
+                for (long long q = qb; q < qe; ++q) if (S.dup_ptr[q + 1] - S.dup_ptr[q] > 1) std::sort(S.dup_src.begin() + S.dup_ptr[q], S.dup_src.begin() + S.dup_ptr[q + 1]);
+            });
+        }
     };
     build_permuted_csc();
     lap("permuted CSC + maps");

@@ -9,11 +9,37 @@
 // Everything here is one-time per sparsity structure: the output is a set of flat
 // int32/int64 arrays that are uploaded once and drive the device kernels.
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 #include <string>
 
 namespace mi355x {
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Memory of the analysis.  The analysis builds and drops a few dozen arrays of the size of the matrix (10^7 .. 10^8 bytes each); from
+// the C library every one of them is a fresh anonymous mapping whose pages are faulted in -- by many threads at once, serialised in the
+// kernel -- and handed back on free: a third of the analysis time at n = 10^6 (measured: 3.9 s -> 2.6 s on 8 cores with glibc told to
+// keep the memory, MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_).  A library must not retune the process's allocator, so the big
+// blocks of the analysis are recycled here instead: while an analysis runs, a freed block of >= 256 KiB is kept and handed to the next
+// request it fits; when the analysis returns, what is still cached goes back to the C library.  Blocks are plain malloc blocks at all
+// times (a vector that outlives the analysis -- the Symbolic arrays -- is freed normally).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct BlockCache {
+    static void* get(size_t bytes);
+    static void  put(void* p, size_t bytes) noexcept;
+    struct Scope { Scope(); ~Scope(); };          // recycling is on while at least one Scope lives (one per running analysis)
+};
+template <class T> struct CacheAlloc {
+    using value_type = T;
+    CacheAlloc() = default;
+    template <class U> CacheAlloc(const CacheAlloc<U>&) noexcept {}
+    T* allocate(size_t n) { return static_cast<T*>(BlockCache::get(n * sizeof(T))); }
+    void deallocate(T* p, size_t n) noexcept { BlockCache::put(p, n * sizeof(T)); }
+    template <class U> bool operator==(const CacheAlloc<U>&) const noexcept { return true; }
+    template <class U> bool operator!=(const CacheAlloc<U>&) const noexcept { return false; }
+};
+template <class T> using avec = std::vector<T, CacheAlloc<T>>;
 
 struct SymbolicOptions {
     int    index_base  = 1;
@@ -42,61 +68,61 @@ enum FrontClass : int { FC_WAVE = 0,   // m <= 32  : one wavefront, front in LDS
 struct Symbolic {
     int n = 0, nnz_in = 0, nnz_a = 0;
     // permutation: perm[new] = old, iperm[old] = new
-    std::vector<int> perm, iperm;
-    std::vector<int> pair_of;              // old index of 2x2 partner or -1
+    avec<int> perm, iperm;
+    avec<int> pair_of;              // old index of 2x2 partner or -1
     int num_pairs = 0;
     // permuted lower CSC pattern (row >= col, sorted rows, diagonal always present & first)
-    std::vector<int> acolptr, arow;        // [n+1], [nnz_a]
-    std::vector<int> trip2slot;            // [nnz_in] triplet -> slot in arow/aval
+    avec<int> acolptr, arow;        // [n+1], [nnz_a]
+    avec<int> trip2slot;            // [nnz_in] triplet -> slot in arow/aval
     // duplicate lists grouped by slot (device gather-sum in fixed order => deterministic)
-    std::vector<int> dup_ptr, dup_src;     // [nnz_a+1], [nnz_in]
+    avec<int> dup_ptr, dup_src;     // [nnz_a+1], [nnz_in]
     // symmetric index pairs for scaling: slot -> (row,col) are arow / column of slot
-    std::vector<int> acol;                 // [nnz_a] column of each slot (permuted numbering)
+    avec<int> acol;                 // [nnz_a] column of each slot (permuted numbering)
     // full symmetric row view of the pattern: for every row i the slots (q) that carry an entry of row i, i.e. column i's
     // own slots and the slots (i, c < i) of earlier columns; lets the equilibration run as a gather (no atomics)
-    std::vector<int> rslot_ptr, rslot_idx; // [n+1], [2*nnz_a - n]  symmetric row view: slots of the entries of row i (both triangles)
-    std::vector<int> rslot_col;            // [2*nnz_a - n] the other index of each of them
+    avec<int> rslot_ptr, rslot_idx; // [n+1], [2*nnz_a - n]  symmetric row view: slots of the entries of row i (both triangles)
+    avec<int> rslot_col;            // [2*nnz_a - n] the other index of each of them
     // supernodes
     int num_sn = 0;
-    std::vector<int> sn_colptr;            // [num_sn+1] pivot column ranges (permuted numbering)
-    std::vector<int> sn_of;                // [n] supernode of permuted column
-    std::vector<int> sn_rowptr;            // [num_sn+1] into sn_rows
-    std::vector<int> sn_rows;              // front row lists: k pivots then sorted update rows (permuted numbering)
-    std::vector<int> rel;                  // aligned with sn_rows: local row in PARENT front, -1 for pivot rows
-    std::vector<int> sn_parent;            // [num_sn] or -1
-    std::vector<int> child_ptr, child_idx; // children lists
-    std::vector<int> sn_level;             // height-based level (leaves = 0)
-    std::vector<int> sn_class;             // FrontClass
-    std::vector<int64_t> panel_off;        // [num_sn] offset (doubles) of the m x k panel in L storage (ld = m)
-    std::vector<int64_t> cb_off;           // [num_sn] offset (doubles) of the (m-k)^2 contribution block (ld = sn_ldt)
+    avec<int> sn_colptr;            // [num_sn+1] pivot column ranges (permuted numbering)
+    avec<int> sn_of;                // [n] supernode of permuted column
+    avec<int> sn_rowptr;            // [num_sn+1] into sn_rows
+    avec<int> sn_rows;              // front row lists: k pivots then sorted update rows (permuted numbering)
+    avec<int> rel;                  // aligned with sn_rows: local row in PARENT front, -1 for pivot rows
+    avec<int> sn_parent;            // [num_sn] or -1
+    avec<int> child_ptr, child_idx; // children lists
+    avec<int> sn_level;             // height-based level (leaves = 0)
+    avec<int> sn_class;             // FrontClass
+    avec<int64_t> panel_off;        // [num_sn] offset (doubles) of the m x k panel in L storage (ld = m)
+    avec<int64_t> cb_off;           // [num_sn] offset (doubles) of the (m-k)^2 contribution block (ld = sn_ldt)
     // In-place separator chains: a BIG front whose row set equals the update rows of a BIG child is not re-assembled -- it
     // LIVES in that child's contribution block (panel = its first k columns, own contribution block = the trailing part),
     // i.e. a right-looking blocked LDL^T of the separator front.  panel_off of such a front points into the cb pool
     // (offset >= l_doubles; L and cb are one allocation) and both leading dimensions are inherited from the child.
-    std::vector<int> sn_ldp, sn_ldt;       // leading dimensions of the panel / of the contribution block
-    std::vector<int> alias_child;          // the child whose contribution block this front lives in, or -1
-    std::vector<int> grp_pos, grp_rem;     // chain groups: position of the front in its group; columns of the LATER links (0 = last link)
-    std::vector<int64_t> cv_off;           // [num_sn] offset of the front's forward-solve vector (in-place chains share one)
-    std::vector<int64_t> gpart_off;        // [num_sn] (group-last BIG fronts) offset of the backward partial sums
+    avec<int> sn_ldp, sn_ldt;       // leading dimensions of the panel / of the contribution block
+    avec<int> alias_child;          // the child whose contribution block this front lives in, or -1
+    avec<int> grp_pos, grp_rem;     // chain groups: position of the front in its group; columns of the LATER links (0 = last link)
+    avec<int64_t> cv_off;           // [num_sn] offset of the front's forward-solve vector (in-place chains share one)
+    avec<int64_t> gpart_off;        // [num_sn] (group-last BIG fronts) offset of the backward partial sums
     int64_t cvec_doubles = 0, gpart_doubles = 0;
     int solve_group = 0;                   // copy of the option: solves per chain group (1) or per link (0)
     int grp_cut_level = 0;                 // from this tree level up every level has only a handful of BIG fronts (the latency-bound top of the tree):
                                            // chain groups do not straddle it, the numeric phase factors the groups above it in one launch each
-    std::vector<int64_t> wb_off;           // [num_sn] offset (doubles) of the m x k scaled-panel copy W = L*D of a BIG front
+    avec<int64_t> wb_off;           // [num_sn] offset (doubles) of the m x k scaled-panel copy W = L*D of a BIG front
                                            // inside the per-level scratch (reused level after level), -1 otherwise
     int64_t wbuf_doubles = 0;
-    std::vector<int64_t> minv_off;         // [num_sn] offset (doubles) of the k x k inverse of the unit-lower pivot block
+    avec<int64_t> minv_off;         // [num_sn] offset (doubles) of the k x k inverse of the unit-lower pivot block
     int64_t minv_doubles = 0;
-    std::vector<int> apos;                 // [nnz_a] local position (row + col*m) of each slot inside its panel
+    avec<int> apos;                 // [nnz_a] local position (row + col*m) of each slot inside its panel
     // level schedule: fronts sorted by (level, class)
     int num_levels = 0;
-    std::vector<int> level_ptr;            // [num_levels*FC_COUNT + 1] into level_sn: bucket (level, class)
-    std::vector<int> level_sn;             // [num_sn]
+    avec<int> level_ptr;            // [num_levels*FC_COUNT + 1] into level_sn: bucket (level, class)
+    avec<int> level_sn;             // [num_sn]
     // multi-GPU ownership: rank owning the supernode (subtree sharding) or -1 = replicated top
-    std::vector<int> sn_owner;
+    avec<int> sn_owner;
     // ... and the range of ranks [sn_glo, sn_glo + sn_gsz) that holds the front (one rank for an owned front, all ranks for the classic replicated
     // top, the ranks beneath it with the subtree-to-subcube mapping); sn_gdepth: bisections above that range = exchange step the front belongs to
-    std::vector<int> sn_glo, sn_gsz, sn_gdepth;
+    avec<int> sn_glo, sn_gsz, sn_gdepth;
     int num_gdepths = 1;
     // statistics
     int64_t nnz_l = 0, flops_factor = 0, sum_sn_rows = 0, cb_doubles = 0, l_doubles = 0;

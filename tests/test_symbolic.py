@@ -70,6 +70,46 @@ def test_duplicates_and_mixed_triangles_are_summed():
     assert np.abs(x2 - 1).max() < 1e-8
 
 
+@pytest.mark.parametrize("case", ["grid_dups", "band", "csr"])
+def test_duplicate_lists_hold_every_triplet_of_a_slot_in_ascending_order(case):
+    """k_gather_values sums the triplets of a slot in the order of these lists (bitwise reproducible values): every triplet appears exactly once,
+    under the slot the triplet map names, in ascending triplet index; slots nobody supplied (an absent diagonal) have an empty list."""
+    if case == "grid_dups":
+        n, r, c, v, _ = kktgen.grid_kkt(14, 11, dof=2, ncon=1, seed=3)
+        rng = np.random.default_rng(0)
+        extra = rng.integers(0, len(v), 300)                                  # duplicates, some of them with the triangle swapped
+        r2, c2 = r[extra].copy(), c[extra].copy()
+        sw = rng.random(300) < 0.5
+        r2[sw], c2[sw] = c[extra][sw], r[extra][sw]
+        r, c, v = np.concatenate([r, r2]), np.concatenate([c, c2]), np.concatenate([v, rng.standard_normal(300)])
+        perm = rng.permutation(len(v)); r, c, v = r[perm].copy(), c[perm].copy(), v[perm].copy()
+    elif case == "band":
+        n, r, c, v, _ = kktgen.lukvl_like(700, seed=4)
+    else:
+        n, r, c, v, _ = kktgen.grid_kkt(9, 7, dof=2, ncon=1, seed=5)
+    s = ipopt_amd.KKTSolver()
+    if case == "csr":
+        K = kktgen.to_scipy(n, r, c, v)
+        import scipy.sparse as sp
+        U = sp.triu(K, format="csr"); U.sort_indices()
+        s.initialize_structure(n, (U.indptr + 1).astype(np.int32), (U.indices + 1).astype(np.int32), fmt=1)
+        nnz = U.nnz
+    else:
+        s.initialize_structure(n, r, c, vals=v)
+        nnz = len(v)
+    I = s.info()
+    t2s, dptr, dsrc = s.symbolic(9, nnz), s.symbolic(21, I.nnz_a + 1), s.symbolic(22, nnz)
+    assert dptr[0] == 0 and dptr[-1] == nnz and np.all(np.diff(dptr) >= 0)
+    assert sorted(dsrc.tolist()) == list(range(nnz))
+    slot_of = np.repeat(np.arange(I.nnz_a), np.diff(dptr))
+    assert np.array_equal(t2s[dsrc], slot_of)
+    inside = np.diff(dsrc) > 0
+    same = slot_of[1:] == slot_of[:-1]
+    assert np.all(inside[same])
+    if case == "grid_dups":
+        assert np.diff(dptr).max() >= 2
+
+
 def test_csr_upper_format_equals_triplet():
     n, r, c, v, _ = kktgen.grid_kkt(6, 5, dof=1, ncon=1, seed=6)
     K = kktgen.to_scipy(n, r, c, v)
