@@ -85,13 +85,14 @@ void* BlockCache::get(size_t bytes)
     if (!p) throw std::bad_alloc();
     return p;
 }
-void BlockCache::put(void* p, size_t) noexcept
+void BlockCache::put(void* p, size_t bytes) noexcept
 {
     if (!p) return;
+    if (bytes < CACHE_MIN_BYTES) { std::free(p); return; }       // (the range never serves a request below the threshold)
     CacheState& C = cache_state();
     char* q = static_cast<char*>(p);
-    if (!C.base || q < C.base || q >= C.base + C.size) { std::free(p); return; }      // (base / size are written once, before any block of the range exists)
     std::lock_guard<std::mutex> lk(C.mu);
+    if (!C.base || q < C.base || q >= C.base + C.size) { std::free(p); return; }
     size_t off = (size_t)(q - C.base);
     auto it = C.live.find(off);
     if (it == C.live.end()) return;               // (cannot happen)

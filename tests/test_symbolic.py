@@ -214,6 +214,38 @@ def test_subtree_to_subcube_mapping_is_a_nested_partition(nranks):
         assert l1 < l0 and tot / l1 > 0.4 * nranks
 
 
+def test_concurrent_analyses_share_the_recycling_allocator():
+    """several handles analysed at the same time from different threads (ctypes drops the GIL): the block cache of the analysis is shared,
+    reference-counted by the running analyses and must neither mix up blocks nor lose them -- same permutations as one after the other, and
+    the resident memory of the process returns to where it was once the handles are gone"""
+    import gc
+    import threading
+
+    def rss():
+        return int(open("/proc/self/statm").read().split()[1]) * 4096
+
+    cases = [kktgen.grid_kkt(70 + 9 * i, 60 + 5 * i, dof=3, ncon=2, seed=i) for i in range(4)]      # big enough for arrays beyond the cache threshold
+    serial = []
+    for n, r, c, v, _ in cases:
+        s = ipopt_amd.KKTSolver(); s.initialize_structure(n, r, c, vals=v); serial.append(s.symbolic(0, n).copy()); del s
+    gc.collect(); base = rss()
+    out, keep = [None] * 4, [None] * 4
+
+    def work(i):
+        n, r, c, v, _ = cases[i]
+        for _ in range(3):
+            s = ipopt_amd.KKTSolver(); s.initialize_structure(n, r, c, vals=v)
+            out[i] = s.symbolic(0, n).copy(); keep[i] = s
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in th]; [t.join() for t in th]
+    for i in range(4):
+        assert np.array_equal(out[i], serial[i])
+    keep[:] = [None] * 4
+    gc.collect()
+    assert rss() <= base + (64 << 20)
+
+
 def test_chain_groups_are_consistent():
     """in-place chains and chain groups (numeric.hip relies on these invariants): an in-place front has exactly its chain
     child's update rows; a group is <= 4 consecutive links on consecutive levels with <= 256 columns; grp_rem = columns
