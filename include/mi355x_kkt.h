@@ -232,16 +232,21 @@ const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
  *       12 apos[nnz_a] (row + col*m position of each permuted-CSC slot inside its supernode panel),
  *       13 level_ptr[num_levels*4+1], 14 level_sn[num_sn] (launch schedule: buckets (level, front class)),
  *       15 grp_pos[num_sn], 16 grp_rem[num_sn] (chain groups: position in the group, columns of the later links),
- *       17 alias_child[num_sn] (in-place chains: the child whose contribution block hosts this front, or -1) */
+ *       17 alias_child[num_sn] (in-place chains: the child whose contribution block hosts this front, or -1),
+ *       18 sn_glo[num_sn], 19 sn_gsz[num_sn] (multi-GPU: the range of ranks [glo, glo + gsz) that holds the front: one rank for an owned
+ *       front, all ranks for the classic replicated top, the ranks beneath it with opts.subcube), 20 sn_gdepth[num_sn] (bisections of the
+ *       machine above that range = the exchange step the front belongs to),
+ *       21 dup_ptr[nnz_a + 1], 22 dup_src[nnz_in] (the triplets of every CSC slot in ascending order: the order in which the device sums
+ *       duplicates) */
 int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t capacity);
 
 /* ---- measurement: device time per kernel kind (hip events on the solver's stream around every launch of an
  * eager, graph-less factor + one solve, accumulated over `reps` repetitions).  ms/launches need
  * MI355X_KKT_KERNEL_COUNT entries.  Used by bench.py for the roofline of the dominant kernel. ---- */
 #define MI355X_KKT_KERNEL_GATHER_SCALE  0   /* value gather + Ruiz equilibration                                   */
-#define MI355X_KKT_KERNEL_FRONT_WAVE    1   /* k_front_lds<64>  : fronts of order <= 32, one wavefront each        */
-#define MI355X_KKT_KERNEL_FRONT_LDS64   2   /* k_front_lds<256> : order <= 64                                      */
-#define MI355X_KKT_KERNEL_FRONT_LDS128  3   /* k_front_lds<256> : order <= 128                                     */
+#define MI355X_KKT_KERNEL_FRONT_WAVE    1   /* k_front_dpp16 + k_front_reg<64,*> : fronts of order <= 32            */
+#define MI355X_KKT_KERNEL_FRONT_LDS64   2   /* k_front_reg<64,8>  : order <= 64, one wavefront each                */
+#define MI355X_KKT_KERNEL_FRONT_LDS128  3   /* k_front_reg<256,*> : order <= 128                                   */
 #define MI355X_KKT_KERNEL_BIG_ASSEMBLE  4
 #define MI355X_KKT_KERNEL_BIG_DIAG      5
 #define MI355X_KKT_KERNEL_BIG_TRSM      6
