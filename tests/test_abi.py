@@ -112,3 +112,27 @@ def test_kernel_code_hash_and_the_cached_traffic_record():
     rec = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_latest.json")))
     assert rec["workload"] == "synth_1e6" and rec["kernel"] == "k_big_schur" and rec["hbm_bytes_per_factorisation"] > 0
     assert re.fullmatch(r"[0-9a-f]{16}", rec["source_hash"]) and re.fullmatch(r"[0-9a-f]{16}", rec["kernel_code_hash"])
+
+
+def test_committed_bench_lines_keep_the_contract():
+    """the round's committed bench lines (profiles/rNN_bench_*.json, written by bench.py on the GPU box) carry every key of the driver's contract,
+    the roofline object and the cpu_baseline object; the default workload is BASELINE configs[3]"""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "profiles", "r0[3-9]_bench_*.json")))
+    assert files
+    for f in files:
+        j = json.loads(open(f).read().strip().splitlines()[-1])
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert k in j, (f, k)
+        assert j["unit"] == "GFLOP/s" and j["dtype"] == "f64" and j["data"] == "synthetic" and j["higher_is_better"] is True and j["vs_baseline"] is None
+        assert "workload" in j["config"] and "model" not in j["config"]
+        r = j["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in r, (f, k)
+        assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-9 * max(1.0, r["frac"])
+        if "cpu_baseline" in j:
+            for k in ("value", "unit", "cores", "kind", "sample"):
+                assert k in j["cpu_baseline"], (f, k)
+            assert j["cpu_baseline"]["kind"] in ("reference", "port")
