@@ -1,6 +1,7 @@
 #!/bin/bash
 # Everything the round's DESIGN.md / profiles/ numbers come from, in one GPU call:
-#   bench lines of the four workloads, rocprofv3 kernel stats + PMC traffic of the default workload, launch timeline, pivot-block phases.
+#   bench lines of the four workloads, rocprofv3 kernel stats + PMC traffic of the default workload, launch timeline, pivot-block phases,
+#   host analysis times, the many-handles stress.
 # usage (on the GPU box, from the repo root):  tools/round_profiles.sh r02
 TAG=${1:-rXX}
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -20,4 +21,6 @@ python tools/clocks.py synth_1e6 > $O/synth_1e6_pivot_block_phases.txt 2>&1
 tools/prof.sh lukvle1_1e6 k_front_reg > $O/prof_lukvle1_1e6.log 2>&1
 cp gpurun_out/prof_lukvle1_1e6/kernel_stats.csv $O/lukvle1_1e6_kernel_stats.csv 2>/dev/null
 cp gpurun_out/prof_lukvle1_1e6/pmc_summary.json $O/lukvle1_1e6_pmc_summary.json 2>/dev/null
+python tools/analysis_time.py lukvle1_1e6 synth_1e6 > $O/analysis_time.txt 2>&1
+timeout 120 python tools/stress_handles.py 60 > $O/stress_handles.txt 2>&1
 ls -la $O
