@@ -114,11 +114,12 @@ def _worker_comm(rank, world, port, case, subcube, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (4, 0, _case_grid), (4, 1, _case_grid), (3, 1, _case_grid), (4, 1, _case_band)],
-                         ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band"])
+@pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (4, 0, _case_grid), (4, 1, _case_grid), (3, 1, _case_grid), (4, 1, _case_band), (8, 1, _case_grid)],
+                         ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band", "8-subcube"])
 def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, case):
     """... with the classic mapping (one top replicated on every rank) and with the subtree-to-subcube mapping: replicated fronts held by the
-    ranks beneath them only, one exchange step per bisection of the machine, the fronts of a sub-range reported upwards by its first rank"""
+    ranks beneath them only, one exchange step per bisection of the machine, the fronts of a sub-range reported upwards by its first rank
+    (8 ranks: three steps, and ranges of the second step that report straight to the fronts of the whole machine)"""
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
