@@ -114,7 +114,9 @@ def _worker_comm(rank, world, port, case, subcube, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (4, 0, _case_grid), (4, 1, _case_grid), (3, 1, _case_grid), (4, 1, _case_band), (8, 1, _case_grid)],
+@pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (4, 0, _case_grid), (4, 1, _case_grid), (3, 1, _case_grid), (4, 1, _case_band),
+                                                pytest.param(8, 1, _case_grid, marks=pytest.mark.skipif(not os.environ.get("MI355X_KKT_TEST_8RANKS"),
+                                                             reason="8 ranks on one GPU: written when no GPU minutes were left, opt-in until it has run once (MI355X_KKT_TEST_8RANKS=1)"))],
                          ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band", "8-subcube"])
 def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, case):
     """... with the classic mapping (one top replicated on every rank) and with the subtree-to-subcube mapping: replicated fronts held by the
