@@ -109,7 +109,7 @@ void BlockCache::put(void* p, size_t bytes) noexcept
         else cache_release_range(C, off, len);
     }
 }
-BlockCache::Scope::Scope() { CacheState& C = cache_state(); std::lock_guard<std::mutex> lk(C.mu); ++C.scopes; }
+BlockCache::Scope::Scope() { CacheState& C = cache_state(); std::lock_guard<std::mutex> lk(C.mu); ++C.scopes; if (C.scopes == 1 && !C.tried && getenv("MI355X_KKT_NO_BLOCKCACHE")) C.tried = true; }      // (development knob: no reservation => every block is malloc)
 BlockCache::Scope::~Scope()
 {
     CacheState& C = cache_state();
