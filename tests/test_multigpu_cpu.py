@@ -79,3 +79,14 @@ def test_subtree_sharded_factor_solve_over_gloo(world, case, subcube):
         assert nsteps == 1 or subcube
         if not subcube:
             assert held == [ntop] * world
+
+
+def test_both_mappings_on_random_systems_at_two_to_nine_ranks():
+    """tools/fuzz_subcube.py, short: every rank of a world is a numpy engine in THIS process and the all-reduces are sums over their buffers
+    -- random grid / band systems, 2..9 ranks (odd counts, ranges that skip a bisection level), classic and subtree-to-subcube mapping: inertia
+    summed over the ranks and the solution on every rank"""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_subcube", os.path.join(root, "tools", "fuzz_subcube.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    mod.main(cases=8, seed=3)
