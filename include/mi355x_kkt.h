@@ -81,7 +81,10 @@ typedef struct mi355x_kkt_options {
     int    solve_group;     /* 1: triangular solves per chain group instead of per link (default 0)       */
     int    subcube;         /* multi-GPU: 1 = subtree-to-subcube mapping -- a front of the top of the tree is replicated only */
                             /* on the ranks whose subtrees lie beneath it; 0 (default) = one top replicated on all ranks      */
-    int    reserved[2];
+    int    delay_rounds;    /* delayed pivoting across fronts: columns that fail the threshold test in their front are moved to the */
+                            /* parent front's supernode and the matrix is refactored, at most this many times per factor() call   */
+                            /* (default 8; 0 = static pivoting: failed pivots are forced and counted in num_small)                */
+    int    reserved[1];
 } mi355x_kkt_options;
 
 typedef struct mi355x_kkt_info {
@@ -103,9 +106,10 @@ typedef struct mi355x_kkt_info {
     int     num_neg;         /* negative eigenvalues of the last factorisation                          */
     int     num_zero;        /* zero pivots (=> singular) of the last factorisation                     */
     int     num_two;         /* 2x2 pivots of the last factorisation                                    */
-    int     num_small;       /* FAILED pivots: no pivot of the front passed the threshold tests with u  */
-                             /* and the structure being static (no delay to the parent) the candidate   */
-                             /* was eliminated anyway; the analogue of info.num_delay (hsl_ma97d.h:103) */
+    int     num_small;       /* pivots of the last factorisation that FAILED the threshold tests with u */
+                             /* and were eliminated anyway (static pivoting): what the delayed-pivot    */
+                             /* rounds could not move (root fronts, round / growth limits, or           */
+                             /* delay_rounds = 0).  0 = every pivot passed the threshold test           */
     int     num_big_fronts;  /* fronts handled by the blocked (global-memory, MFMA) path                */
     double  time_analyse;    /* host seconds, last analyse                                              */
     double  time_factor_ms;  /* device ms (hip events on the solver's stream), last factor              */
@@ -115,7 +119,10 @@ typedef struct mi355x_kkt_info {
     int     num_fast_blocks; /* last factorisation: pivot blocks of big fronts accepted on the blocked a-posteriori path  */
                              /* (natural order, every multiplier <= 1/max(u, pivtolmax, 0.01)); the other big fronts'    */
                              /* pivot blocks took the strict threshold-pivoting loop                                     */
-    double  reserved[6];
+    int     num_delayed;     /* columns moved to a parent front since analyse() because they failed the threshold tests in their own (a column */
+                             /* that moved up twice counts twice): info.num_delay of MA97 (hsl_ma97d.h:103, IpMa97SolverInterface.cpp:719-779) */
+    int     num_restructures;/* structure edits (+ refactorisations) those delays have cost since analyse()                                  */
+    double  reserved[5];
 } mi355x_kkt_info;
 
 /* fill opts with the defaults documented above */
@@ -221,6 +228,16 @@ int  mi355x_kkt_matching_scaling(int n, int nnz, const int* irn, const int* jcn,
  * many there are (idx may be NULL / shorter).  This is what DetermineDependentRows needs
  * (IpSparseSymLinearSolverInterface.hpp:240-255; MUMPS' PIVNUL_LIST, IpMumpsSolverInterface.cpp:617-709). */
 int  mi355x_kkt_zero_pivots(mi355x_kkt_handle h, int* idx, int capacity, int* count);
+/* Delayed pivoting across fronts -- what MA27 / MA57 / MA97 / MUMPS / SPRAL do with a fully-summed column that finds no acceptable pivot in
+ * its front (Duff & Reid 1983; consequences read at IpMa97SolverInterface.cpp:719-779, IpMa27TSolverInterface.cpp:565-622,
+ * IpSpralSolverInterface.cpp:199-204).  factor / refactor / factor_assembled do it themselves (opts.delay_rounds); the two pieces are exposed:
+ *   _failed_pivots   the columns (caller's index base, ascending) the last factorisation eliminated although they failed the threshold tests
+ *   _delay_columns   move the given columns from their front's supernode to the parent front's and rebuild the symbolic structures (host work;
+ *                    a handle with a device sets the numeric side up again; the next factor() uses the new structure).  *moved = columns
+ *                    that moved (a root front has no parent); a column that has been moved before climbs 2, 4, 8 ... tree levels. */
+int  mi355x_kkt_failed_pivots(mi355x_kkt_handle h, int* idx, int capacity, int* count);
+int  mi355x_kkt_delay_columns(mi355x_kkt_handle h, const int* cols, int count, int* moved);
+int  mi355x_kkt_set_delay_rounds(mi355x_kkt_handle h, int rounds);      /* opts.delay_rounds at run time (0 = static pivoting) */
 const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
 
 /* ---- symbolic introspection (host logic tests, debugging; sizes via get_info) ---- */

@@ -6,6 +6,7 @@
 #include "matching_scaling.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <new>
 #include <string>
@@ -21,6 +22,11 @@ struct mi355x_kkt_handle_s {
     bool analysed = false, numeric_ready = false, factored = false;
     bool stats_stale = false;      // the scaling mode / factors changed since the factorisation `last` describes: its u_sensitive verdict no longer applies
     FactorStats last;
+    SymbolicOptions so;            // what analyse() ran with: the structure is edited again with the same options when pivots are delayed
+    int64_t base_nnz_l = 0;        // nnz(L) of the analysis (the delayed-pivot edits may not grow the factor without bound)
+    int num_delayed = 0;           // columns moved to a parent front since analyse() (a column that moved twice counts twice), MA97's num_delay
+    int num_restructures = 0;      // structure edits since analyse()
+    std::vector<unsigned char> delay_count;   // per column (caller's numbering, 0-based): how often it has been moved up
     std::string err;
     std::vector<double> host_vals_nodev;   // plain host staging buffer handed out when no device exists (values only, never computed on)
 };
@@ -35,6 +41,7 @@ void mi355x_kkt_default_options(mi355x_kkt_options* o)
     o->nd_leaf = 32; o->nemin = 8; o->max_sn_cols = 64;
     o->pivtol = 1e-8; o->pivtolmax = 1e-4; o->small = 1e-20;
     o->refine_steps = 0; o->use_graph = 1; o->nranks = 1; o->rank = 0; o->verbose = 0; o->leaf_cols = 0; o->tree_merge = 0; o->wide_panels = 0; o->chain_group = 4; o->solve_group = 0; o->subcube = 0;
+    o->delay_rounds = 8;
 }
 
 int mi355x_kkt_create(mi355x_kkt_handle* h, const mi355x_kkt_options* opts)
@@ -61,18 +68,25 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
     try {
         h->analysed = false; h->numeric_ready = false; h->factored = false;
         delete h->num; h->num = nullptr;
-        SymbolicOptions so;
+        h->num_delayed = 0; h->num_restructures = 0; h->delay_count.clear();
+        SymbolicOptions& so = h->so; so = SymbolicOptions();
         so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
         so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 64 ? 64 : h->opts.max_sn_cols) : 64;   // 64: LDS budget of k_big_trsm (104 KiB at k = 65)
         so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose; so.leaf_cols = h->opts.leaf_cols; so.tree_merge = h->opts.tree_merge; so.wide_panels = h->opts.wide_panels; so.chain_group = h->opts.chain_group > 0 ? h->opts.chain_group : 4; so.solve_group = h->opts.solve_group; so.subcube = h->opts.subcube;
         // the device's first touch and the pinned staging buffer do not depend on the analysis: made on a thread next to it
+        // (the device is resolved HERE: HIP's current device is per thread, the warm-up thread would otherwise touch device 0 whatever the caller selected)
         void* pre = nullptr;
-        std::thread warm([&] { try { pre = Numeric::prewarm(h->opts.device, (size_t)(nnz > 0 ? nnz : 1)); } catch (...) { pre = nullptr; } });
+        const int warm_dev = Numeric::resolve_device(h->opts.device);
+        struct Warm {      // joined (and its buffer released) on EVERY path out of this scope, exceptions included: a joinable std::thread that is destroyed terminates the process
+            std::thread t; void** pre; bool taken = false;
+            ~Warm() { if (t.joinable()) t.join(); if (!taken && *pre) { Numeric::prewarm_discard(*pre); *pre = nullptr; } }
+        } warm{std::thread(), &pre};
+        if (warm_dev >= 0) warm.t = std::thread([&pre, warm_dev, nnz] { try { pre = Numeric::prewarm(warm_dev, (size_t)(nnz > 0 ? nnz : 1)); } catch (...) { pre = nullptr; } });
         const bool aok = analyse(h->sym, so, n, nnz, row, col, format, vals);
-        warm.join();
-        if (!aok) { Numeric::prewarm_discard(pre); h->err = h->sym.error; return MI355X_KKT_FATAL; }
-        h->analysed = true;
+        if (warm.t.joinable()) warm.t.join();
+        if (!aok) { h->err = h->sym.error; return MI355X_KKT_FATAL; }
+        h->analysed = true; h->base_nnz_l = h->sym.nnz_l;
         // device setup is attempted right away so that values_buffer() can hand out pinned memory;
         // without a GPU the symbolic result stays queryable and factor()/solve() fail loudly.
         h->num = new Numeric();
@@ -82,6 +96,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         no.refine_steps = h->opts.refine_steps; no.use_graph = h->opts.use_graph; no.rank = h->opts.rank; no.nranks = so.nranks;
         no.verbose = h->opts.verbose;
         no.prewarmed_vals = pre; no.prewarmed_count = (size_t)(nnz > 0 ? nnz : 1);
+        warm.taken = true;                     // (setup owns the buffer from here on, whether it succeeds or not)
         h->numeric_ready = h->num->setup(h->sym, no);
         if (!h->numeric_ready) h->err = h->num->error();
         return MI355X_KKT_SUCCESS;
@@ -96,6 +111,44 @@ double* mi355x_kkt_values_buffer(mi355x_kkt_handle h)
     try { h->host_vals_nodev.resize(h->sym.nnz_in > 0 ? h->sym.nnz_in : 1); return h->host_vals_nodev.data(); } catch (...) { return nullptr; }
 }
 
+// Delayed pivoting across fronts (the behaviour of MA27 / MA57 / MA97 / MUMPS / SPRAL whose consequences the reference adapters read:
+// IpMa97SolverInterface.cpp:719-779 info.num_delay, IpMa27TSolverInterface.cpp:565-622 "grow the workspace and factor again"): when the
+// factorisation had to eliminate columns that failed the threshold test -- every candidate of their front had failed, or a multiplier
+// below a pivot block came out above 1/u -- those columns are moved to the parent front's supernode (symbolic.cpp restructure_delays),
+// everything that depends on the structure is set up again and the SAME values are refactored; up to opts.delay_rounds times per call.
+// The edited structure stays for the following factorisations.  0 rounds = static pivoting (failed pivots forced and counted in num_small).
+static bool apply_delays(mi355x_kkt_handle h, const std::vector<int>& marks_perm, int* moved)
+{
+    Symbolic ns;
+    *moved = 0;
+    if (marks_perm.empty()) return false;
+    // a column that has been delayed before and fails again climbs 2, 4, 8 ... levels: along a separator chain the rows that hold its large
+    // entries become fully summed many links further up, and every visit of a link on the way costs a refactorisation
+    if ((int)h->delay_count.size() != h->sym.n) h->delay_count.assign(h->sym.n, 0);
+    std::vector<int> hops(marks_perm.size());
+    for (size_t q = 0; q < marks_perm.size(); ++q) hops[q] = 1 << std::min<int>(h->delay_count[h->sym.perm[marks_perm[q]]], 6);
+    std::vector<char> acted;
+    if (!restructure_delays(h->sym, h->so, marks_perm, hops, ns, moved, &acted)) return false;
+    if (ns.nnz_l > 4 * h->base_nnz_l + 4000000) { *moved = 0; return false; }      // the factor may grow, not explode: static pivoting from here on
+    for (size_t q = 0; q < marks_perm.size(); ++q) if (acted[q]) { unsigned char& c = h->delay_count[h->sym.perm[marks_perm[q]]]; if (c < 255) ++c; }
+    h->sym = std::move(ns);
+    h->num_delayed += *moved; h->num_restructures++;
+    return true;
+}
+static bool delay_and_refactor(mi355x_kkt_handle h, FactorStats& st)
+{
+    // (a forced candidate with nothing usable in its column is counted as a ZERO pivot, not in num_small: both can carry marks)
+    for (int round = 0; round < h->opts.delay_rounds && (st.num_small > 0 || st.num_zero > 0); ++round) {
+        std::vector<int> marks; int moved = 0;
+        if (!h->num->failed_pivots(marks)) { h->err = h->num->error(); return false; }
+        if (!apply_delays(h, marks, &moved)) break;                      // nothing that can move (root fronts) or the growth cap: keep the static result
+        if (!h->num->restructure(h->sym)) { h->err = h->num->error(); h->numeric_ready = false; return false; }
+        if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: %d failed pivots, %d columns delayed to their parent fronts (round %d), refactoring\n", st.num_small, moved, round + 1);
+        if (!h->num->factor(nullptr, true, st)) { h->err = h->num->error(); return false; }
+    }
+    return true;
+}
+
 static int do_factor(mi355x_kkt_handle h, const double* dvals, bool reuse, int* num_neg, int* num_zero)
 {
     if (!h) return MI355X_KKT_FATAL;
@@ -105,6 +158,7 @@ static int do_factor(mi355x_kkt_handle h, const double* dvals, bool reuse, int* 
         if (h->sym.n == 0) { h->last = FactorStats(); h->factored = true; if (num_neg) *num_neg = 0; if (num_zero) *num_zero = 0; return MI355X_KKT_SUCCESS; }
         FactorStats st;
         if (!h->num->factor(dvals, reuse, st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
+        if (!delay_and_refactor(h, st)) return MI355X_KKT_FATAL;
         h->last = st; h->factored = true; h->stats_stale = false;
         if (num_neg) *num_neg = st.num_neg;
         if (num_zero) *num_zero = st.num_zero;
@@ -183,6 +237,38 @@ int mi355x_kkt_zero_pivots(mi355x_kkt_handle h, int* idx, int capacity, int* cou
     } catch (...) { h->err = "zero_pivots: unexpected exception"; return MI355X_KKT_FATAL; }
 }
 
+/* the columns the last factorisation eliminated although they failed the threshold test (after the delayed-pivot rounds: what is left) */
+int mi355x_kkt_failed_pivots(mi355x_kkt_handle h, int* idx, int capacity, int* count)
+{
+    if (!h || !count) return MI355X_KKT_FATAL;
+    if (!h->factored || !h->numeric_ready) { h->err = "failed_pivots: no factorisation available"; return MI355X_KKT_FATAL; }
+    try {
+        std::vector<int> z;
+        if (h->sym.n > 0 && !h->num->failed_pivots(z)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
+        for (int& c : z) c = h->sym.perm[c];
+        std::sort(z.begin(), z.end());
+        *count = (int)z.size();
+        if (idx) for (int i = 0; i < (int)z.size() && i < capacity; ++i) idx[i] = z[i] + h->opts.index_base;
+        return MI355X_KKT_SUCCESS;
+    } catch (...) { h->err = "failed_pivots: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+/* the structural edit itself, driven by the caller: host work only (the device side follows when there is one) */
+int mi355x_kkt_delay_columns(mi355x_kkt_handle h, const int* cols, int count, int* moved)
+{
+    if (!h || (count > 0 && !cols)) return MI355X_KKT_FATAL;
+    if (!h->analysed) { h->err = "delay_columns: analyse() has not been called"; return MI355X_KKT_FATAL; }
+    try {
+        std::vector<int> marks; marks.reserve(count > 0 ? count : 0);
+        for (int i = 0; i < count; ++i) { const int c = cols[i] - h->opts.index_base; if (c < 0 || c >= h->sym.n) { h->err = "delay_columns: index out of range"; return MI355X_KKT_FATAL; } marks.push_back(h->sym.iperm[c]); }
+        int mv = 0;
+        const bool ok = apply_delays(h, marks, &mv);
+        if (moved) *moved = mv;
+        if (ok) { h->factored = false; if (h->numeric_ready && !h->num->restructure(h->sym)) { h->err = h->num->error(); h->numeric_ready = false; return MI355X_KKT_FATAL; } }
+        return MI355X_KKT_SUCCESS;
+    } catch (const std::bad_alloc&) { h->err = "delay_columns: out of host memory"; return MI355X_KKT_FATAL; }
+    catch (...) { h->err = "delay_columns: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+
 // ---- device-side value assembly ----
 int mi355x_kkt_assembly_define(mi355x_kkt_handle h, int nseg, const int64_t* offset, const int64_t* length)
 {
@@ -207,6 +293,7 @@ int mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const 
     try {
         FactorStats st;
         if (!h->num->factor_assembled(scale, shift, st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
+        if (!delay_and_refactor(h, st)) return MI355X_KKT_FATAL;
         h->last = st; h->factored = true; h->stats_stale = false;
         if (num_neg) *num_neg = st.num_neg;
         if (num_zero) *num_zero = st.num_zero;
@@ -270,6 +357,13 @@ int mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u)
     return MI355X_KKT_SUCCESS;
 }
 
+int mi355x_kkt_set_delay_rounds(mi355x_kkt_handle h, int rounds)
+{
+    if (!h || rounds < 0) return MI355X_KKT_FATAL;
+    h->opts.delay_rounds = rounds;
+    return MI355X_KKT_SUCCESS;
+}
+
 int mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax)
 {
     if (!h) return MI355X_KKT_FATAL;
@@ -314,6 +408,7 @@ int mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info)
     info->num_neg = h->last.num_neg; info->num_zero = h->last.num_zero; info->num_two = h->last.num_two; info->num_small = h->last.num_small;
     info->u_sensitive = h->factored ? h->last.u_sensitive : 1; info->pivtol = h->opts.pivtol;
     info->num_fast_blocks = h->factored ? h->last.num_fast : 0;
+    info->num_delayed = h->num_delayed; info->num_restructures = h->num_restructures;
     info->time_analyse = S.time_analyse;
     if (h->num) { info->time_factor_ms = h->num->last_factor_ms(); info->time_solve_ms = h->num->last_solve_ms(); }
     return MI355X_KKT_SUCCESS;

@@ -58,6 +58,9 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
    roptions->AddLowerBoundedIntegerOption("mi355x_verbose", "Verbosity of the MI355X backend.", 0, 0, "");
    // multi-GPU: one Ipopt process per GPU, every process runs the same algorithm, the KKT factorisation is shared
    // (elimination-tree subtrees per rank, RCCL all-reduce at the subtree joins); cf. the SPRAL knobs IpSpralSolverInterface.cpp:55-67
+   roptions->AddLowerBoundedIntegerOption("mi355x_delay_rounds", "Delayed-pivot rounds per factorisation.", 0, 8,
+                                          "Columns that fail the pivot threshold in their front are moved to the parent front and the matrix is refactored, "
+                                          "at most this many times per factorisation (what MA27 / MA57 / MA97 / MUMPS do inside one call); 0 = static pivoting.");
    roptions->AddLowerBoundedIntegerOption("mi355x_nranks", "Number of processes (GPUs) sharing each KKT factorisation.", 0, 0,
                                           "0: take WORLD_SIZE / OMPI_COMM_WORLD_SIZE from the environment (1 if unset).");
    roptions->AddLowerBoundedIntegerOption("mi355x_rank", "Rank of this process among mi355x_nranks.", -1, -1,
@@ -110,6 +113,10 @@ void Mi355xSolverInterface::ReadNumericOptions(const OptionsList& options, const
       if( options.GetIntegerValue("mi355x_max_sn_cols", iv, prefix) )
       {
          kopts.max_sn_cols = iv;
+      }
+      if( options.GetIntegerValue("mi355x_delay_rounds", iv, prefix) )
+      {
+         kopts.delay_rounds = iv;
       }
       if( options.GetIntegerValue("mi355x_device", iv, prefix) )
       {
@@ -344,6 +351,15 @@ ESymSolverStatus Mi355xSolverInterface::MultiSolve(bool new_matrix, const Index*
       negevals_ = nneg;
       Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X factor: %d negative eigenvalues, %d zero pivots (status %d)\n",
                      nneg, nzero, st);
+      {
+         // what the MA97 adapter prints from info.num_delay (IpMa97SolverInterface.cpp:719-779): delayed pivots since the analysis
+         mi355x_kkt_info kinfo;
+         if( mi355x_kkt_get_info(handle_, &kinfo) == MI355X_KKT_SUCCESS && (kinfo.num_delayed > 0 || kinfo.num_small > 0) )
+         {
+            Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X factor: %d delayed pivots in %d structure edits so far, %d pivots forced\n",
+                           kinfo.num_delayed, kinfo.num_restructures, kinfo.num_small);
+         }
+      }
       if( st == MI355X_KKT_SINGULAR )
       {
          return SYMSOLVER_SINGULAR;
@@ -398,8 +414,11 @@ ESymSolverStatus Mi355xSolverInterface::DetermineDependentRows(const Index* /*ia
    int nneg = 0, nzero = 0;
    // (no equilibration here: exact cancellations between dependent rows should stay exact; the MUMPS adapter likewise
    //  switches its permuting scaling off for this call, IpMumpsSolverInterface.cpp:632-641)
+   //  and no delayed-pivot rounds: a dependent row stays a zero pivot wherever it is eliminated, moving it up only costs refactorisations)
    mi355x_kkt_set_scaling(handle_, 0, NULL);
+   mi355x_kkt_set_delay_rounds(handle_, 0);
    int st = mi355x_kkt_factor(handle_, NULL, &nneg, &nzero);
+   mi355x_kkt_set_delay_rounds(handle_, kopts_.delay_rounds);
    mi355x_kkt_set_scaling(handle_, kopts_.scaling, NULL);
    if( st == MI355X_KKT_FATAL )
    {

@@ -29,7 +29,7 @@ void fill_info(Keep* k, mi355x_ma97_info* info)
     if (!k->h || mi355x_kkt_get_info(k->h, &I) != 0) return;
     info->maxdepth = I.num_levels; info->maxfront = I.maxfront; info->maxsupernode = I.maxsupernode;
     info->num_factor = (long)I.nnz_l; info->num_flops = (long)I.flops_factor; info->num_sup = I.num_sn;
-    info->num_neg = I.num_neg; info->num_two = I.num_two; info->num_delay = I.num_small; info->matrix_rank = I.n - I.num_zero;
+    info->num_neg = I.num_neg; info->num_two = I.num_two; info->num_delay = I.num_delayed + I.num_small;      /* columns moved to a parent front + what had to be forced */ info->matrix_rank = I.n - I.num_zero;
 }
 
 bool do_analyse(Keep* k, const mi355x_ma97_control* c, const double* val, mi355x_ma97_info* info)

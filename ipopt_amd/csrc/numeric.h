@@ -59,10 +59,16 @@ public:
     bool   get_scaling(double* out_orig_numbering);                             // factors of the last factorisation
     // first touch of the device (context, code objects) and the pinned staging buffer: independent of the analysis, so the C API runs it on a
     // thread next to it (0.1-0.3 s of an Ipopt run's LinearSystemSymbolicFactorization otherwise).  Returns the buffer or nullptr.
+    static int   resolve_device(int device);              // on the caller's thread: the ordinal `device` (or the current device for -1) means, -1 without a device
     static void* prewarm(int device, size_t count);
     static void prewarm_discard(void* p);
     static bool ruiz_triplet(int device, int n, int nnz, const int* irn, const int* jcn, const double* a, int base, int sweeps, double* out, std::string& err);
     bool   zero_pivots(std::vector<int>& idx0);           // columns (original numbering, 0-based) with a zero pivot in the last factorisation
+    // delayed pivoting across fronts: the columns (CURRENT permuted numbering) the last factorisation could not pivot, and the re-setup of
+    // everything that depends on the elimination structure once symbolic.cpp has moved them to their parent fronts (values, assembly and
+    // primal-dual state, scaling factors, communicator and the pinned buffers handed to the caller survive)
+    bool   failed_pivots(std::vector<int>& cols_perm);
+    bool   restructure(const Symbolic& S);
     // device-side value assembly: triplet values = concatenated segments, each  scale * src + shift  from a device-resident source
     bool   assembly_define(int nseg, const int64_t* off, const int64_t* len);
     double* assembly_buffer(int seg);                      // pinned staging of the segment's source values

@@ -305,32 +305,49 @@ public:
         prof_used = 0; prof_kind.clear();
     }
     ~NumericImpl() { release(); for (auto e : prof_ev) (void)hipEventDestroy(e); }
-    void release() {
+    // keep = true (restructure): what does not depend on the elimination structure survives -- the communicator, the streams, the pinned
+    // staging buffers handed out to the caller (values_buffer, assembly buffers), the device copy of the triplet values, the assembly
+    // sources, the primal-dual workspace (it reads the triplet values and calls solve), the caller's scaling factors (original numbering)
+    double* keep_tvals = nullptr;
+    void release(bool keep = false) {
         DeviceGuard guard(dev);
-        if (rccl.comm && rccl.CommDestroy) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
-        comm_kind = 0;
+        if (!keep) { if (rccl.comm && rccl.CommDestroy) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
+                     comm_kind = 0; }
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
-        for (void* p : allocs) (void)hipFree(p);
+        keep_tvals = nullptr;
+        for (void* p : allocs) {
+            if (keep && p == (void*)V.tvals) { keep_tvals = (double*)p; continue; }
+            if (keep && p == (void*)d_user_scale) continue;
+            (void)hipFree(p);
+        }
         allocs.clear();
+        if (keep && keep_tvals) allocs.push_back(keep_tvals);
+        if (keep && d_user_scale) allocs.push_back(d_user_scale); else d_user_scale = nullptr;
         if (d_rhs) { (void)hipFree(d_rhs); d_rhs = nullptr; d_rhs_cap = 0; }
-        if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
-        if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
-        asm_.nseg = 0;
-        pd_free();
-        if (h_vals) { (void)hipHostFree(h_vals); h_vals = nullptr; }
-        if (h_stats) { (void)hipHostFree(h_stats); h_stats = nullptr; }
-        if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
-        if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        if (!keep) {
+            if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
+            if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
+            asm_.nseg = 0;
+            pd_free();
+            if (h_vals) { (void)hipHostFree(h_vals); h_vals = nullptr; }
+            if (h_stats) { (void)hipHostFree(h_stats); h_stats = nullptr; }
+            if (ev0) { (void)hipEventDestroy(ev0); ev0 = nullptr; }
+            if (ev1) { (void)hipEventDestroy(ev1); ev1 = nullptr; }
+        }
         for (auto e : la_evA) if (e) (void)hipEventDestroy(e);
         for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
         la_evA.clear(); la_evB.clear();
         { std::vector<GrpSched*> all{&gs_single, &gs_local}; for (auto& g : gs_stage) all.push_back(&g);
           for (GrpSched* g : all) { for (auto e : g->evA) if (e) (void)hipEventDestroy(e); for (auto e : g->evB) if (e) (void)hipEventDestroy(e); g->evA.clear(); g->evB.clear(); } }
         for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
-        if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
-        if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
-        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        ch_bulk_last = ch_far_last = la_last = nullptr; ch_bulk_pending = ch_far_pending = la_pending = false;
+        if (!keep) {
+            if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
+            if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
+            if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        }
+        arena_doubles = 0; toprhs_doubles = 0;
         ready = false;
     }
     template <class T, class A> bool upload(const std::vector<T, A>& h, const T** d) {
@@ -345,18 +362,28 @@ public:
         *d = p; return true;
     }
 
-    bool setup(const Symbolic& Sy, const NumericOptions& o) {
-        release(); S = &Sy; opt = o;
+    // Delayed pivots changed the structure (symbolic.cpp restructure_delays): everything derived from it is rebuilt, the rest (see release) stays
+    bool restructure(const Symbolic& Sy) {
+        if (!have_device || !stream) { err_ = "restructure: solver not set up"; return false; }
+        { DeviceGuard guard(dev); (void)hipStreamSynchronize(stream); if (stream2) (void)hipStreamSynchronize(stream2); if (stream3) (void)hipStreamSynchronize(stream3); }
+        const NumericOptions o = opt;
+        const bool hv = have_values;
+        if (!setup(Sy, o, true)) return false;
+        have_values = hv;
+        return true;
+    }
+    bool setup(const Symbolic& Sy, const NumericOptions& o, bool keep = false) {
+        release(keep); S = &Sy; opt = o;
         auto now_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         double t_prev = now_();
         auto lap = [&](const char* what) { if (opt.verbose >= 2) { const double t = now_(); fprintf(stderr, "[mi355x_kkt]   setup %-28s %.3f s\n", what, t - t_prev); t_prev = t; } };
         int ndev = 0;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
             err_ = "no HIP device available: the MI355X KKT backend has no CPU fallback"; have_device = false; return false; }
-        if (opt.device >= 0) dev = opt.device; else HIPCHK(hipGetDevice(&dev));
+        if (keep) { /* the device of the first setup */ } else if (opt.device >= 0) dev = opt.device; else HIPCHK(hipGetDevice(&dev));
         DeviceGuard guard(dev);
         have_device = true;
-        {   // the main stream carries the latency-bound pivot chains: highest priority; the look-ahead stream the lowest
+        if (!keep) {   // the main stream carries the latency-bound pivot chains: highest priority; the look-ahead stream the lowest
             int plo = 0, phi = 0;
             (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
             HIPCHK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, phi));
@@ -368,14 +395,16 @@ public:
         if (const char* e = getenv("MI355X_KKT_CHAIN_LA_MAXF")) chain_maxf = std::max(1, atoi(e));
         if (const char* e = getenv("MI355X_KKT_LA_WGS")) la_wgs = std::max(1, atoi(e));          // development knobs
         if (const char* e = getenv("MI355X_KKT_LA_MIN_NT")) la_min_nt = std::max(3, atoi(e));
-        HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
-        if (opt.prewarmed_vals && opt.prewarmed_count >= std::max<size_t>(Sy.nnz_in, 1)) h_vals = (double*)opt.prewarmed_vals;       // (made while the analysis ran)
-        else {
-            if (opt.prewarmed_vals) (void)hipHostFree(opt.prewarmed_vals);
-            HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
+        if (!keep) {
+            HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
+            if (opt.prewarmed_vals && opt.prewarmed_count >= std::max<size_t>(Sy.nnz_in, 1)) h_vals = (double*)opt.prewarmed_vals;       // (made while the analysis ran)
+            else {
+                if (opt.prewarmed_vals) (void)hipHostFree(opt.prewarmed_vals);
+                HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
+            }
+            HIPCHK(hipHostMalloc((void**)&h_stats, 8 * sizeof(int), hipHostMallocDefault));
         }
         opt.prewarmed_vals = nullptr;
-        HIPCHK(hipHostMalloc((void**)&h_stats, 8 * sizeof(int), hipHostMallocDefault));
         lap("device, streams, pinned buffer");
         std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
@@ -526,7 +555,7 @@ public:
         // sweep runs the whole segment: workgroups wait on flags for exactly what they consume (see k_fwd_chain / k_bwd_chain) ----
         std::vector<ChainLink> chl; std::vector<ChainDesc> chd; std::vector<int> chwait, wgf, wgb;
         int ntailflags = 0, ndots = 0;
-        chain_segs.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
+        chain_segs.clear(); in_seg.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
         chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
         V.fastpiv = getenv("MI355X_KKT_NO_FASTPIV") == nullptr ? 1 : 0;
@@ -916,8 +945,9 @@ public:
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
             !upload(Sy.perm, &V.perm)) return false;
         lap("uploads");
-        double* tv = nullptr;
-        if (!dalloc(&tv, Sy.nnz_in)) return false; V.tvals = tv;
+        double* tv = keep ? keep_tvals : nullptr;
+        if (!tv && !dalloc(&tv, Sy.nnz_in)) return false;
+        V.tvals = tv;
         V.rslot_len = (int)Sy.rslot_idx.size();
         if (!dalloc(&V.arv, Sy.rslot_idx.size()) || !dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.scale2, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
@@ -926,8 +956,8 @@ public:
             !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
             !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
-        if (opt.scaling == 3) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
-        else if (opt.scaling == 2) opt.scaling = 1;       // (user factors can only come through set_scaling)
+        if (opt.scaling == 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
+        else if (opt.scaling == 2 && !d_user_scale) opt.scaling = 1;       // (user factors can only come through set_scaling)
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
         if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 128)) return false; }
@@ -1613,6 +1643,7 @@ public:
         HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
         st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4] != 0; st.num_fast = h_stats[7];
+        if (h_stats[5] != 0) { err_ = "factor: a panel workgroup timed out waiting for its pivot block on some rank (workgroups not co-resident?)"; return false; }      // (a sum over the ranks)
         return true;
     }
     bool enqueue_fwd_local(const double* src) {
@@ -1690,8 +1721,28 @@ public:
         if (!ready) { err_ = "zero_pivots: solver not set up"; return false; }
         std::vector<int> z(S->n);
         if (S->n > 0) HIPCHK(hipMemcpy(z.data(), V.zpiv, (size_t)S->n * sizeof(int), hipMemcpyDeviceToHost));
-        for (int i = 0; i < S->n; ++i) if (z[i]) out.push_back(S->perm[i]);
+        for (int i = 0; i < S->n; ++i) if (z[i] & 1) out.push_back(S->perm[i]);      // (bit 1: delayed-pivot mark, failed_pivots)
         std::sort(out.begin(), out.end());
+        return true;
+    }
+    // the columns (CURRENT permuted numbering) the last factorisation could not pivot and eliminated by static pivoting: the
+    // delayed pivots of a solver with dynamic fronts (bit 1 of zpiv: ldlt_reg when every candidate of a front had failed, k_big_trsm a posteriori).
+    // Multi-GPU: every rank sees the marks of the fronts it factored; the union is formed through the communicator (same list on every rank).
+    bool failed_pivots(std::vector<int>& out) {
+        DeviceGuard guard(dev);
+        out.clear();
+        if (!ready) { err_ = "failed_pivots: solver not set up"; return false; }
+        const int n = S->n;
+        std::vector<int> z(std::max(n, 1));
+        if (n > 0) HIPCHK(hipMemcpy(z.data(), V.zpiv, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
+        if (multi && comm_kind != 0 && n > 0) {
+            for (int i = 0; i < n; ++i) z[i] = (z[i] >> 1) & 1;
+            HIPCHK(hipMemcpyAsync(V.colfail, z.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+            if (!allreduce(V.colfail, n, 1)) return false;
+            HIPCHK(hipMemcpyAsync(z.data(), V.colfail, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            for (int i = 0; i < n; ++i) if (z[i]) out.push_back(i);
+        } else for (int i = 0; i < n; ++i) if (z[i] & 2) out.push_back(i);
         return true;
     }
     bool debug_clocks(unsigned long long* out) {
@@ -1752,6 +1803,16 @@ Numeric::Numeric() : p_(new NumericImpl) {}
 Numeric::~Numeric() { delete p_; }
 bool Numeric::setup(const Symbolic& S, const NumericOptions& opt) { return p_->setup(S, opt); }
 double* Numeric::values_buffer() { return p_->h_vals; }
+// the ordinal a handle created with `device` will use, resolved on the CALLER's thread (HIP's current device is per thread: a helper thread
+// asking for "the current device" gets device 0 whatever the caller selected); -1: no usable device
+int Numeric::resolve_device(int device)
+{
+    if (device >= 0) return device;
+    int ndev = 0, dev = -1;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
 void* Numeric::prewarm(int device, size_t count)
 {
     int ndev = 0;
@@ -1788,6 +1849,8 @@ bool Numeric::solve_top_and_bwd(double* drhs) { return p_->solve_top_and_bwd(drh
 bool Numeric::set_scaling(int mode, const double* user) { return p_->set_scaling(mode, user); }
 bool Numeric::get_scaling(double* out) { return p_->get_scaling(out); }
 bool Numeric::zero_pivots(std::vector<int>& out) { return p_->zero_pivots(out); }
+bool Numeric::failed_pivots(std::vector<int>& out) { return p_->failed_pivots(out); }
+bool Numeric::restructure(const Symbolic& S) { return p_->restructure(S); }
 bool Numeric::assembly_define(int nseg, const int64_t* off, const int64_t* len) { return p_->assembly_define(nseg, off, len); }
 double* Numeric::assembly_buffer(int seg) { return p_->assembly_buffer(seg); }
 bool Numeric::assembly_upload(int seg) { return p_->assembly_upload(seg); }

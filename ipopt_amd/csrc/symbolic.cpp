@@ -567,6 +567,322 @@ double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock:
 
 } // namespace
 
+// ---------------------------------------------------------------------------------------
+// Everything that follows from (permutation, permuted pattern, supernode partition): row structures, relative indices,
+// levels, classes, multi-GPU ownership, storage.  Shared by analyse() and restructure_delays().
+// ---------------------------------------------------------------------------------------
+static bool finish_analysis(Symbolic& S, const SymbolicOptions& opt, const std::function<void(const char*)>& lap)
+{
+    const int n = S.n;
+    const int nsn = S.num_sn;
+    S.sn_of.resize(n);
+    for (int s = 0; s < nsn; ++s) for (int j = S.sn_colptr[s]; j < S.sn_colptr[s + 1]; ++j) S.sn_of[j] = s;
+
+    lap("supernodes");
+    // ---- 9. supernodal row structures ----
+    S.sn_rowptr.assign(nsn + 1, 0); S.sn_parent.assign(nsn, -1);
+    S.sn_rows.clear(); S.sn_rows.reserve((size_t)n * 4);
+    {
+        vector<int> mark(n, -1), upd;
+        vector<int> chead(nsn, -1), cnext(nsn, -1);
+        for (int s = 0; s < nsn; ++s) {
+            int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1];
+            upd.clear();
+            for (int j = c0; j < c1; ++j)
+                for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) { int i = S.arow[p]; if (i >= c1 && mark[i] != s) { mark[i] = s; upd.push_back(i); } }
+            for (int c = chead[s]; c != -1; c = cnext[c]) {
+                int kc = S.sn_colptr[c + 1] - S.sn_colptr[c];
+                for (int p = S.sn_rowptr[c] + kc; p < S.sn_rowptr[c + 1]; ++p) { int i = S.sn_rows[p]; if (i >= c1 && mark[i] != s) { mark[i] = s; upd.push_back(i); } }
+            }
+            std::sort(upd.begin(), upd.end());
+            S.sn_rowptr[s] = (int)S.sn_rows.size();
+            for (int j = c0; j < c1; ++j) S.sn_rows.push_back(j);
+            S.sn_rows.insert(S.sn_rows.end(), upd.begin(), upd.end());
+            S.sn_rowptr[s + 1] = (int)S.sn_rows.size();
+            if (!upd.empty()) { int p = S.sn_of[upd[0]]; S.sn_parent[s] = p; cnext[s] = chead[p]; chead[p] = s; }
+        }
+    }
+    S.sum_sn_rows = (int64_t)S.sn_rows.size();
+    // children lists (ascending)
+    S.child_ptr.assign(nsn + 1, 0);
+    for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_ptr[S.sn_parent[s] + 1]++;
+    for (int s = 0; s < nsn; ++s) S.child_ptr[s + 1] += S.child_ptr[s];
+    S.child_idx.resize(S.child_ptr[nsn]);
+    { vector<int> pos(S.child_ptr.begin(), S.child_ptr.end() - 1);
+      for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_idx[pos[S.sn_parent[s]]++] = s; }
+
+    lap("row structures");
+    {   // symmetric row view of the permuted pattern (equilibration gather)
+        const int nnzA = S.nnz_a;
+        S.rslot_ptr.assign(n + 1, 0);
+        for (int q = 0; q < nnzA; ++q) { S.rslot_ptr[S.arow[q] + 1]++; if (S.arow[q] != S.acol[q]) S.rslot_ptr[S.acol[q] + 1]++; }
+        for (int i = 0; i < n; ++i) S.rslot_ptr[i + 1] += S.rslot_ptr[i];
+        S.rslot_idx.resize(S.rslot_ptr[n]);
+        vector<int> pos(S.rslot_ptr.begin(), S.rslot_ptr.end() - 1);
+        S.rslot_col.resize(S.rslot_ptr[n]);
+        for (int q = 0; q < nnzA; ++q) {
+            const int r = S.arow[q], c = S.acol[q];
+            S.rslot_col[pos[r]] = c; S.rslot_idx[pos[r]++] = q;
+            if (r != c) { S.rslot_col[pos[c]] = r; S.rslot_idx[pos[c]++] = q; }
+        }
+    }
+    // ---- 10. relative indices, A scatter positions, levels, offsets, stats ----
+    S.rel.assign(S.sn_rows.size(), -1);
+    {
+        const int T = analysis_threads();
+        std::atomic<int> bad(0);
+        parallel_chunks(nsn, T, [&](long long sb, long long se, int) {        // (supernodes are independent; chunks of consecutive supernodes carry similar work)
+            for (int s = (int)sb; s < (int)se; ++s) {
+                int p = S.sn_parent[s]; if (p < 0) continue;
+                int k = S.sn_colptr[s + 1] - S.sn_colptr[s];
+                int p0 = S.sn_colptr[p], p1 = S.sn_colptr[p + 1], kp = p1 - p0;
+                int q = S.sn_rowptr[p] + kp, qe = S.sn_rowptr[p + 1];
+                for (int t = S.sn_rowptr[s] + k; t < S.sn_rowptr[s + 1]; ++t) {
+                    int r = S.sn_rows[t];
+                    if (r < p1) { S.rel[t] = r - p0; continue; }
+                    while (q < qe && S.sn_rows[q] < r) ++q;
+                    if (q >= qe || S.sn_rows[q] != r) { bad.store(1, std::memory_order_relaxed); break; }
+                    S.rel[t] = kp + (q - (S.sn_rowptr[p] + kp));
+                }
+            }
+        });
+        if (bad.load()) { S.error = "analyse: internal error (child row missing in parent front)"; return false; }
+        S.apos.resize(S.nnz_a);
+        parallel_chunks(nsn, T, [&](long long sb, long long se, int) {
+            for (int s = (int)sb; s < (int)se; ++s) {
+                int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1], k = c1 - c0;
+                int m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+                for (int j = c0; j < c1; ++j) {
+                    int q = S.sn_rowptr[s] + k, qe = S.sn_rowptr[s + 1];
+                    for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) {
+                        int i = S.arow[p], lr;
+                        if (i < c1) lr = i - c0;
+                        else { while (q < qe && S.sn_rows[q] < i) ++q;
+                               if (q >= qe || S.sn_rows[q] != i) { bad.store(2, std::memory_order_relaxed); break; }
+                               lr = k + (q - (S.sn_rowptr[s] + k)); }
+                        S.apos[p] = lr + (j - c0) * m;
+                    }
+                }
+            }
+        });
+        if (bad.load()) { S.error = "analyse: internal error (A row missing in front)"; return false; }
+    }
+    S.sn_level.assign(nsn, 0);
+    for (int s = 0; s < nsn; ++s) { int p = S.sn_parent[s]; if (p >= 0) S.sn_level[p] = std::max(S.sn_level[p], S.sn_level[s] + 1); }
+    S.num_levels = 0; for (int s = 0; s < nsn; ++s) S.num_levels = std::max(S.num_levels, S.sn_level[s] + 1);
+    S.sn_class.resize(nsn);
+    for (int s = 0; s < nsn; ++s) {
+        int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+        S.sn_class[s] = m <= 32 ? FC_WAVE : (m <= 64 ? FC_LDS64 : (m <= 128 ? FC_LDS128 : FC_BIG));
+        if (S.sn_class[s] == FC_BIG) S.num_big++;
+        S.nnz_l += k * m - k * (k - 1) / 2;
+        for (int64_t j = 0; j < k; ++j) { int64_t c = m - j; S.flops_factor += (c - 1) * (c + 2); }
+        S.maxfront = std::max<int>(S.maxfront, (int)m); S.maxsupernode = std::max<int>(S.maxsupernode, (int)k);
+    }
+    S.minv_off.resize(nsn);
+    { int64_t mo = 0; for (int s = 0; s < nsn; ++s) { int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s]; S.minv_off[s] = mo; mo += k * k; } S.minv_doubles = mo; }
+    // level schedule buckets (level, class)
+    S.level_ptr.assign((size_t)S.num_levels * FC_COUNT + 1, 0);
+    for (int s = 0; s < nsn; ++s) S.level_ptr[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s] + 1]++;
+    for (size_t b = 0; b + 1 < S.level_ptr.size(); ++b) S.level_ptr[b + 1] += S.level_ptr[b];
+    S.level_sn.resize(nsn);
+    { vector<int> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
+      for (int s = 0; s < nsn; ++s) S.level_sn[pos[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s]]++] = s; }
+
+    lap("rel/apos/levels");
+    // ---- 11. multi-GPU ownership: proportional subtree-to-rank mapping ----
+    S.sn_owner.assign(nsn, opt.nranks > 1 ? -1 : 0);
+    S.sn_glo.assign(nsn, 0); S.sn_gsz.assign(nsn, std::max(1, opt.nranks)); S.sn_gdepth.assign(nsn, 0); S.num_gdepths = 1;
+    if (opt.nranks > 1 && opt.subcube) {
+        // SUBTREE-TO-SUBCUBE mapping: a front of the top of the tree is needed only by the ranks whose subtrees lie beneath it, so it is
+        // replicated on THAT range of ranks [glo, glo + gsz) instead of on all of them.  Recursive bisection of (set of sibling subtrees,
+        // range of ranks): a set is split into two bins of about equal work (LPT), the range in proportion; the heaviest member of a set is
+        // OPENED -- its front joins the replicated part of the range, its children join the set -- while that shortens the critical rank's
+        // work (a lone member is always opened: that is how a separator chain stays with its range).  A range of one rank owns what is left.
+        // gdepth = number of bisections above the range: the exchange steps run deepest ranges first, all ranges of one depth in ONE
+        // collective (every rank takes part in every step, which is what keeps the sequence deadlock-free by construction).
+        vector<double> work(nsn, 0.0), own(nsn, 0.0);
+        for (int s = 0; s < nsn; ++s) {
+            double k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+            own[s] = k * m * m + 64.0; work[s] += own[s];
+            if (S.sn_parent[s] >= 0) work[S.sn_parent[s]] += work[s];
+        }
+        struct Split { vector<int> bin[2]; double load[2]; int g[2]; double crit; };
+        auto split_set = [&](const vector<int>& set, int g) {
+            vector<int> order(set);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
+            Split best; best.crit = -1;
+            for (int g0 = 1; g0 < g; ++g0) {              // every way of sharing the range out; the members go, heaviest first, where the load per rank stays lowest
+                if (g > 4 && g0 != g / 2 && g0 != g - g / 2 && g0 != 1 && g0 != g - 1) continue;
+                Split sp; sp.load[0] = sp.load[1] = 0; sp.g[0] = g0; sp.g[1] = g - g0;
+                for (int c : order) { const int b = (sp.load[0] + work[c]) / sp.g[0] <= (sp.load[1] + work[c]) / sp.g[1] ? 0 : 1; sp.bin[b].push_back(c); sp.load[b] += work[c]; }
+                sp.crit = std::max(sp.load[0] / sp.g[0], sp.load[1] / sp.g[1]);
+                if (best.crit < 0 || sp.crit < best.crit * (1.0 - 1e-12)) best = sp;
+            }
+            return best;
+        };
+        std::function<void(int, int)> own_subtree = [&](int root, int r) {
+            vector<int> st(1, root);
+            while (!st.empty()) { const int s = st.back(); st.pop_back(); S.sn_owner[s] = r; S.sn_glo[s] = r; S.sn_gsz[s] = 1; S.sn_gdepth[s] = 0;
+                                  for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) st.push_back(S.child_idx[q]); }
+        };
+        int maxdepth = 0;
+        std::function<void(vector<int>, int, int, int)> assign = [&](vector<int> set, int a, int g, int depth) {
+            if (set.empty()) return;
+            if (g == 1) { for (int c : set) own_subtree(c, a); return; }
+            for (int guard = 0; guard < nsn; ++guard) {
+                int heavy = set[0];
+                for (int c : set) if (work[c] > work[heavy] || (work[c] == work[heavy] && c < heavy)) heavy = c;
+                const bool can_open = S.child_ptr[heavy + 1] > S.child_ptr[heavy];
+                bool open = false;
+                if (set.size() == 1) open = can_open;
+                else if (can_open) {
+                    vector<int> set2;
+                    for (int c : set) if (c != heavy) set2.push_back(c);
+                    for (int q = S.child_ptr[heavy]; q < S.child_ptr[heavy + 1]; ++q) set2.push_back(S.child_idx[q]);
+                    open = own[heavy] + split_set(set2, g).crit < 0.98 * split_set(set, g).crit;
+                }
+                if (!open) break;
+                S.sn_owner[heavy] = -1; S.sn_glo[heavy] = a; S.sn_gsz[heavy] = g; S.sn_gdepth[heavy] = depth; maxdepth = std::max(maxdepth, depth);
+                set.erase(std::find(set.begin(), set.end(), heavy));
+                for (int q = S.child_ptr[heavy]; q < S.child_ptr[heavy + 1]; ++q) set.push_back(S.child_idx[q]);
+                if (set.empty()) return;
+            }
+            if (set.size() == 1) { own_subtree(set[0], a); return; }      // a leaf front nobody can split: one rank takes it
+            Split sp = split_set(set, g);
+            assign(sp.bin[0], a, sp.g[0], depth + 1);
+            assign(sp.bin[1], a + sp.g[0], sp.g[1], depth + 1);
+        };
+        vector<int> roots;
+        for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] < 0) roots.push_back(s);
+        assign(roots, 0, opt.nranks, 0);
+        S.num_gdepths = maxdepth + 1;
+    } else if (opt.nranks > 1) {
+        // subtree work estimates
+        vector<double> work(nsn, 0.0);
+        for (int s = 0; s < nsn; ++s) {
+            double k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+            work[s] += k * m * m + 64.0;   // flops-ish + launch overhead weight
+            if (S.sn_parent[s] >= 0) work[S.sn_parent[s]] += work[s];
+        }
+        // grow a frontier of subtree roots from the tree roots until there are enough, balanced pieces
+        std::set<std::pair<double,int>, std::greater<std::pair<double,int>>> front;
+        double total = 0;
+        for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] < 0) { front.insert({work[s], s}); total += work[s]; }
+        const double target = total / opt.nranks;
+        auto total_sub = [](const std::set<std::pair<double,int>, std::greater<std::pair<double,int>>>& f) { double t = 0; for (auto& e : f) t += e.first; return t; };
+        int guard = 0;
+        while (!front.empty() && guard++ < nsn) {
+            auto top = *front.begin();
+            // split the heaviest frontier subtree until there are >= 2 pieces per rank and none is heavier than 60% of a
+            // rank's share: deeper cuts only move work into the REPLICATED top, which every rank repeats (Amdahl)
+            bool enough = ((int)front.size() >= 2 * opt.nranks && top.first <= 0.6 * target) ||
+                          ((int)front.size() >= opt.nranks && top.first <= 1.15 * (total_sub(front) / opt.nranks));
+            if (enough) break;
+            int s = top.second;
+            if (S.child_ptr[s + 1] == S.child_ptr[s]) {   // leaf: cannot split; stop if it is the biggest
+                break;
+            }
+            front.erase(front.begin());
+            // s moves to the replicated top; its children join the frontier
+            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) front.insert({work[S.child_idx[q]], S.child_idx[q]});
+        }
+        // greedy LPT assignment of frontier subtrees to ranks
+        vector<double> load(opt.nranks, 0.0);
+        vector<int> root_owner(nsn, -2);
+        for (auto& e : front) { int r = (int)(std::min_element(load.begin(), load.end()) - load.begin()); load[r] += e.first; root_owner[e.second] = r; }
+        // propagate ownership down (parents have larger indices than children)
+        for (int s = nsn - 1; s >= 0; --s) {
+            if (root_owner[s] >= 0) S.sn_owner[s] = root_owner[s];
+            else if (S.sn_parent[s] >= 0 && S.sn_owner[S.sn_parent[s]] >= 0) S.sn_owner[s] = S.sn_owner[S.sn_parent[s]];
+            else S.sn_owner[s] = -1;
+        }
+        for (int s = 0; s < nsn; ++s) if (S.sn_owner[s] >= 0) { S.sn_glo[s] = S.sn_owner[s]; S.sn_gsz[s] = 1; }
+    }
+    lap("ownership");
+    // ---- 12. storage: panels, contribution blocks, in-place separator chains (needs the ownership map) ----
+    S.panel_off.assign(nsn, 0); S.cb_off.assign(nsn, 0); S.sn_ldp.assign(nsn, 0); S.sn_ldt.assign(nsn, 0); S.alias_child.assign(nsn, -1);
+    {
+        auto K = [&](int s) { return (int64_t)(S.sn_colptr[s + 1] - S.sn_colptr[s]); };
+        auto Mf = [&](int s) { return (int64_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]); };
+        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG)
+            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
+                const int c = S.child_idx[q];
+                if (S.sn_class[c] == FC_BIG && Mf(c) - K(c) == Mf(s) && S.sn_owner[c] == S.sn_owner[s] && S.sn_glo[c] == S.sn_glo[s] && S.sn_gsz[c] == S.sn_gsz[s]) { S.alias_child[s] = c; break; }
+            }
+        int64_t loff = 0, coff = 0;
+        for (int s = 0; s < nsn; ++s) if (S.alias_child[s] < 0) loff += Mf(s) * K(s);
+        S.l_doubles = loff;
+        loff = 0;
+        for (int s = 0; s < nsn; ++s) {
+            const int64_t k = K(s), m = Mf(s), mu = m - k;
+            const int ac = S.alias_child[s];
+            if (ac < 0) {
+                S.panel_off[s] = loff; loff += m * k; S.sn_ldp[s] = (int)m;
+                S.cb_off[s] = coff; coff += mu * mu; S.sn_ldt[s] = (int)mu;
+            } else {        // children precede parents, so the child's placement is final
+                const int64_t ldc = S.sn_ldt[ac];
+                S.panel_off[s] = S.l_doubles + S.cb_off[ac]; S.sn_ldp[s] = (int)ldc;
+                S.cb_off[s] = S.cb_off[ac] + k * ldc + k; S.sn_ldt[s] = (int)ldc;
+            }
+        }
+        S.cb_doubles = coff;
+        // chain groups: up to `chain_group` consecutive links of an in-place chain (<= 256 columns, consecutive levels) are
+        // ONE unit for the trailing update (a single rank-(sum k) update at the last link; the links before it only update
+        // the group's own remaining columns) and for the triangular solves (one launch pair per group).
+        const int gmax = std::max(1, std::min(opt.chain_group, 4));
+        S.solve_group = opt.solve_group;
+        S.grp_pos.assign(nsn, 0); S.grp_rem.assign(nsn, 0);
+        {   // the latency-bound top of the tree: the levels from which on no level has more than `maxch` BIG fronts
+            int maxch = 8;
+            if (const char* e = getenv("MI355X_KKT_GRP_MAXCHAINS")) maxch = std::max(0, atoi(e));
+            vector<int> nbig(S.num_levels, 0);
+            for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) nbig[S.sn_level[s]]++;
+            S.grp_cut_level = S.num_levels;
+            for (int lv = S.num_levels - 1; lv >= 0 && nbig[lv] <= maxch; --lv) S.grp_cut_level = lv;
+        }
+        vector<int> gcols(nsn, 0), alias_parent(nsn, -1);
+        for (int s = 0; s < nsn; ++s) {
+            const int ac = S.alias_child[s];
+            gcols[s] = (int)K(s);
+            // (a link joins its chain child's group only if that child is its ONLY child: nothing but the chain itself writes into the
+            //  front, so a whole group can be factored in one launch sequence at the level of its first link -- numeric.hip, k_grp_*)
+            if (ac >= 0 && S.grp_pos[ac] + 1 < gmax && gcols[ac] + K(s) <= 256 && S.sn_level[s] == S.sn_level[ac] + 1 &&
+                S.child_ptr[s + 1] - S.child_ptr[s] == 1 && !(S.sn_level[s] >= S.grp_cut_level && S.sn_level[ac] < S.grp_cut_level)) {
+                S.grp_pos[s] = S.grp_pos[ac] + 1; gcols[s] = gcols[ac] + (int)K(s); alias_parent[ac] = s;
+            }
+        }
+        for (int s = nsn - 1; s >= 0; --s) { const int p = alias_parent[s]; if (p >= 0) S.grp_rem[s] = S.grp_rem[p] + (int)K(p); }
+        // forward-solve vectors: an in-place chain shares ONE vector (the parent's entries are the child's update entries)
+        S.cv_off.assign(nsn, 0);
+        int64_t cvo = 0;
+        for (int s = 0; s < nsn; ++s) {
+            const int ac = S.alias_child[s];
+            if (ac >= 0) S.cv_off[s] = S.cv_off[ac] + K(ac);
+            else { S.cv_off[s] = cvo; cvo += Mf(s); }
+        }
+        S.cvec_doubles = cvo;
+        // W = L*D panels of the BIG fronts: per-level scratch in banks (level mod 8) so that the panels of a chain group
+        // (<= 4 consecutive levels) are all alive at the group's trailing update; partial sums of the backward dot products
+        S.wb_off.assign(nsn, -1); S.gpart_off.assign(nsn, -1);
+        vector<int64_t> lvl_used(S.num_levels, 0), lvl_part(S.num_levels, 0);
+        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) {
+            const int lv = S.sn_level[s];
+            S.wb_off[s] = lvl_used[lv]; lvl_used[lv] += Mf(s) * K(s);
+            S.gpart_off[s] = lvl_part[lv]; lvl_part[lv] += ((Mf(s) - K(s) + 255) / 256 + 1) * (int64_t)gcols[s];
+        }
+        // 8 banks: the group after a look-ahead split (numeric.hip) must not overwrite the W panels its predecessor still reads
+        int64_t bank[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bank_base[8];
+        for (int lv = 0; lv < S.num_levels; ++lv) bank[lv & 7] = std::max(bank[lv & 7], lvl_used[lv]);
+        S.wbuf_doubles = 0;
+        for (int b = 0; b < 8; ++b) { bank_base[b] = S.wbuf_doubles; S.wbuf_doubles += bank[b]; }
+        for (int s = 0; s < nsn; ++s) if (S.wb_off[s] >= 0) S.wb_off[s] += bank_base[S.sn_level[s] & 7];
+        S.gpart_doubles = 0;
+        for (int64_t u : lvl_part) S.gpart_doubles = std::max(S.gpart_doubles, u);
+    }
+    return true;
+}
+
 // =======================================================================================
 bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int* ri, const int* ci,
              int format, const double* vals)
@@ -941,316 +1257,128 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
             }
         }
     }
-    const int nsn = S.num_sn;
-    S.sn_of.resize(n);
-    for (int s = 0; s < nsn; ++s) for (int j = S.sn_colptr[s]; j < S.sn_colptr[s + 1]; ++j) S.sn_of[j] = s;
-
-    lap("supernodes");
-    // ---- 9. supernodal row structures ----
-    S.sn_rowptr.assign(nsn + 1, 0); S.sn_parent.assign(nsn, -1);
-    S.sn_rows.clear(); S.sn_rows.reserve((size_t)n * 4);
-    {
-        vector<int> mark(n, -1), upd;
-        vector<int> chead(nsn, -1), cnext(nsn, -1);
-        for (int s = 0; s < nsn; ++s) {
-            int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1];
-            upd.clear();
-            for (int j = c0; j < c1; ++j)
-                for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) { int i = S.arow[p]; if (i >= c1 && mark[i] != s) { mark[i] = s; upd.push_back(i); } }
-            for (int c = chead[s]; c != -1; c = cnext[c]) {
-                int kc = S.sn_colptr[c + 1] - S.sn_colptr[c];
-                for (int p = S.sn_rowptr[c] + kc; p < S.sn_rowptr[c + 1]; ++p) { int i = S.sn_rows[p]; if (i >= c1 && mark[i] != s) { mark[i] = s; upd.push_back(i); } }
-            }
-            std::sort(upd.begin(), upd.end());
-            S.sn_rowptr[s] = (int)S.sn_rows.size();
-            for (int j = c0; j < c1; ++j) S.sn_rows.push_back(j);
-            S.sn_rows.insert(S.sn_rows.end(), upd.begin(), upd.end());
-            S.sn_rowptr[s + 1] = (int)S.sn_rows.size();
-            if (!upd.empty()) { int p = S.sn_of[upd[0]]; S.sn_parent[s] = p; cnext[s] = chead[p]; chead[p] = s; }
-        }
-    }
-    S.sum_sn_rows = (int64_t)S.sn_rows.size();
-    // children lists (ascending)
-    S.child_ptr.assign(nsn + 1, 0);
-    for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_ptr[S.sn_parent[s] + 1]++;
-    for (int s = 0; s < nsn; ++s) S.child_ptr[s + 1] += S.child_ptr[s];
-    S.child_idx.resize(S.child_ptr[nsn]);
-    { vector<int> pos(S.child_ptr.begin(), S.child_ptr.end() - 1);
-      for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_idx[pos[S.sn_parent[s]]++] = s; }
-
-    lap("row structures");
-    {   // symmetric row view of the permuted pattern (equilibration gather)
-        const int nnzA = S.nnz_a;
-        S.rslot_ptr.assign(n + 1, 0);
-        for (int q = 0; q < nnzA; ++q) { S.rslot_ptr[S.arow[q] + 1]++; if (S.arow[q] != S.acol[q]) S.rslot_ptr[S.acol[q] + 1]++; }
-        for (int i = 0; i < n; ++i) S.rslot_ptr[i + 1] += S.rslot_ptr[i];
-        S.rslot_idx.resize(S.rslot_ptr[n]);
-        vector<int> pos(S.rslot_ptr.begin(), S.rslot_ptr.end() - 1);
-        S.rslot_col.resize(S.rslot_ptr[n]);
-        for (int q = 0; q < nnzA; ++q) {
-            const int r = S.arow[q], c = S.acol[q];
-            S.rslot_col[pos[r]] = c; S.rslot_idx[pos[r]++] = q;
-            if (r != c) { S.rslot_col[pos[c]] = r; S.rslot_idx[pos[c]++] = q; }
-        }
-    }
-    // ---- 10. relative indices, A scatter positions, levels, offsets, stats ----
-    S.rel.assign(S.sn_rows.size(), -1);
-    {
-        const int T = analysis_threads();
-        std::atomic<int> bad(0);
-        parallel_chunks(nsn, T, [&](long long sb, long long se, int) {        // (supernodes are independent; chunks of consecutive supernodes carry similar work)
-            for (int s = (int)sb; s < (int)se; ++s) {
-                int p = S.sn_parent[s]; if (p < 0) continue;
-                int k = S.sn_colptr[s + 1] - S.sn_colptr[s];
-                int p0 = S.sn_colptr[p], p1 = S.sn_colptr[p + 1], kp = p1 - p0;
-                int q = S.sn_rowptr[p] + kp, qe = S.sn_rowptr[p + 1];
-                for (int t = S.sn_rowptr[s] + k; t < S.sn_rowptr[s + 1]; ++t) {
-                    int r = S.sn_rows[t];
-                    if (r < p1) { S.rel[t] = r - p0; continue; }
-                    while (q < qe && S.sn_rows[q] < r) ++q;
-                    if (q >= qe || S.sn_rows[q] != r) { bad.store(1, std::memory_order_relaxed); break; }
-                    S.rel[t] = kp + (q - (S.sn_rowptr[p] + kp));
-                }
-            }
-        });
-        if (bad.load()) { S.error = "analyse: internal error (child row missing in parent front)"; return false; }
-        S.apos.resize(S.nnz_a);
-        parallel_chunks(nsn, T, [&](long long sb, long long se, int) {
-            for (int s = (int)sb; s < (int)se; ++s) {
-                int c0 = S.sn_colptr[s], c1 = S.sn_colptr[s + 1], k = c1 - c0;
-                int m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
-                for (int j = c0; j < c1; ++j) {
-                    int q = S.sn_rowptr[s] + k, qe = S.sn_rowptr[s + 1];
-                    for (int p = S.acolptr[j]; p < S.acolptr[j + 1]; ++p) {
-                        int i = S.arow[p], lr;
-                        if (i < c1) lr = i - c0;
-                        else { while (q < qe && S.sn_rows[q] < i) ++q;
-                               if (q >= qe || S.sn_rows[q] != i) { bad.store(2, std::memory_order_relaxed); break; }
-                               lr = k + (q - (S.sn_rowptr[s] + k)); }
-                        S.apos[p] = lr + (j - c0) * m;
-                    }
-                }
-            }
-        });
-        if (bad.load()) { S.error = "analyse: internal error (A row missing in front)"; return false; }
-    }
-    S.sn_level.assign(nsn, 0);
-    for (int s = 0; s < nsn; ++s) { int p = S.sn_parent[s]; if (p >= 0) S.sn_level[p] = std::max(S.sn_level[p], S.sn_level[s] + 1); }
-    S.num_levels = 0; for (int s = 0; s < nsn; ++s) S.num_levels = std::max(S.num_levels, S.sn_level[s] + 1);
-    S.sn_class.resize(nsn);
-    for (int s = 0; s < nsn; ++s) {
-        int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
-        S.sn_class[s] = m <= 32 ? FC_WAVE : (m <= 64 ? FC_LDS64 : (m <= 128 ? FC_LDS128 : FC_BIG));
-        if (S.sn_class[s] == FC_BIG) S.num_big++;
-        S.nnz_l += k * m - k * (k - 1) / 2;
-        for (int64_t j = 0; j < k; ++j) { int64_t c = m - j; S.flops_factor += (c - 1) * (c + 2); }
-        S.maxfront = std::max<int>(S.maxfront, (int)m); S.maxsupernode = std::max<int>(S.maxsupernode, (int)k);
-    }
-    S.minv_off.resize(nsn);
-    { int64_t mo = 0; for (int s = 0; s < nsn; ++s) { int64_t k = S.sn_colptr[s + 1] - S.sn_colptr[s]; S.minv_off[s] = mo; mo += k * k; } S.minv_doubles = mo; }
-    // level schedule buckets (level, class)
-    S.level_ptr.assign((size_t)S.num_levels * FC_COUNT + 1, 0);
-    for (int s = 0; s < nsn; ++s) S.level_ptr[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s] + 1]++;
-    for (size_t b = 0; b + 1 < S.level_ptr.size(); ++b) S.level_ptr[b + 1] += S.level_ptr[b];
-    S.level_sn.resize(nsn);
-    { vector<int> pos(S.level_ptr.begin(), S.level_ptr.end() - 1);
-      for (int s = 0; s < nsn; ++s) S.level_sn[pos[(size_t)S.sn_level[s] * FC_COUNT + S.sn_class[s]]++] = s; }
-
-    lap("rel/apos/levels");
-    // ---- 11. multi-GPU ownership: proportional subtree-to-rank mapping ----
-    S.sn_owner.assign(nsn, opt.nranks > 1 ? -1 : 0);
-    S.sn_glo.assign(nsn, 0); S.sn_gsz.assign(nsn, std::max(1, opt.nranks)); S.sn_gdepth.assign(nsn, 0); S.num_gdepths = 1;
-    if (opt.nranks > 1 && opt.subcube) {
-        // SUBTREE-TO-SUBCUBE mapping: a front of the top of the tree is needed only by the ranks whose subtrees lie beneath it, so it is
-        // replicated on THAT range of ranks [glo, glo + gsz) instead of on all of them.  Recursive bisection of (set of sibling subtrees,
-        // range of ranks): a set is split into two bins of about equal work (LPT), the range in proportion; the heaviest member of a set is
-        // OPENED -- its front joins the replicated part of the range, its children join the set -- while that shortens the critical rank's
-        // work (a lone member is always opened: that is how a separator chain stays with its range).  A range of one rank owns what is left.
-        // gdepth = number of bisections above the range: the exchange steps run deepest ranges first, all ranges of one depth in ONE
-        // collective (every rank takes part in every step, which is what keeps the sequence deadlock-free by construction).
-        vector<double> work(nsn, 0.0), own(nsn, 0.0);
-        for (int s = 0; s < nsn; ++s) {
-            double k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
-            own[s] = k * m * m + 64.0; work[s] += own[s];
-            if (S.sn_parent[s] >= 0) work[S.sn_parent[s]] += work[s];
-        }
-        struct Split { vector<int> bin[2]; double load[2]; int g[2]; double crit; };
-        auto split_set = [&](const vector<int>& set, int g) {
-            vector<int> order(set);
-            std::sort(order.begin(), order.end(), [&](int a, int b) { return work[a] != work[b] ? work[a] > work[b] : a < b; });
-            Split best; best.crit = -1;
-            for (int g0 = 1; g0 < g; ++g0) {              // every way of sharing the range out; the members go, heaviest first, where the load per rank stays lowest
-                if (g > 4 && g0 != g / 2 && g0 != g - g / 2 && g0 != 1 && g0 != g - 1) continue;
-                Split sp; sp.load[0] = sp.load[1] = 0; sp.g[0] = g0; sp.g[1] = g - g0;
-                for (int c : order) { const int b = (sp.load[0] + work[c]) / sp.g[0] <= (sp.load[1] + work[c]) / sp.g[1] ? 0 : 1; sp.bin[b].push_back(c); sp.load[b] += work[c]; }
-                sp.crit = std::max(sp.load[0] / sp.g[0], sp.load[1] / sp.g[1]);
-                if (best.crit < 0 || sp.crit < best.crit * (1.0 - 1e-12)) best = sp;
-            }
-            return best;
-        };
-        std::function<void(int, int)> own_subtree = [&](int root, int r) {
-            vector<int> st(1, root);
-            while (!st.empty()) { const int s = st.back(); st.pop_back(); S.sn_owner[s] = r; S.sn_glo[s] = r; S.sn_gsz[s] = 1; S.sn_gdepth[s] = 0;
-                                  for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) st.push_back(S.child_idx[q]); }
-        };
-        int maxdepth = 0;
-        std::function<void(vector<int>, int, int, int)> assign = [&](vector<int> set, int a, int g, int depth) {
-            if (set.empty()) return;
-            if (g == 1) { for (int c : set) own_subtree(c, a); return; }
-            for (int guard = 0; guard < nsn; ++guard) {
-                int heavy = set[0];
-                for (int c : set) if (work[c] > work[heavy] || (work[c] == work[heavy] && c < heavy)) heavy = c;
-                const bool can_open = S.child_ptr[heavy + 1] > S.child_ptr[heavy];
-                bool open = false;
-                if (set.size() == 1) open = can_open;
-                else if (can_open) {
-                    vector<int> set2;
-                    for (int c : set) if (c != heavy) set2.push_back(c);
-                    for (int q = S.child_ptr[heavy]; q < S.child_ptr[heavy + 1]; ++q) set2.push_back(S.child_idx[q]);
-                    open = own[heavy] + split_set(set2, g).crit < 0.98 * split_set(set, g).crit;
-                }
-                if (!open) break;
-                S.sn_owner[heavy] = -1; S.sn_glo[heavy] = a; S.sn_gsz[heavy] = g; S.sn_gdepth[heavy] = depth; maxdepth = std::max(maxdepth, depth);
-                set.erase(std::find(set.begin(), set.end(), heavy));
-                for (int q = S.child_ptr[heavy]; q < S.child_ptr[heavy + 1]; ++q) set.push_back(S.child_idx[q]);
-                if (set.empty()) return;
-            }
-            if (set.size() == 1) { own_subtree(set[0], a); return; }      // a leaf front nobody can split: one rank takes it
-            Split sp = split_set(set, g);
-            assign(sp.bin[0], a, sp.g[0], depth + 1);
-            assign(sp.bin[1], a + sp.g[0], sp.g[1], depth + 1);
-        };
-        vector<int> roots;
-        for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] < 0) roots.push_back(s);
-        assign(roots, 0, opt.nranks, 0);
-        S.num_gdepths = maxdepth + 1;
-    } else if (opt.nranks > 1) {
-        // subtree work estimates
-        vector<double> work(nsn, 0.0);
-        for (int s = 0; s < nsn; ++s) {
-            double k = S.sn_colptr[s + 1] - S.sn_colptr[s], m = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
-            work[s] += k * m * m + 64.0;   // flops-ish + launch overhead weight
-            if (S.sn_parent[s] >= 0) work[S.sn_parent[s]] += work[s];
-        }
-        // grow a frontier of subtree roots from the tree roots until there are enough, balanced pieces
-        std::set<std::pair<double,int>, std::greater<std::pair<double,int>>> front;
-        double total = 0;
-        for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] < 0) { front.insert({work[s], s}); total += work[s]; }
-        const double target = total / opt.nranks;
-        auto total_sub = [](const std::set<std::pair<double,int>, std::greater<std::pair<double,int>>>& f) { double t = 0; for (auto& e : f) t += e.first; return t; };
-        int guard = 0;
-        while (!front.empty() && guard++ < nsn) {
-            auto top = *front.begin();
-            // split the heaviest frontier subtree until there are >= 2 pieces per rank and none is heavier than 60% of a
-            // rank's share: deeper cuts only move work into the REPLICATED top, which every rank repeats (Amdahl)
-            bool enough = ((int)front.size() >= 2 * opt.nranks && top.first <= 0.6 * target) ||
-                          ((int)front.size() >= opt.nranks && top.first <= 1.15 * (total_sub(front) / opt.nranks));
-            if (enough) break;
-            int s = top.second;
-            if (S.child_ptr[s + 1] == S.child_ptr[s]) {   // leaf: cannot split; stop if it is the biggest
-                break;
-            }
-            front.erase(front.begin());
-            // s moves to the replicated top; its children join the frontier
-            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) front.insert({work[S.child_idx[q]], S.child_idx[q]});
-        }
-        // greedy LPT assignment of frontier subtrees to ranks
-        vector<double> load(opt.nranks, 0.0);
-        vector<int> root_owner(nsn, -2);
-        for (auto& e : front) { int r = (int)(std::min_element(load.begin(), load.end()) - load.begin()); load[r] += e.first; root_owner[e.second] = r; }
-        // propagate ownership down (parents have larger indices than children)
-        for (int s = nsn - 1; s >= 0; --s) {
-            if (root_owner[s] >= 0) S.sn_owner[s] = root_owner[s];
-            else if (S.sn_parent[s] >= 0 && S.sn_owner[S.sn_parent[s]] >= 0) S.sn_owner[s] = S.sn_owner[S.sn_parent[s]];
-            else S.sn_owner[s] = -1;
-        }
-        for (int s = 0; s < nsn; ++s) if (S.sn_owner[s] >= 0) { S.sn_glo[s] = S.sn_owner[s]; S.sn_gsz[s] = 1; }
-    }
-    lap("ownership");
-    // ---- 12. storage: panels, contribution blocks, in-place separator chains (needs the ownership map) ----
-    S.panel_off.assign(nsn, 0); S.cb_off.assign(nsn, 0); S.sn_ldp.assign(nsn, 0); S.sn_ldt.assign(nsn, 0); S.alias_child.assign(nsn, -1);
-    {
-        auto K = [&](int s) { return (int64_t)(S.sn_colptr[s + 1] - S.sn_colptr[s]); };
-        auto Mf = [&](int s) { return (int64_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]); };
-        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG)
-            for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
-                const int c = S.child_idx[q];
-                if (S.sn_class[c] == FC_BIG && Mf(c) - K(c) == Mf(s) && S.sn_owner[c] == S.sn_owner[s] && S.sn_glo[c] == S.sn_glo[s] && S.sn_gsz[c] == S.sn_gsz[s]) { S.alias_child[s] = c; break; }
-            }
-        int64_t loff = 0, coff = 0;
-        for (int s = 0; s < nsn; ++s) if (S.alias_child[s] < 0) loff += Mf(s) * K(s);
-        S.l_doubles = loff;
-        loff = 0;
-        for (int s = 0; s < nsn; ++s) {
-            const int64_t k = K(s), m = Mf(s), mu = m - k;
-            const int ac = S.alias_child[s];
-            if (ac < 0) {
-                S.panel_off[s] = loff; loff += m * k; S.sn_ldp[s] = (int)m;
-                S.cb_off[s] = coff; coff += mu * mu; S.sn_ldt[s] = (int)mu;
-            } else {        // children precede parents, so the child's placement is final
-                const int64_t ldc = S.sn_ldt[ac];
-                S.panel_off[s] = S.l_doubles + S.cb_off[ac]; S.sn_ldp[s] = (int)ldc;
-                S.cb_off[s] = S.cb_off[ac] + k * ldc + k; S.sn_ldt[s] = (int)ldc;
-            }
-        }
-        S.cb_doubles = coff;
-        // chain groups: up to `chain_group` consecutive links of an in-place chain (<= 256 columns, consecutive levels) are
-        // ONE unit for the trailing update (a single rank-(sum k) update at the last link; the links before it only update
-        // the group's own remaining columns) and for the triangular solves (one launch pair per group).
-        const int gmax = std::max(1, std::min(opt.chain_group, 4));
-        S.solve_group = opt.solve_group;
-        S.grp_pos.assign(nsn, 0); S.grp_rem.assign(nsn, 0);
-        {   // the latency-bound top of the tree: the levels from which on no level has more than `maxch` BIG fronts
-            int maxch = 8;
-            if (const char* e = getenv("MI355X_KKT_GRP_MAXCHAINS")) maxch = std::max(0, atoi(e));
-            vector<int> nbig(S.num_levels, 0);
-            for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) nbig[S.sn_level[s]]++;
-            S.grp_cut_level = S.num_levels;
-            for (int lv = S.num_levels - 1; lv >= 0 && nbig[lv] <= maxch; --lv) S.grp_cut_level = lv;
-        }
-        vector<int> gcols(nsn, 0), alias_parent(nsn, -1);
-        for (int s = 0; s < nsn; ++s) {
-            const int ac = S.alias_child[s];
-            gcols[s] = (int)K(s);
-            // (a link joins its chain child's group only if that child is its ONLY child: nothing but the chain itself writes into the
-            //  front, so a whole group can be factored in one launch sequence at the level of its first link -- numeric.hip, k_grp_*)
-            if (ac >= 0 && S.grp_pos[ac] + 1 < gmax && gcols[ac] + K(s) <= 256 && S.sn_level[s] == S.sn_level[ac] + 1 &&
-                S.child_ptr[s + 1] - S.child_ptr[s] == 1 && !(S.sn_level[s] >= S.grp_cut_level && S.sn_level[ac] < S.grp_cut_level)) {
-                S.grp_pos[s] = S.grp_pos[ac] + 1; gcols[s] = gcols[ac] + (int)K(s); alias_parent[ac] = s;
-            }
-        }
-        for (int s = nsn - 1; s >= 0; --s) { const int p = alias_parent[s]; if (p >= 0) S.grp_rem[s] = S.grp_rem[p] + (int)K(p); }
-        // forward-solve vectors: an in-place chain shares ONE vector (the parent's entries are the child's update entries)
-        S.cv_off.assign(nsn, 0);
-        int64_t cvo = 0;
-        for (int s = 0; s < nsn; ++s) {
-            const int ac = S.alias_child[s];
-            if (ac >= 0) S.cv_off[s] = S.cv_off[ac] + K(ac);
-            else { S.cv_off[s] = cvo; cvo += Mf(s); }
-        }
-        S.cvec_doubles = cvo;
-        // W = L*D panels of the BIG fronts: per-level scratch in banks (level mod 8) so that the panels of a chain group
-        // (<= 4 consecutive levels) are all alive at the group's trailing update; partial sums of the backward dot products
-        S.wb_off.assign(nsn, -1); S.gpart_off.assign(nsn, -1);
-        vector<int64_t> lvl_used(S.num_levels, 0), lvl_part(S.num_levels, 0);
-        for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) {
-            const int lv = S.sn_level[s];
-            S.wb_off[s] = lvl_used[lv]; lvl_used[lv] += Mf(s) * K(s);
-            S.gpart_off[s] = lvl_part[lv]; lvl_part[lv] += ((Mf(s) - K(s) + 255) / 256 + 1) * (int64_t)gcols[s];
-        }
-        // 8 banks: the group after a look-ahead split (numeric.hip) must not overwrite the W panels its predecessor still reads
-        int64_t bank[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bank_base[8];
-        for (int lv = 0; lv < S.num_levels; ++lv) bank[lv & 7] = std::max(bank[lv & 7], lvl_used[lv]);
-        S.wbuf_doubles = 0;
-        for (int b = 0; b < 8; ++b) { bank_base[b] = S.wbuf_doubles; S.wbuf_doubles += bank[b]; }
-        for (int s = 0; s < nsn; ++s) if (S.wb_off[s] >= 0) S.wb_off[s] += bank_base[S.sn_level[s] & 7];
-        S.gpart_doubles = 0;
-        for (int64_t u : lvl_part) S.gpart_doubles = std::max(S.gpart_doubles, u);
-    }
+    if (!finish_analysis(S, opt, lap)) return false;
     S.time_analyse = now_s() - t0;
     if (opt.verbose)
         fprintf(stderr, "[mi355x_kkt] analyse: n=%d nnzA=%d pairs=%d nsn=%d levels=%d maxfront=%d maxsn=%d nnzL=%lld flops=%.3g big=%d  %.3fs\n",
-                n, S.nnz_a, S.num_pairs, nsn, S.num_levels, S.maxfront, S.maxsupernode, (long long)S.nnz_l, (double)S.flops_factor, S.num_big, S.time_analyse);
+                n, S.nnz_a, S.num_pairs, S.num_sn, S.num_levels, S.maxfront, S.maxsupernode, (long long)S.nnz_l, (double)S.flops_factor, S.num_big, S.time_analyse);
+    return true;
+}
+
+// =======================================================================================
+// Delayed pivoting ACROSS fronts, as an edit of the supernode partition.
+//
+// What MA27 / MA57 / MA97 / MUMPS / SPRAL do when a fully-summed column of a front finds no pivot that passes the threshold
+// test: the column stays uneliminated, becomes part of the contribution block and is a fully-summed column of the PARENT front,
+// where more of its row is summed and more partners are available (Duff & Reid 1983; the adapters read the consequences:
+// IpMa97SolverInterface.cpp:719-779 info.num_delay, IpMa27TSolverInterface.cpp:565-622 workspace growth + refactorisation).
+// Here the device structures are static (addresses, launch lists, hipGraphs), so a delay is a change of the STRUCTURE: the
+// failed columns of a front leave its supernode and join the parent's, the symbolic structures are rebuilt from the edited
+// partition (no new ordering: the permutation only moves the delayed columns behind their former siblings), the numeric side
+// is set up again and the matrix is refactored -- MA27's "grow the workspace and call MA27BD again" in our terms.  The edited
+// structure is kept for the following factorisations (same sparsity, similar numbers: Ipopt's next iteration).
+//
+// `marked`: columns (CURRENT permuted numbering) the last factorisation could not pivot (bit 1 of DevView::zpiv).  ALL of them move, whatever
+// lies beneath them: measured on the hostile sets (tools/hostile_delay_run.py), waiting for the fronts below a mark to come clean first
+// ("a forced pivot poisons what its ancestors see") makes the marks of a separator chain climb ONE link per refactorisation -- 22-30 rounds
+// where 4-8 do with everything moving at once, at +10 % nnz(L); a column delayed without need costs fill, not correctness.  Root fronts have
+// nowhere to delay to.  A parent that would exceed max_sn_cols columns is cut into a chain of supernodes (delayed columns first, together
+// with as many of the parent's own as fit).
+// =======================================================================================
+bool restructure_delays(const Symbolic& C, const SymbolicOptions& opt, const std::vector<int>& marked, const std::vector<int>& hops, Symbolic& S, int* moved_out, std::vector<char>* acted)
+{
+    BlockCache::Scope recycle;
+    const double t0 = now_s(); double tl = t0;
+    auto lap = [&](const char* what) { if (opt.verbose >= 2) { double t = now_s(); fprintf(stderr, "[mi355x_kkt]   (delay) %-20s %.3f s\n", what, t - tl); tl = t; } };
+    const int n = C.n, nsn0 = C.num_sn;
+    if (moved_out) *moved_out = 0;
+    S = Symbolic();
+    if (n == 0 || nsn0 == 0) { S.error = "restructure: empty structure"; return false; }
+    // ---- which marks count, and where their columns go ----
+    vector<char> mk(n, 0);
+    vector<int> nmark(nsn0, 0), target(n, -1);            // target[j]: the front column j moves to
+    for (size_t q = 0; q < marked.size(); ++q) {
+        const int j = marked[q];
+        if (j >= 0 && j < n && !mk[j]) { mk[j] = 1; nmark[C.sn_of[j]]++; target[j] = q < hops.size() ? std::max(1, hops[q]) : 1; }      // (levels to climb, for now)
+    }
+    vector<int> incount(nsn0 + 1, 0);
+    int moved = 0;
+    for (int s = 0; s < nsn0; ++s) {
+        const int p = C.sn_parent[s];
+        if (nmark[s] == 0) continue;
+        for (int j = C.sn_colptr[s]; j < C.sn_colptr[s + 1]; ++j) if (mk[j]) {
+            if (p < 0) { mk[j] = 0; continue; }                                             // a root front has nowhere to delay to
+            int t = p;                                                                      // a column that failed before climbs several levels at once
+            for (int h = target[j]; h > 1 && C.sn_parent[t] >= 0; --h) t = C.sn_parent[t];
+            target[j] = t; incount[t + 1]++; ++moved;
+        }
+    }
+    if (moved_out) *moved_out = moved;
+    if (acted) { acted->assign(marked.size(), 0); for (size_t q = 0; q < marked.size(); ++q) { const int j = marked[q]; if (j >= 0 && j < n && mk[j]) (*acted)[q] = 1; } }
+    if (moved == 0) { S.error = "restructure: nothing to delay"; return false; }
+    for (int s = 0; s < nsn0; ++s) incount[s + 1] += incount[s];
+    vector<int> incoming(moved), fillp(incount.begin(), incount.end() - 1);
+    for (int j = 0; j < n; ++j) if (mk[j]) incoming[fillp[target[j]]++] = j;               // (ascending column order inside every target)
+    // ---- the new partition: supernodes in their old order, [columns delayed into it] + [its own remaining columns], cut at maxcols ----
+    const int maxcols = std::max(2, opt.max_sn_cols);
+    vector<int> newpos; newpos.reserve(n);            // newpos[t] = column (current numbering) at new position t
+    vector<int> ncolptr; ncolptr.reserve((size_t)nsn0 + 16);
+    for (int s = 0; s < nsn0; ++s) {
+        const int start = (int)newpos.size();
+        for (int q = incount[s]; q < incount[s + 1]; ++q) newpos.push_back(incoming[q]);
+        for (int j = C.sn_colptr[s]; j < C.sn_colptr[s + 1]; ++j) if (!mk[j]) newpos.push_back(j);
+        const int cnt = (int)newpos.size() - start;
+        for (int o = 0; o < cnt; o += maxcols) ncolptr.push_back(start + o);
+    }
+    if ((int)newpos.size() != n) { S.error = "restructure: internal error (partition does not cover the columns)"; return false; }
+    const int nsn = (int)ncolptr.size();
+    ncolptr.push_back(n);
+    // ---- permutation ----
+    S.n = n; S.nnz_in = C.nnz_in; S.nnz_a = C.nnz_a; S.num_pairs = C.num_pairs; S.pair_of = C.pair_of;
+    vector<int> newlab(n);
+    S.perm.resize(n); S.iperm.resize(n);
+    for (int t = 0; t < n; ++t) { newlab[newpos[t]] = t; S.perm[t] = C.perm[newpos[t]]; }
+    for (int t = 0; t < n; ++t) S.iperm[S.perm[t]] = t;
+    lap("partition");
+    // ---- permuted lower CSC from the current one: relabel, re-bucket, sort the rows of every column; slots keep their triplets ----
+    {
+        const int nnzA = C.nnz_a, T = analysis_threads();
+        vector<int> pc(nnzA), pr(nnzA);
+        parallel_chunks(nnzA, T, [&](long long qb, long long qe, int) {
+            for (long long q = qb; q < qe; ++q) { const int a = newlab[C.arow[q]], b = newlab[C.acol[q]]; pc[q] = std::min(a, b); pr[q] = std::max(a, b); }
+        });
+        vector<int> cnt, src;
+        parallel_bucket(nnzA, n, T, [&](long long q) { return pc[q]; }, cnt, src);
+        S.acolptr = cnt;
+        vector<int> old2new(nnzA), new2old(nnzA); S.arow.resize(nnzA); S.acol.resize(nnzA);
+        parallel_chunks(n, T, [&](long long jb, long long je, int) {
+            vector<std::pair<int,int>> tmp;
+            for (int j = (int)jb; j < (int)je; ++j) {
+                const int q0 = cnt[j], q1 = cnt[j + 1];
+                tmp.clear();
+                for (int q = q0; q < q1; ++q) tmp.emplace_back(pr[src[q]], src[q]);
+                if (q1 - q0 > 1) std::sort(tmp.begin(), tmp.end());
+                for (int q = q0; q < q1; ++q) { S.arow[q] = tmp[q - q0].first; S.acol[q] = j; old2new[tmp[q - q0].second] = q; new2old[q] = tmp[q - q0].second; }
+            }
+        });
+        S.trip2slot.resize(C.trip2slot.size());
+        parallel_chunks((long long)C.trip2slot.size(), T, [&](long long tb, long long te, int) { for (long long t = tb; t < te; ++t) S.trip2slot[t] = old2new[C.trip2slot[t]]; });
+        S.dup_ptr.assign((size_t)nnzA + 1, 0);
+        for (int q = 0; q < nnzA; ++q) S.dup_ptr[q + 1] = S.dup_ptr[q] + (C.dup_ptr[new2old[q] + 1] - C.dup_ptr[new2old[q]]);
+        S.dup_src.resize(C.dup_src.size());
+        parallel_chunks(nnzA, T, [&](long long qb, long long qe, int) {
+            for (long long q = qb; q < qe; ++q) { const int o = new2old[q]; const int* sp = C.dup_src.data() + C.dup_ptr[o]; int* dp = S.dup_src.data() + S.dup_ptr[q];
+                                                  for (int e = 0; e < C.dup_ptr[o + 1] - C.dup_ptr[o]; ++e) dp[e] = sp[e]; }
+        });
+    }
+    lap("permuted CSC");
+    S.num_sn = nsn;
+    S.sn_colptr.assign(ncolptr.begin(), ncolptr.end());
+    if (!finish_analysis(S, opt, lap)) return false;
+    S.time_analyse = now_s() - t0;
+    if (opt.verbose)
+        fprintf(stderr, "[mi355x_kkt] delayed pivots: %d columns moved to their parent fronts; nsn=%d levels=%d maxfront=%d nnzL=%lld flops=%.3g  %.3fs\n",
+                moved, nsn, S.num_levels, S.maxfront, (long long)S.nnz_l, (double)S.flops_factor, S.time_analyse);
     return true;
 }
 

@@ -136,4 +136,12 @@ struct Symbolic {
 bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int* row, const int* col,
              int format, const double* vals);
 
+// Delayed pivoting across fronts as an edit of the supernode partition (symbolic.cpp): the columns `marked` (CURRENT permuted
+// numbering of `cur`) that a factorisation could not pivot leave their supernode and join the parent's; `out` is the complete
+// analysis of the edited structure.  *moved = columns actually moved (a root front has no parent).  false + out.error when nothing
+// moved or on an internal error.
+// hops[q] (optional, parallel to marked): tree levels column marked[q] climbs (1 = to the parent; a column that has failed before climbs further).
+bool restructure_delays(const Symbolic& cur, const SymbolicOptions& opt, const std::vector<int>& marked, const std::vector<int>& hops, Symbolic& out, int* moved,
+                        std::vector<char>* acted = nullptr);      // acted[q]: marked[q] did move
+
 } // namespace mi355x

@@ -29,7 +29,7 @@ class _Options(C.Structure):
                 ("scaling", C.c_int), ("nd_leaf", C.c_int), ("nemin", C.c_int), ("max_sn_cols", C.c_int),
                 ("pivtol", C.c_double), ("pivtolmax", C.c_double), ("small", C.c_double),
                 ("refine_steps", C.c_int), ("use_graph", C.c_int), ("nranks", C.c_int), ("rank", C.c_int),
-                ("verbose", C.c_int), ("leaf_cols", C.c_int), ("tree_merge", C.c_int), ("wide_panels", C.c_int), ("chain_group", C.c_int), ("solve_group", C.c_int), ("subcube", C.c_int), ("reserved", C.c_int * 2)]
+                ("verbose", C.c_int), ("leaf_cols", C.c_int), ("tree_merge", C.c_int), ("wide_panels", C.c_int), ("chain_group", C.c_int), ("solve_group", C.c_int), ("subcube", C.c_int), ("delay_rounds", C.c_int), ("reserved", C.c_int * 1)]
 
 
 class _Info(C.Structure):
@@ -40,7 +40,7 @@ class _Info(C.Structure):
                 ("num_pairs", C.c_int), ("num_neg", C.c_int), ("num_zero", C.c_int), ("num_two", C.c_int),
                 ("num_small", C.c_int), ("num_big_fronts", C.c_int), ("time_analyse", C.c_double),
                 ("time_factor_ms", C.c_double), ("time_solve_ms", C.c_double), ("pivtol", C.c_double), ("u_sensitive", C.c_int),
-                ("num_fast_blocks", C.c_int), ("reserved", C.c_double * 6)]
+                ("num_fast_blocks", C.c_int), ("num_delayed", C.c_int), ("num_restructures", C.c_int), ("reserved", C.c_double * 5)]
 
 
 @dataclass
@@ -48,7 +48,7 @@ class KKTInfo:
     n: int; nnz_in: int; nnz_a: int; nnz_l: int; flops_factor: int; flops_solve: int; bytes_factor: int
     bytes_solve: int; sum_sn_rows: int; cb_doubles: int; num_sn: int; num_levels: int; maxfront: int
     maxsupernode: int; num_pairs: int; num_neg: int; num_zero: int; num_two: int; num_small: int
-    num_big_fronts: int; time_analyse: float; time_factor_ms: float; time_solve_ms: float; pivtol: float; u_sensitive: int; num_fast_blocks: int
+    num_big_fronts: int; time_analyse: float; time_factor_ms: float; time_solve_ms: float; pivtol: float; u_sensitive: int; num_fast_blocks: int; num_delayed: int; num_restructures: int
 
 
 def library_path() -> str:
@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
     "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
-    "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
+    "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_failed_pivots", "mi355x_kkt_delay_columns", "mi355x_kkt_set_delay_rounds", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
     "mi355x_kkt_pd_define", "mi355x_kkt_pd_put_data", "mi355x_kkt_pd_put", "mi355x_kkt_pd_get", "mi355x_kkt_pd_solve_once", "mi355x_kkt_pd_residual",
 ]
 KERNEL_KINDS = ["gather_scale", "front_wave", "front_lds64", "front_lds128", "big_assemble", "big_diag", "big_trsm", "big_schur",
@@ -120,6 +120,9 @@ def load_library():
     lib.mi355x_kkt_ruiz_scaling.argtypes = [C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.mi355x_kkt_matching_scaling.argtypes = [C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, ip]
     lib.mi355x_kkt_zero_pivots.argtypes = [vp, vp, C.c_int, ip]
+    lib.mi355x_kkt_failed_pivots.argtypes = [vp, vp, C.c_int, ip]
+    lib.mi355x_kkt_delay_columns.argtypes = [vp, vp, C.c_int, ip]
+    lib.mi355x_kkt_set_delay_rounds.argtypes = [vp, C.c_int]
     lib.mi355x_kkt_assembly_define.argtypes = [vp, C.c_int, vp, vp]
     lib.mi355x_kkt_assembly_buffer.argtypes = [vp, C.c_int]
     lib.mi355x_kkt_assembly_buffer.restype = dp
@@ -377,6 +380,27 @@ class KKTSolver:
         out = np.zeros(max(cnt.value, 1), dtype=np.int32)
         self.lib.mi355x_kkt_zero_pivots(self._h, out.ctypes.data, cnt.value, C.byref(cnt))
         return out[:cnt.value]
+
+    # --- delayed pivoting across fronts (include/mi355x_kkt.h): what the last factorisation had to force, and the structural edit ---
+    def failed_pivots(self) -> np.ndarray:
+        cnt = C.c_int(0)
+        if self.lib.mi355x_kkt_failed_pivots(self._h, None, 0, C.byref(cnt)) != 0:
+            raise KKTError("failed_pivots: " + self.last_error())
+        out = np.zeros(max(cnt.value, 1), dtype=np.int32)
+        self.lib.mi355x_kkt_failed_pivots(self._h, out.ctypes.data, cnt.value, C.byref(cnt))
+        return out[:cnt.value]
+
+    def delay_columns(self, cols) -> int:
+        """move the columns (caller's index base) to their parent fronts; returns how many moved"""
+        c = np.ascontiguousarray(cols, dtype=np.int32)
+        moved = C.c_int(0)
+        if self.lib.mi355x_kkt_delay_columns(self._h, c.ctypes.data, int(c.shape[0]), C.byref(moved)) != 0:
+            raise KKTError("delay_columns: " + self.last_error())
+        return moved.value
+
+    def set_delay_rounds(self, rounds: int):
+        if self.lib.mi355x_kkt_set_delay_rounds(self._h, int(rounds)) != 0:
+            raise KKTError("set_delay_rounds: rounds >= 0")
 
     def info(self) -> KKTInfo:
         i = _Info()

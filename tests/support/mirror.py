@@ -99,7 +99,7 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True, cnorm=None):
     force = False
     upd = list(range(k, m)) if see_update_rows else []
     L = np.zeros((m, k)); order = []; ptype = []; dinv = []; doff = []
-    st = dict(nneg=0, nzero=0, ntwo=0, ndelay=0, chg=0)
+    st = dict(nneg=0, nzero=0, ntwo=0, ndelay=0, chg=0, delayed=set())      # delayed: physical rows that were alive when every candidate had failed
 
     def colmax(col, rows):
         return max((abs(F[i, col]) for i in rows), default=0.0)
@@ -107,6 +107,7 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True, cnorm=None):
     while alive:
         if not tryb:
             force = True; tryb = list(alive)
+            st["delayed"].update(alive)          # every candidate failed: they are the DELAYED pivots (the kernels mark them; the host moves them to the parent front)
         j = tryb[0]
         ztol = max(small, ZERO_REL * cm0[j])
         ajj = abs(F[j, j])
@@ -234,7 +235,7 @@ def ldlt_block_static(A, k, u, u2, small=1e-20, cnorm=None):
         A[j + 1:, j + 1:] -= np.outer(l, w)
         dinv[j] = 1.0 / d
         nneg += int(d < 0)
-    return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0)
+    return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0, delayed=set())
 
 
 FAST16_MIN_M = 65    # fronts of order 65 .. 128 (the 256-thread front kernel) with <= 16 pivots try the static path first
@@ -267,7 +268,7 @@ def ldlt_front_static(F, k, u, u2, small=1e-20, cnorm=None):
         dinv[j] = 1.0 / d
         nneg += int(d < 0)
     F[:, :] = A
-    return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0)
+    return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0, delayed=set())
 
 
 def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_blocks=True):
@@ -284,7 +285,7 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_bloc
         if parent[s] >= 0:
             children[parent[s]].append(s)
     fac, cbs, cvec = [None] * nsn, [None] * nsn, [None] * nsn
-    tot = dict(num_neg=0, num_zero=0, num_two=0, num_delay=0, u_sensitive=0, num_fast=0)
+    tot = dict(num_neg=0, num_zero=0, num_two=0, num_delay=0, u_sensitive=0, num_fast=0, marks=[])     # marks: permuted columns flagged as delayed pivots
     b = rhs[sym["perm"]].astype(float).copy()
     # inf-norm of every column of the (symmetric) input matrix, permuted numbering
     cn = np.zeros(n)
@@ -331,10 +332,19 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_bloc
             Dinv = _dinv_matrix(st)
             W = np.linalg.solve(L11, F[k:, :k][:, P].T).T            # W21 = A21 P L11^{-T}
             L21 = W @ Dinv
-            st["ndelay"] += int((np.abs(L21).max(axis=0) * u > 1.0).sum()) if m > k else 0
+            if m > k:          # a posteriori: a column of L21 with a multiplier above 1/u is a failed pivot (k_big_trsm) -- the column and its 2x2 partner are marked
+                bad = np.nonzero(np.abs(L21).max(axis=0) * u > 1.0)[0]
+                st["ndelay"] += int(bad.size)
+                for j in bad:
+                    st["delayed"].add(int(P[j]))
+                    if st["ptype"][j] == 2:
+                        st["delayed"].add(int(P[j + 1]))
+                    elif st["ptype"][j] == 3:
+                        st["delayed"].add(int(P[j - 1]))
             cb = F[k:, k:] - L21 @ W.T
         tot["num_neg"] += st["nneg"]; tot["num_zero"] += st["nzero"]; tot["num_two"] += st["ntwo"]; tot["num_delay"] += st["ndelay"]
         tot["u_sensitive"] |= st["chg"]
+        tot["marks"] += [c0 + int(p) for p in sorted(st["delayed"])]
         Dinv = _dinv_matrix(st)
         fac[s] = (P, L11, L21, Dinv)
         cbs[s] = cb
@@ -362,3 +372,21 @@ def _dinv_matrix(st):
         if pt == 2:
             Di[j, j + 1] = Di[j + 1, j] = st["doff"][j]
     return Di
+
+
+
+def factor_solve_delayed(solver, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, rounds=8, fast_blocks=True):
+    """The delayed-pivot loop of the C library (api.cpp delay_and_refactor) with the numpy specification in place of the HIP factorisation:
+    factor on the current structure; while pivots had to be forced, hand the marked columns to mi355x_kkt_delay_columns (the host-side
+    structural edit, symbolic.cpp restructure_delays -- the SAME code the product runs) and factor again on the edited structure.
+    Returns (x, stats of the last factorisation, number of structure edits, columns moved in total)."""
+    edits = moved_total = 0
+    while True:
+        sym = fetch(solver)
+        x, st = factor_solve_pivoted(sym, vals, rhs, u=u, u2=u2, small=small, fast_blocks=fast_blocks)
+        if edits >= rounds or not st["marks"]:          # (marks without a counted failure exist: a forced candidate with nothing usable is a ZERO pivot, not a num_delay)
+            return x, st, edits, moved_total
+        moved = solver.delay_columns(sym["perm"][np.array(st["marks"], dtype=int)] + 1)
+        if moved == 0:
+            return x, st, edits, moved_total
+        edits += 1; moved_total += moved

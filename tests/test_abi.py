@@ -45,7 +45,9 @@ def test_option_struct_layout_matches_header():
     assert (o.pivtol, o.pivtolmax, o.small) == (1e-8, 1e-4, 1e-20)
     assert (o.use_graph, o.nranks, o.rank) == (1, 1, 0)
     assert (o.chain_group, o.solve_group, o.subcube) == (4, 0, 0)      # (subcube took the first of the reserved ints: same struct size)
-    assert ctypes.sizeof(o) == ctypes.sizeof(kkt._Options) and list(o.reserved) == [0, 0]
+    assert o.delay_rounds == 8                                          # (delay_rounds took the next reserved int)
+    assert ctypes.sizeof(o) == ctypes.sizeof(kkt._Options) == 112 and list(o.reserved) == [0]
+    assert ctypes.sizeof(kkt._Info) == 200                              # num_delayed / num_restructures live in what was reserved[0]
 
 
 def _has_gpu():

@@ -28,7 +28,7 @@ def test_hip_pivot_statistics_equal_the_specification(kat, msc):
     xt = np.arange(1.0, n + 1.0); b = K @ xt
     seen = []
     for u in (1e-8, 1e-4):
-        s, st, x = hip_run(n, r, c, v, b, u, max_sn_cols=msc, **kktgen.KAT_OPTS)
+        s, st, x = hip_run(n, r, c, v, b, u, max_sn_cols=msc, delay_rounds=0, **kktgen.KAT_OPTS)      # (static pivoting: the per-front rules against their specification)
         xs, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=1e-4)
         I = s.info()
         assert st == kkt.SUCCESS
@@ -99,7 +99,7 @@ def test_seeded_systems_at_several_u(u):
         n, r, c, v, neg = gen()
         K = kktgen.to_scipy(n, r, c, v)
         b = K @ np.ones(n)
-        s, st, x = hip_run(n, r, c, v, b, u, scaling=0)
+        s, st, x = hip_run(n, r, c, v, b, u, scaling=0, delay_rounds=0)
         _, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=1e-4)
         I = s.info()
         assert st == 0 and I.num_neg == neg == spec["num_neg"]
@@ -123,7 +123,7 @@ def test_zero_pivot_list_names_the_dependent_rows():
     r = np.concatenate([jr + ncol, np.arange(n)]).astype(np.int32) + 1
     c = np.concatenate([jc, np.arange(n)]).astype(np.int32) + 1
     v = np.concatenate([J[jr, jc], np.ones(ncol), np.zeros(nrow)])
-    s = ipopt_amd.KKTSolver(scaling=0)                 # as the adapter's DetermineDependentRows does
+    s = ipopt_amd.KKTSolver(scaling=0, delay_rounds=0)                 # as the adapter's DetermineDependentRows does
     s.initialize_structure(n, r, c, vals=v)
     s.values()[:] = v
     st = s.multi_solve(True, None)
@@ -143,7 +143,7 @@ def test_hostile_grid_hip_equals_the_specification(u):
     n, r, c, v = kktgen.hostile_grid_kkt(16, 16, seed=3)
     K = kktgen.to_scipy(n, r, c, v)
     xt = np.ones(n); b = K @ xt
-    s, st, x = hip_run(n, r, c, v, b, u, scaling=0, pivtolmax=max(u, 1e-4))
+    s, st, x = hip_run(n, r, c, v, b, u, scaling=0, pivtolmax=max(u, 1e-4), delay_rounds=0)
     xs, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=max(u, 1e-4))
     _, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=u)
     I = s.info()
@@ -162,7 +162,7 @@ def test_small_fronts_static_path_and_its_fallback_equal_the_specification(u):
     n, r, c, v = kktgen.hostile_band_kkt(2000, frac=0.15, tiny=1e-2, seed=4)
     K = kktgen.to_scipy(n, r, c, v)
     xt = np.ones(n); b = K @ xt
-    s, st, x = hip_run(n, r, c, v, b, u, scaling=0, pivtolmax=max(u, 1e-4))
+    s, st, x = hip_run(n, r, c, v, b, u, scaling=0, pivtolmax=max(u, 1e-4), delay_rounds=0)
     xs, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=max(u, 1e-4))
     _, oneg, _, _ = ko.factor_solve(n, r, c, v, b, u=u)
     I = s.info()
@@ -171,3 +171,84 @@ def test_small_fronts_static_path_and_its_fallback_equal_the_specification(u):
            (spec["num_neg"], spec["num_zero"], spec["num_two"], spec["num_delay"], spec["u_sensitive"]), (I, spec)
     assert I.num_neg == oneg and (spec["num_two"] == 0 if u == 1e-8 else spec["num_two"] >= 20)
     assert np.abs(x - xt).max() <= 1e-9 and np.abs(x - xs).max() <= 1e-9
+
+
+# ------------------------------------------------------------------------------------------------------
+# Delayed pivoting across fronts: factor() moves the columns that failed the threshold tests to their
+# parent fronts and refactors.  The specification of the loop is tests/support/mirror.py::factor_solve_delayed, pinned on the
+# CPU against the delaying oracle (tests/test_pivoting_spec.py); both sides drive the SAME host code for the structural edit.
+# ------------------------------------------------------------------------------------------------------
+HOSTILE = {
+    "grid_1e-9": lambda: kktgen.hostile_grid_kkt(16, 16, seed=3, tiny=1e-9),
+    "band_1e-6": lambda: kktgen.hostile_band_kkt(2000, frac=0.15, tiny=1e-6, seed=4),
+    "grid_1e-9_dense": lambda: kktgen.hostile_grid_kkt(16, 16, seed=3, tiny=1e-9, frac=0.6),
+}
+
+
+@pytest.mark.parametrize("u", [1e-8, 0.01])
+@pytest.mark.parametrize("case", sorted(HOSTILE))
+def test_delayed_pivots_hip_equals_the_specification_and_the_oracle(case, u):
+    n, r, c, v = HOSTILE[case]()
+    K = kktgen.to_scipy(n, r, c, v)
+    xt = np.ones(n); b = K @ xt
+    _, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=u)
+    # the specification of the loop, on a handle of its own
+    ref = ipopt_amd.KKTSolver(scaling=0)
+    ref.initialize_structure(n, r, c, vals=v)
+    xs, spec, edits, moved = mirror.factor_solve_delayed(ref, v, b, u=u, u2=max(u, 1e-4), rounds=8)
+    # the product
+    s, st, x = hip_run(n, r, c, v, b, u, scaling=0, pivtolmax=max(u, 1e-4))
+    I = s.info()
+    assert st == kkt.SUCCESS and ozero == 0
+    assert (I.num_neg, I.num_zero, I.num_small) == (oneg, 0, 0), (I, spec)                       # the oracle's inertia, nothing forced
+    assert (I.num_delayed, I.num_restructures) == (moved, edits), (I, moved, edits)              # the same columns moved in the same rounds ...
+    assert (I.num_two, I.u_sensitive, I.num_fast_blocks) == (spec["num_two"], spec["u_sensitive"], spec["num_fast"]), (I, spec)
+    assert np.array_equal(mirror.fetch(s)["perm"], mirror.fetch(ref)["perm"]) and I.nnz_l == ref.info().nnz_l      # ... into the same structure
+    if case != "grid_1e-9" or u == 0.01:
+        assert moved > 0 and edits >= 1
+    assert len(s.failed_pivots()) == 0
+    res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+    assert res <= (1e-12 if u == 0.01 else 1e-2) and np.abs(x - xs).max() <= (1e-8 if u == 0.01 else 1e-1)
+    # the edited structure stays: the next factorisation of the same matrix needs no further edit, and gives the same answer bit for bit
+    x2 = b.copy()
+    assert s.multi_solve(True, x2) == kkt.SUCCESS and s.info().num_restructures == edits and np.array_equal(x2, x)
+
+
+def test_delays_off_reproduces_static_pivoting_and_failed_pivots_lists_the_forced_columns():
+    n, r, c, v = HOSTILE["band_1e-6"]()
+    K = kktgen.to_scipy(n, r, c, v); b = K @ np.ones(n)
+    s, st, x = hip_run(n, r, c, v, b, 1e-8, scaling=0, delay_rounds=0)
+    _, spec = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=1e-8, u2=1e-4)
+    I = s.info()
+    assert st == kkt.SINGULAR and (I.num_zero, I.num_small, I.num_delayed, I.num_restructures) == (spec["num_zero"], spec["num_delay"], 0, 0)
+    sym = mirror.fetch(s)
+    assert sorted((sym["perm"][np.array(spec["marks"], dtype=int)] + 1).tolist()) == s.failed_pivots().tolist()       # the marks of the kernels are the specification's
+
+
+def test_delayed_pivots_keep_the_callers_buffers_and_the_device_state():
+    """a structure edit in the middle of the life of a handle: the pinned values buffer the caller holds stays valid, refactor() works from the
+    device copy of the values, the scaling mode survives, and device-side assembly keeps its sources."""
+    n, r, c, v = HOSTILE["band_1e-6"]()
+    K = kktgen.to_scipy(n, r, c, v); b = K @ np.ones(n)
+    s = ipopt_amd.KKTSolver(pivtol=0.01, pivtolmax=0.01, scaling=1)
+    s.initialize_structure(n, r, c, vals=v)
+    buf = s.values()
+    addr = buf.ctypes.data
+    buf[:] = v
+    x = b.copy()
+    assert s.multi_solve(True, x) == kkt.SUCCESS
+    I = s.info()
+    assert I.num_restructures >= 1 and I.num_small == 0 and s.values().ctypes.data == addr
+    res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+    assert res <= 1e-12
+    buf[:] = 0.0                                   # a refactorisation reads the device copy, not the staging buffer
+    s._refactor = True
+    x2 = b.copy()
+    assert s.multi_solve(False, x2) == kkt.SUCCESS and np.array_equal(x2, x)
+    # device-side assembly on the edited structure: one segment, scale 2 => the solution halves
+    s.assembly_define([len(v)])
+    s.assembly_set(0, v)
+    st, neg, zero = s.factor_assembled([2.0], [0.0])
+    x3 = b.copy()
+    assert st == kkt.SUCCESS and s.multi_solve(False, x3) == kkt.SUCCESS
+    assert np.abs(2.0 * x3 - x).max() <= 1e-9 * max(1.0, np.abs(x).max())

@@ -177,3 +177,78 @@ def test_band_with_small_diagonals_static_order_first_then_strict(u):
     assert np.abs(x - xt).max() <= 1e-10 and np.abs(xo - xt).max() <= 1e-7
     assert st_strict["num_two"] >= 100                        # what the strict rule alone would do
     assert (st["num_two"] == 0) if u == 1e-8 else (20 <= st["num_two"] < st_strict["num_two"])
+
+
+# ------------------------------------------------------------------------------------------------------
+# Delayed pivoting across fronts (api.cpp delay_and_refactor + symbolic.cpp restructure_delays): the loop of the C library with
+# the numpy specification in place of the HIP factorisation -- the structural edit itself is the product's own host code,
+# reached through mi355x_kkt_delay_columns, which works without a GPU.
+# ------------------------------------------------------------------------------------------------------
+HOSTILE = {
+    "grid_1e-9": lambda: kktgen.hostile_grid_kkt(16, 16, seed=3, tiny=1e-9),
+    "band_1e-6": lambda: kktgen.hostile_band_kkt(2000, frac=0.15, tiny=1e-6, seed=4),
+    "grid_1e-9_dense": lambda: kktgen.hostile_grid_kkt(16, 16, seed=3, tiny=1e-9, frac=0.6),
+}
+
+
+@pytest.mark.parametrize("u", [1e-8, 0.01])
+@pytest.mark.parametrize("case", sorted(HOSTILE))
+def test_delayed_pivots_reach_the_delaying_oracles_inertia(case, u):
+    """where static pivoting ends in zero pivots (SINGULAR) or forced pivots, moving the failed columns to their
+    parent fronts and refactoring must end with NO forced and NO zero pivot and the inertia of the oracle, which delays
+    (oracle/ldlt_oracle.c) -- within the default number of rounds."""
+    n, r, c, v = HOSTILE[case]()
+    K = kktgen.to_scipy(n, r, c, v)
+    xt = np.ones(n); b = K @ xt
+    _, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=u)
+    s = ipopt_amd.KKTSolver(scaling=0)
+    s.initialize_structure(n, r, c, vals=v)
+    _, st0 = mirror.factor_solve_pivoted(mirror.fetch(s), v, b, u=u, u2=max(u, 1e-4))
+    nl0 = s.info().nnz_l
+    x, st, edits, moved = mirror.factor_solve_delayed(s, v, b, u=u, u2=max(u, 1e-4), rounds=8)
+    I = s.info()
+    assert ozero == 0 and st["num_neg"] == oneg and st["num_zero"] == 0 and st["num_delay"] == 0 and not st["marks"], (st0, st)
+    assert (I.num_delayed, I.num_restructures) == (moved, edits)
+    if st0["num_delay"] or st0["num_zero"]:
+        assert 1 <= edits <= 8 and moved > 0 and I.nnz_l <= 2 * nl0            # the structure grew, it did not explode
+    else:
+        assert edits == 0 and I.nnz_l == nl0
+    if case == "band_1e-6":
+        assert st0["num_zero"] > 100                                        # the static result was SINGULAR: the deviation VERDICT r03 names
+    # the edited structure is a valid symbolic factorisation (block elimination walks it with all its assertions) ...
+    mirror.factor_solve(mirror.fetch(s), v, b)          # (its inertia / solution mean nothing here: it inverts the hostile pivot blocks without pivoting)
+    # ... and with every multiplier bounded by 1/u the factorisation is as accurate as that bound allows
+    res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
+    assert res <= (1e-12 if u == 0.01 else 1e-2), res
+
+
+def test_delay_columns_moves_columns_to_the_parent_front():
+    """the structural edit on its own: the moved column leaves its supernode, is a fully-summed column of the parent's, the partition
+    still covers every column once, a supernode never exceeds max_sn_cols, and a column that moves again climbs two levels."""
+    n, r, c, v, neg = kktgen.grid_kkt(14, 14, dof=3, ncon=2, seed=2)
+    K = kktgen.to_scipy(n, r, c, v); b = K @ np.ones(n)
+    s = ipopt_amd.KKTSolver(scaling=0)
+    s.initialize_structure(n, r, c, vals=v)
+    sym = mirror.fetch(s)
+    leaf = next(f for f in range(sym["info"].num_sn) if sym["level"][f] == 0 and sym["parent"][f] >= 0 and sym["parent"][sym["parent"][f]] >= 0 and sym["parent"][sym["parent"][sym["parent"][f]]] >= 0)
+    col = sym["perm"][sym["colptr"][leaf]]                       # caller's numbering (0-based)
+    chain = [leaf]
+    while sym["parent"][chain[-1]] >= 0:
+        chain.append(sym["parent"][chain[-1]])
+    first_cols = [sym["perm"][sym["colptr"][f + 1] - 1] for f in chain]      # the last column of every front on the way up: an anchor that does not move
+    def front_of(sy, orig):
+        ip = np.empty(n, dtype=int); ip[sy["perm"]] = np.arange(n)
+        return int(np.searchsorted(sy["colptr"], ip[orig], side="right") - 1)
+    assert s.delay_columns([col + 1]) == 1
+    s1 = mirror.fetch(s)
+    assert front_of(s1, col) == front_of(s1, first_cols[1])                 # one level up
+    assert sorted(s1["perm"].tolist()) == list(range(n)) and np.diff(s1["colptr"]).max() <= 64
+    assert s.delay_columns([col + 1]) == 1
+    s2 = mirror.fetch(s)
+    assert front_of(s2, col) == front_of(s2, first_cols[3])                 # a repeat offender climbs two levels
+    x, nb = mirror.factor_solve(s2, v, b)
+    assert nb == neg and np.abs(x - 1).max() <= 1e-8
+    root = int(np.nonzero(s2["parent"] < 0)[0][0])
+    assert s.delay_columns([s2["perm"][s2["colptr"][root]] + 1]) == 0          # a root front has nowhere to delay to
+    I = s.info()
+    assert (I.num_delayed, I.num_restructures) == (2, 2)
