@@ -451,6 +451,13 @@ int mi355x_kkt_debug_clocks(mi355x_kkt_handle h, unsigned long long* out128)
     try { return h->num->debug_clocks(out128) ? 0 : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
 }
 
+/* development aid, not part of the public header: pivot data of the last factorisation (permuted numbering, pivot order inside a front) */
+int mi355x_kkt_debug_pivots(mi355x_kkt_handle h, double* dinv, double* doff, int* ptype, int* lperm)
+{
+    if (!h || !h->numeric_ready || !h->factored) return MI355X_KKT_FATAL;
+    try { return h->num->debug_pivots(dinv, doff, ptype, lperm) ? 0 : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
+}
+
 // ---- multi-GPU ----
 int mi355x_kkt_comm_unique_id(void* out128)
 {

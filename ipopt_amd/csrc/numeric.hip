@@ -1745,6 +1745,15 @@ public:
         } else for (int i = 0; i < n; ++i) if (z[i] & 2) out.push_back(i);
         return true;
     }
+    // development aid: D^{-1}, the 2x2 off-diagonals, pivot types and the within-front pivot order of the last factorisation (permuted numbering)
+    bool debug_pivots(double* dinv, double* doff, int* ptype, int* lperm) {
+        DeviceGuard guard(dev);
+        if (!ready) return false;
+        const size_t n = S->n;
+        HIPCHK(hipMemcpy(dinv, V.dinv, n * sizeof(double), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(doff, V.doff, n * sizeof(double), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(ptype, V.ptype, n * sizeof(int), hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(lperm, V.lperm, n * sizeof(int), hipMemcpyDeviceToHost));
+        return true;
+    }
     bool debug_clocks(unsigned long long* out) {
         DeviceGuard guard(dev);
         if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
@@ -1840,6 +1849,7 @@ double Numeric::last_solve_ms() const { return p_->solve_ms; }
 const std::string& Numeric::error() const { return p_->err_; }
 bool Numeric::profile(int reps, double* ms, int* launches) { return p_->profile(reps, ms, launches); }
 bool Numeric::debug_clocks(unsigned long long* out) { return p_->debug_clocks(out); }
+bool Numeric::debug_pivots(double* a, double* b, int* c, int* d) { return p_->debug_pivots(a, b, c, d); }
 bool Numeric::factor_local(const double* dvals) { return p_->factor_local(dvals); }
 bool Numeric::top_arena(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "top_arena: not a multi-GPU handle"; return false; } *d = p_->V.arena; *nd = p_->arena_doubles; return true; }
 bool Numeric::factor_top(FactorStats& st) { return p_->factor_top(st); }

@@ -271,7 +271,7 @@ def ldlt_front_static(F, k, u, u2, small=1e-20, cnorm=None):
     return dict(ord=np.arange(k), ptype=[1] * k, dinv=dinv, doff=np.zeros(k), L=L, nneg=nneg, nzero=0, ntwo=0, ndelay=0, chg=0, delayed=set())
 
 
-def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_blocks=True):
+def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_blocks=True, debug=False):
     """multifrontal LDL^T with the pivoting rules of the HIP kernels (no scaling: use scaling=0 on the GPU side).
     Returns (x, dict(num_neg, num_zero, num_two, num_delay, u_sensitive, num_fast)); num_fast = pivot blocks of big fronts
     accepted on the natural-order a-posteriori path (ldlt_block_static), the others took the strict rule."""
@@ -286,6 +286,8 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_bloc
             children[parent[s]].append(s)
     fac, cbs, cvec = [None] * nsn, [None] * nsn, [None] * nsn
     tot = dict(num_neg=0, num_zero=0, num_two=0, num_delay=0, u_sensitive=0, num_fast=0, marks=[])     # marks: permuted columns flagged as delayed pivots
+    if debug:
+        tot["dbg"] = []                # per front: (s, c0, k, m, pivot order, pivot types, diagonal of D^{-1})
     b = rhs[sym["perm"]].astype(float).copy()
     # inf-norm of every column of the (symmetric) input matrix, permuted numbering
     cn = np.zeros(n)
@@ -347,6 +349,8 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_bloc
         tot["marks"] += [c0 + int(p) for p in sorted(st["delayed"])]
         Dinv = _dinv_matrix(st)
         fac[s] = (P, L11, L21, Dinv)
+        if "dbg" in tot:
+            tot["dbg"].append((s, c0, k, m, P.copy(), np.array(st["ptype"]), np.diag(Dinv).copy()))
         cbs[s] = cb
         y = np.linalg.solve(L11, bs[:k][P])
         cvec[s] = bs[k:] - L21 @ y
