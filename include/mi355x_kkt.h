@@ -84,7 +84,9 @@ typedef struct mi355x_kkt_options {
     int    delay_rounds;    /* delayed pivoting across fronts: columns that fail the threshold test in their front are moved to the */
                             /* parent front's supernode and the matrix is refactored, at most this many times per factor() call   */
                             /* (default 8; 0 = static pivoting: failed pivots are forced and counted in num_small)                */
-    int    reserved[1];
+    int    smart_quality;   /* IncreaseQuality: 0 (default) = raise u whenever it is below pivtolmax, as the reference adapters do     */
+                            /* (IpMa97SolverInterface.cpp:822-854); 1 = answer "cannot improve" at once when the last factorisation  */
+                            /* recorded that no pivot decision depends on u up to pivtolmax (skips an identical refactorisation)      */
 } mi355x_kkt_options;
 
 typedef struct mi355x_kkt_info {
@@ -204,8 +206,8 @@ int  mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u);
 int  mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax);
 /* IncreaseQuality (IpSparseSymLinearSolverInterface.hpp:220): raises u <- min(pivtolmax, u^0.75) (the rule of
  * IpMa97SolverInterface.cpp:822-854, IpMa27TSolverInterface.cpp:724-740) and returns 1 -- the caller then refactors,
- * mi355x_kkt_refactor -- or returns 0 when u is at its maximum or when the last factorisation found that no pivot decision
- * depends on u up to pivtolmax (nothing a refactorisation could improve).  *new_u (may be NULL) receives the new u. */
+ * mi355x_kkt_refactor -- or returns 0 when u is at its maximum (with opts.smart_quality = 1 also when the last factorisation found
+ * that no pivot decision depends on u up to pivtolmax: nothing a refactorisation could improve).  *new_u (may be NULL) receives the new u. */
 int  mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u);
 int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
 /* Symmetric scaling at run time (the option `scaling` only sets the initial mode): 0 none, 1 Ruiz inf-norm equilibration

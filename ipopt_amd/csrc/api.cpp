@@ -41,7 +41,7 @@ void mi355x_kkt_default_options(mi355x_kkt_options* o)
     o->nd_leaf = 32; o->nemin = 8; o->max_sn_cols = 64;
     o->pivtol = 1e-8; o->pivtolmax = 1e-4; o->small = 1e-20;
     o->refine_steps = 0; o->use_graph = 1; o->nranks = 1; o->rank = 0; o->verbose = 0; o->leaf_cols = 0; o->tree_merge = 0; o->wide_panels = 0; o->chain_group = 4; o->solve_group = 0; o->subcube = 0;
-    o->delay_rounds = 8;
+    o->delay_rounds = 8; o->smart_quality = 0;
 }
 
 int mi355x_kkt_create(mi355x_kkt_handle* h, const mi355x_kkt_options* opts)
@@ -378,13 +378,15 @@ int mi355x_kkt_set_pivtolmax(mi355x_kkt_handle h, double umax)
  * whether ANY pivot decision would come out differently at u = pivtolmax (a pivot that passes the threshold tests at umax
  * passes them at every smaller u).  Returns 1 and stores the new u when the caller should refactor, 0 when the quality
  * cannot be increased (u already at its maximum, or no decision depends on u: Ipopt then goes straight to its
- * perturbation fallback instead of burning refactorisations, IpPDFullSpaceSolver.cpp:290-301). */
+ * perturbation fallback instead of burning refactorisations, IpPDFullSpaceSolver.cpp:290-301).  That shortcut is OPT-IN
+ * (opts.smart_quality, adapter option mi355x_smart_quality): by default u is raised whenever it is below its maximum, exactly as the
+ * reference adapters do, so that Ipopt's 'q' info character and the refactorisation appear where they appear with MA27 / MA97. */
 int mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u)
 {
     if (!h) return 0;
     const double umax = h->opts.pivtolmax > h->opts.pivtol ? h->opts.pivtolmax : h->opts.pivtol;
     if (h->opts.pivtol >= umax) return 0;
-    if (h->factored && !h->stats_stale && !h->last.u_sensitive) return 0;
+    if (h->opts.smart_quality && h->factored && !h->stats_stale && !h->last.u_sensitive) return 0;      // (opt-in: the reference adapters always raise u)
     double u = std::pow(h->opts.pivtol, 0.75);
     if (u > umax) u = umax;
     h->opts.pivtol = u;

@@ -61,6 +61,9 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
    roptions->AddLowerBoundedIntegerOption("mi355x_delay_rounds", "Delayed-pivot rounds per factorisation.", 0, 8,
                                           "Columns that fail the pivot threshold in their front are moved to the parent front and the matrix is refactored, "
                                           "at most this many times per factorisation (what MA27 / MA57 / MA97 / MUMPS do inside one call); 0 = static pivoting.");
+   roptions->AddStringOption2("mi355x_smart_quality", "IncreaseQuality answers 'no' when the last factorisation did not depend on the pivot tolerance.", "no",
+                              "no", "raise the pivot tolerance whenever it is below mi355x_pivtolmax (what the MA27 / MA57 / MA97 adapters do)",
+                              "yes", "skip the refactorisation when no pivot decision would change up to mi355x_pivtolmax");
    roptions->AddLowerBoundedIntegerOption("mi355x_nranks", "Number of processes (GPUs) sharing each KKT factorisation.", 0, 0,
                                           "0: take WORLD_SIZE / OMPI_COMM_WORLD_SIZE from the environment (1 if unset).");
    roptions->AddLowerBoundedIntegerOption("mi355x_rank", "Rank of this process among mi355x_nranks.", -1, -1,
@@ -113,6 +116,10 @@ void Mi355xSolverInterface::ReadNumericOptions(const OptionsList& options, const
       if( options.GetIntegerValue("mi355x_max_sn_cols", iv, prefix) )
       {
          kopts.max_sn_cols = iv;
+      }
+      if( options.GetStringValue("mi355x_smart_quality", sv, prefix) )
+      {
+         kopts.smart_quality = (sv == "yes") ? 1 : 0;
       }
       if( options.GetIntegerValue("mi355x_delay_rounds", iv, prefix) )
       {

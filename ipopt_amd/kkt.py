@@ -29,7 +29,7 @@ class _Options(C.Structure):
                 ("scaling", C.c_int), ("nd_leaf", C.c_int), ("nemin", C.c_int), ("max_sn_cols", C.c_int),
                 ("pivtol", C.c_double), ("pivtolmax", C.c_double), ("small", C.c_double),
                 ("refine_steps", C.c_int), ("use_graph", C.c_int), ("nranks", C.c_int), ("rank", C.c_int),
-                ("verbose", C.c_int), ("leaf_cols", C.c_int), ("tree_merge", C.c_int), ("wide_panels", C.c_int), ("chain_group", C.c_int), ("solve_group", C.c_int), ("subcube", C.c_int), ("delay_rounds", C.c_int), ("reserved", C.c_int * 1)]
+                ("verbose", C.c_int), ("leaf_cols", C.c_int), ("tree_merge", C.c_int), ("wide_panels", C.c_int), ("chain_group", C.c_int), ("solve_group", C.c_int), ("subcube", C.c_int), ("delay_rounds", C.c_int), ("smart_quality", C.c_int)]
 
 
 class _Info(C.Structure):

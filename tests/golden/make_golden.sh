@@ -14,7 +14,9 @@ D=../../oracle/_ref
 export MKL_NUM_THREADS=1 OMP_NUM_THREADS=1
 run() {  # name problem N record?
   name=$1; p=$2; n=$3; rec=$4
-  if [ "$rec" = rec ]; then $D/ref_driver $p $n --record $name.kktrec > /tmp/$name.log; else $D/ref_driver $p $n > /tmp/$name.log; fi
+  if [ "$rec" = rec ]; then $D/ref_driver $p $n --record $name.kktrec > /tmp/$name.log;
+  elif [ "${rec#rec}" != "$rec" ]; then $D/ref_driver $p $n --record $name.kktrec --max-records ${rec#rec} > /tmp/$name.log;      # recN: the first N boundary calls only
+  else $D/ref_driver $p $n > /tmp/$name.log; fi
   grep -E "^ +[0-9]+r? " /tmp/$name.log | awk '{print $1, $2, $3, $4, $5, $7, $10}' > $name.iters
   grep DRIVER_SUMMARY /tmp/$name.log | sed 's/^DRIVER_SUMMARY //' > $name.summary
   echo "$name: $(wc -l < $name.iters) iteration lines"
@@ -22,8 +24,9 @@ run() {  # name problem N record?
 run hs071 hs071 0 rec
 run lukvle1_100 LukVlE1 100 rec
 run mbndry1_8 MBndryCntrl1 8 rec
-run lukvle1_10000 LukVlE1 10000 norec
-run mbndry1_100 MBndryCntrl1 100 norec
+# BASELINE.json configs[1] and [2]: iteration tables + the first four calls across the boundary (a full recording is 20 MB)
+run lukvle1_10000 LukVlE1 10000 rec4
+run mbndry1_100 MBndryCntrl1 100 rec4
 run lukvle1_1000000 LukVlE1 1000000 norec
 # more problem classes of examples/ScalableProblems (inequalities, other PDE controls, 3-D): iteration tables only
 run lukvli1_10000 LukVlI1 10000 norec
@@ -31,6 +34,7 @@ run lukvle5_10000 LukVlE5 10000 norec
 run mbndry2_100 MBndryCntrl2 100 norec
 run mdist1_100 MDistCntrl1 100 norec
 run mbndry3d_12 MBndryCntrl_3D 12 norec
+run mbndry3d_30 MBndryCntrl_3D 30 norec      # 3-D separators (fronts of ~2 000 rows at KKT dimension 50 600): SURVEY 8(d)-5's MFMA-bound family at a size the CPU run takes 17 s for
 run mbndry1_300 MBndryCntrl1 300 norec
 # the CUTEst-style ~10^6 stand-in of BASELINE.json configs[4] (n = 492 800, m = 490 000; examples/ScalableProblems/solve_problem.cpp:28-91),
 # 8 MKL threads (the iteration table does not depend on the thread count; one thread takes a minute per run)

@@ -46,7 +46,7 @@ def test_option_struct_layout_matches_header():
     assert (o.use_graph, o.nranks, o.rank) == (1, 1, 0)
     assert (o.chain_group, o.solve_group, o.subcube) == (4, 0, 0)      # (subcube took the first of the reserved ints: same struct size)
     assert o.delay_rounds == 8                                          # (delay_rounds took the next reserved int)
-    assert ctypes.sizeof(o) == ctypes.sizeof(kkt._Options) == 112 and list(o.reserved) == [0]
+    assert ctypes.sizeof(o) == ctypes.sizeof(kkt._Options) == 112 and o.smart_quality == 0
     assert ctypes.sizeof(kkt._Info) == 200                              # num_delayed / num_restructures live in what was reserved[0]
 
 

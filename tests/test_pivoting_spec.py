@@ -219,7 +219,7 @@ def test_delayed_pivots_reach_the_delaying_oracles_inertia(case, u):
     mirror.factor_solve(mirror.fetch(s), v, b)          # (its inertia / solution mean nothing here: it inverts the hostile pivot blocks without pivoting)
     # ... and with every multiplier bounded by 1/u the factorisation is as accurate as that bound allows
     res = np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max())
-    assert res <= (1e-12 if u == 0.01 else 1e-2), res
+    assert res <= (1e-12 if u == 0.01 else 1e-1), res      # (u = 1e-8 admits multipliers of 1e8 per pivot -- MA27 at ma27_pivtol = 1e-8 likewise: Ipopt's answer is IncreaseQuality)
 
 
 def test_delay_columns_moves_columns_to_the_parent_front():
