@@ -560,6 +560,7 @@ public:
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
         V.fastpiv = getenv("MI355X_KKT_NO_FASTPIV") == nullptr ? 1 : 0;
         V.asm_pull = getenv("MI355X_KKT_NO_ASM_PULL") == nullptr ? 1 : 0;
+        asm_v1 = getenv("MI355X_KKT_ASM_V1") != nullptr;      // (the one-wavefront-per-column assembly kernel of rounds 1-3)
         V.fastu = 1e-4; if (const char* e = getenv("MI355X_KKT_FASTPIV_FLOOR")) V.fastu = atof(e);      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
         if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
         pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
@@ -987,6 +988,7 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_grp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_assemble2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
@@ -1051,7 +1053,7 @@ public:
             if ((single || multi) && grouped && lv >= S->grp_cut_level) {
                 // the chain groups whose first link sits on this level, one launch each (the multi-GPU schedules have their own group lists)
                 if (!drain_chain()) return false;
-                if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nb), dim3(256), 0, stream, V, b0, top_mode);
+                if (!(single && lv_asm_skip[lv])) launch_assemble(mm, nb, b0, top_mode);
                 return launch_groups(lv, single ? gs_single : (top_mode ? *gs_cur : gs_local));
             }
             if (!single) { const bool sm = mm <= 640; return launch_big(lv, b0, sm ? b1 : b0, b1, top_mode, mm, kk, sm ? tiles64 : 0, sm ? 0 : tiles, false); }
@@ -1122,11 +1124,17 @@ public:
         } else if (G.tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.tiles[lv], nb), dim3(1024), 0, stream, V, bs, 0, 0, 0);
         return true;
     }
+    bool asm_v1 = false;
+    void launch_assemble(int mm, int nfronts, int b0, int top_mode) {
+        if (asm_v1) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
+        const int ldi = (mm + 15) & ~15;                    // the children's inverse row maps of one front in LDS: ASM_MAXCH x ldi ints (<= 78 KiB at the largest front)
+        LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble2, dim3((mm + ASM_CH - 1) / ASM_CH, nfronts), dim3(256), (size_t)ASM_MAXCH * ldi * sizeof(int), stream, V, b0, top_mode, ldi);
+    }
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
         if (single && lv_chain[lv] && !prof_on && !top_mode) return launch_big_chain(lv, b0, bs, b1, mm, kk, tiles_small, tiles);
         if (!drain_chain()) return false;
         const int nball = b1 - b0;
-        if (!(single && lv_asm_skip[lv])) LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nball), dim3(256), 0, stream, V, b0, top_mode);
+        if (!(single && lv_asm_skip[lv])) launch_assemble(mm, nball, b0, top_mode);
         const int nrb = (mm + 63) / 64;
         if (fuse_dt && (single || multi) && kk <= 64 && nball * (1 + nrb) <= fuse_dt_maxwg) {      // (multi-GPU: local subtrees and replicated top alike; the per-kernel profile books the fused launch under the pivot blocks)
             // few fronts on the level: pivot block + panel solve in one flag-synchronised launch (k_big_diag_trsm)
