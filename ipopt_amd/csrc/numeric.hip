@@ -988,7 +988,7 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_grp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_big_assemble2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_assemble2, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));      // (+ 80 bytes of static LDS)
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
