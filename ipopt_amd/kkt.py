@@ -52,7 +52,8 @@ class KKTInfo:
 
 
 def library_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355x_kkt.so")
+    # (MI355X_KKT_LIBRARY: development aid -- an A/B variant of the library built by `make variant`, see ipopt_amd/Makefile)
+    return os.environ.get("MI355X_KKT_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libmi355x_kkt.so")
 
 
 _LIB = None
