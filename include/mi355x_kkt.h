@@ -59,7 +59,9 @@ typedef struct mi355x_kkt_options {
     int    matching;        /* 1 (default) = pre-pair zero-diagonal rows with a partner column so that  */
                             /* the pair is one 2x2-capable supernode; 0 = off                           */
     int    scaling;         /* 0 none, 1 (default) = symmetric Ruiz inf-norm equilibration on device,   */
-                            /* 3 = maximum-product matching scaling (MC64-style; host, per factorisation) */
+                            /* 3 = maximum-product matching scaling (MC64-style; host, per factorisation), */
+                            /* 4 = the same computed at the first factorisation and REUSED until          */
+                            /*     IncreaseQuality asks for better (MA97's "...-reuse" switches)          */
     int    nd_leaf;         /* ND stops splitting below this many (compressed) nodes; default 32        */
     int    nemin;           /* relaxed-supernode amalgamation: always merge below this #cols; default 8 */
     int    max_sn_cols;     /* cap on columns of an amalgamated supernode; default (and max) 64                */
@@ -212,7 +214,8 @@ int  mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u);
 int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
 /* Symmetric scaling at run time (the option `scaling` only sets the initial mode): 0 none, 1 Ruiz inf-norm equilibration
  * on the device (the algorithm of MC77), 2 the caller's factors (n doubles, caller's numbering; copied), 3 maximum-product
- * matching scaling (the job of MC64: Duff & Koster 2001; host algorithm, recomputed at every factorisation while selected).  _get_scaling returns the factors the last
+ * matching scaling (the job of MC64: Duff & Koster 2001; host algorithm, recomputed at every factorisation while selected), 4 the same computed once and
+ * reused until mi355x_kkt_increase_quality or a new _set_scaling (IpMa97SolverInterface.cpp:725-771: SWITCH_AT_START_REUSE / ON_DEMAND_REUSE).  _get_scaling returns the factors the last
  * factorisation used.  Together they give the MA97 call protocol its meaning: control.scaling > 0 => compute and hand back in
  * scale[], control.scaling == 0 with scale != NULL => reuse the caller-held factors, else none (IpMa97SolverInterface.cpp:641-678). */
 int  mi355x_kkt_set_scaling(mi355x_kkt_handle h, int mode, const double* user_factors);

@@ -196,28 +196,32 @@ int mi355x_kkt_matching_scaling(int n, int nnz, const int* irn, const int* jcn, 
 {
     if (n < 0 || nnz < 0 || !factors || (nnz > 0 && (!irn || !jcn || !a))) return MI355X_KKT_FATAL;
     try {
-        // canonical lower entries, duplicates summed, then the full symmetric pattern by columns
-        std::vector<std::pair<long long, double>> e; e.reserve(nnz);
+        // the full symmetric pattern by columns (both triangles), duplicates summed: bucket the entries by column, sort every (short) column by
+        // row, merge equal rows -- in triplet order inside a column, so the sums do not depend on anything but the input
+        for (int t = 0; t < nnz; ++t) { const int i = irn[t] - index_base, j = jcn[t] - index_base; if (i < 0 || j < 0 || i >= n || j >= n) return MI355X_KKT_FATAL; }
+        std::vector<int> cnt((size_t)n + 1, 0);
+        for (int t = 0; t < nnz; ++t) { const int i = irn[t] - index_base, j = jcn[t] - index_base; cnt[j + 1]++; if (i != j) cnt[i + 1]++; }
+        for (int j = 0; j < n; ++j) cnt[j + 1] += cnt[j];
+        std::vector<int> rows(cnt[n]), fill(cnt.begin(), cnt.end() - 1); std::vector<double> vals(cnt[n]);
         for (int t = 0; t < nnz; ++t) {
-            int i = irn[t] - index_base, j = jcn[t] - index_base;
-            if (i < 0 || j < 0 || i >= n || j >= n) return MI355X_KKT_FATAL;
-            if (i < j) std::swap(i, j);
-            e.emplace_back((long long)j * n + i, a[t]);
+            const int i = irn[t] - index_base, j = jcn[t] - index_base;
+            rows[fill[j]] = i; vals[fill[j]++] = a[t];
+            if (i != j) { rows[fill[i]] = j; vals[fill[i]++] = a[t]; }
         }
-        std::sort(e.begin(), e.end(), [](const std::pair<long long, double>& x, const std::pair<long long, double>& y) { return x.first < y.first; });
-        std::vector<int> li, lj; std::vector<double> lv;
-        for (size_t q = 0; q < e.size(); ++q) {
-            if (!li.empty() && (long long)lj.back() * n + li.back() == e[q].first) lv.back() += e[q].second;
-            else { lj.push_back((int)(e[q].first / n)); li.push_back((int)(e[q].first % n)); lv.push_back(e[q].second); }
+        std::vector<int> ptr((size_t)n + 1, 0), idx; std::vector<double> av;
+        idx.reserve(cnt[n]); av.reserve(cnt[n]);
+        std::vector<std::pair<int, double>> col;
+        for (int j = 0; j < n; ++j) {
+            col.clear();
+            for (int p = cnt[j]; p < cnt[j + 1]; ++p) col.emplace_back(rows[p], vals[p]);
+            std::stable_sort(col.begin(), col.end(), [](const std::pair<int, double>& x, const std::pair<int, double>& y) { return x.first < y.first; });
+            for (size_t q = 0; q < col.size(); ++q) {
+                if (q > 0 && col[q].first == col[q - 1].first) av.back() += col[q].second;
+                else { idx.push_back(col[q].first); av.push_back(col[q].second); }
+            }
+            ptr[j + 1] = (int)idx.size();
         }
-        std::vector<int> ptr(n + 1, 0);
-        for (size_t q = 0; q < li.size(); ++q) { ptr[lj[q] + 1]++; if (li[q] != lj[q]) ptr[li[q] + 1]++; }
-        for (int j = 0; j < n; ++j) ptr[j + 1] += ptr[j];
-        std::vector<int> idx(ptr[n]), fill(ptr.begin(), ptr.end() - 1); std::vector<double> av(ptr[n]);
-        for (size_t q = 0; q < li.size(); ++q) {
-            idx[fill[lj[q]]] = li[q]; av[fill[lj[q]]++] = std::fabs(lv[q]);
-            if (li[q] != lj[q]) { idx[fill[li[q]]] = lj[q]; av[fill[li[q]]++] = std::fabs(lv[q]); }
-        }
+        for (double& x : av) x = std::fabs(x);
         return matching_scaling(n, ptr.data(), idx.data(), av.data(), factors, num_unmatched) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL;
     } catch (...) { return MI355X_KKT_FATAL; }
 }
@@ -387,6 +391,7 @@ int mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u)
     const double umax = h->opts.pivtolmax > h->opts.pivtol ? h->opts.pivtolmax : h->opts.pivtol;
     if (h->opts.pivtol >= umax) return 0;
     if (h->opts.smart_quality && h->factored && !h->stats_stale && !h->last.u_sensitive) return 0;      // (opt-in: the reference adapters always raise u)
+    if (h->num && h->opts.scaling == 4) h->num->invalidate_matching();      // a reused matching scaling is computed afresh when the caller asks for better quality
     double u = std::pow(h->opts.pivtol, 0.75);
     if (u > umax) u = umax;
     h->opts.pivtol = u;

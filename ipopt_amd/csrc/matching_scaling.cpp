@@ -15,6 +15,10 @@
 #include <limits>
 #include <queue>
 #include <vector>
+#include <chrono>
+#include <thread>
+#include <cstdio>
+#include <cstdlib>
 
 namespace mi355x {
 
@@ -22,27 +26,63 @@ bool matching_scaling(int n, const int* ptr, const int* idx, const double* absva
 {
     // full symmetric pattern: column j holds the rows idx[ptr[j] .. ptr[j+1]) with |values| absval[...]
     const double INF = std::numeric_limits<double>::infinity();
+    const bool timing = getenv("MI355X_KKT_MATCH_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
+    auto lap = [&](const char* w) { if (timing) { const double t = now(); fprintf(stderr, "[match] %-12s %.3f s\n", w, t - t0); t0 = t; } };
     std::vector<double> cmaxlog(n, 0.0), u(n, INF), v(n, 0.0);
     std::vector<double> cost(ptr[n]);
     std::vector<char> empty_col(n, 0);
-    for (int j = 0; j < n; ++j) {
-        double mx = 0.0;
-        for (int p = ptr[j]; p < ptr[j + 1]; ++p) mx = std::max(mx, absval[p]);
-        if (!(mx > 0.0)) { empty_col[j] = 1; continue; }
-        cmaxlog[j] = std::log(mx);
-        for (int p = ptr[j]; p < ptr[j + 1]; ++p) cost[p] = absval[p] > 0.0 ? cmaxlog[j] - std::log(absval[p]) : INF;
+    {   // the logarithms are most of the set-up: columns are independent, a few threads take them
+        const int T = (ptr[n] > (1 << 20)) ? (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())) : 1;
+        auto work = [&](int jb, int je) {
+            for (int j = jb; j < je; ++j) {
+                double mx = 0.0;
+                for (int p = ptr[j]; p < ptr[j + 1]; ++p) mx = std::max(mx, absval[p]);
+                if (!(mx > 0.0)) { empty_col[j] = 1; continue; }
+                cmaxlog[j] = std::log(mx);
+                for (int p = ptr[j]; p < ptr[j + 1]; ++p) cost[p] = absval[p] > 0.0 ? cmaxlog[j] - std::log(absval[p]) : INF;
+            }
+        };
+        if (T <= 1) work(0, n);
+        else { std::vector<std::thread> th; for (int t = 0; t < T; ++t) th.emplace_back(work, (int)((long long)n * t / T), (int)((long long)n * (t + 1) / T)); for (auto& x : th) x.join(); }
     }
-    // initial duals: v = 0 (every column has a zero-cost entry), u_i = min_j c_ij; greedy matching on tight entries
+    lap("costs");
+    // initial duals (the start MC64 makes): u_i = min_j c_ij, then v_j = min_i (c_ij - u_i) -- feasible, and every column has a tight entry;
+    // greedy matching on tight entries, then one alternation per column still free: a tight row of it that is matched to a column with another
+    // tight, free row gives way.  What is left goes through the shortest augmenting paths below.
     for (int j = 0; j < n; ++j) for (int p = ptr[j]; p < ptr[j + 1]; ++p) u[idx[p]] = std::min(u[idx[p]], cost[p]);
     for (int i = 0; i < n; ++i) if (u[i] == INF) u[i] = 0.0;
+    for (int j = 0; j < n; ++j) {
+        if (empty_col[j]) continue;
+        double mn = INF;
+        for (int p = ptr[j]; p < ptr[j + 1]; ++p) mn = std::min(mn, cost[p] - u[idx[p]]);
+        v[j] = (mn == INF) ? 0.0 : mn;
+    }
     std::vector<int> mrow(n, -1), mcol(n, -1);      // mrow[i] = column matched to row i, mcol[j] = row matched to column j
+    auto tight = [&](int p, int j) { return cost[p] - u[idx[p]] - v[j] <= 0.0; };
     for (int j = 0; j < n; ++j) {
         if (empty_col[j]) continue;
         for (int p = ptr[j]; p < ptr[j + 1]; ++p) {
             const int i = idx[p];
-            if (mrow[i] < 0 && cost[p] - u[i] - v[j] <= 0.0) { mrow[i] = j; mcol[j] = i; break; }
+            if (mrow[i] < 0 && tight(p, j)) { mrow[i] = j; mcol[j] = i; break; }
         }
     }
+    for (int j = 0; j < n; ++j) {
+        if (empty_col[j] || mcol[j] >= 0) continue;
+        for (int p = ptr[j]; p < ptr[j + 1] && mcol[j] < 0; ++p) {
+            const int i = idx[p];
+            if (!tight(p, j)) continue;
+            const int j2 = mrow[i];                 // (matched: the greedy pass would have taken a free tight row)
+            if (j2 < 0) { mrow[i] = j; mcol[j] = i; break; }
+            for (int q = ptr[j2]; q < ptr[j2 + 1]; ++q) {
+                const int i2 = idx[q];
+                if (mrow[i2] < 0 && tight(q, j2)) { mrow[i2] = j2; mcol[j2] = i2; mrow[i] = j; mcol[j] = i; break; }
+            }
+        }
+    }
+    { int nm = 0; for (int j = 0; j < n; ++j) nm += mcol[j] >= 0; if (timing) fprintf(stderr, "[match] greedy matched %d of %d\n", nm, n); }
+    lap("greedy");
     std::vector<double> dist(n, INF);
     std::vector<int> pred(n, -1), touched, fin_rows;
     std::vector<char> done(n, 0);
@@ -86,6 +126,7 @@ bool matching_scaling(int n, const int* ptr, const int* idx, const double* absva
         } else ++unmatched;
         for (int i : touched) { dist[i] = INF; pred[i] = -1; done[i] = 0; }
     }
+    lap("augment");
     for (int i = 0; i < n; ++i) {
         const double r = std::exp(u[i]), q = empty_col[i] ? 1.0 : std::exp(v[i] - cmaxlog[i]);
         double s = std::sqrt(r * q);

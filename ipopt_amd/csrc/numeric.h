@@ -56,8 +56,9 @@ public:
     bool   solve_fwd_local(double* drhs);
     bool   top_rhs(double** dptr, int64_t* ndoubles);
     bool   solve_top_and_bwd(double* drhs);
-    bool   set_scaling(int mode, const double* user_factors_orig_numbering);   // 0 none, 1 Ruiz (device), 2 the caller's factors
+    bool   set_scaling(int mode, const double* user_factors_orig_numbering);   // 0 none, 1 Ruiz (device), 2 the caller's factors, 3 matching (every factorisation), 4 matching (computed once, reused)
     bool   get_scaling(double* out_orig_numbering);                             // factors of the last factorisation
+    void   invalidate_matching();                                                // scaling mode 4: compute the matching scaling afresh at the next factorisation
     // first touch of the device (context, code objects) and the pinned staging buffer: independent of the analysis, so the C API runs it on a
     // thread next to it (0.1-0.3 s of an Ipopt run's LinearSystemSymbolicFactorization otherwise).  Returns the buffer or nullptr.
     static int   resolve_device(int device);              // on the caller's thread: the ordinal `device` (or the current device for -1) means, -1 without a device

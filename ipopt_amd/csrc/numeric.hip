@@ -95,13 +95,14 @@ public:
     bool set_scaling(int mode, const double* user) {
         DeviceGuard guard(dev);
         if (!ready) { err_ = "set_scaling: solver not set up"; return false; }
-        if (mode < 0 || mode > 3 || (mode == 2 && !user)) { err_ = "set_scaling: mode 0 (none), 1 (ruiz), 2 (user factors, non-null) or 3 (matching)"; return false; }
+        if (mode < 0 || mode > 4 || (mode == 2 && !user)) { err_ = "set_scaling: mode 0 (none), 1 (ruiz), 2 (user factors, non-null), 3 (matching) or 4 (matching, reused)"; return false; }
+        match_valid = false;                                  // (mode 4: the factors of an earlier selection do not survive a new one)
         if (mode == 2) {
             if (!d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
             HIPCHK(hipMemcpyAsync(d_user_scale, user, (size_t)S->n * sizeof(double), hipMemcpyHostToDevice, stream));
             HIPCHK(hipStreamSynchronize(stream));      // `user` is the caller's pageable memory
         }
-        if (mode == 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
+        if (mode >= 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         if (mode != opt.scaling && g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }     // the captured sequence differs
         opt.scaling = mode;
         return true;
@@ -109,6 +110,10 @@ public:
     // scaling mode 3: maximum-product matching scaling (MC64-style, matching_scaling.cpp) of the values now in V.tvals.  Host
     // algorithm, like the analysis: gather on the device, one D2H of the nnz(A) summed values, the matching, one H2D of n
     // factors -- which the factorisation then applies exactly like caller-supplied ones.
+    // scaling mode 4 = mode 3 computed ONCE and kept: the factors of the first factorisation serve the following ones until the caller asks for
+    // better quality (IncreaseQuality -> invalidate_matching) -- MA97's "...-reuse" switches (IpMa97SolverInterface.cpp:725-771,824-840)
+    bool match_valid = false;
+    void invalidate_matching() { match_valid = false; }
     bool compute_matching_scaling() {
         const Symbolic& Sy = *S;
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
@@ -957,7 +962,7 @@ public:
             !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
             !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
-        if (opt.scaling == 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
+        if (opt.scaling >= 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2 && !d_user_scale) opt.scaling = 1;       // (user factors can only come through set_scaling)
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
@@ -1215,7 +1220,7 @@ public:
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
             have_values = true;
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
-        if (opt.scaling == 3 && Sy.n > 0 && !compute_matching_scaling()) return false;
+        if ((opt.scaling == 3 || (opt.scaling == 4 && !match_valid)) && Sy.n > 0) { if (!compute_matching_scaling()) return false; match_valid = true; }
         HIPCHK(hipEventRecord(ev0, stream));
         // A factorisation with look-ahead forks onto the second stream: it is launched eagerly (measured equal to the graph
         // replay on these ~10^3-launch sequences, whose kernels are long), because a two-stream hipGraph replays up to 1.5x
@@ -1609,7 +1614,7 @@ public:
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
             have_values = true;
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
-        if (opt.scaling == 3 && n > 0 && !compute_matching_scaling()) return false;
+        if ((opt.scaling == 3 || (opt.scaling == 4 && !match_valid)) && n > 0) { if (!compute_matching_scaling()) return false; match_valid = true; }
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_factor_prologue, dim3(grid1d(n)), dim3(256), 0, stream, V);
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
@@ -1866,6 +1871,7 @@ bool Numeric::top_rhs(double** d, int64_t* nd) { if (!p_->multi) { p_->err_ = "t
 bool Numeric::solve_top_and_bwd(double* drhs) { return p_->solve_top_and_bwd(drhs); }
 bool Numeric::set_scaling(int mode, const double* user) { return p_->set_scaling(mode, user); }
 bool Numeric::get_scaling(double* out) { return p_->get_scaling(out); }
+void Numeric::invalidate_matching() { p_->invalidate_matching(); }
 bool Numeric::zero_pivots(std::vector<int>& out) { return p_->zero_pivots(out); }
 bool Numeric::failed_pivots(std::vector<int>& out) { return p_->failed_pivots(out); }
 bool Numeric::restructure(const Symbolic& S) { return p_->restructure(S); }
