@@ -290,7 +290,7 @@ int  mi355x_kkt_profile(mi355x_kkt_handle h, int reps, double* ms, int* launches
  * Create every rank's handle with opts.nranks = P, opts.rank = r, analyse the SAME structure on every rank, then give the
  * handle a communicator.  From then on the ordinary entry points (factor / refactor / solve / solve_device*) run the
  * distributed sequence themselves, on the solver's stream, without host synchronisation between the phases:
- *     factor:  own subtrees -> all-reduce(top arena, fp64 sum) -> replicated top -> all-reduce(inertia counters)
+ *     factor:  own subtrees -> all-reduce(top arena: lower triangles of the join fronts, fp64 sum) -> replicated top -> all-reduce(inertia counters)
  *     solve :  local forward -> all-reduce(top rhs) -> replicated top fwd/bwd -> local backward -> all-reduce(solution)
  * Inputs (values, right-hand sides) are identical on every rank, outputs (inertia, status, solution) too -- which is what
  * Ipopt needs when every rank runs the same (deterministic) algorithm around its share of the linear algebra; cf. the
@@ -305,6 +305,16 @@ typedef int (*mi355x_kkt_allreduce_fn)(void* ctx, void* dptr, int64_t count, int
 int  mi355x_kkt_comm_unique_id(void* out128);
 int  mi355x_kkt_set_comm_rccl(mi355x_kkt_handle h, const void* unique_id128);
 int  mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn fn, void* ctx);
+/* Range-local exchange.  A replicated front is held by a RANGE of ranks [rank_lo, rank_lo + nranks_in_range) and what it receives comes from
+ * ranks of that range only, so its arena square (lower triangle, packed) and its top right-hand side are summed among those ranks alone:
+ * with RCCL through one sub-communicator per exchange step (ncclCommSplit, created by _set_comm_rccl; without it -- or with
+ * MI355X_KKT_NO_SUBCOMM -- every step is ONE all-reduce over the whole communicator, ranks outside a range contributing zeros), with a
+ * callback communicator through this optional second callback (same contract as mi355x_kkt_allreduce_fn, plus the range; ctx is the one
+ * given to _set_comm_callbacks; only ranks of the range call it).
+ *   _exchange_bytes   bytes of all arena squares / all top right-hand sides of the current structure (what the exchange steps move) */
+typedef int (*mi355x_kkt_allreduce_range_fn)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream, int rank_lo, int nranks_in_range);
+int  mi355x_kkt_set_comm_range_callback(mi355x_kkt_handle h, mi355x_kkt_allreduce_range_fn fn);
+int  mi355x_kkt_exchange_bytes(mi355x_kkt_handle h, int64_t* arena_bytes, int64_t* rhs_bytes);
 /* The phases are also exposed one by one (a caller that wants to overlap or replace the collectives): */
 /* The top-of-tree fronts live in one contiguous device buffer ("top arena").  After
  * factor_local() each rank holds its own subtrees' Schur contributions there; the caller

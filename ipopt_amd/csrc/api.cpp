@@ -483,6 +483,19 @@ int mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn f
     if (!h->numeric_ready) { h->err = "set_comm_callbacks: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
     try { if (!h->num->set_comm_callback(fn, ctx)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
+int mi355x_kkt_set_comm_range_callback(mi355x_kkt_handle h, mi355x_kkt_allreduce_range_fn fn)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready) { h->err = "set_comm_range_callback: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    try { return h->num->set_comm_range_callback(fn) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_exchange_bytes(mi355x_kkt_handle h, int64_t* arena_bytes, int64_t* rhs_bytes)
+{
+    if (!h || !h->numeric_ready) return MI355X_KKT_FATAL;
+    if (arena_bytes) *arena_bytes = h->num->exchange_bytes(0);
+    if (rhs_bytes) *rhs_bytes = h->num->exchange_bytes(1);
+    return MI355X_KKT_SUCCESS;
+}
 #define MG_GUARD if (!h) return MI355X_KKT_FATAL; if (!h->numeric_ready) { h->err = "multi-GPU call without a device"; return MI355X_KKT_FATAL; }
 int mi355x_kkt_factor_local(mi355x_kkt_handle h, const double* dvals) { MG_GUARD try { if (!h->num->factor_local(dvals)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }
 int mi355x_kkt_top_arena(mi355x_kkt_handle h, double** d, int64_t* nd) { MG_GUARD try { if (!h->num->top_arena(d, nd)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return 0; } catch (...) { return MI355X_KKT_FATAL; } }

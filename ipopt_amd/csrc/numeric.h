@@ -86,6 +86,10 @@ public:
     // communicator of a multi-GPU handle: with one set, factor()/solve_*() run the whole distributed sequence themselves
     bool   set_comm_rccl(const void* unique_id128);                                   // RCCL (dlopen'ed), ncclCommInitRank(nranks, id, rank)
     bool   set_comm_callback(int (*allreduce)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream), void* ctx);
+    // optional, for a callback communicator: in-place sum over the ranks [rank_lo, rank_lo + nranks_in_range) only (this rank is one of them);
+    // with it a range of ranks sums its part of an exchange step among itself instead of the whole machine summing everything
+    bool   set_comm_range_callback(int (*allreduce_range)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream, int rank_lo, int nranks_in_range));
+    long long exchange_bytes(int what) const;        // bytes of the arena squares (0) / top right-hand sides (1) of all exchange steps
     static bool rccl_unique_id(void* out128, std::string& err);                       // ncclGetUniqueId (rank 0 creates, the launcher distributes)
 private:
     NumericImpl* p_;

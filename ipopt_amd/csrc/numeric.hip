@@ -190,6 +190,8 @@ public:
     std::vector<JoinList> join;
     int ndepth = 1;
     std::vector<long long> abeg, aend, tbeg, tend;            // per step: its part of the arena / of the top right-hand sides
+    struct RangeSeg { int d, glo, gsz; long long abeg, aend, tbeg, tend; };      // ... and inside a step the part of every range of ranks [glo, glo + gsz)
+    std::vector<RangeSeg> rsegs;
     long long arena_doubles = 0, toprhs_doubles = 0;
     bool multi = false;
 
@@ -243,8 +245,12 @@ public:
         ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
         ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
         ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+        ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;      // (RCCL >= 2.18; optional)
         const char* (*GetErrorString)(ncclResult_t) = nullptr;
+        std::vector<ncclComm_t> sub;       // per exchange step: the communicator of the range of ranks this rank belongs to there (null: none / the whole machine)
+        bool sub_ok = false;
     } rccl;
+    int (*comm_range_fn)(void*, void*, int64_t, int, void*, int, int) = nullptr;
     int comm_kind = 0;                     // 0 none, 1 callback, 2 RCCL
     int (*comm_fn)(void*, void*, int64_t, int, void*) = nullptr; void* comm_ctx = nullptr;
     static bool rccl_load(Rccl& R, std::string& err) {
@@ -260,6 +266,7 @@ public:
         R.CommInitRank = (decltype(R.CommInitRank))dlsym(R.lib, "ncclCommInitRank");
         R.AllReduce = (decltype(R.AllReduce))dlsym(R.lib, "ncclAllReduce");
         R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
+        R.CommSplit = (decltype(R.CommSplit))dlsym(R.lib, "ncclCommSplit");
         R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
         if (!R.GetUniqueId || !R.CommInitRank || !R.AllReduce || !R.CommDestroy) { err = "librccl.so lacks the nccl* entry points"; return false; }
         return true;
@@ -268,11 +275,76 @@ public:
         DeviceGuard guard(dev);
         if (!ready || !multi) { err_ = "set_comm_rccl: not a multi-GPU handle (nranks > 1 at create, analyse first)"; return false; }
         if (!rccl_load(rccl, err_)) return false;
+        destroy_subcomms();
         if (rccl.comm) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
         ncclUniqueId id; std::memcpy(&id, id128, sizeof(id));
         ncclResult_t r = rccl.CommInitRank(&rccl.comm, opt.nranks, id, opt.rank);
         if (r != ncclSuccess) { err_ = std::string("ncclCommInitRank: ") + (rccl.GetErrorString ? rccl.GetErrorString(r) : "error"); rccl.comm = nullptr; return false; }
-        comm_kind = 2; return true;
+        comm_kind = 2;
+        make_subcomms();
+        return true;
+    }
+    // One sub-communicator per exchange step for the range of ranks this rank belongs to there (ncclCommSplit: collective over the whole
+    // communicator, every rank calls it once per step that has a range smaller than the machine -- the symbolic structures are identical on
+    // every rank, so they agree on which steps those are).  Without ncclCommSplit (or if a split fails) the steps fall back to ONE all-reduce
+    // over the whole communicator, ranks outside a range contributing zeros: correct, only more traffic.
+    void destroy_subcomms() {
+        for (ncclComm_t c : rccl.sub) if (c && rccl.CommDestroy) (void)rccl.CommDestroy(c);
+        rccl.sub.clear(); rccl.sub_ok = false;
+    }
+    void make_subcomms() {
+        destroy_subcomms();
+        if (comm_kind != 2 || !rccl.comm || !rccl.CommSplit || getenv("MI355X_KKT_NO_SUBCOMM")) return;
+        rccl.sub.assign(ndepth, nullptr);
+        bool ok = true;
+        for (int d = 0; d < ndepth; ++d) {
+            bool partial = false; int color = -1;      // NCCL_SPLIT_NOCOLOR
+            for (const RangeSeg& sg : rsegs) if (sg.d == d && sg.gsz < opt.nranks) { partial = true; if (sg.glo <= opt.rank && opt.rank < sg.glo + sg.gsz) color = sg.glo; }
+            if (!partial) continue;
+            ncclComm_t nc = nullptr;
+            if (rccl.CommSplit(rccl.comm, color, opt.rank, &nc, nullptr) != ncclSuccess) ok = false;
+            rccl.sub[d] = nc;
+        }
+        // (a failed split on one rank may have succeeded on another: the fallback must be taken by everybody, which a sum over the ranks decides)
+        int* flag = d_stats;      // scratch int on the device
+        const int bad = ok ? 0 : 1;
+        if (hipMemcpyAsync(flag, &bad, sizeof(int), hipMemcpyHostToDevice, stream) == hipSuccess &&
+            rccl.AllReduce(flag, flag, 1, ncclInt32, ncclSum, rccl.comm, stream) == ncclSuccess) {
+            int tot = 1;
+            if (hipMemcpyAsync(&tot, flag, sizeof(int), hipMemcpyDeviceToHost, stream) == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) rccl.sub_ok = tot == 0;
+        }
+        if (!rccl.sub_ok) { for (ncclComm_t& c : rccl.sub) { if (c && rccl.CommDestroy) (void)rccl.CommDestroy(c); c = nullptr; } }
+        if (opt.verbose) fprintf(stderr, "[mi355x_kkt] rank %d: range-local collectives %s\n", opt.rank, rccl.sub_ok ? "on (ncclCommSplit)" : "off (whole-communicator all-reduce per step)");
+    }
+    bool set_comm_range_callback(int (*fn)(void*, void*, int64_t, int, void*, int, int)) { comm_range_fn = fn; return true; }
+    bool range_local() const { return (comm_kind == 2 && rccl.sub_ok) || (comm_kind == 1 && comm_range_fn != nullptr); }
+    // in-place sum of `count` elements over the ranks [glo, glo + gsz) (this rank is one of them), stream-ordered
+    bool allreduce_range(void* dptr, long long count, int dtype, int d, int glo, int gsz) {
+        if (count <= 0) return true;
+        if (gsz >= opt.nranks) return allreduce(dptr, count, dtype);
+        if (comm_kind == 2) {
+            ncclComm_t c = rccl.sub[d];
+            if (!c) { err_ = "internal: no sub-communicator for a range this rank belongs to"; return false; }
+            ncclResult_t r = rccl.AllReduce(dptr, dptr, (size_t)count, dtype == 0 ? ncclDouble : ncclInt32, ncclSum, c, stream);
+            if (r != ncclSuccess) { err_ = std::string("ncclAllReduce (range): ") + (rccl.GetErrorString ? rccl.GetErrorString(r) : "error"); return false; }
+            return true;
+        }
+        if (comm_range_fn(comm_ctx, dptr, (int64_t)count, dtype, (void*)stream, glo, gsz) != 0) { err_ = "range all-reduce callback failed"; return false; }
+        return true;
+    }
+    // the exchange of one step: its arena squares (what == 0) or top right-hand sides (what == 1) summed over the ranks that hold the fronts
+    bool exchange_step(int d, int what) {
+        double* base = what == 0 ? V.arena : V.top_rhs;
+        if (range_local()) {
+            for (const RangeSeg& sg : rsegs) {
+                if (sg.d != d || !(sg.glo <= opt.rank && opt.rank < sg.glo + sg.gsz)) continue;
+                const long long b = what == 0 ? sg.abeg : sg.tbeg, e = what == 0 ? sg.aend : sg.tend;
+                if (!allreduce_range(base + b, e - b, 0, d, sg.glo, sg.gsz)) return false;
+            }
+            return true;
+        }
+        const long long b = what == 0 ? abeg[d] : tbeg[d], e = what == 0 ? aend[d] : tend[d];
+        return e > b ? allreduce(base + b, e - b, 0) : true;
     }
     bool set_comm_callback(int (*fn)(void*, void*, int64_t, int, void*), void* ctx) {
         if (!ready || !multi) { err_ = "set_comm_callbacks: not a multi-GPU handle (nranks > 1 at create, analyse first)"; return false; }
@@ -316,8 +388,9 @@ public:
     double* keep_tvals = nullptr;
     void release(bool keep = false) {
         DeviceGuard guard(dev);
+        destroy_subcomms();                      // (the ranges follow the structure: split again after a restructure)
         if (!keep) { if (rccl.comm && rccl.CommDestroy) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
-                     comm_kind = 0; }
+                     comm_kind = 0; comm_range_fn = nullptr; }
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
         keep_tvals = nullptr;
@@ -462,13 +535,28 @@ public:
             // that is all the all-reduce has to carry (A is replicated input, not reduced).  Both laid out step by step, the same on every rank.
             std::vector<char> is_join(Sy.num_sn, 0);
             for (int c = 0; c < Sy.num_sn; ++c) if (crosses(c)) is_join[Sy.sn_parent[c]] = 1;
+            // Only the LOWER triangle of a square travels (packed by columns, the layout the front kernels assemble into), and inside a step the
+            // squares are grouped by the range of ranks that holds their front: what a front receives comes from ranks of its own range only, so
+            // a range sums its part among its own ranks (sub-communicator / range callback) -- the other ranks neither send nor receive it.
             abeg.assign(ndepth, 0); aend.assign(ndepth, 0); tbeg.assign(ndepth, 0); tend.assign(ndepth, 0);
+            rsegs.clear();
             for (int d = 0; d < ndepth; ++d) {
                 abeg[d] = arena_doubles; tbeg[d] = toprhs_doubles;
+                std::vector<std::pair<int, int>> ranges;
                 for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && Sy.sn_gdepth[s] == d) {
-                    const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
-                    troff[s] = toprhs_doubles; toprhs_doubles += m;
-                    if (is_join[s]) { aoff[s] = arena_doubles; arena_doubles += m * m; }
+                    const std::pair<int, int> rg(Sy.sn_glo[s], Sy.sn_gsz[s]);
+                    if (std::find(ranges.begin(), ranges.end(), rg) == ranges.end()) ranges.push_back(rg);
+                }
+                std::sort(ranges.begin(), ranges.end());
+                for (const auto& rg : ranges) {
+                    RangeSeg sg{d, rg.first, rg.second, arena_doubles, 0, toprhs_doubles, 0};
+                    for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && Sy.sn_gdepth[s] == d && Sy.sn_glo[s] == rg.first && Sy.sn_gsz[s] == rg.second) {
+                        const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
+                        troff[s] = toprhs_doubles; toprhs_doubles += m;
+                        if (is_join[s]) { aoff[s] = arena_doubles; arena_doubles += m * (m + 1) / 2; }
+                    }
+                    sg.aend = arena_doubles; sg.tend = toprhs_doubles;
+                    rsegs.push_back(sg);
                 }
                 aend[d] = arena_doubles; tend[d] = toprhs_doubles;
             }
@@ -1007,7 +1095,9 @@ public:
         // sweeps of a small system could meet flags / tagged messages left in recycled device memory by an earlier handle (or process) before
         // the zero fill has landed
         HIPCHK(hipDeviceSynchronize());
-        ready = true; return true;
+        ready = true;
+        if (keep && comm_kind == 2) make_subcomms();
+        return true;
     }
 
     static int schur_tiles64(const Symbolic& Sy, int s) {
@@ -1646,7 +1736,7 @@ public:
     bool factor_dist(const double* dvals, bool reuse, FactorStats& st) {
         if (!enqueue_factor_local(dvals, reuse)) return false;
         for (int d = ndepth - 1; d >= 0; --d) {
-            if (aend[d] > abeg[d] && !allreduce(V.arena + abeg[d], aend[d] - abeg[d], 0)) return false;
+            if (!exchange_step(d, 0)) return false;
             if (!enqueue_factor_step(d)) return false;
         }
         if (!enqueue_stats()) return false;
@@ -1676,7 +1766,7 @@ public:
             const double* src = dsrc + (size_t)r * lds_; double* col = drhs + (size_t)r * ld;
             if (!enqueue_fwd_local(src)) return false;
             for (int d = ndepth - 1; d >= 0; --d) {
-                if (tend[d] > tbeg[d] && !allreduce(V.top_rhs + tbeg[d], tend[d] - tbeg[d], 0)) return false;
+                if (!exchange_step(d, 1)) return false;
                 if (!launch_solve_sweep(sch_stage[d], true, 1, d == 0)) return false;
                 if (d > 0 && !report_to_top_rhs(1 + d)) return false;
             }
@@ -1916,6 +2006,8 @@ bool Numeric::ruiz_triplet(int device, int n, int nnz, const int* irn, const int
 }
 bool Numeric::set_comm_rccl(const void* unique_id128) { return p_->set_comm_rccl(unique_id128); }
 bool Numeric::set_comm_callback(int (*fn)(void*, void*, int64_t, int, void*), void* ctx) { return p_->set_comm_callback(fn, ctx); }
+bool Numeric::set_comm_range_callback(int (*fn)(void*, void*, int64_t, int, void*, int, int)) { return p_->set_comm_range_callback(fn); }
+long long Numeric::exchange_bytes(int what) const { long long b = 0; for (const auto& sg : p_->rsegs) b += 8 * (what == 0 ? sg.aend - sg.abeg : sg.tend - sg.tbeg); return b; }
 bool Numeric::rccl_unique_id(void* out128, std::string& err)
 {
     NumericImpl::Rccl R;

@@ -59,6 +59,7 @@ def library_path() -> str:
 _LIB = None
 # int (*)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream)  -- mi355x_kkt_allreduce_fn
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
+ALLREDUCE_RANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int, C.c_int)      # + rank_lo, nranks_in_range
 
 # every symbol include/mi355x_kkt.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -68,7 +69,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
-    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks",
+    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks", "mi355x_kkt_set_comm_range_callback", "mi355x_kkt_exchange_bytes",
     "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_failed_pivots", "mi355x_kkt_delay_columns", "mi355x_kkt_set_delay_rounds", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
     "mi355x_kkt_pd_define", "mi355x_kkt_pd_put_data", "mi355x_kkt_pd_put", "mi355x_kkt_pd_get", "mi355x_kkt_pd_solve_once", "mi355x_kkt_pd_residual",
 ]
@@ -137,6 +138,8 @@ def load_library():
     lib.mi355x_kkt_pd_residual.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.mi355x_kkt_set_comm_rccl.argtypes = [vp, vp]
     lib.mi355x_kkt_set_comm_callbacks.argtypes = [vp, ALLREDUCE_FN, vp]
+    lib.mi355x_kkt_set_comm_range_callback.argtypes = [vp, ALLREDUCE_RANGE_FN]
+    lib.mi355x_kkt_exchange_bytes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     _LIB = lib
     return lib
 
@@ -322,18 +325,32 @@ class KKTSolver:
         if self.lib.mi355x_kkt_set_comm_rccl(self._h, buf) != 0:
             raise KKTError("set_comm_rccl: " + self.last_error())
 
-    def set_comm_callback(self, fn):
-        """fn(dptr: int, count: int, dtype: int (0 fp64, 1 int32), hip_stream: int) -> None; must leave the buffer summed over the ranks"""
-        def _cb(ctx, dptr, count, dtype, stream):
-            try:
-                fn(int(dptr), int(count), int(dtype), int(stream or 0))
-                return 0
-            except Exception:          # never let an exception cross the C ABI
-                import traceback; traceback.print_exc()
-                return 1
-        self._comm_cb = ALLREDUCE_FN(_cb)       # keep the thunk alive as long as the handle
+    def set_comm_callback(self, fn, fn_range=None):
+        """fn(dptr: int, count: int, dtype: int (0 fp64, 1 int32), hip_stream: int) -> None; must leave the buffer summed over the ranks.
+        fn_range(dptr, count, dtype, hip_stream, rank_lo, nranks_in_range) (optional): the same over a range of ranks only"""
+        def _wrap(f):
+            def _cb(ctx, *a):
+                try:
+                    f(*[int(x or 0) for x in a])
+                    return 0
+                except Exception:          # never let an exception cross the C ABI
+                    import traceback; traceback.print_exc()
+                    return 1
+            return _cb
+        self._comm_cb = ALLREDUCE_FN(_wrap(fn))       # keep the thunks alive as long as the handle
         if self.lib.mi355x_kkt_set_comm_callbacks(self._h, self._comm_cb, None) != 0:
             raise KKTError("set_comm_callbacks: " + self.last_error())
+        if fn_range is not None:
+            self._comm_range_cb = ALLREDUCE_RANGE_FN(_wrap(fn_range))
+            if self.lib.mi355x_kkt_set_comm_range_callback(self._h, self._comm_range_cb) != 0:
+                raise KKTError("set_comm_range_callback: " + self.last_error())
+
+    def exchange_bytes(self):
+        """(bytes of all arena squares, bytes of all top right-hand sides) of the current multi-GPU structure"""
+        a, t = C.c_int64(0), C.c_int64(0)
+        if self.lib.mi355x_kkt_exchange_bytes(self._h, C.byref(a), C.byref(t)) != 0:
+            raise KKTError("exchange_bytes: no device-side set-up")
+        return a.value, t.value
 
     _refactor = False
 

@@ -63,6 +63,12 @@ class HipEngine:
     def arena(self, d=0):
         return self._view(self.s.lib.mi355x_kkt_top_arena)
 
+    def exchange_segments(self, d, what):
+        """[(rank_lo, nranks_in_range, tensor)] this rank takes part in at step d (what 0: arena squares, 1: top right-hand sides);
+        the phase entry points serve the classic mapping: one range, the whole machine"""
+        t = self.arena(d) if what == 0 else self.top_rhs(d)
+        return [(0, self.nranks, t)] if t.numel() > 0 else []
+
     def factor_step(self, d):
         neg, zero = C.c_int(0), C.c_int(0)
         if self.s.lib.mi355x_kkt_factor_top(self.s._h, C.byref(neg), C.byref(zero)) != 0:
@@ -101,15 +107,20 @@ class DistributedKKT:
 
     def __init__(self, engine, dist):
         self.e, self.dist = engine, dist
+        self.groups = range_groups(dist, engine.nranks)  # (collective: every rank creates every group, in the same order)
+
+    def _exchange(self, d, what):
+        # a range of ranks sums its part of the step among itself (its sub-communicator); ranks outside it are not involved
+        for lo, g, t in self.e.exchange_segments(d, what):
+            if t.numel() > 0:
+                self.dist.all_reduce(t, group=self.groups[(lo, g)])
+        self.e.sync()
 
     def factor(self, vals):
         e, dist = self.e, self.dist
         e.factor_local(vals)                             # own subtrees + what they contribute to the replicated fronts above them
         for d in reversed(range(e.num_steps())):
-            arena = e.arena(d)
-            if arena.numel() > 0:
-                dist.all_reduce(arena)                   # sum of the contributions from outside each front's range of ranks
-                e.sync()
+            self._exchange(d, 0)                         # sum of the contributions from outside each front's range of ranks
             e.factor_step(d)
         neg, zero = e.counters()
         cnt = e.counters_tensor(neg, zero)
@@ -123,10 +134,7 @@ class DistributedKKT:
         e, dist = self.e, self.dist
         e.fwd_local(rhs)
         for d in reversed(range(e.num_steps())):
-            tr = e.top_rhs(d)
-            if tr.numel() > 0:
-                dist.all_reduce(tr)
-                e.sync()
+            self._exchange(d, 1)
             e.fwd_step(d)
         e.bwd(rhs)                                       # replicated fronts (nothing to exchange on the way down), own subtrees, own solution pieces
         dist.all_reduce(rhs)
@@ -134,15 +142,35 @@ class DistributedKKT:
         return rhs
 
 
-def gloo_allreduce_callback(torch, dist):
-    """the ONE collective the C library needs (mi355x_kkt_allreduce_fn), supplied from Python over any process group --
-    used where RCCL cannot run: several ranks sharing one GPU (the single-GPU test box)."""
+def range_groups(dist, world):
+    """{(rank_lo, nranks): process group} for every contiguous range of ranks (the whole world: None = the default group).  new_group is a
+    collective over the WORLD, so every rank creates every group in the same order -- which ranges a structure uses is not known to the ranks
+    outside them, and a delayed-pivot edit may change them."""
+    groups = {(0, world): None}
+    for g in range(2, world):
+        for lo in range(0, world - g + 1):
+            groups[(lo, g)] = dist.new_group(list(range(lo, lo + g)))
+    return groups
+
+
+def gloo_allreduce_callback(torch, dist, world=None):
+    """the collectives the C library needs (mi355x_kkt_allreduce_fn and, when `world` is given, mi355x_kkt_allreduce_range_fn), supplied from
+    Python over any process group -- used where RCCL cannot run: several ranks sharing one GPU (the single-GPU test box)."""
     def fn(dptr, count, dtype, stream):
         t = torch.as_tensor(_DevArray(dptr, count, "<f8" if dtype == 0 else "<i4"), device="cuda")
         torch.cuda.synchronize()          # the library's stream has produced the buffer
         dist.all_reduce(t)
         torch.cuda.synchronize()
-    return fn
+    if world is None:
+        return fn
+    groups = range_groups(dist, world)
+
+    def fn_range(dptr, count, dtype, stream, lo, g):
+        t = torch.as_tensor(_DevArray(dptr, count, "<f8" if dtype == 0 else "<i4"), device="cuda")
+        torch.cuda.synchronize()
+        dist.all_reduce(t, group=groups[(lo, g)])
+        torch.cuda.synchronize()
+    return fn, fn_range
 
 
 class CommKKT:
@@ -159,7 +187,8 @@ class CommKKT:
             dist.broadcast_object_list(box, src=0)
             self.s.set_comm_rccl(box[0])
         else:
-            self.s.set_comm_callback(gloo_allreduce_callback(torch, dist))
+            fn, fn_range = gloo_allreduce_callback(torch, dist, nranks)
+            self.s.set_comm_callback(fn, fn_range if not os.environ.get("MI355X_KKT_NO_SUBCOMM") else None)
 
 
 def partition_model(s, I, own, world):
@@ -179,7 +208,33 @@ def partition_model(s, I, own, world):
     total = float(f.sum())
     crit = max(per_rank) if per_rank else total
     steps = int(gd[top].max()) + 1 if top.any() else 1
-    return {"flops_total": total, "flops_replicated_fronts": float(f[top].sum()), "flops_replicated_on_the_most_loaded_rank": float(max(f[h].sum() for h in held)) if held else 0.0,
+    # what the exchange steps move.  A join front (one with a child from outside its range) receives the lower triangle of its square, every
+    # replicated front its top right-hand side; a range of g ranks sums its part among itself (ring all-reduce: every rank sends and receives
+    # 2 (g - 1) / g of the bytes); the steps run one after the other, the ranges of a step side by side.
+    par = s.symbolic(4, I.num_sn)
+    same = lambda a, b: own[a] < 0 and own[b] < 0 and glo[a] == glo[b] and gsz[a] == gsz[b]
+    join = np.zeros(I.num_sn, dtype=bool)
+    for ch in range(I.num_sn):
+        p = par[ch]
+        if p >= 0 and own[p] < 0 and not same(ch, p):
+            join[p] = True
+    comm = []
+    for d in range(steps):
+        ranges = sorted(set((int(glo[q]), int(gsz[q])) for q in np.nonzero(top & (gd == d))[0]))
+        rows = []
+        for lo, g in ranges:
+            sel = top & (gd == d) & (glo == lo) & (gsz == g)
+            ab = int((m[sel & join] * (m[sel & join] + 1) // 2).sum() * 8); tb = int(m[sel].sum() * 8)
+            rows.append({"ranks": [lo, lo + g], "arena_bytes": ab, "rhs_bytes": tb, "bytes_on_every_link_of_the_ring": 2.0 * (g - 1) / g * ab})
+        comm.append(rows)
+    arena_total = sum(r["arena_bytes"] for rows in comm for r in rows)
+    per_link = sum(max((r["bytes_on_every_link_of_the_ring"] for r in rows), default=0.0) for rows in comm)        # critical path: the slowest range of every step
+    whole = 2.0 * (world - 1) / world * arena_total                                                             # ... and with ONE all-reduce over the whole machine per step
+    return {"exchange": {"arena_bytes_total": arena_total, "arena_bytes_if_full_squares": int(sum((m[top & join] ** 2).sum() for _ in [0]) * 8),
+                         "per_step": comm, "ring_bytes_on_the_critical_path": per_link, "ring_bytes_without_sub_communicators": whole,
+                         "predicted_ms_per_factorisation": {"at_100_GB/s": per_link / 100e9 * 1e3, "at_200_GB/s": per_link / 200e9 * 1e3},
+                         "what": "lower triangles of the join fronts' squares, summed inside the range of ranks that holds each front (one sub-communicator per step)"},
+            "flops_total": total, "flops_replicated_fronts": float(f[top].sum()), "flops_replicated_on_the_most_loaded_rank": float(max(f[h].sum() for h in held)) if held else 0.0,
             "flops_most_loaded_rank": crit, "flops_least_loaded_rank": min(per_rank) if per_rank else total,
             "replicated_fronts": int(top.sum()), "replicated_fronts_held_per_rank": [int(h.sum()) for h in held], "exchange_steps": steps,
             "predicted_speedup_bound": total / crit if crit else 1.0,
@@ -274,8 +329,14 @@ def bench_main(args, rank, world, local):
                        "supernodes": I.num_sn, "replicated_top_supernodes": int((own < 0).sum()), "num_neg": nneg, "scaled_residual": res},
             "same_workload_1gpu": {"ms_per_step": dt1 * 1e3, "value": flops_step / dt1 / 1e9, "speedup": dt1 / dt},
             "partition_model": partition_model(s, I, own, world),
+            "range_local_collectives": not bool(os.environ.get("MI355X_KKT_NO_SUBCOMM")),
             "roofline": roof,
         }
+    if rank == 0:
+        # the partition's bound with the exchange steps on top: T_N = T_1 / bound + the ring time of the arena squares (measured T_1 of this run)
+        pm = line["partition_model"]; ex = pm["exchange"]["predicted_ms_per_factorisation"]
+        t1 = line["same_workload_1gpu"]["ms_per_step"]
+        pm["predicted_speedup_with_exchange"] = {kk: t1 / (t1 / pm["predicted_speedup_bound"] + ms) for kk, ms in ex.items()}
     dist.barrier()
     if rank == 0:
         print(json.dumps(line))

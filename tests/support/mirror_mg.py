@@ -39,18 +39,46 @@ class MirrorEngine:
         self.kind = lambda c: 0 if own[c] >= 0 else 1 + gd[c]
         self.step = [[s for s in range(self.nsn) if self.held(s) and gd[s] == d] for d in range(self.nsteps)]
         join = set(par[c] for c in range(self.nsn) if self.crosses(c))
-        # layout: step by step, the same on every rank (fronts of ranges this rank is not in stay zero here)
-        self.aoff, self.toff, self.abounds, self.tbounds, a, t = {}, {}, [], [], 0, 0
+        # layout: step by step and, inside a step, range of ranks by range of ranks -- the same on every rank (fronts of ranges this rank is
+        # not in stay zero here); a square travels as its LOWER triangle packed by columns (numeric.hip: RangeSeg, arena_off)
+        self.aoff, self.toff, self.abounds, self.tbounds, self.segs, a, t = {}, {}, [], [], [], 0, 0
         for d in range(self.nsteps):
             a0, t0 = a, t
-            for s in range(self.nsn):
-                if own[s] < 0 and gd[s] == d:
-                    m = sy["rowptr"][s + 1] - sy["rowptr"][s]
-                    self.toff[s] = t; t += m
-                    if s in join:
-                        self.aoff[s] = a; a += m * m
+            ranges = sorted(set((int(glo[s]), int(gsz[s])) for s in range(self.nsn) if own[s] < 0 and gd[s] == d))
+            for lo, g in ranges:
+                sa, st = a, t
+                for s in range(self.nsn):
+                    if own[s] < 0 and gd[s] == d and glo[s] == lo and gsz[s] == g:
+                        m = int(sy["rowptr"][s + 1] - sy["rowptr"][s])
+                        self.toff[s] = t; t += m
+                        if s in join:
+                            self.aoff[s] = a; a += m * (m + 1) // 2
+                self.segs.append((d, lo, g, sa, a, st, t))
             self.abounds.append((a0, a)); self.tbounds.append((t0, t))
         self._arena = np.zeros(a); self._toprhs = np.zeros(t)
+
+    def exchange_segments(self, d, what):
+        """[(rank_lo, nranks_in_range, tensor)] of step d this rank takes part in (what 0: arena squares, 1: top right-hand sides)"""
+        buf = self._arena if what == 0 else self._toprhs
+        out = []
+        for (sd, lo, g, a0, a1, t0, t1) in self.segs:
+            if sd == d and lo <= self.rank < lo + g:
+                b, e = (a0, a1) if what == 0 else (t0, t1)
+                if e > b:
+                    out.append((lo, g, torch.from_numpy(buf[b:e])))
+        return out
+
+    @staticmethod
+    def _tril_index(m):
+        # position of (i, c), i >= c, in the column-packed lower triangle
+        c, i = np.triu_indices(m)            # pairs with c <= i, column by column
+        return i, c
+
+    def _square(self, s, m):
+        """the (symmetric) m x m matrix an arena square stands for"""
+        i, c = self._tril_index(m)
+        F = np.zeros((m, m)); F[i, c] = self._arena[self.aoff[s]:self.aoff[s] + m * (m + 1) // 2]
+        return F + np.tril(F, -1).T
 
     def num_steps(self):
         return self.nsteps
@@ -89,8 +117,9 @@ class MirrorEngine:
         for ch in range(self.nsn):
             if self.crosses(ch) and self.kind(ch) == kind and self.reporter(ch) == self.rank:
                 p = sy["parent"][ch]; m = self._front_dims(p)[3]
-                F = self._arena[self.aoff[p]:self.aoff[p] + m * m].reshape(m, m)
-                rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
+                F = np.zeros((m, m)); rl = self._rel(ch); F[np.ix_(rl, rl)] += self.cb[ch]
+                i, c = self._tril_index(m)
+                self._arena[self.aoff[p]:self.aoff[p] + m * (m + 1) // 2] += F[i, c]
 
     def factor_local(self, vals):
         sy = self.sym
@@ -115,7 +144,7 @@ class MirrorEngine:
     def factor_step(self, d):
         for s in self.step[d]:
             c0, k, r, m = self._front_dims(s)
-            F = self._arena[self.aoff[s]:self.aoff[s] + m * m].reshape(m, m).copy() if s in self.aoff else np.zeros((m, m))
+            F = self._square(s, m) if s in self.aoff else np.zeros((m, m))
             self._a_entries(s, F)                      # A is replicated input: every rank adds it itself
             for ch in self.children[s]:
                 if self.same(ch, s):

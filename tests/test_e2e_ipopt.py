@@ -278,3 +278,18 @@ def test_hsllib_route_with_explicit_ma97_scaling(scaling, tmp_path, golden_dir):
     gsum = json.load(open(os.path.join(golden_dir, "mbndry1_100.summary")))
     assert summ[0]["iterations"] == gsum["iterations"]
     assert abs(summ[0]["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+def test_matching_scaling_reused_across_an_ipopt_run_at_kkt_dimension_2e5(tmp_path, golden_dir):
+    """`mi355x_scaling matching` = maximum-product matching scaling computed at the first factorisation and REUSED (MA97's
+    '...-reuse' switches, IpMa97SolverInterface.cpp:725-771) on LukVlE1 n = 10^5 (KKT dimension 2 * 10^5): same iteration count and objective as the
+    reference run, and the factorisation timer shows ONE matching, not one per factorisation (the host algorithm costs ~50 ms at this size)."""
+    iters, summ, out = _run(DRIVER, ["LukVlE1", "100000", "--solver", "mi355x", "--set", "mi355x_scaling", "matching"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    _, summ_always, out2 = _run(DRIVER, ["LukVlE1", "100000", "--solver", "mi355x", "--set", "mi355x_scaling", "matching-always"], tmp_path)
+    assert "EXIT: Optimal Solution Found." in out2
+    assert summ[0]["iterations"] == summ_always[0]["iterations"]
+    assert abs(summ[0]["objective"] - summ_always[0]["objective"]) <= 1e-8 * max(1.0, abs(summ_always[0]["objective"]))
+    # one matching against one per factorisation
+    assert summ[0]["LinearSystemFactorization"] < 0.6 * summ_always[0]["LinearSystemFactorization"], (summ[0], summ_always[0])

@@ -306,6 +306,36 @@ def test_matching_scaling_mode():
     assert Ks.max() <= 1.0 + 1e-10 and np.allclose(Ks.max(axis=1).toarray().ravel(), 1.0, rtol=1e-10)
 
 
+def test_matching_scaling_is_reused_until_quality_is_asked_for():
+    """scaling mode 4 (adapter: mi355x_scaling matching): the matching scaling of the FIRST factorisation serves the following ones -- MA97's
+    '...-reuse' switches, IpMa97SolverInterface.cpp:725-771 -- until IncreaseQuality, which has it computed afresh (:824-840)"""
+    n, r, c, v, neg = kktgen.grid_kkt(20, 18, dof=2, ncon=1, seed=41, sigma_exp=8.0)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg, scaling=4)
+    f1 = s.get_scaling().copy()
+    ref = np.zeros(n)
+    lib = kkt.load_library()
+    assert lib.mi355x_kkt_matching_scaling(n, len(v), r.ctypes.data, c.ctypes.data, v.ctypes.data, 1, ref.ctypes.data, None) == 0
+    assert st == 0 and sres(K, x, b) <= RES_TOL and np.allclose(f1, ref, rtol=1e-12)
+    # a second matrix (other values, same structure): factors of the first one are kept
+    rng = np.random.default_rng(5)
+    v2 = v * (1.0 + 0.3 * rng.random(len(v)))
+    K2 = kktgen.to_scipy(n, r, c, v2); b2 = K2 @ np.ones(n)
+    s.values()[:] = v2
+    x2 = b2.copy()
+    assert s.multi_solve(True, x2, True, neg) == 0 and sres(K2, x2, b2) <= RES_TOL
+    assert np.array_equal(s.get_scaling(), f1)
+    # IncreaseQuality: computed afresh from the matrix now in place
+    assert s.increase_quality()
+    x3 = b2.copy()
+    assert s.multi_solve(False, x3, True, neg) == 0 and sres(K2, x3, b2) <= RES_TOL
+    ref2 = np.zeros(n)
+    assert lib.mi355x_kkt_matching_scaling(n, len(v2), r.ctypes.data, c.ctypes.data, v2.ctypes.data, 1, ref2.ctypes.data, None) == 0
+    f3 = s.get_scaling()
+    assert np.allclose(f3, ref2, rtol=1e-12) and not np.array_equal(f3, f1)
+
+
 def test_sync_free_chain_sweeps_match_the_level_by_level_solves(monkeypatch):
     """the flag-synchronised chain sweeps (one launch per run of pure chain levels) against the launch-per-level solves:
     same solution to rounding (the summation order along the chain differs), deterministic across repetitions"""

@@ -59,6 +59,16 @@ def _case_band():
     return kktgen.lukvl_like(20000, seed=9)
 
 
+def _case_hostile():
+    # pivots fail their fronts' threshold tests: every rank must reach the same delayed-pivot edits (the marks are summed over the ranks)
+    n, r, c, v = kktgen.hostile_grid_kkt(16, 16, seed=3, tiny=1e-9)
+    K = kktgen.to_scipy(n, r, c, v).toarray()
+    return n, r, c, v, int((np.linalg.eigvalsh(K) < 0).sum())
+
+
+_case_hostile.opts = dict(pivtol=0.01, pivtolmax=0.01, scaling=0, delay_rounds=12)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("case", [_case_grid, _case_band], ids=["grid", "band"])
 def test_hip_multigpu_path_matches_single_gpu(world, case):
@@ -89,7 +99,7 @@ def _worker_comm(rank, world, port, case, subcube, ret):
     n, r, c, v, neg = case()
     K = kktgen.to_scipy(n, r, c, v)
     # RCCL refuses several ranks on one device, so the library gets the one collective it needs as a callback (gloo)
-    s = CommKKT(rank, world, 0, n, r, c, v, dist, use_rccl=False, subcube=subcube).s
+    s = CommKKT(rank, world, 0, n, r, c, v, dist, use_rccl=False, subcube=subcube, **getattr(case, "opts", {})).s
     out = []
     for rep in range(2):
         s.values()[:] = v
@@ -99,7 +109,7 @@ def _worker_comm(rank, world, port, case, subcube, ret):
         st = s.multi_solve(True, x, True, neg)             # the plug-in contract, unchanged: factor + inertia check + solve
         x2 = (2.0 * b).copy(); st2 = s.multi_solve(False, x2)
         res = float(np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max()))
-        out.append((st, st2, s.number_of_neg_evals(), res, float(np.abs(x2 - 2.0 * x).max()), s.info().num_two, s.info().num_small, x.copy()))
+        out.append((st, st2, s.number_of_neg_evals(), res, float(np.abs(x2 - 2.0 * x).max()), s.info().num_two, s.info().num_small, s.info().num_restructures, x.copy()))
     gathered = [None] * world
     dist.all_gather_object(gathered, [o[-1] for o in out])
     I = s.info()
@@ -115,13 +125,20 @@ def _worker_comm(rank, world, port, case, subcube, ret):
 
 
 @pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (4, 0, _case_grid), (4, 1, _case_grid), (3, 1, _case_grid), (4, 1, _case_band),
-                                                pytest.param(8, 1, _case_grid, marks=pytest.mark.skipif(not os.environ.get("MI355X_KKT_TEST_8RANKS"),
-                                                             reason="8 ranks on one GPU: written when no GPU minutes were left, opt-in until it has run once (MI355X_KKT_TEST_8RANKS=1)"))],
-                         ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band", "8-subcube"])
-def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, case):
+                                                (8, 1, _case_grid), (2, 0, _case_hostile), (4, 1, _case_hostile)],
+                         ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band", "8-subcube", "2-delayed-pivots", "4-subcube-delayed-pivots"])
+@pytest.mark.parametrize("range_local", [True, False], ids=["range-local", "whole-machine"])
+def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, case, range_local, monkeypatch):
     """... with the classic mapping (one top replicated on every rank) and with the subtree-to-subcube mapping: replicated fronts held by the
     ranks beneath them only, one exchange step per bisection of the machine, the fronts of a sub-range reported upwards by its first rank
-    (8 ranks: three steps, and ranges of the second step that report straight to the fronts of the whole machine)"""
+    (8 ranks: three steps, and ranges of the second step that report straight to the fronts of the whole machine).  range-local: a range of
+    ranks sums its part of a step among itself (the range callback = what the RCCL sub-communicators do); whole-machine: one all-reduce over
+    everybody per step, zeros from the ranks outside a range (the fall-back without ncclCommSplit).  The hostile case has every rank move
+    the same failed columns to their parent fronts (marks summed over the ranks) and refactor."""
+    if not range_local:
+        if world < 3 or case is _case_band:
+            pytest.skip("the fall-back differs from the range-local exchange only with sub-ranges; one band case is enough")
+        monkeypatch.setenv("MI355X_KKT_NO_SUBCOMM", "1")
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()
@@ -133,8 +150,10 @@ def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, c
         p.join(timeout=120)
         assert p.exitcode == 0
     assert same
-    for st, st2, nneg, res, lin, ntwo, nsmall in out:
+    for st, st2, nneg, res, lin, ntwo, nsmall, nedits in out:
         assert st == 0 and st2 == 0 and nneg == neg and res <= 1e-12 and lin <= 1e-9
+        if case is _case_hostile:
+            assert nsmall == 0 and nedits >= 1
     if subcube:
         assert nsteps >= 2 and min(held) < ntop
     else:
@@ -157,3 +176,53 @@ def test_rccl_communicator_of_one_rank(monkeypatch):
     b = K @ np.ones(n); x = b.copy()
     assert s.multi_solve(True, x, True, neg) == 0
     assert np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max()) <= 1e-12
+
+
+def _worker_rccl2(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ipopt_amd
+    n, r, c, v, neg = _case_grid()
+    s = ipopt_amd.KKTSolver(device=0, nranks=world, rank=rank)
+    s.initialize_structure(n, r, c, vals=v)
+    box = [ipopt_amd.KKTSolver.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    try:
+        s.set_comm_rccl(box[0])
+        K = kktgen.to_scipy(n, r, c, v)
+        s.values()[:] = v
+        b = K @ np.ones(n); x = b.copy()
+        st = s.multi_solve(True, x, True, neg)
+        res = float(np.abs(K @ x - b).max() / (abs(K).sum(axis=1).max() * np.abs(x).max() + np.abs(b).max()))
+        ret.put((rank, "ok", st, res))
+    except Exception as e:                       # RCCL may refuse two ranks on one device: report what it said
+        ret.put((rank, "refused", str(e)[:300], None))
+
+
+def test_rccl_two_ranks_on_the_one_device_or_a_clear_refusal():
+    """RCCL with more than one rank has never run here (one GPU per box).  Two ranks on device 0: either RCCL accepts
+    them -- then the whole distributed sequence must work over it -- or it refuses duplicate devices at ncclCommInitRank, which must come back
+    as an error message through the C ABI (no hang, no crash)."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rccl2, args=(rk, 2, port, ret)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in range(2):
+            got.append(ret.get(timeout=180))
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.kill()
+    assert len(got) == 2
+    kinds = {g[1] for g in got}
+    assert len(kinds) == 1, got                                   # both ranks agree
+    if kinds == {"ok"}:
+        assert all(g[2] == 0 and g[3] <= 1e-12 for g in got), got
+    else:
+        assert all("nccl" in g[2].lower() or "rccl" in g[2].lower() for g in got), got

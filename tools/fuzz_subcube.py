@@ -22,10 +22,20 @@ def run_world(world, subcube, n, r, c, v, neg, rng):
         for b in bufs:
             b.numpy()[:] = tot
 
+    def exchange(d, what):
+        # range-local: a range of ranks sums its part of the step among ITS ranks; the others hold zeros there and stay out of it
+        segs = {}
+        for e in engs:
+            for lo, g, t in e.exchange_segments(d, what):
+                segs.setdefault((lo, g), []).append((e.rank, t))
+        for (lo, g), members in segs.items():
+            assert sorted(rk for rk, _ in members) == list(range(lo, lo + g)), (lo, g, [rk for rk, _ in members])
+            allreduce([t for _, t in members])
+
     for e in engs:
         e.factor_local(v)
     for d in reversed(range(steps)):
-        allreduce([e.arena(d) for e in engs])
+        exchange(d, 0)
         for e in engs:
             e.factor_step(d)
     nneg = sum(e.counters()[0] for e in engs)
@@ -35,7 +45,7 @@ def run_world(world, subcube, n, r, c, v, neg, rng):
     for e, b in zip(engs, rhs):
         e.fwd_local(b)
     for d in reversed(range(steps)):
-        allreduce([e.top_rhs(d) for e in engs])
+        exchange(d, 1)
         for e in engs:
             e.fwd_step(d)
     for e, b in zip(engs, rhs):
