@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 #include <string>
 #include <cmath>
 
@@ -54,7 +55,7 @@ int main(int argc, char** argv)
    if( threads.empty() ) threads.push_back(0);
    int neg = -1, status = 0;
    std::vector<Number> x(n);
-   std::vector<double> leg_factor, leg_solve;
+   std::vector<double> leg_factor, leg_solve, leg_median;
    double t_first = 0;
    bool first = true;
    for( size_t leg = 0; leg < threads.size(); ++leg )
@@ -62,6 +63,7 @@ int main(int argc, char** argv)
       if( threads[leg] > 0 ) MKL_Set_Num_Threads(threads[leg]);
       double t_factor = 0, t_solve = 0;
       int timed = 0;
+      std::vector<double> steps;       // every timed factor+solves step of the leg (the median is what is reported)
       for( int it = 0; it < nfactor; ++it )
       {
          Number* vals = iface->GetValuesArrayPtr();
@@ -84,10 +86,12 @@ int main(int argc, char** argv)
          // the very first MultiSolve contains the symbolic analysis; the first of every later leg is a warm-up
          if( first ) { t_first = (t2 - t1) + (t1 - tc); first = false; }
          else if( it == 0 && nfactor > 1 ) { }
-         else { t_factor += (t2 - tc); t_solve += ts; ++timed; }
+         else { t_factor += (t2 - tc); t_solve += ts; ++timed; steps.push_back((t2 - tc) + ts); }
       }
       if( timed == 0 ) timed = 1;
       leg_factor.push_back(t_factor / timed); leg_solve.push_back(t_solve / timed);
+      std::sort(steps.begin(), steps.end());
+      leg_median.push_back(steps.empty() ? t_factor / timed + t_solve / timed : steps[steps.size() / 2]);
    }
    if( argc > 4 && std::string(argv[4]) != "-" )
    {
@@ -103,7 +107,7 @@ int main(int argc, char** argv)
           "\"factor_plus_first_solve_s\": %.6f, \"extra_solves_s\": %.6f, \"reps\": %d, \"best_threads\": %d, \"legs\": [",
           n, nnz, status, neg, t_conv, t_first, t_factor, t_solve, reps, threads[best]);
    for( size_t leg = 0; leg < threads.size(); ++leg )
-      printf("%s{\"threads\": %d, \"factor_plus_first_solve_s\": %.6f, \"extra_solves_s\": %.6f}", leg ? ", " : "", threads[leg], leg_factor[leg], leg_solve[leg]);
-   printf("], \"x0\": %.17g, \"xsum\": %.17g}\n", x[0], resid);
+      printf("%s{\"threads\": %d, \"factor_plus_first_solve_s\": %.6f, \"extra_solves_s\": %.6f, \"median_step_s\": %.6f}", leg ? ", " : "", threads[leg], leg_factor[leg], leg_solve[leg], leg_median[leg]);
+   printf("], \"median_step_s\": %.6f, \"x0\": %.17g, \"xsum\": %.17g}\n", leg_median[best], x[0], resid);
    return 0;
 }

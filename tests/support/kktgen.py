@@ -164,3 +164,33 @@ def hostile_band_kkt(n, seed=0, frac=0.3, tiny=1e-6):
     hit = diag[rng.random(diag.shape[0]) < frac]
     v[hit] = tiny * rng.uniform(0.1, 1.0, hit.shape[0]) * rng.choice([-1.0, 1.0], hit.shape[0])
     return nn, r, c, v
+
+
+def recorded_kkt(path, which=-1):
+    """The KKT system of one factorisation of a boundary recording (tests/golden/*.kktrec, written by the reference's RecordingSolverInterface
+    in oracle/ref_driver.cpp): (n, row, col, values, expected negative eigenvalues) as 1-based triplets of the lower triangle.  `which`
+    counts the calls that carried a new matrix.  Reader kept apart from oracle/ (bench.py's GPU legs must not import the checker)."""
+    buf = open(path, "rb").read()
+    assert buf[:8] == b"KKTREC1\n"
+    off, mats, ia, ja, fmt, dim = 8, [], None, None, 0, 0
+    while off < len(buf):
+        hdr = np.frombuffer(buf, dtype=np.int32, count=8, offset=off); off += 32
+        if hdr[0] == 0:
+            dim, nnz, fmt, nia = int(hdr[1]), int(hdr[2]), int(hdr[3]), int(hdr[4])
+            ia = np.frombuffer(buf, dtype=np.int32, count=nia, offset=off).copy(); off += 4 * nia
+            ja = np.frombuffer(buf, dtype=np.int32, count=nnz, offset=off).copy(); off += 4 * nnz
+        else:
+            dim, nnz, nrhs, newm, check, req, status = (int(v) for v in hdr[1:8])
+            neg = int(np.frombuffer(buf, dtype=np.int32, count=1, offset=off)[0]); off += 4
+            if newm:
+                a = np.frombuffer(buf, dtype=np.float64, count=nnz, offset=off).copy(); off += 8 * nnz
+                mats.append((a, neg, status))
+            off += 16 * dim * nrhs
+    a, neg, status = mats[which]
+    if fmt == 0:                                   # triplets as recorded
+        r, c = ia.astype(np.int32), ja.astype(np.int32)
+    else:                                          # CSR of the upper triangle (EMatrixFormat 1 / 2: 0- / 1-offset): row = position in ia
+        base = 0 if fmt == 1 else 1
+        rows = np.repeat(np.arange(dim, dtype=np.int32), np.diff(ia)) + 1
+        r, c = rows, (ja - base + 1).astype(np.int32)
+    return dim, r, c, a, neg

@@ -10,6 +10,25 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- p
 find $OUT/trace -name "*kernel_stats*" | head -3
 f=$(find $OUT/trace -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $OUT/kernel_stats.csv && head -25 $f
+# the dominant kernel's time as rocprofv3 sees it in the TIMED schedule (look-ahead stream on): profiles/rocprof_latest.json, from which
+# bench.py computes roofline.frac_rocprof next to the hip-event figure (the two must not drift apart unseen)
+python3 - <<PY
+import csv, json, subprocess
+rows = list(csv.DictReader(open("$OUT/kernel_stats.csv"))) if __import__("os").path.exists("$OUT/kernel_stats.csv") else []
+tot = {}
+for r in rows:
+    tot[r["Name"].split("(")[0].replace("void ", "")] = (int(r["Calls"]), float(r["TotalDurationNs"]))
+nf = max(tot.get("mi355x::k_reduce_stats", (1, 0))[0], 1)       # exactly one per factorisation
+sel = {k: v for k, v in tot.items() if "$KERN" in k}
+if sel:
+    sh = subprocess.run(["python3", "-c", "import sys; sys.path.insert(0, '$R'); import bench; print(bench.source_hash())"], capture_output=True, text=True).stdout.strip()
+    kh = subprocess.run(["python3", "-c", "import sys; sys.path.insert(0, '$R'); import bench; print(bench.kernel_code_hash('$KERN'))"], capture_output=True, text=True).stdout.strip()
+    json.dump({"workload": "$WL", "kernel": "$KERN", "source_hash": sh, "kernel_code_hash": (None if kh in ("", "None") else kh), "factorisations": nf,
+               "kernels": {k: {"calls_per_factorisation": c / nf, "ms_per_factorisation": ns / nf / 1e6} for k, (c, ns) in sel.items()},
+               "ms_per_factorisation": sum(ns for c, ns in sel.values()) / nf / 1e6,
+               "note": "rocprofv3 --kernel-trace --stats of bench.py --steps 20 (tools/prof.sh): total duration of every kernel whose name contains the dominant kernel's, per factorisation"},
+              open("$OUT/rocprof_latest.json", "w"), indent=1)
+PY
 # separate PMC passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2: one pass each)
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o pmc -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-also > /dev/null 2> $OUT/pmc_fetch.log
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o pmc -- python $R/bench.py --workload $WL --steps 3 --warmup 1 --no-cpu-baseline --no-also > /dev/null 2> $OUT/pmc_write.log

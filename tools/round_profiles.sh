@@ -13,6 +13,8 @@ cp gpurun_out/prof_synth_1e6/kernel_stats.csv $O/synth_1e6_kernel_stats.csv 2>/d
 cp gpurun_out/prof_synth_1e6/pmc_summary.json $O/synth_1e6_pmc_summary.json 2>/dev/null
 cp gpurun_out/prof_synth_1e6/traffic_latest.json $O/traffic_latest.json 2>/dev/null
 cp gpurun_out/prof_synth_1e6/traffic_latest.json profiles/traffic_latest.json 2>/dev/null      # (this copy of the tree; commit the one under $O)
+cp gpurun_out/prof_synth_1e6/rocprof_latest.json $O/rocprof_latest.json 2>/dev/null
+cp gpurun_out/prof_synth_1e6/rocprof_latest.json profiles/rocprof_latest.json 2>/dev/null
 cp gpurun_out/prof_synth_1e6/bench_under_trace.json $O/synth_1e6_bench_under_rocprof.json 2>/dev/null
 python bench.py > $O/bench_synth_1e6.json 2> $O/bench_synth_1e6.err
 for wl in grid_1e5 lukvle1_1e6 lukvle1_1e4; do python bench.py --workload $wl --no-e2e > $O/bench_$wl.json 2> $O/bench_$wl.err; done
