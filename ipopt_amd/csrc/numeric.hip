@@ -103,7 +103,10 @@ public:
             HIPCHK(hipStreamSynchronize(stream));      // `user` is the caller's pageable memory
         }
         if (mode >= 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
-        if (mode != opt.scaling && g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }     // the captured sequence differs
+        if (mode != opt.scaling) {      // the captured sequences differ
+            if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
+            if (g_factor_full) { (void)hipGraphExecDestroy(g_factor_full); g_factor_full = nullptr; }
+        }
         opt.scaling = mode;
         return true;
     }
@@ -392,6 +395,7 @@ public:
         if (!keep) { if (rccl.comm && rccl.CommDestroy) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
                      comm_kind = 0; comm_range_fn = nullptr; }
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
+        if (g_factor_full) { (void)hipGraphExecDestroy(g_factor_full); g_factor_full = nullptr; }
         if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; }
         keep_tvals = nullptr;
         for (void* p : allocs) {
@@ -480,7 +484,7 @@ public:
                 if (opt.prewarmed_vals) (void)hipHostFree(opt.prewarmed_vals);
                 HIPCHK(hipHostMalloc((void**)&h_vals, std::max<size_t>(Sy.nnz_in, 1) * sizeof(double), hipHostMallocDefault));
             }
-            HIPCHK(hipHostMalloc((void**)&h_stats, 8 * sizeof(int), hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void**)&h_stats, 12 * sizeof(int), hipHostMallocDefault));
         }
         opt.prewarmed_vals = nullptr;
         lap("device, streams, pinned buffer");
@@ -1047,7 +1051,7 @@ public:
             !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
-            !dalloc(&d_stats, 8) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
+            !dalloc(&d_stats, 12) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
             !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         if (opt.scaling >= 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
@@ -1129,6 +1133,10 @@ public:
             if (V.fastpiv && wave_mmin[lv] <= 16) {      // fronts of order <= 16: four per wavefront on the static-order path first; what it accepts is skipped below
                 const int n16 = sg ? tiny16[lv] : nb;
                 if (n16 > 0) { LAUNCH(KK_FRONT_WAVE, k_front_dpp16, dim3((n16 + 3) / 4), dim3(64), 0, stream, V, b0, n16, top_mode); fl |= 2; }
+                // OPTIMISTIC schedule: every front of the bucket has order <= 16 and the static-order kernel accepts (nearly) everything it is given
+                // (LukVlE1 10^6: all 164 000 fronts) -- the strict launch behind it would find nothing to do, 4-8 us each, 21 of them per
+                // factorisation.  It is left out; a front the kernel rejects raises qstat[4] and factor() runs the full schedule again.
+                if (optimistic && n16 == nb) return true;
             }
             if (nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 2>), dim3(nt), dim3(64), rl, stream, V, b0, fl);
             if (nb - nt > 0) LAUNCH(KK_FRONT_WAVE, (k_front_reg<64, 4>), dim3(nb - nt), dim3(64), rl, stream, V, b0 + nt, fl);
@@ -1299,10 +1307,23 @@ public:
         return true;
     }
 
+    bool optimistic = false;                 // (set per factorisation: see launch_bucket)
+    hipGraphExec_t g_factor_full = nullptr;  // the schedule with every strict launch (g_factor: the optimistic one)
     bool factor(const double* dvals, bool reuse, FactorStats& st) {
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "factor: solver not set up (no device?)"; return false; }
         if (multi) return factor_dist(dvals, reuse, st);          // needs a communicator (set_comm_*), fails loudly otherwise
+        static const bool opt_off = getenv("MI355X_KKT_NO_OPTIMISTIC") != nullptr;
+        optimistic = V.fastpiv && !opt_off && !prof_on;
+        if (!factor_once(dvals, reuse, st)) return false;
+        if (optimistic && h_stats[8] != 0) {                      // some front was left for a strict launch that was not there: the full schedule, same values
+            optimistic = false;
+            if (opt.verbose) fprintf(stderr, "[mi355x_kkt] factor: the optimistic schedule met a front for the strict kernels, running the full one\n");
+            return factor_once(nullptr, true, st);
+        }
+        return true;
+    }
+    bool factor_once(const double* dvals, bool reuse, FactorStats& st) {
         const Symbolic& Sy = *S;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
         if (!reuse) {
@@ -1316,8 +1337,12 @@ public:
         // replay on these ~10^3-launch sequences, whose kernels are long), because a two-stream hipGraph replays up to 1.5x
         // slower once another solver's graphs have been created and destroyed in the same process (ROCm 7.2).
         if (opt.use_graph && !la_any) {
-            if (!g_factor || graph_pivtol != V.pivtol || graph_pivtol2 != V.pivtol2) {
+            if (graph_pivtol != V.pivtol || graph_pivtol2 != V.pivtol2) {      // (both schedules were captured with the old thresholds)
                 if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
+                if (g_factor_full) { (void)hipGraphExecDestroy(g_factor_full); g_factor_full = nullptr; }
+            }
+            hipGraphExec_t& g_factor = optimistic ? this->g_factor : g_factor_full;
+            if (!g_factor) {
                 hipGraph_t g = nullptr;
                 HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
                 bool ok = enqueue_factor();
@@ -1335,7 +1360,7 @@ public:
             if (!enqueue_factor()) return false;
         }
         HIPCHK(hipEventRecord(ev1, stream));
-        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 8 * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_stats, d_stats, 12 * sizeof(int), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); factor_ms = ms;
         st.num_neg = h_stats[0]; st.num_zero = h_stats[1]; st.num_two = h_stats[2]; st.num_small = h_stats[3]; st.u_sensitive = h_stats[4]; st.num_fast = h_stats[7];
