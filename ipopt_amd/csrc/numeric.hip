@@ -657,6 +657,7 @@ public:
         fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
         V.fastpiv = getenv("MI355X_KKT_NO_FASTPIV") == nullptr ? 1 : 0;
         V.asm_pull = getenv("MI355X_KKT_NO_ASM_PULL") == nullptr ? 1 : 0;
+        if (const char* e = getenv("MI355X_KKT_GRP_RBW_MAX")) grp_rbw_max = std::max(1, atoi(e));
         asm_v1 = getenv("MI355X_KKT_ASM_V1") != nullptr;      // (the one-wavefront-per-column assembly kernel of rounds 1-3)
         V.fastu = 1e-4; if (const char* e = getenv("MI355X_KKT_FASTPIV_FLOOR")) V.fastu = atof(e);      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
         if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
@@ -1210,8 +1211,12 @@ public:
         const int b0 = G.g0[lv], b1 = G.g1[lv], bs = b0 + G.split[lv];
         if (b1 == b0) return true;
         {
-            const int st = (b1 - b0) * (4 + G.nrb[lv]) <= 256 ? 1 : 0;
-            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + G.nrb[lv]), dim3(256), std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0)), stream, V, b0, st);
+            // as many 64-row blocks per row-block workgroup as it takes for the launch to fit the chip (one workgroup per CU)
+            int rbw = 1;
+            while (rbw < grp_rbw_max && (b1 - b0) * (4 + (G.nrb[lv] + rbw - 1) / rbw) > 256) rbw *= 2;
+            const int nrbw = (G.nrb[lv] + rbw - 1) / rbw;
+            const int st = (b1 - b0) * (4 + nrbw) <= 256 ? 1 : 0;
+            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + nrbw), dim3(256), std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0)), stream, V, b0, st, rbw);
         }
         if (bs > b0 && G.tiles64[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(G.tiles64[lv], bs - b0), dim3(256), 0, stream, V, b0, 0);
         if (b1 == bs) return true;
@@ -1227,6 +1232,7 @@ public:
         } else if (G.tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.tiles[lv], nb), dim3(1024), 0, stream, V, bs, 0, 0, 0);
         return true;
     }
+    int grp_rbw_max = 8;
     bool asm_v1 = false;
     void launch_assemble(int mm, int nfronts, int b0, int top_mode) {
         if (asm_v1) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
