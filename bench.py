@@ -49,6 +49,9 @@ def make_workload(name):
         return kktgen.grid_kkt(500, 400, dof=3, ncon=2, seed=20260923, sigma_exp=8.0)
     if name == "mbndry1_100":      # BASELINE.json configs[2]: the matrix of the 4th boundary call of the reference's own MBndryCntrl1 N = 100 run
         return kktgen.recorded_kkt(os.path.join(ROOT, "tests", "golden", "mbndry1_100.kktrec"), which=-1)
+    if name.startswith("npz:"):     # development aid: a recorded system, e.g. npz:.dev_pivstat/mb3d_30.npz (n, r, c, v, neg)
+        d = np.load(name[4:])
+        return int(d["n"]), d["r"], d["c"], d["v"], int(d["neg"])
     raise SystemExit(f"unknown workload {name}")
 
 

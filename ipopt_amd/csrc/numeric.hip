@@ -973,6 +973,14 @@ public:
                    gs_stage.assign(ndepth, GrpSched());
                    for (int d = 0; d < ndepth; ++d) if (!build_groups(gs_stage[d], 2 + d)) return false; }
         }
+        asm_fast_ok.assign(lvl_list.size(), 0);
+        for (size_t q = 0; q < lvl_list.size(); ++q) {
+            const int sn = lvl_list[q];
+            int nch = 0;
+            for (int c = Sy.child_ptr[sn]; c < Sy.child_ptr[sn + 1]; ++c) if (Sy.child_idx[c] != Sy.alias_child[sn]) ++nch;
+            const bool chain_only = Sy.alias_child[sn] >= 0 && nch == 0;      // (pure in-place link: nothing to assemble either way)
+            asm_fast_ok[q] = (chain_only || (Sy.alias_child[sn] < 0 && nch <= 6)) ? 1 : 0;
+        }
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
@@ -1233,9 +1241,16 @@ public:
         return true;
     }
     int grp_rbw_max = 8;
+    std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path
     bool asm_v1 = false;
+    // The column-chunk kernel pays where a level is MANY fronts of a few hundred rows (short columns: the one-wavefront-per-column kernel runs at the
+    // latency of its load chain there) and every front can take its fast path (at most ASM_MAXCH children to pull, not an in-place link with other
+    // children, no arena): measured 4.1 -> 2.0 ms per factorisation on synth_1e6, but 3.4 -> 8.7 ms on MBndryCntrl_3D 30, whose levels are a
+    // handful of fronts of ~1000 rows with a dozen children each -- there the column kernel has four times the workgroups and no preamble.
     void launch_assemble(int mm, int nfronts, int b0, int top_mode) {
-        if (asm_v1) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
+        bool v2 = !asm_v1 && nfronts >= 32 && !top_mode;
+        for (int q = b0; q < b0 + nfronts && v2; ++q) v2 = asm_fast_ok[q] != 0;
+        if (!v2) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
         const int ldi = (mm + 15) & ~15;                    // the children's inverse row maps of one front in LDS: ASM_MAXCH x ldi ints (<= 78 KiB at the largest front)
         LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble2, dim3((mm + ASM_CH - 1) / ASM_CH, nfronts), dim3(256), (size_t)ASM_MAXCH * ldi * sizeof(int), stream, V, b0, top_mode, ldi);
     }
@@ -1314,16 +1329,17 @@ public:
     }
 
     bool optimistic = false;                 // (set per factorisation: see launch_bucket)
+    bool optimistic_ok = true;               // no factorisation of this handle has needed a strict launch the optimistic schedule leaves out
     hipGraphExec_t g_factor_full = nullptr;  // the schedule with every strict launch (g_factor: the optimistic one)
     bool factor(const double* dvals, bool reuse, FactorStats& st) {
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "factor: solver not set up (no device?)"; return false; }
         if (multi) return factor_dist(dvals, reuse, st);          // needs a communicator (set_comm_*), fails loudly otherwise
         static const bool opt_off = getenv("MI355X_KKT_NO_OPTIMISTIC") != nullptr;
-        optimistic = V.fastpiv && !opt_off && !prof_on;
+        optimistic = V.fastpiv && !opt_off && !prof_on && optimistic_ok;
         if (!factor_once(dvals, reuse, st)) return false;
         if (optimistic && h_stats[8] != 0) {                      // some front was left for a strict launch that was not there: the full schedule, same values
-            optimistic = false;
+            optimistic = false; optimistic_ok = false;            // ... and from now on for this structure: a matrix family that needs the strict kernels once needs them again
             if (opt.verbose) fprintf(stderr, "[mi355x_kkt] factor: the optimistic schedule met a front for the strict kernels, running the full one\n");
             return factor_once(nullptr, true, st);
         }

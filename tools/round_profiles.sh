@@ -17,7 +17,10 @@ cp gpurun_out/prof_synth_1e6/rocprof_latest.json $O/rocprof_latest.json 2>/dev/n
 cp gpurun_out/prof_synth_1e6/rocprof_latest.json profiles/rocprof_latest.json 2>/dev/null
 cp gpurun_out/prof_synth_1e6/bench_under_trace.json $O/synth_1e6_bench_under_rocprof.json 2>/dev/null
 python bench.py > $O/bench_synth_1e6.json 2> $O/bench_synth_1e6.err
-for wl in grid_1e5 lukvle1_1e6 lukvle1_1e4; do python bench.py --workload $wl --no-e2e > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+for wl in grid_1e5 lukvle1_1e6 lukvle1_1e4 mbndry1_100; do python bench.py --workload $wl --no-e2e > $O/bench_$wl.json 2> $O/bench_$wl.err; done
+python bench.py --e2e-only MBndryCntrl_3D:30:1,16 > $O/e2e_mbndry3d_30.json 2> $O/e2e_mbndry3d_30.err
+(make -s -C tools/micro >/dev/null 2>&1; tools/prof_mfma.sh synth_1e6 > $O/synth_1e6_mfma_util.txt 2>&1)
+python -m pytest tests/test_multigpu_gpu.py -q > $O/multigpu_gpu_tests.log 2>&1
 tools/timeline.sh synth_1e6 $TAG > $O/synth_1e6_timeline.txt 2>&1
 python tools/clocks.py synth_1e6 > $O/synth_1e6_pivot_block_phases.txt 2>&1
 tools/prof.sh lukvle1_1e6 k_front_reg > $O/prof_lukvle1_1e6.log 2>&1

@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 WL=${1:-synth_1e6}; TAG=${2:-run}
-OUT=$R/gpurun_out/timeline_${WL}_$TAG
+WLN=$(basename ${WL%.npz}); OUT=$R/gpurun_out/timeline_${WLN#npz:}_$TAG
 rm -rf $OUT; mkdir -p $OUT
 rocprofv3 --kernel-trace --output-format csv -d $OUT/t -o t -- python $R/tools/factor_loop.py $WL 4 > $OUT/run.log 2>&1
 f=$(find $OUT/t -name "*kernel_trace.csv" | head -1)
