@@ -74,18 +74,24 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
         so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 64 ? 64 : h->opts.max_sn_cols) : 64;   // 64: LDS budget of k_big_trsm (104 KiB at k = 65)
         so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose; so.leaf_cols = h->opts.leaf_cols; so.tree_merge = h->opts.tree_merge; so.wide_panels = h->opts.wide_panels; so.chain_group = h->opts.chain_group > 0 ? h->opts.chain_group : 4; so.solve_group = h->opts.solve_group; so.subcube = h->opts.subcube;
-        // the device's first touch and the pinned staging buffer do not depend on the analysis: made on a thread next to it
-        // (the device is resolved HERE: HIP's current device is per thread, the warm-up thread would otherwise touch device 0 whatever the caller selected)
+        // The device's first touch (runtime, context, code objects) and the pinned staging buffer do not depend on the analysis: the two run side by side.
+        // HIP's "current device" belongs to the CALLING thread (a helper thread asking for it gets device 0 whatever the caller selected), and finding it
+        // out initialises the runtime -- a good part of what is to be overlapped -- so the CALLER does the warm-up and the helper thread the analysis,
+        // which is plain host code.  The thread is joined on every path out of this scope, exceptions included (a joinable std::thread that is destroyed
+        // terminates the process); what it threw comes back as its error.
         void* pre = nullptr;
-        const int warm_dev = Numeric::resolve_device(h->opts.device);
-        struct Warm {      // joined (and its buffer released) on EVERY path out of this scope, exceptions included: a joinable std::thread that is destroyed terminates the process
-            std::thread t; void** pre; bool taken = false;
-            ~Warm() { if (t.joinable()) t.join(); if (!taken && *pre) { Numeric::prewarm_discard(*pre); *pre = nullptr; } }
-        } warm{std::thread(), &pre};
-        if (warm_dev >= 0) warm.t = std::thread([&pre, warm_dev, nnz] { try { pre = Numeric::prewarm(warm_dev, (size_t)(nnz > 0 ? nnz : 1)); } catch (...) { pre = nullptr; } });
-        const bool aok = analyse(h->sym, so, n, nnz, row, col, format, vals);
-        if (warm.t.joinable()) warm.t.join();
-        if (!aok) { h->err = h->sym.error; return MI355X_KKT_FATAL; }
+        bool aok = false; std::string aerr;
+        {
+            struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } an;
+            an.t = std::thread([&] {
+                try { aok = analyse(h->sym, so, n, nnz, row, col, format, vals); if (!aok) aerr = h->sym.error; }
+                catch (const std::bad_alloc&) { aok = false; aerr = "analyse: out of host memory"; }
+                catch (...) { aok = false; aerr = "analyse: unexpected exception"; }
+            });
+            try { pre = Numeric::prewarm(h->opts.device, (size_t)(nnz > 0 ? nnz : 1)); } catch (...) { pre = nullptr; }
+        }
+        struct PreGuard { void*& p; bool taken; ~PreGuard() { if (!taken && p) { Numeric::prewarm_discard(p); p = nullptr; } } } pg{pre, false};      // (released on every path on which setup() does not take it)
+        if (!aok) { h->err = aerr; return MI355X_KKT_FATAL; }
         h->analysed = true; h->base_nnz_l = h->sym.nnz_l;
         // device setup is attempted right away so that values_buffer() can hand out pinned memory;
         // without a GPU the symbolic result stays queryable and factor()/solve() fail loudly.
@@ -96,7 +102,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         no.refine_steps = h->opts.refine_steps; no.use_graph = h->opts.use_graph; no.rank = h->opts.rank; no.nranks = so.nranks;
         no.verbose = h->opts.verbose;
         no.prewarmed_vals = pre; no.prewarmed_count = (size_t)(nnz > 0 ? nnz : 1);
-        warm.taken = true;                     // (setup owns the buffer from here on, whether it succeeds or not)
+        pg.taken = true;                       // (setup owns the buffer from here on, whether it succeeds or not)
         h->numeric_ready = h->num->setup(h->sym, no);
         if (!h->numeric_ready) h->err = h->num->error();
         return MI355X_KKT_SUCCESS;
