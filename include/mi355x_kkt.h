@@ -121,7 +121,7 @@ typedef struct mi355x_kkt_info {
     double  pivtol;          /* the u the next factorisation will use                                   */
     int     u_sensitive;     /* last factorisation: 1 if some pivot decision would differ at u=pivtolmax */
     int     num_fast_blocks; /* last factorisation: pivot blocks of big fronts accepted on the blocked a-posteriori path  */
-                             /* (natural order, every multiplier <= 1/max(u, pivtolmax, 0.01)); the other big fronts'    */
+                             /* (natural order, every multiplier <= 1/max(u, pivtolmax, 1e-4)); the other big fronts'    */
                              /* pivot blocks took the strict threshold-pivoting loop                                     */
     int     num_delayed;     /* columns moved to a parent front since analyse() because they failed the threshold tests in their own (a column */
                              /* that moved up twice counts twice): info.num_delay of MA97 (hsl_ma97d.h:103, IpMa97SolverInterface.cpp:719-779) */

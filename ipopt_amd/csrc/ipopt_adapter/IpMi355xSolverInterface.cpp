@@ -449,7 +449,7 @@ ESymSolverStatus Mi355xSolverInterface::DetermineDependentRows(const Index* /*ia
 
 // Rendez-vous of the ranks of one job: rank 0 creates the ncclUniqueId and hands it to the others through a small file.
 //   * the record is {magic, job tag, generation, id}: the job tag comes from the launcher's environment (MI355X_KKT_JOB_ID, or torchrun's
-//     TORCHELASTIC_RUN_ID / MASTER_PORT, or SLURM_JOB_ID), the generation counts the communicators this process has set up (every rank
+//     TORCHELASTIC_RUN_ID / MASTER_PORT, SLURM_JOB_ID, or Open MPI's PMIX_NAMESPACE / OMPI_MCA_ess_base_jobid), the generation counts the communicators this process has set up (every rank
 //     sets them up in the same order) -- a reader only accepts the record of ITS job and ITS generation, a file left behind by an earlier
 //     run or by the previous set-up of the same run is ignored (and, without a launcher tag, so is any file older than this process);
 //   * rank 0 unlinks whatever is there first, writes a private temporary (O_EXCL, 0600) and renames it into place; it removes the file
@@ -467,8 +467,9 @@ const unsigned int COMM_MAGIC = 0x4b4b4d49u;      // "IMKK"
 
 unsigned long long comm_job_tag()
 {
-   const char* names[4] = {"MI355X_KKT_JOB_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "MASTER_PORT"};
-   for( int q = 0; q < 4; ++q )
+   // (Open MPI's mpirun / PRRTE set none of the first three: OMPI_MCA_ess_base_jobid / PMIX_NAMESPACE identify the job there)
+   const char* names[6] = {"MI355X_KKT_JOB_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PMIX_NAMESPACE", "OMPI_MCA_ess_base_jobid", "MASTER_PORT"};
+   for( int q = 0; q < 6; ++q )
    {
       const char* e = getenv(names[q]);
       if( e && *e )
@@ -543,7 +544,17 @@ bool Mi355xSolverInterface::SetupCommunicator()
          {
             CommRecord in;
             const bool whole = fread(&in, 1, sizeof(in), f) == sizeof(in);
-            const bool fresh = job != 0ull || (fstat(fileno(f), &sb) == 0 && sb.st_mtime + 30 >= g_process_start);
+            // without any job tag the only protection against a stale file of an earlier job is its age: written no more than
+            // MI355X_KKT_COMM_FRESH_S seconds (default 600: staggered starts, slow imports, clock skew on a shared file system) before this
+            // rank loaded the library
+            static const long fresh_s = getenv("MI355X_KKT_COMM_FRESH_S") ? atol(getenv("MI355X_KKT_COMM_FRESH_S")) : 600;
+            const bool have_stat = fstat(fileno(f), &sb) == 0;
+            const bool fresh = job != 0ull || (have_stat && sb.st_mtime + fresh_s >= g_process_start);
+            if( whole && !fresh && tries % 100 == 0 )
+            {
+               Jnlst().Printf(J_WARNING, J_LINEAR_ALGEBRA, "mi355x: rank %d ignores %s: no job tag in the environment and the file is older than %ld s "
+                              "(set MI355X_KKT_JOB_ID on every rank, or MI355X_KKT_COMM_FRESH_S)\n", kopts_.rank, path.c_str(), fresh_s);
+            }
             fclose(f);
             if( whole && fresh && in.magic == COMM_MAGIC && in.job == job && in.generation == generation )
             {

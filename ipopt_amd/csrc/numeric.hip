@@ -1823,8 +1823,11 @@ public:
             HIPCHK(hipGetLastError());
             if (!allreduce(col, S->n, 0)) return false;
         }
-        HIPCHK(hipEventRecord(ev1, stream)); HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipEventRecord(ev1, stream));
+        if (!chain_segs.empty()) HIPCHK(hipMemcpyAsync(h_stats + 6, V.sepoch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
         float ms = 0; HIPCHK(hipEventElapsedTime(&ms, ev0, ev1)); solve_ms = ms;
+        if (!chain_segs.empty() && h_stats[6] != 0) { err_ = "solve: a chain sweep timed out waiting for its predecessor on this rank (workgroups not co-resident: several ranks on one GPU?)"; return false; }
         return true;
     }
     bool factor_top(FactorStats& st) {
