@@ -161,7 +161,7 @@ public:
     // grouped schedule (single GPU): per level the chain groups whose FIRST link sits there (entries = FrontMeta of the LAST link, sorted by
     // order, split at 1024 rows like the BIG buckets), launch geometry, look-ahead tiles
     bool grouped = false;
-    struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2; std::vector<hipEvent_t> evA, evB; };
+    struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2, p1t, la3, nsplit; std::vector<hipEvent_t> evA, evB; };      // p1t: 64 x 64 tiles of a split front's part 1, la3: tiles of the fronts not split, nsplit: split fronts (among the large ones)
     GrpSched gs_single, gs_local;              // one-GPU schedule; multi-GPU: the rank's own subtrees
     std::vector<GrpSched> gs_stage;            // multi-GPU: the replicated fronts this rank holds, per exchange step (sn_gdepth)
     GrpSched* gs_cur = nullptr;                // ... the step launch_fronts is working on
@@ -175,7 +175,7 @@ public:
     std::vector<char> lv_chain; bool chain_la = true; int chain_maxf = 64;
     std::vector<hipEvent_t> chD, chLA, chN, chG1, chFar;
     hipEvent_t ch_bulk_last = nullptr, ch_far_last = nullptr; bool ch_bulk_pending = false, ch_far_pending = false;
-    hipStream_t stream2 = nullptr; bool la_pending = false; hipEvent_t la_last = nullptr; bool lookahead = true, la_any = false; int la_wgs = 1 << 20, la_min_nt = 12;
+    hipStream_t stream2 = nullptr; bool la_pending = false; hipEvent_t la_last = nullptr; bool lookahead = true, la_any = false; int la_wgs = 1 << 20, la_min_nt = 8;
     std::vector<size_t> reg_lds;
     std::vector<int> mid_split; std::vector<size_t> mid_lds;   // per level: leading FC_LDS128 fronts of order <= 96 (6x6-tile kernel, 2 workgroups per CU) and their LDS need
     std::vector<int> tiny_split;      // per level: number of leading FC_WAVE fronts of order <= 16 that use the 2x2-tile kernel
@@ -808,7 +808,7 @@ public:
                 gt.push_back(G); gcols_of[sn] += G.k;
             }
         }
-        // look-ahead candidates: group-last BIG fronts (>= 12 tile rows) whose chain continues with a PURE next group (links
+        // look-ahead candidates: group-last BIG fronts (>= la_min_nt = 8 tile rows; 12 before part 1 had its 64 x 64 tiles) whose chain continues with a PURE next group (links
         // whose only child is the chain child: nothing but the chain itself writes into the front before the next full update)
         std::vector<char> split_of(Sy.num_sn, 0);
         la_tiles1.assign(Sy.num_levels, 0); la_tiles2.assign(Sy.num_levels, 0); la_full.assign(Sy.num_levels, 0);
@@ -934,7 +934,7 @@ public:
             // which: 0 = every front (one GPU), 1 = the rank's own subtrees, 2 + d = the replicated fronts of exchange step d held by this rank (an
             // in-place chain never crosses an ownership boundary -- symbolic.cpp only aliases fronts of one owner and one range of ranks -- so neither does a group)
             auto build_groups = [&](GrpSched& G, int which) -> bool {
-                for (auto* v : {&G.g0, &G.g1, &G.split, &G.nrb, &G.tiles64, &G.tiles, &G.la1, &G.la2}) v->assign(Sy.num_levels, 0);
+                for (auto* v : {&G.g0, &G.g1, &G.split, &G.nrb, &G.tiles64, &G.tiles, &G.la1, &G.la2, &G.p1t, &G.la3, &G.nsplit}) v->assign(Sy.num_levels, 0);
                 G.evA.assign(Sy.num_levels, nullptr); G.evB.assign(Sy.num_levels, nullptr);
                 if (!grouped) return true;
                 std::vector<std::vector<int>> at(Sy.num_levels);
@@ -959,6 +959,8 @@ public:
                             G.tiles[lv] = std::max(G.tiles[lv], schur_tiles(Sy, sn));
                             G.la1[lv] = std::max(G.la1[lv], split_of[sn] ? 2 * nt - 1 : tri_tiles(nt));
                             if (split_of[sn]) G.la2[lv] = std::max(G.la2[lv], ((nt - 2) * (nt - 1) / 2 + 7) / 8 * 8);
+                            if (split_of[sn]) { const int n64 = (mu + 63) / 64; int c = 0; for (int tc = 0; tc < 4 && tc < n64; ++tc) c += n64 - tc; G.p1t[lv] = std::max(G.p1t[lv], c); ++G.nsplit[lv]; }
+                            else G.la3[lv] = std::max(G.la3[lv], tri_tiles(nt));
                         }
                     }
                     G.split[lv] = nsmall; G.g1[lv] = (int)lvl_list.size();
@@ -1231,7 +1233,12 @@ public:
         const int nb = b1 - bs;
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }      // a full update may touch what an earlier part 2 is still writing
         if (G.la2[lv] > 0 && !prof_on) {
-            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.la1[lv], nb), dim3(1024), 0, stream, V, bs, 1, 0, 0);
+            // part 1 in 64 x 64 tiles where the 128 x 128 ones would leave most of the chip idle (k_big_schur_p1); the fronts of the list that are not split
+            // get their whole update from a launch of their own then
+            if (p1_small_tiles && G.la1[lv] * nb <= 512) {
+                LAUNCH(KK_BIG_SCHUR, k_big_schur_p1, dim3(G.p1t[lv], nb), dim3(1024), 0, stream, V, bs);
+                if (G.nsplit[lv] < nb) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.la3[lv], nb), dim3(1024), 0, stream, V, bs, 4, 0, 0);
+            } else LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.la1[lv], nb), dim3(1024), 0, stream, V, bs, 1, 0, 0);
             HIPCHK(hipEventRecord(G.evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, G.evA[lv], 0));
             hipLaunchKernelGGL(k_big_schur, dim3(std::min(G.la2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, bs, 2, G.la2[lv], 0);
@@ -1241,6 +1248,7 @@ public:
         return true;
     }
     int grp_rbw_max = 8;
+    bool p1_small_tiles = getenv("MI355X_KKT_NO_P1_SMALL") == nullptr;
     std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path
     bool asm_v1 = false;
     // The column-chunk kernel pays where a level is MANY fronts of a few hundred rows (short columns: the one-wavefront-per-column kernel runs at the
@@ -1296,10 +1304,13 @@ public:
     // 2 the caller's factors) and the column norms of the scaled matrix that anchor the zero-pivot test
     void enqueue_scaling() {
         const Symbolic& Sy = *S; const int n = Sy.n;
-        LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
+        // Ruiz on short rows (LukVl: 6 entries per row): the row view is written by the first sweep (-16 us of 350; at 39 entries per row the flat pass + sweep are faster: +37 us)
+        const bool fuse0 = opt.scaling == 1 && (long long)V.rslot_len < 16ll * n;
+        if (!fuse0) LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
         if (opt.scaling >= 2) LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);     // 2: the caller's factors, 3: matching (computed just before)
         else if (opt.scaling) {
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2, (double*)nullptr);
+            if (fuse0) LAUNCH(KK_GATHER_SCALE, k_abs_rowview_sweep0, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, V.scale2);
+            else LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2, (double*)nullptr);
             LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, (double*)nullptr);
             LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2, (double*)nullptr);
             LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, V.cnorm);
