@@ -128,8 +128,51 @@ template <class T> using vector = avec<T>;       // every array of the analysis 
 
 // static-chunk parallel loop on std::thread (the analysis is the only multi-threaded host code; T <= 16)
 int analysis_threads() { unsigned h = std::thread::hardware_concurrency(); int t = h ? std::min((int)h, 32) : 1; const char* e = getenv("MI355X_KKT_THREADS"); if (e) t = atoi(e); return std::max(1, std::min(t, 256)); }      // default: up to 32 (measured on the 2 x 64-core host of the GPU box); MI355X_KKT_THREADS overrides
+// The parallel loops of one analysis share a set of parked worker threads (PoolScope, opened by analyse / restructure_delays on the thread that runs the
+// analysis): a region costs a wake-up instead of creating and joining T threads -- ~0.8 ms per region at T = 32, some 40 regions per analysis.
+struct WorkerPool {
+    int nworkers;
+    std::vector<std::thread> th;
+    std::mutex mu; std::condition_variable cv, cvd;
+    const std::function<void(int)>* job = nullptr;
+    int ntasks = 0, remaining = 0; unsigned gen = 0; bool stop = false;
+    explicit WorkerPool(int n) : nworkers(n) { th.reserve(n); for (int w = 0; w < n; ++w) th.emplace_back([this, w] { loop(w); }); }
+    ~WorkerPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv.notify_all(); for (auto& x : th) x.join(); }
+    void loop(int w) {
+        unsigned seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            const std::function<void(int)>* j = job; const int nt = ntasks;
+            lk.unlock();
+            if (w + 1 < nt) (*j)(w + 1);
+            lk.lock();
+            if (--remaining == 0) cvd.notify_one();
+        }
+    }
+    void run(int T, const std::function<void(int)>& fn) {      // fn(0) on the caller, fn(1 .. T-1) on the workers
+        { std::lock_guard<std::mutex> lk(mu); job = &fn; ntasks = T; remaining = nworkers; ++gen; }
+        cv.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(mu);
+        cvd.wait(lk, [&] { return remaining == 0; });
+    }
+};
+thread_local WorkerPool* tl_pool = nullptr;
+struct PoolScope {
+    WorkerPool* mine = nullptr;
+    explicit PoolScope(int T) { if (!tl_pool && T > 1 && getenv("MI355X_KKT_NO_POOL") == nullptr) { mine = new WorkerPool(T - 1); tl_pool = mine; } }
+    ~PoolScope() { if (mine) { tl_pool = nullptr; delete mine; } }
+};
 template <class F> void parallel_chunks(long long n, int T, F fn) {
     if (T <= 1 || n < 4096) { fn(0LL, n, 0); return; }
+    if (tl_pool && T - 1 <= tl_pool->nworkers) {
+        const std::function<void(int)> job = [&](int t) { fn(n * t / T, n * (t + 1) / T, t); };
+        tl_pool->run(T, job);
+        return;
+    }
     std::vector<std::thread> th; th.reserve(T);
     for (int t = 0; t < T; ++t) { long long b = n * t / T, e = n * (t + 1) / T; th.emplace_back([=, &fn] { fn(b, e, t); }); }
     for (auto& x : th) x.join();
@@ -888,6 +931,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
              int format, const double* vals)
 {
     BlockCache::Scope recycle;          // (declared first: destroyed last, after every array of the analysis has been returned)
+    PoolScope workers(analysis_threads());
     double t0 = now_s(), tl = t0;
     auto lap = [&](const char* what) { if (opt.verbose >= 2) { double t = now_s(); fprintf(stderr, "[mi355x_kkt]   %-28s %.3f s\n", what, t - tl); tl = t; } };
     S = Symbolic();
@@ -918,15 +962,46 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     }
     Graph CG; CG.n = nc; CG.xadj.assign(nc + 1, 0);
     {
-        vector<int> mark(nc, -1); vector<int> tmp; tmp.reserve(adj.size());
-        for (int c = 0; c < nc; ++c) {
-            int mem[2] = { cfirst[c], S.pair_of[cfirst[c]] };
-            mark[c] = c;
-            for (int k = 0; k < 2; ++k) { int i = mem[k]; if (i < 0) continue;
-                for (int p = xadj[i]; p < xadj[i + 1]; ++p) { int d = cid[adj[p]]; if (mark[d] != c) { mark[d] = c; tmp.push_back(d); } } }
-            CG.xadj[c + 1] = (int)tmp.size();
-        }
-        CG.adj = std::move(tmp);
+        // neighbours of a compressed node = the compressed nodes of its members' neighbours, each once, in the order of first occurrence (the order the serial
+        // construction with one mark array produced: the dissection walks these lists, so the order is part of the ordering).  Chunks of nodes on threads,
+        // each with its own output, stitched together behind a prefix sum.
+        const int T = analysis_threads();
+        const int TC = (T <= 1 || nc < 4096) ? 1 : T;
+        std::vector<vector<int>> part(TC);
+        parallel_chunks(nc, TC, [&](long long cb, long long ce, int t) {
+            vector<int>& out = part[t];
+            out.reserve((size_t)((xadj[n] / std::max(nc, 1)) * (ce - cb) + 16));
+            vector<int> cand, uniq; vector<char> used;
+            for (int c = (int)cb; c < (int)ce; ++c) {
+                const int mem[2] = { cfirst[c], S.pair_of[cfirst[c]] };
+                const size_t o0 = out.size();
+                int deg = 0;
+                for (int k = 0; k < 2; ++k) if (mem[k] >= 0) deg += xadj[mem[k] + 1] - xadj[mem[k]];
+                if (deg <= 48) {
+                    for (int k = 0; k < 2; ++k) { const int i = mem[k]; if (i < 0) continue;
+                        for (int p = xadj[i]; p < xadj[i + 1]; ++p) {
+                            const int d = cid[adj[p]];
+                            if (d == c) continue;
+                            bool seen = false;
+                            for (size_t q = o0; q < out.size(); ++q) if (out[q] == d) { seen = true; break; }
+                            if (!seen) out.push_back(d);
+                        } }
+                } else {
+                    cand.clear();
+                    for (int k = 0; k < 2; ++k) { const int i = mem[k]; if (i < 0) continue; for (int p = xadj[i]; p < xadj[i + 1]; ++p) { const int d = cid[adj[p]]; if (d != c) cand.push_back(d); } }
+                    uniq.assign(cand.begin(), cand.end());
+                    std::sort(uniq.begin(), uniq.end()); uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+                    used.assign(uniq.size(), 0);
+                    for (int d : cand) { const size_t u = std::lower_bound(uniq.begin(), uniq.end(), d) - uniq.begin(); if (!used[u]) { used[u] = 1; out.push_back(d); } }
+                }
+                CG.xadj[c + 1] = (int)(out.size() - o0);
+            }
+        });
+        for (int c = 0; c < nc; ++c) CG.xadj[c + 1] += CG.xadj[c];
+        CG.adj.resize((size_t)CG.xadj[nc]);
+        parallel_chunks(nc, TC, [&](long long cb, long long, int t) {      // (the same chunks: thread t copies its own output)
+            if (!part[t].empty()) std::memcpy(CG.adj.data() + CG.xadj[cb], part[t].data(), part[t].size() * sizeof(int));
+        });
     }
 
     lap("compressed graph");
@@ -1288,6 +1363,7 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
 bool restructure_delays(const Symbolic& C, const SymbolicOptions& opt, const std::vector<int>& marked, const std::vector<int>& hops, Symbolic& S, int* moved_out, std::vector<char>* acted)
 {
     BlockCache::Scope recycle;
+    PoolScope workers(analysis_threads());
     const double t0 = now_s(); double tl = t0;
     auto lap = [&](const char* what) { if (opt.verbose >= 2) { double t = now_s(); fprintf(stderr, "[mi355x_kkt]   (delay) %-20s %.3f s\n", what, t - tl); tl = t; } };
     const int n = C.n, nsn0 = C.num_sn;
