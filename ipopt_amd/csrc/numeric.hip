@@ -1043,6 +1043,49 @@ public:
         }
         lap("host-side schedules and tables");
         if (!upload(fm, &V.fmeta) || !upload(cm, &V.cmeta) || !upload(gt, &V.gtab)) return false;
+        {   // leaf chains (k_leaf_chain): the levels below lc_levels hold nothing but fronts of order <= 16 with at most one child -- every such front is a
+            // link of the chain that starts at its leaf
+            lc_levels = 0; lc_nchains = 0;
+            std::vector<int> lcp, lcf; std::vector<LeafLink> lcl;
+            if (!multi && V.fastpiv && getenv("MI355X_KKT_NO_LEAFCHAIN") == nullptr) {
+                int L = 0;
+                for (; L < Sy.num_levels && L < 16; ++L) {
+                    bool okl = true; int cnt = 0;
+                    for (int fc = 0; fc < FC_COUNT && okl; ++fc) {
+                        const int b0 = Sy.level_ptr[(size_t)L * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)L * FC_COUNT + fc + 1];
+                        if (fc != FC_WAVE) { if (b1 > b0) okl = false; continue; }
+                        for (int q = b0; q < b1 && okl; ++q) {
+                            const int sn = lvl_list[q]; ++cnt;
+                            if (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn] > 16 || Sy.child_ptr[sn + 1] - Sy.child_ptr[sn] > 1) okl = false;
+                        }
+                    }
+                    if (!okl || cnt == 0) break;
+                }
+                if (L >= 2 && Sy.level_ptr[(size_t)0 * FC_COUNT + FC_WAVE + 1] - Sy.level_ptr[(size_t)0 * FC_COUNT + FC_WAVE] >= 1024) {
+                    lc_levels = L;
+                    std::vector<int> fmw(Sy.num_sn, -1);
+                    for (int lv = 0; lv < L; ++lv) for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE + 1]; ++q) fmw[lvl_list[q]] = q;
+                    lcp.push_back(0);
+                    for (int q = Sy.level_ptr[(size_t)0 * FC_COUNT + FC_WAVE]; q < Sy.level_ptr[(size_t)0 * FC_COUNT + FC_WAVE + 1]; ++q) {
+                        for (int cur = lvl_list[q]; cur >= 0 && Sy.sn_level[cur] < L; cur = Sy.sn_parent[cur]) lcf.push_back(fmw[cur]);
+                        lcp.push_back((int)lcf.size());
+                    }
+                    lc_nchains = (int)lcp.size() - 1;
+                    if ((int)lcf.size() != Sy.level_ptr[(size_t)(L - 1) * FC_COUNT + FC_WAVE + 1] - Sy.level_ptr[(size_t)0 * FC_COUNT + FC_WAVE]) { lc_levels = 0; lc_nchains = 0; }   // (cannot happen: every front below L is on exactly one chain)
+                    if (opt.verbose && lc_levels) fprintf(stderr, "[mi355x_kkt] leaf chains: %d chains over the bottom %d levels (%zu fronts) in one launch per sweep\n", lc_nchains, lc_levels, lcf.size());
+                }
+            }
+            if (lcp.empty()) lcp.push_back(0);
+            for (int q : lcf) {
+                const FrontMeta& M = fm[q]; LeafLink K;
+                K.s = M.s; K.c0 = M.c0; K.k = M.k; K.m = M.m; K.aq0 = M.aq0; K.aq1 = M.aq1; K.ldp = M.ldp; K.r0 = M.r0; K.pad = 0;
+                K.relbase = M.r0 + M.k;                                  // (V.rel + relbase: where the front's update rows sit in its parent)
+                K.panel_off = M.panel_off; K.minv_off = M.minv_off; K.cb_off = M.cb_off; K.cv = M.cv;
+                lcl.push_back(K);
+            }
+            if (lcl.empty()) lcl.push_back(LeafLink());
+            if (!upload(lcp, &V.lc_ptr) || !upload(lcl, &V.lc_link)) return false;
+        }
         // the inertia / pivot counts are summed over the ranks: a replicated front is counted by the first rank of its range (-1 in this rank's view), -3 = not here
         std::vector<int> stat_owner(Sy.sn_owner.begin(), Sy.sn_owner.end());
         if (multi) for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_owner[sn] < 0) stat_owner[sn] = Sy.sn_glo[sn] == opt.rank ? -1 : -3;
@@ -1248,6 +1291,7 @@ public:
         return true;
     }
     int grp_rbw_max = 8;
+    int lc_levels = 0, lc_nchains = 0;      // leaf chains: the tree levels below lc_levels are lc_nchains chains of fronts of order <= 16 (k_leaf_chain)
     bool p1_small_tiles = getenv("MI355X_KKT_NO_P1_SMALL") == nullptr;
     std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path
     bool asm_v1 = false;
@@ -1324,7 +1368,9 @@ public:
         LAUNCH(KK_STATS, k_factor_prologue, dim3(grid1d(n)), dim3(256), 0, stream, V);
         LAUNCH(KK_GATHER_SCALE, k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         enqueue_scaling();
-        for (int lv = 0; lv < Sy.num_levels; ++lv) {
+        const int lc = (optimistic && lc_levels > 0) ? lc_levels : 0;      // the leaf chains: one launch for their levels (optimistic schedule only: no strict kernel behind it)
+        if (lc > 0) LAUNCH(KK_FRONT_WAVE, k_leaf_chain, dim3((lc_nchains + 3) / 4), dim3(64), 0, stream, V, lc_nchains);
+        for (int lv = lc; lv < Sy.num_levels; ++lv) {
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
@@ -1423,7 +1469,9 @@ public:
             }
             auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
             if (!chain_segs.empty()) LAUNCH(KK_SOLVE_PERM, k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
-            for (int lv = 0; lv < Sy.num_levels; ++lv) {
+            const int lcs = (pair_solve && lc_levels > 0) ? lc_levels : 0;
+            if (lcs > 0) LAUNCH(KK_FWD_WAVE, k_fwd_leafchain, dim3((lc_nchains + 3) / 4), dim3(64), 0, stream, V, lc_nchains);
+            for (int lv = lcs; lv < Sy.num_levels; ++lv) {
                 if (seg_at_lv0[lv] >= 0) {      // a run of pure chain levels: one sync-free launch for all of them
                     const ChainSeg& sg = chain_segs[seg_at_lv0[lv]];
                     LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(320), 0, stream, V, sg.wgf0);
@@ -1446,7 +1494,7 @@ public:
                                   LAUNCH(KK_FWD_BIG_UPD, k_fwd_grp_upd, dim3((big_maxm[lv] + 63) / 64, ng), dim3(256), 0, stream, V, g0); } }
                 }
             }
-            for (int lv = Sy.num_levels - 1; lv >= 0; --lv) {
+            for (int lv = Sy.num_levels - 1; lv >= lcs; --lv) {
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
                     LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(320), 0, stream, V, sg.wgb0);
@@ -1471,6 +1519,7 @@ public:
                                LAUNCH(KK_BWD_BIG, k_bwd_grp, dim3(ng), dim3(256), 0, stream, V, g0); } }
                 }
             }
+            if (lcs > 0) LAUNCH(KK_BWD_WAVE, k_bwd_leafchain, dim3((lc_nchains + 3) / 4), dim3(64), 0, stream, V, lc_nchains);
         }
         if (nref > 0) LAUNCH(KK_SOLVE_PERM, k_refine_finish, dim3(grid1d(n)), dim3(256), 0, stream, V);
         HIPCHK(hipGetLastError());
