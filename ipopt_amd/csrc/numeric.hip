@@ -1061,7 +1061,7 @@ public:
                     }
                     if (!okl || cnt == 0) break;
                 }
-                if (L >= 2 && Sy.level_ptr[(size_t)0 * FC_COUNT + FC_WAVE + 1] - Sy.level_ptr[(size_t)0 * FC_COUNT + FC_WAVE] >= 1024) {
+                if (L >= 2) {
                     lc_levels = L;
                     std::vector<int> fmw(Sy.num_sn, -1);
                     for (int lv = 0; lv < L; ++lv) for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE + 1]; ++q) fmw[lvl_list[q]] = q;
@@ -1469,7 +1469,8 @@ public:
             }
             auto lds_solve = [](int mmax, int kmax) { return (size_t)(mmax + 3 * kmax) * sizeof(double) + 16; };
             if (!chain_segs.empty()) LAUNCH(KK_SOLVE_PERM, k_bump_epoch, dim3(1), dim3(64), 0, stream, V.sepoch);
-            const int lcs = (pair_solve && lc_levels > 0) ? lc_levels : 0;
+            int lcs = (pair_solve && lc_levels > 0) ? lc_levels : 0;
+            for (int lv = 0; lv < lcs; ++lv) if (seg_at_lv0[lv] >= 0) { lcs = 0; break; }      // (a small tree: one data-flow sweep already covers these levels)
             if (lcs > 0) LAUNCH(KK_FWD_WAVE, k_fwd_leafchain, dim3((lc_nchains + 3) / 4), dim3(64), 0, stream, V, lc_nchains);
             for (int lv = lcs; lv < Sy.num_levels; ++lv) {
                 if (seg_at_lv0[lv] >= 0) {      // a run of pure chain levels: one sync-free launch for all of them

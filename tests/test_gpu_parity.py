@@ -187,9 +187,12 @@ def test_optional_code_paths_stay_exact(opts):
         assert s.info().maxsupernode > 96          # the panel solve of a > 96-column panel does not stage L11 in LDS (budget): that path ran
 
 
-def test_lookahead_split_updates_are_exact_and_reproducible(monkeypatch):
+@pytest.mark.parametrize("part1", ["tiles64", "tiles128"])
+def test_lookahead_split_updates_are_exact_and_reproducible(monkeypatch, part1):
     """the two-stream look-ahead of the group-end trailing updates (normally only on very large fronts) forced onto a
-    mid-size system: same inertia, converged solve, bitwise identical to the single-stream factorisation"""
+    mid-size system: same inertia, converged solve, bitwise identical to the single-stream factorisation -- with part 1 (the first 256
+    columns, on the main stream) in 64 x 64 tiles (k_big_schur_p1, the default where few tiles are in the launch) and in the 128 x 128 ones"""
+    if part1 == "tiles128": monkeypatch.setenv("MI355X_KKT_NO_P1_SMALL", "1")
     n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)        # fronts up to ~1 200 rows: several split updates
     K = kktgen.to_scipy(n, r, c, v)
     b = K @ np.ones(n)
@@ -203,6 +206,25 @@ def test_lookahead_split_updates_are_exact_and_reproducible(monkeypatch):
     assert np.array_equal(x0, x1)
     x2 = b.copy(); s1.multi_solve(True, x2)
     assert np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("n", [1000, 40000])
+def test_leaf_chains_equal_the_level_by_level_schedule_bitwise(monkeypatch, n):
+    """the bottom levels of a banded KKT system's tree are chains of fronts of order <= 16: one launch per sweep walks them (k_leaf_chain, k_fwd_leafchain,
+    k_bwd_leafchain) with the contribution blocks handed on in registers / LDS -- same arithmetic as the per-level kernels: same inertia, bitwise the same solution,
+    and the oracle's"""
+    nn, r, c, v, neg = kktgen.lukvl_like(n, seed=41)
+    K = kktgen.to_scipy(nn, r, c, v)
+    b = K @ np.linspace(1.0, 2.0, nn)
+    monkeypatch.setenv("MI355X_KKT_NO_LEAFCHAIN", "1")
+    s0, st0, x0 = gpu_factor_solve(nn, r, c, v, b, check=True, required=neg)
+    monkeypatch.delenv("MI355X_KKT_NO_LEAFCHAIN")
+    s1, st1, x1 = gpu_factor_solve(nn, r, c, v, b, check=True, required=neg)
+    assert st0 == st1 == kkt.SUCCESS and s1.number_of_neg_evals() == s0.number_of_neg_evals() == neg
+    assert np.array_equal(x0, x1)
+    assert sres(K, x1, b) <= RES_TOL
+    xo, oneg, ozero, _ = ko.factor_solve(nn, r, c, v, rhs=b, u=1e-8)
+    assert oneg == neg and np.abs(x1 - xo).max() <= 1e-7 * max(1.0, np.abs(xo).max())
 
 
 def test_device_side_assembly_equals_host_assembly_bitwise():
