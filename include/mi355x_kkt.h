@@ -62,6 +62,8 @@ typedef struct mi355x_kkt_options {
                             /* 3 = maximum-product matching scaling (MC64-style; host, per factorisation), */
                             /* 4 = the same computed at the first factorisation and REUSED until          */
                             /*     IncreaseQuality asks for better (MA97's "...-reuse" switches)          */
+                            /* 5 = maximum-product matching scaling ON THE DEVICE (Jacobi auction,        */
+                            /*     kernels_match.hip.inc), per factorisation; 6 = the same, reused like 4 */
     int    nd_leaf;         /* ND stops splitting below this many (compressed) nodes; default 32        */
     int    nemin;           /* relaxed-supernode amalgamation: always merge below this #cols; default 8 */
     int    max_sn_cols;     /* cap on columns of an amalgamated supernode; default (and max) 64                */
@@ -126,7 +128,10 @@ typedef struct mi355x_kkt_info {
     int     num_delayed;     /* columns moved to a parent front since analyse() because they failed the threshold tests in their own (a column */
                              /* that moved up twice counts twice): info.num_delay of MA97 (hsl_ma97d.h:103, IpMa97SolverInterface.cpp:719-779) */
     int     num_restructures;/* structure edits (+ refactorisations) those delays have cost since analyse()                                  */
-    double  reserved[5];
+    double  matching_ms;     /* scaling modes 5 / 6: device time of the last matching-scaling computation (hip events)                                */
+    int     matching_rounds; /* ... its auction rounds (all phases)                                                                                    */
+    int     matching_unmatched; /* ... columns left without a row when it ended (modes 3 / 4: structural deficiency found by the host algorithm)       */
+    double  reserved[3];
 } mi355x_kkt_info;
 
 /* fill opts with the defaults documented above */
@@ -215,7 +220,9 @@ int  mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info);
 /* Symmetric scaling at run time (the option `scaling` only sets the initial mode): 0 none, 1 Ruiz inf-norm equilibration
  * on the device (the algorithm of MC77), 2 the caller's factors (n doubles, caller's numbering; copied), 3 maximum-product
  * matching scaling (the job of MC64: Duff & Koster 2001; host algorithm, recomputed at every factorisation while selected), 4 the same computed once and
- * reused until mi355x_kkt_increase_quality or a new _set_scaling (IpMa97SolverInterface.cpp:725-771: SWITCH_AT_START_REUSE / ON_DEMAND_REUSE).  _get_scaling returns the factors the last
+ * reused until mi355x_kkt_increase_quality or a new _set_scaling (IpMa97SolverInterface.cpp:725-771: SWITCH_AT_START_REUSE / ON_DEMAND_REUSE), 5 / 6 = the job of
+ * 3 / 4 done on the device by a Jacobi auction (feasible duals by construction: |s_i a_ij s_j| <= 1 on every entry; the matched entries of the unsymmetrised
+ * scaling are >= e^(-1/64); info.matching_ms / _rounds / _unmatched describe the last computation).  _get_scaling returns the factors the last
  * factorisation used.  Together they give the MA97 call protocol its meaning: control.scaling > 0 => compute and hand back in
  * scale[], control.scaling == 0 with scale != NULL => reuse the caller-held factors, else none (IpMa97SolverInterface.cpp:641-678). */
 int  mi355x_kkt_set_scaling(mi355x_kkt_handle h, int mode, const double* user_factors);

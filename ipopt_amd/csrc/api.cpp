@@ -397,7 +397,7 @@ int mi355x_kkt_increase_quality(mi355x_kkt_handle h, double* new_u)
     const double umax = h->opts.pivtolmax > h->opts.pivtol ? h->opts.pivtolmax : h->opts.pivtol;
     if (h->opts.pivtol >= umax) return 0;
     if (h->opts.smart_quality && h->factored && !h->stats_stale && !h->last.u_sensitive) return 0;      // (opt-in: the reference adapters always raise u)
-    if (h->num && h->opts.scaling == 4) h->num->invalidate_matching();      // a reused matching scaling is computed afresh when the caller asks for better quality
+    if (h->num && (h->opts.scaling == 4 || h->opts.scaling == 6)) h->num->invalidate_matching();      // a reused matching scaling is computed afresh when the caller asks for better quality
     double u = std::pow(h->opts.pivtol, 0.75);
     if (u > umax) u = umax;
     h->opts.pivtol = u;
@@ -423,7 +423,7 @@ int mi355x_kkt_get_info(mi355x_kkt_handle h, mi355x_kkt_info* info)
     info->num_fast_blocks = h->factored ? h->last.num_fast : 0;
     info->num_delayed = h->num_delayed; info->num_restructures = h->num_restructures;
     info->time_analyse = S.time_analyse;
-    if (h->num) { info->time_factor_ms = h->num->last_factor_ms(); info->time_solve_ms = h->num->last_solve_ms(); }
+    if (h->num) { info->time_factor_ms = h->num->last_factor_ms(); info->time_solve_ms = h->num->last_solve_ms(); h->num->matching_stats(&info->matching_ms, &info->matching_rounds, &info->matching_unmatched); }
     return MI355X_KKT_SUCCESS;
 }
 

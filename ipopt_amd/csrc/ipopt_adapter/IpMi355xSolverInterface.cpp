@@ -40,9 +40,11 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
                                     false, 1e-8, "Relative threshold u of the 1x1 / 2x2 pivot tests (MA27/MA57 tests against the whole front column).");
    roptions->AddBoundedNumberOption("mi355x_pivtolmax", "Maximum pivot tolerance for the MI355X LDL^T solver.", 0.,
                                     true, 0.5, false, 1e-4, "IncreaseQuality raises the tolerance u <- u^0.75 up to this value.");
-   roptions->AddStringOption4("mi355x_scaling", "Symmetric scaling of the KKT matrix inside the backend.", "ruiz", "none",
+   roptions->AddStringOption6("mi355x_scaling", "Symmetric scaling of the KKT matrix inside the backend.", "ruiz", "none",
                               "no scaling", "ruiz", "4 sweeps of inf-norm Ruiz equilibration on the device (the algorithm of MC77)", "matching",
                               "maximum-product matching scaling (the job of MC64), computed on the host at the first factorisation and reused until IncreaseQuality (ma97_switch ...-reuse)", "matching-always",
+                              "the same, recomputed at every factorisation", "matching-device",
+                              "maximum-product matching scaling computed ON THE DEVICE (Jacobi auction), at the first factorisation and reused until IncreaseQuality", "matching-device-always",
                               "the same, recomputed at every factorisation");
    roptions->AddStringOption3("mi355x_ordering", "Fill-reducing ordering.", "nd", "nd",
                               "nested dissection with minimum-degree leaves", "md", "minimum degree", "natural", "identity");
@@ -96,7 +98,7 @@ void Mi355xSolverInterface::ReadNumericOptions(const OptionsList& options, const
       }
       if( options.GetStringValue("mi355x_scaling", sv, prefix) )
       {
-         kopts.scaling = (sv == "none") ? 0 : (sv == "matching" ? 4 : (sv == "matching-always" ? 3 : 1));
+         kopts.scaling = (sv == "none") ? 0 : (sv == "matching" ? 4 : (sv == "matching-always" ? 3 : (sv == "matching-device" ? 6 : (sv == "matching-device-always" ? 5 : 1))));
       }
       if( options.GetStringValue("mi355x_ordering", sv, prefix) )
       {

@@ -106,7 +106,9 @@ void ma97_factor_d(int /*matrix_type*/, const int /*ptr*/[], const int /*row*/[]
         //   control.scaling == 0, scale NULL   no scaling
         // HSL's choices map onto ours: 1 (MC64) and 3 (MC64 from the matching ordering) -> matching scaling; 2 (MC77) and 4 (MC30) ->
         // Ruiz equilibration (MC77 IS Ruiz's algorithm)
-        const int mode = (control && control->scaling > 0) ? ((control->scaling == 1 || control->scaling == 3) ? 3 : 1) : (scale ? 2 : 0);
+        // (MI355X_KKT_MA97_MATCHING=device: the matching scaling is computed by the device auction, scaling mode 5, instead of the host algorithm)
+        static const int match_mode = [] { const char* e = getenv("MI355X_KKT_MA97_MATCHING"); return (e && std::strcmp(e, "device") == 0) ? 5 : 3; }();
+        const int mode = (control && control->scaling > 0) ? ((control->scaling == 1 || control->scaling == 3) ? match_mode : 1) : (scale ? 2 : 0);
         if (mi355x_kkt_set_scaling(k->h, mode, scale) != 0) { info->flag = -1; return; }
         double* buf = mi355x_kkt_values_buffer(k->h);
         if (!buf) { info->flag = -1; return; }
@@ -116,7 +118,7 @@ void ma97_factor_d(int /*matrix_type*/, const int /*ptr*/[], const int /*row*/[]
         if (fkeep) *fkeep = k;
         fill_info(k, info);
         if (st == MI355X_KKT_FATAL) { info->flag = -1; return; }
-        if (scale && (mode == 1 || mode == 3) && mi355x_kkt_get_scaling(k->h, scale) != 0) { info->flag = -1; return; }   // hand the factors back for reuse
+        if (scale && (mode == 1 || mode == 3 || mode == 5) && mi355x_kkt_get_scaling(k->h, scale) != 0) { info->flag = -1; return; }   // hand the factors back for reuse
         if (st == MI355X_KKT_SINGULAR) info->flag = (control && control->action) ? 7 : -7;
         else info->flag = 0;
     } catch (...) { info->flag = -1; }

@@ -43,6 +43,7 @@ public:
     void   set_pivtol(double u);
     void   set_pivtolmax(double u);
     double last_factor_ms() const;
+    void   matching_stats(double* ms, int* rounds, int* unmatched) const;      // the last matching-scaling computation (scaling modes 3-6)
     double last_solve_ms() const;
     const std::string& error() const;
     static constexpr int kNumKernelKinds = 18;
@@ -56,7 +57,7 @@ public:
     bool   solve_fwd_local(double* drhs);
     bool   top_rhs(double** dptr, int64_t* ndoubles);
     bool   solve_top_and_bwd(double* drhs);
-    bool   set_scaling(int mode, const double* user_factors_orig_numbering);   // 0 none, 1 Ruiz (device), 2 the caller's factors, 3 matching (every factorisation), 4 matching (computed once, reused)
+    bool   set_scaling(int mode, const double* user_factors_orig_numbering);   // 0 none, 1 Ruiz (device), 2 the caller's factors, 3 matching (host, every factorisation), 4 matching (host, computed once, reused), 5 / 6 the same on the device
     bool   get_scaling(double* out_orig_numbering);                             // factors of the last factorisation
     void   invalidate_matching();                                                // scaling mode 4: compute the matching scaling afresh at the next factorisation
     // first touch of the device (context, code objects) and the pinned staging buffer: independent of the analysis, so the C API runs it on a

@@ -61,6 +61,7 @@ static constexpr double ZERO_REL = 1e-14;                // zero-pivot test rela
 #include "kernels_solve.hip.inc"
 #include "kernels_big.hip.inc"
 #include "kernels_pd_multigpu.hip.inc"
+#include "kernels_match.hip.inc"
 // ------------------------------------------------------------------------------------------------
 // host-side orchestration
 // ------------------------------------------------------------------------------------------------
@@ -95,7 +96,7 @@ public:
     bool set_scaling(int mode, const double* user) {
         DeviceGuard guard(dev);
         if (!ready) { err_ = "set_scaling: solver not set up"; return false; }
-        if (mode < 0 || mode > 4 || (mode == 2 && !user)) { err_ = "set_scaling: mode 0 (none), 1 (ruiz), 2 (user factors, non-null), 3 (matching) or 4 (matching, reused)"; return false; }
+        if (mode < 0 || mode > 6 || (mode == 2 && !user)) { err_ = "set_scaling: mode 0 (none), 1 (ruiz), 2 (user factors, non-null), 3 (matching, host), 4 (matching, host, reused), 5 (matching, device) or 6 (matching, device, reused)"; return false; }
         match_valid = false;                                  // (mode 4: the factors of an earlier selection do not survive a new one)
         if (mode == 2) {
             if (!d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(S->n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
@@ -128,11 +129,85 @@ public:
         int unmatched = 0;
         if (!matching_scaling(Sy.n, Sy.rslot_ptr.data(), Sy.rslot_col.data(), absval.data(), sp.data(), &unmatched)) { err_ = "matching scaling failed"; return false; }
         for (int i = 0; i < Sy.n; ++i) so[Sy.perm[i]] = sp[i];
+        match_unmatched = unmatched; match_rounds = 0; match_ms = 0.f;
         if (opt.verbose) fprintf(stderr, "[mi355x_kkt] matching scaling: %d unmatched columns\n", unmatched);
         HIPCHK(hipMemcpyAsync(d_user_scale, so.data(), (size_t)Sy.n * sizeof(double), hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));          // `so` is about to go out of scope
         return true;
     }
+    // scaling modes 5 / 6: the same job on the DEVICE (kernels_match.hip.inc: Jacobi auction over the symmetric row view; specification
+    // tests/support/auction_spec.py).  Nothing crosses PCIe but the free-column counts that steer the rounds.  Mode 6 = computed once and kept like mode 4.
+    std::vector<void*> match_allocs;
+    MatchView MV{};
+    int match_unmatched = 0, match_rounds = 0, match_launches = 0;
+    float match_ms = 0.f;
+    void match_free() { for (void* p : match_allocs) (void)hipFree(p); match_allocs.clear(); MV = MatchView{}; }
+    template <class T> bool match_alloc(T** d, size_t count) { T* p = nullptr; HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T))); match_allocs.push_back(p); *d = p; return true; }
+    bool compute_matching_device() {
+        const Symbolic& Sy = *S; const int n = Sy.n;
+        if (MV.n != n || MV.len != V.rslot_len || match_allocs.empty()) {
+            match_free();
+            const size_t len = (size_t)V.rslot_len;
+            if (!match_alloc(&MV.b, len) || !match_alloc(&MV.logcmax, n) || !match_alloc(&MV.price, n) || !match_alloc(&MV.bidval, n) || !match_alloc(&MV.owner, n) ||
+                !match_alloc(&MV.mrow, n) || !match_alloc(&MV.wcol, n) || !match_alloc(&MV.bidrow, n) || !match_alloc(&MV.bidkey, n) || !match_alloc(&MV.list0, n) ||
+                !match_alloc(&MV.list1, n) || !match_alloc(&MV.cnt, 8)) return false;
+            MV.n = n; MV.len = V.rslot_len;
+        }
+        MV.ptr = V.rslot_ptr; MV.col = V.rslot_col; MV.arv = V.arv; MV.perm = V.perm;       // (a structure edit for delayed pivots relabels the row view)
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        HIPCHK(hipEventRecord(e0, stream));
+        hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
+        hipLaunchKernelGGL(k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
+        hipLaunchKernelGGL(k_match_init, dim3(grid1d(8ll * n)), dim3(256), 0, stream, MV);
+        int hc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto read_cnt = [&]() -> bool { HIPCHK(hipMemcpyAsync(hc, MV.cnt, sizeof hc, hipMemcpyDeviceToHost, stream)); HIPCHK(hipStreamSynchronize(stream)); return true; };
+        const double eps_final = 1.0 / 64;
+        const int phase_rounds = 256, final_rounds = 8192, batch = 8;
+        match_rounds = 0; match_launches = 3;
+        for (double eps = 0.25; ; eps = std::max(eps / 4.0, eps_final)) {
+            const bool last = eps <= eps_final;
+            const int cap = last ? final_rounds : phase_rounds;
+            HIPCHK(hipMemsetAsync(MV.cnt, 0, 8 * sizeof(int), stream));
+            hipLaunchKernelGGL(k_match_phase, dim3(grid1d(8ll * n)), dim3(256), 0, stream, MV, eps);
+            ++match_launches;
+            if (!read_cnt()) return false;
+            int cur = 0, nfree = hc[0], rounds = 0;
+            while (nfree > 0 && rounds < cap) {
+                if (nfree <= MATCH_TAIL) {
+                    hipLaunchKernelGGL(k_match_tail, dim3(1), dim3(1024), 0, stream, MV, cur, eps, cap - rounds);
+                    ++match_launches;
+                    if (!read_cnt()) return false;
+                    cur = hc[4]; nfree = hc[cur]; rounds += hc[3];
+                    break;                          // (the tail kernel walks until no column is free or the limit)
+                }
+                const int nb = std::min(batch, cap - rounds);
+                for (int r = 0; r < nb; ++r) {
+                    hipLaunchKernelGGL(k_match_bid, dim3(grid1d(8ll * nfree)), dim3(256), 0, stream, MV, cur, eps);
+                    hipLaunchKernelGGL(k_match_win, dim3(grid1d(nfree)), dim3(256), 0, stream, MV, cur);
+                    hipLaunchKernelGGL(k_match_apply, dim3(grid1d(nfree)), dim3(256), 0, stream, MV, cur);
+                    cur ^= 1;
+                }
+                match_launches += 3 * nb; rounds += nb;
+                if (!read_cnt()) return false;
+                nfree = hc[cur];
+            }
+            match_rounds += rounds;
+            if (last) break;
+        }
+        HIPCHK(hipMemsetAsync(MV.cnt, 0, 8 * sizeof(int), stream));
+        hipLaunchKernelGGL(k_match_final, dim3(grid1d(8ll * n)), dim3(256), 0, stream, MV, d_user_scale);
+        ++match_launches;
+        HIPCHK(hipEventRecord(e1, stream));
+        if (!read_cnt()) return false;
+        match_unmatched = hc[2];
+        (void)hipEventElapsedTime(&match_ms, e0, e1);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        if (opt.verbose) fprintf(stderr, "[mi355x_kkt] matching scaling on the device: %d rounds, %d launches, %.3f ms, %d unmatched columns\n", match_rounds, match_launches, match_ms, match_unmatched);
+        return true;
+    }
+    bool want_matching() const { return opt.scaling == 3 || opt.scaling == 5 || ((opt.scaling == 4 || opt.scaling == 6) && !match_valid); }
+    bool run_matching() { return opt.scaling >= 5 ? compute_matching_device() : compute_matching_scaling(); }
     // the symmetric scaling of the last factorisation, original numbering (what MA97 writes into scale[])
     bool get_scaling(double* out) {
         DeviceGuard guard(dev);
@@ -407,6 +482,7 @@ public:
         if (keep && keep_tvals) allocs.push_back(keep_tvals);
         if (keep && d_user_scale) allocs.push_back(d_user_scale); else d_user_scale = nullptr;
         if (d_rhs) { (void)hipFree(d_rhs); d_rhs = nullptr; d_rhs_cap = 0; }
+        match_free();
         if (!keep) {
             if (asm_pool) { (void)hipFree(asm_pool); asm_pool = nullptr; }
             if (asm_hpool) { (void)hipHostFree(asm_hpool); asm_hpool = nullptr; }
@@ -1410,7 +1486,7 @@ public:
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
             have_values = true;
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
-        if ((opt.scaling == 3 || (opt.scaling == 4 && !match_valid)) && Sy.n > 0) { if (!compute_matching_scaling()) return false; match_valid = true; }
+        if (want_matching() && Sy.n > 0) { if (!run_matching()) return false; match_valid = true; }
         HIPCHK(hipEventRecord(ev0, stream));
         // A factorisation with look-ahead forks onto the second stream: it is launched eagerly (measured equal to the graph
         // replay on these ~10^3-launch sequences, whose kernels are long), because a two-stream hipGraph replays up to 1.5x
@@ -1812,7 +1888,7 @@ public:
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
             have_values = true;
         } else if (!have_values) { err_ = "refactor: no values on the device yet"; return false; }
-        if ((opt.scaling == 3 || (opt.scaling == 4 && !match_valid)) && n > 0) { if (!compute_matching_scaling()) return false; match_valid = true; }
+        if (want_matching() && n > 0) { if (!run_matching()) return false; match_valid = true; }
         HIPCHK(hipEventRecord(ev0, stream));
         hipLaunchKernelGGL(k_factor_prologue, dim3(grid1d(n)), dim3(256), 0, stream, V);
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
@@ -2059,6 +2135,7 @@ bool Numeric::solve_device2(int nrhs, const double* db, int ldb, double* dx, int
 void Numeric::set_pivtol(double u) { p_->opt.pivtol = u; }
 void Numeric::set_pivtolmax(double u) { p_->opt.pivtolmax = u; }
 double Numeric::last_factor_ms() const { return p_->factor_ms; }
+void Numeric::matching_stats(double* ms, int* rounds, int* unmatched) const { *ms = p_->match_ms; *rounds = p_->match_rounds; *unmatched = p_->match_unmatched; }
 double Numeric::last_solve_ms() const { return p_->solve_ms; }
 const std::string& Numeric::error() const { return p_->err_; }
 bool Numeric::profile(int reps, double* ms, int* launches) { return p_->profile(reps, ms, launches); }

@@ -40,7 +40,7 @@ class _Info(C.Structure):
                 ("num_pairs", C.c_int), ("num_neg", C.c_int), ("num_zero", C.c_int), ("num_two", C.c_int),
                 ("num_small", C.c_int), ("num_big_fronts", C.c_int), ("time_analyse", C.c_double),
                 ("time_factor_ms", C.c_double), ("time_solve_ms", C.c_double), ("pivtol", C.c_double), ("u_sensitive", C.c_int),
-                ("num_fast_blocks", C.c_int), ("num_delayed", C.c_int), ("num_restructures", C.c_int), ("reserved", C.c_double * 5)]
+                ("num_fast_blocks", C.c_int), ("num_delayed", C.c_int), ("num_restructures", C.c_int), ("matching_ms", C.c_double), ("matching_rounds", C.c_int), ("matching_unmatched", C.c_int), ("reserved", C.c_double * 3)]
 
 
 @dataclass
@@ -49,6 +49,7 @@ class KKTInfo:
     bytes_solve: int; sum_sn_rows: int; cb_doubles: int; num_sn: int; num_levels: int; maxfront: int
     maxsupernode: int; num_pairs: int; num_neg: int; num_zero: int; num_two: int; num_small: int
     num_big_fronts: int; time_analyse: float; time_factor_ms: float; time_solve_ms: float; pivtol: float; u_sensitive: int; num_fast_blocks: int; num_delayed: int; num_restructures: int
+    matching_ms: float; matching_rounds: int; matching_unmatched: int
 
 
 def library_path() -> str:

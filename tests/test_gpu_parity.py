@@ -358,6 +358,96 @@ def test_matching_scaling_is_reused_until_quality_is_asked_for():
     assert np.allclose(f3, ref2, rtol=1e-12) and not np.array_equal(f3, f1)
 
 
+def _device_matching_checks(n, r, c, v, f, eps=1.0 / 64):
+    """what the device auction promises (tests/support/auction_spec.py, tests/test_auction_spec.py): every scaled entry <= 1; dual objective within n eps of the
+    exact optimum (the host algorithm's factors): 0 <= 2 (sum log s_exact - sum log s) <= n eps"""
+    K = kktgen.to_scipy(n, r, c, v)
+    Ks = abs(K).multiply(f[:, None]).multiply(f[None, :]).tocsr()
+    assert np.all(f > 0) and np.all(np.isfinite(f)) and Ks.max() <= 1.0 + 1e-12
+    ref = np.zeros(n)
+    assert kkt.load_library().mi355x_kkt_matching_scaling(n, len(v), r.ctypes.data, c.ctypes.data, v.ctypes.data, 1, ref.ctypes.data, None) == 0
+    gap = 2.0 * (np.log(ref).sum() - np.log(f).sum())
+    assert -1e-8 * n <= gap <= n * eps + 1e-8 * n, (gap, n * eps)
+    return Ks
+
+
+@pytest.mark.parametrize("case", ["grid_small", "lukvl", "grid", "grid_wide_values"])
+def test_device_matching_scaling_mode(case):
+    """scaling mode 5: the maximum-product matching scaling computed ON THE DEVICE by a Jacobi auction
+    (kernels_match.hip.inc; the job of MC64 behind ma97_scaling mc64 / spral_scaling matching).  The factors are feasible duals of the assignment problem:
+    every scaled entry <= 1, the dual objective within n/64 of the exact optimum of the host algorithm; on these families every column is matched and the
+    result agrees with the numpy specification (same rounds: the decisions are order independent)."""
+    from tests.support import auction_spec
+    gen = {"grid_small": lambda: kktgen.grid_kkt(20, 18, dof=2, ncon=1, seed=41, sigma_exp=8.0),      # < 1024 columns free from the start: the one-workgroup kernel only
+           "lukvl": lambda: kktgen.lukvl_like(60000, seed=5, sigma_scale=1e3),
+           "grid": lambda: kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31),
+           "grid_wide_values": lambda: kktgen.grid_kkt(60, 50, dof=2, ncon=2, seed=7, sigma_exp=8.0)}[case]
+    n, r, c, v, neg = gen()
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg, scaling=5)
+    assert st == 0 and sres(K, x, b) <= RES_TOL
+    f = s.get_scaling()
+    Ks = _device_matching_checks(n, r, c, v, f)
+    info = s.info()
+    assert info.matching_unmatched == 0 and info.matching_rounds > 0 and info.matching_ms > 0
+    assert Ks.max(axis=1).toarray().min() >= 0.9
+    A = abs(K).tocsc(); A.sum_duplicates()
+    stats = {}
+    spec, un = auction_spec.auction_scaling(n, A.indptr, A.indices, A.data, stats=stats)
+    assert un == 0
+    # the specification works in the caller's numbering, the device in the permuted one: ties on equal values may fall differently, the outcome's quality does not
+    if info.matching_rounds == stats["rounds"]:
+        assert np.allclose(f, spec, rtol=1e-6)
+    print(f"{case}: n={n} device matching {info.matching_ms:.3f} ms, {info.matching_rounds} rounds (specification: {stats['rounds']})")
+    # a second factorisation computes it afresh from the new values (mode 5 = per factorisation), deterministically
+    x2 = b.copy(); assert s.multi_solve(True, x2, True, neg) == 0 and np.array_equal(s.get_scaling(), f) and np.array_equal(x2, x)
+
+
+def test_device_matching_scaling_is_reused_until_quality_is_asked_for():
+    """scaling mode 6 (adapter: mi355x_scaling matching-device) = mode 5 computed at the first factorisation and kept until IncreaseQuality -- the reuse
+    protocol of mode 4 / MA97's '...-reuse' switches (IpMa97SolverInterface.cpp:725-771,824-840)"""
+    n, r, c, v, neg = kktgen.grid_kkt(40, 30, dof=2, ncon=1, seed=41, sigma_exp=8.0)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = K @ np.ones(n)
+    s, st, x = gpu_factor_solve(n, r, c, v, b, check=True, required=neg, scaling=6)
+    f1 = s.get_scaling().copy()
+    assert st == 0 and sres(K, x, b) <= RES_TOL
+    _device_matching_checks(n, r, c, v, f1)
+    rng = np.random.default_rng(5)
+    v2 = v * (1.0 + 0.3 * rng.random(len(v)))
+    K2 = kktgen.to_scipy(n, r, c, v2); b2 = K2 @ np.ones(n)
+    s.values()[:] = v2
+    x2 = b2.copy()
+    assert s.multi_solve(True, x2, True, neg) == 0 and sres(K2, x2, b2) <= RES_TOL
+    assert np.array_equal(s.get_scaling(), f1)
+    assert s.increase_quality()
+    x3 = b2.copy()
+    assert s.multi_solve(False, x3, True, neg) == 0 and sres(K2, x3, b2) <= RES_TOL
+    f3 = s.get_scaling()
+    assert not np.array_equal(f3, f1)
+    _device_matching_checks(n, r, c, v2, f3)
+
+
+def test_device_matching_on_a_structurally_deficient_pattern():
+    """a pattern without a perfect matching (two columns whose only entries share a row): the auction ends (a column whose best value has fallen below
+    -300 stops bidding), reports the columns it left unmatched, and the factors are finite with every scaled entry <= 1; the factorisation reports SINGULAR as without scaling"""
+    n = 4
+    r = np.array([1, 2, 3, 3, 4], dtype=np.int32); c = np.array([1, 2, 1, 2, 4], dtype=np.int32)
+    v = np.array([0.0, 0.0, 2.0, 5.0, 3.0])
+    s = ipopt_amd.KKTSolver(scaling=5)
+    s.initialize_structure(n, r, c, vals=v)
+    s.values()[:] = v
+    x = np.ones(n)
+    st = s.multi_solve(True, x, False, 0)
+    assert st in (kkt.SUCCESS, kkt.SINGULAR)
+    info = s.info()
+    assert info.matching_unmatched >= 1
+    f = s.get_scaling()
+    Ks = abs(kktgen.to_scipy(n, r, c, v)).multiply(f[:, None]).multiply(f[None, :])
+    assert np.all(np.isfinite(f)) and np.all(f > 0) and Ks.max() <= 1.0 + 1e-12
+
+
 def test_sync_free_chain_sweeps_match_the_level_by_level_solves(monkeypatch):
     """the flag-synchronised chain sweeps (one launch per run of pure chain levels) against the launch-per-level solves:
     same solution to rounding (the summation order along the chain differs), deterministic across repetitions"""
