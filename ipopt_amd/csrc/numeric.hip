@@ -1059,10 +1059,25 @@ public:
             const bool chain_only = Sy.alias_child[sn] >= 0 && nch == 0;      // (pure in-place link: nothing to assemble either way)
             asm_fast_ok[q] = (chain_only || (Sy.alias_child[sn] < 0 && nch <= 6)) ? 1 : 0;
         }
+        // tfuse: the contribution block of a front is formed by its trailing update (k_big_schur64: T = sum of the children's contributions - L21 W21^T, written
+        // once) instead of being assembled, read back and written again.  For the fronts whose whole update is ONE k_big_schur64 launch of the single-GPU
+        // schedule: assembled (not in place on a child), order <= 1024, a unit of their own (no chain group), below the grouped top of the tree.
+        std::vector<char> tfuse_of(Sy.num_sn, 0);
+        ntfuse = 0;
+        if (!multi && getenv("MI355X_KKT_NO_TFUSE") == nullptr)
+            for (int sn = 0; sn < Sy.num_sn; ++sn) {
+                const int m = Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn], k = Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn], nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
+                if (Sy.sn_class[sn] != FC_BIG || Sy.alias_child[sn] >= 0 || m > 1024 || m <= k || nch > 16) continue;
+                if (Sy.grp_pos[sn] != 0 || Sy.grp_rem[sn] != 0) continue;
+                if (grouped && Sy.sn_level[sn] >= Sy.grp_cut_level) continue;
+                tfuse_of[sn] = 1; ++ntfuse;
+            }
+        if (opt.verbose) fprintf(stderr, "[mi355x_kkt] contribution blocks formed by their update (not assembled): %d of %d big fronts\n", ntfuse, Sy.num_big);
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
             FrontMeta& M = fm[q];
+            M.tfuse = tfuse_of[sn];
             M.s = sn; M.c0 = Sy.sn_colptr[sn]; M.k = Sy.sn_colptr[sn + 1] - M.c0; M.r0 = Sy.sn_rowptr[sn]; M.m = Sy.sn_rowptr[sn + 1] - M.r0;
             M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.alias = Sy.alias_child[sn] >= 0 ? 1 : 0;
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
@@ -1248,6 +1263,7 @@ public:
         return Sy.grp_rem[s] > 0 ? nt * ((Sy.grp_rem[s] + 127) / 128) : tri_tiles(nt);
     }
     static size_t trsm_lds(int kk) { return trsm_lds_bytes(kk, false); }
+    static int schur_grid(int tiles) { return SCHUR_GM == 2 ? 16 * ((tiles + 7) / 8) : tiles; }      // workgroups of a k_big_schur launch over `tiles` 128 x 128 tiles (kernels_big.hip.inc: SCHUR_HALVES)
     int grid1d(long long n) const { long long g = (n + 255) / 256; return (int)std::min<long long>(std::max<long long>(g, 1), 2048); }
 
 
@@ -1322,13 +1338,13 @@ public:
             const int nb = b1 - bs;
             if (la_full[lv] && ch_far_pending) { HIPCHK(hipStreamWaitEvent(stream3, ch_far_last, 0)); ch_far_pending = false; }   // a full update touches what the previous far part writes
             if (la_tiles2[lv] > 0) {
-                hipLaunchKernelGGL(k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream3, V, bs, 1, 0, 1);
+                hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(la_tiles1[lv]), nb), dim3(SCHUR_NT), 0, stream3, V, bs, 1, 0, 1);
                 HIPCHK(hipEventRecord(chG1[lv], stream3));
                 HIPCHK(hipStreamWaitEvent(stream2, chG1[lv], 0));
-                hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, bs, 2, la_tiles2[lv], 0);
+                hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(std::min(la_tiles2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, bs, 2, la_tiles2[lv], 0);
                 HIPCHK(hipEventRecord(chFar[lv], stream2));
                 ch_far_last = chFar[lv]; ch_far_pending = true;
-            } else if (tiles > 0) hipLaunchKernelGGL(k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream3, V, bs, 0, 0, 1);
+            } else if (tiles > 0) hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(tiles), nb), dim3(SCHUR_NT), 0, stream3, V, bs, 0, 0, 1);
         }
         HIPCHK(hipEventRecord(chN[lv], stream3));
         ch_bulk_last = chN[lv]; ch_bulk_pending = true;
@@ -1356,17 +1372,18 @@ public:
             // get their whole update from a launch of their own then
             if (p1_small_tiles && G.la1[lv] * nb <= 512) {
                 LAUNCH(KK_BIG_SCHUR, k_big_schur_p1, dim3(G.p1t[lv], nb), dim3(1024), 0, stream, V, bs);
-                if (G.nsplit[lv] < nb) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.la3[lv], nb), dim3(1024), 0, stream, V, bs, 4, 0, 0);
-            } else LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.la1[lv], nb), dim3(1024), 0, stream, V, bs, 1, 0, 0);
+                if (G.nsplit[lv] < nb) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(G.la3[lv]), nb), dim3(SCHUR_NT), 0, stream, V, bs, 4, 0, 0);
+            } else LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(G.la1[lv]), nb), dim3(SCHUR_NT), 0, stream, V, bs, 1, 0, 0);
             HIPCHK(hipEventRecord(G.evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, G.evA[lv], 0));
-            hipLaunchKernelGGL(k_big_schur, dim3(std::min(G.la2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, bs, 2, G.la2[lv], 0);
+            hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(std::min(G.la2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, bs, 2, G.la2[lv], 0);
             HIPCHK(hipEventRecord(G.evB[lv], stream2));
             la_last = G.evB[lv]; la_pending = true;
-        } else if (G.tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(G.tiles[lv], nb), dim3(1024), 0, stream, V, bs, 0, 0, 0);
+        } else if (G.tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(G.tiles[lv]), nb), dim3(SCHUR_NT), 0, stream, V, bs, 0, 0, 0);
         return true;
     }
     int grp_rbw_max = 8;
+    int ntfuse = 0;
     int lc_levels = 0, lc_nchains = 0;      // leaf chains: the tree levels below lc_levels are lc_nchains chains of fronts of order <= 16 (k_leaf_chain)
     bool p1_small_tiles = getenv("MI355X_KKT_NO_P1_SMALL") == nullptr;
     std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path
@@ -1410,13 +1427,13 @@ public:
             HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false;
         }
         if (single && la_tiles2[lv] > 0 && !prof_on) {
-            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(la_tiles1[lv], nb), dim3(1024), 0, stream, V, b0, 1, 0, 0);
+            LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(la_tiles1[lv]), nb), dim3(SCHUR_NT), 0, stream, V, b0, 1, 0, 0);
             HIPCHK(hipEventRecord(la_evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, la_evA[lv], 0));
-            hipLaunchKernelGGL(k_big_schur, dim3(std::min(la_tiles2[lv], la_wgs), nb), dim3(1024), 0, stream2, V, b0, 2, la_tiles2[lv], 0);
+            hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(std::min(la_tiles2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, b0, 2, la_tiles2[lv], 0);
             HIPCHK(hipEventRecord(la_evB[lv], stream2));
             la_last = la_evB[lv]; la_pending = true;
-        } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(tiles, nb), dim3(1024), 0, stream, V, b0, 0, 0, 0);
+        } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(tiles), nb), dim3(SCHUR_NT), 0, stream, V, b0, 0, 0, 0);
         return true;
     }
 
