@@ -44,9 +44,9 @@ def make_workload(name):
     if name == "lukvle1_1e6":
         return kktgen.lukvl_like(1_000_000, seed=20260923)
     if name == "grid_1e5":
-        return kktgen.grid_kkt(160, 125, dof=3, ncon=2, seed=20260923, sigma_exp=8.0)
+        return kktgen.grid_kkt(160, 125, dof=3, ncon=2, seed=20260923, sigma_exp=8.0, rng="xoshiro")
     if name == "synth_1e6":
-        return kktgen.grid_kkt(500, 400, dof=3, ncon=2, seed=20260923, sigma_exp=8.0)
+        return kktgen.grid_kkt(500, 400, dof=3, ncon=2, seed=20260923, sigma_exp=8.0, rng="xoshiro")      # xoshiro256** seeded by splitmix64(20260923)
     if name == "mbndry1_100":      # BASELINE.json configs[2]: the matrix of the 4th boundary call of the reference's own MBndryCntrl1 N = 100 run
         return kktgen.recorded_kkt(os.path.join(ROOT, "tests", "golden", "mbndry1_100.kktrec"), which=-1)
     if name.startswith("npz:"):     # development aid: a recorded system, e.g. npz:.dev_pivstat/mb3d_30.npz (n, r, c, v, neg)
@@ -443,6 +443,18 @@ def main():
                     also[w2]["cpu_baseline"] = {"ms_per_step": cb2["seconds_per_step"] * 1e3, "cores": cb2["cores"], "kind": cb2["kind"], "ms_per_step_by_threads": cb2["legs"],
                                                 "parity_vs_gpu": cb2["parity"], "speedup": cb2["seconds_per_step"] / dt2}
                     also[w2]["what"] = "BASELINE.json configs[2]: the KKT system of the 4th boundary call of the reference's MBndryCntrl1 N = 100 run (tests/golden/mbndry1_100.kktrec)"
+                if w2 == "lukvle1_1e6":      # the maximum-product matching scaling (the job of MC64) on the device, per factorisation (scaling mode 5)
+                    s2.set_scaling(5)
+                    for _ in range(2):
+                        st5 = s2.factor_device(dv2.data_ptr())
+                    s2.solve_device2(db2.data_ptr(), dx2.data_ptr())
+                    x5 = dx2.cpu().numpy(); I5 = s2.info()
+                    also[w2]["matching_scaling_on_device"] = {
+                        "ms": I5.matching_ms, "auction_rounds": I5.matching_rounds, "unmatched_columns": I5.matching_unmatched, "factor_ms_behind_it": I5.time_factor_ms,
+                        "num_neg_ok": bool(st5[0] == 0 and st5[1] == neg2),
+                        "scaled_residual": float(np.abs(K2 @ x5 - b2).max() / (abs(K2).sum(axis=1).max() * np.abs(x5).max() + np.abs(b2).max())),
+                        "what": "mi355x_kkt_set_scaling(5): Jacobi auction over the symmetric row view (kernels_match.hip.inc), hip events around the whole computation"}
+                    s2.set_scaling(1)
                 del s2, dv2, db2, dx2
             except Exception as e:      # never lose the main line over the extras
                 also[w2] = {"error": str(e)[:200]}

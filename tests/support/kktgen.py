@@ -9,6 +9,34 @@ from __future__ import annotations
 import numpy as np
 
 
+class Xoshiro256:
+    """xoshiro256** seeded through splitmix64 (tests/support/xoshiro256.c): ONE sequential stream of doubles uniform in [0, 1) -- the generator SURVEY.md 8(d)
+    item 4 names for the synthetic system of BASELINE.json configs[3].  uniform(lo, hi, size) consumes prod(size) values, C order."""
+    _lib = None
+
+    def __init__(self, seed):
+        import ctypes, os, subprocess
+        if Xoshiro256._lib is None:
+            here = os.path.dirname(os.path.abspath(__file__))
+            so = os.path.join(here, "lib", "libxoshiro256.so")
+            if not os.path.exists(so):
+                subprocess.check_call(["make", "-s", "-C", here])
+            Xoshiro256._lib = ctypes.CDLL(so)
+            Xoshiro256._lib.xoshiro256_seed.argtypes = [ctypes.c_uint64, ctypes.c_void_p]
+            Xoshiro256._lib.xoshiro256_fill.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+        self.state = np.zeros(4, dtype=np.uint64)
+        Xoshiro256._lib.xoshiro256_seed(int(seed), self.state.ctypes.data)
+
+    def random(self, size):
+        shape = (size,) if np.isscalar(size) else tuple(size)
+        out = np.empty(int(np.prod(shape, dtype=np.int64)), dtype=np.float64)
+        Xoshiro256._lib.xoshiro256_fill(self.state.ctypes.data, out.size, out.ctypes.data)
+        return out.reshape(shape)
+
+    def uniform(self, lo, hi, size):
+        return lo + (hi - lo) * self.random(size)
+
+
 def _finish(n, rows, cols, vals):
     return n, np.concatenate(rows).astype(np.int32) + 1, np.concatenate(cols).astype(np.int32) + 1, np.concatenate(vals).astype(np.float64)
 
@@ -44,12 +72,18 @@ def lukvl_like(n, seed=0, delta_c=0.0, sigma_scale=1.0):
     return kkt_from_blocks((hi, hj, hv), Sigma, (ji, jj, jv.ravel()), np.full(m, delta_c), n, m) + (m,)
 
 
-def grid_kkt(nx_grid, ny_grid, dof=1, ncon=1, seed=0, delta_c=0.0, sigma_exp=3.0):
+def grid_kkt(nx_grid, ny_grid, dof=1, ncon=1, seed=0, delta_c=0.0, sigma_exp=3.0, rng="pcg64"):
     """PDE-constrained-like KKT on an nx x ny grid (scaled down): `dof` primal
     unknowns and `ncon` (<= dof) constraints per node, 9-point coupling.  H SPD by diagonal
-    dominance, J full row rank through a dominant anchor entry => inertia (n_x, m, 0) exactly."""
+    dominance, J full row rank through a dominant anchor entry => inertia (n_x, m, 0) exactly.
+    rng = "xoshiro": the values come from ONE xoshiro256** stream seeded by splitmix64(seed) (the bench workloads synth_1e6 /
+    grid_1e5), consumed in this loop order: (1) the H blocks -- for the stencil offsets (di, dj) in (-1, 0, 1)^2 row-major, for the nodes p that have
+    that neighbour q with q <= p, in the order i + nx j of a meshgrid walked i-major: dof x dof values of U(-1, 1), row-major; (2) one U(0.1, 1) per
+    diagonal entry of H in the order the entries were generated; (3) Sigma: one U(-e, e) exponent per primal unknown; (4) J: for the stencil offsets and
+    nodes in the same order (all neighbours, no q <= p filter), ncon x dof values 0.05 U(-1, 1); (5) an array of the same shape of 1 + U(0, 1), of which
+    the anchor positions (p = q, constraint c on dof c) are used."""
     assert ncon <= dof
-    rng = np.random.default_rng(seed)
+    rng = Xoshiro256(seed) if rng == "xoshiro" else np.random.default_rng(seed)
     N = nx_grid * ny_grid
     ii, jj_ = np.meshgrid(np.arange(nx_grid), np.arange(ny_grid), indexing="ij")
     pid = (ii + nx_grid * jj_).ravel()
