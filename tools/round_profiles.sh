@@ -27,5 +27,6 @@ tools/prof.sh lukvle1_1e6 k_front_reg > $O/prof_lukvle1_1e6.log 2>&1
 cp gpurun_out/prof_lukvle1_1e6/kernel_stats.csv $O/lukvle1_1e6_kernel_stats.csv 2>/dev/null
 cp gpurun_out/prof_lukvle1_1e6/pmc_summary.json $O/lukvle1_1e6_pmc_summary.json 2>/dev/null
 python tools/analysis_time.py lukvle1_1e6 synth_1e6 > $O/analysis_time.txt 2>&1
+(python tools/match_time.py lukvle1_1e6 synth_1e6 2>&1 | grep -v "^\[mi355x_kkt\]   \|look-ahead\|data-flow\|grouped\|chain look") > $O/matching_scaling_device.txt 2>&1
 timeout 120 python tools/stress_handles.py 60 > $O/stress_handles.txt 2>&1
 ls -la $O
