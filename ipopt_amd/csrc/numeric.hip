@@ -1446,11 +1446,17 @@ public:
         if (!fuse0) LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
         if (opt.scaling >= 2) LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);     // 2: the caller's factors, 3: matching (computed just before)
         else if (opt.scaling) {
-            if (fuse0) LAUNCH(KK_GATHER_SCALE, k_abs_rowview_sweep0, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, V.scale2);
-            else LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2, (double*)nullptr);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, (double*)nullptr);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2, (double*)nullptr);
-            LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, V.cnorm);
+            static const int lpr_env = getenv("MI355X_KKT_RUIZ_LPR") ? atoi(getenv("MI355X_KKT_RUIZ_LPR")) : 0;
+            const int lpr = lpr_env ? lpr_env : ((long long)V.rslot_len < 8ll * n ? 2 : 8);      // short rows (LukVl: ~5 entries): 2 lanes per row (measured 0.89 / 0.82 / 0.80 ms per factorisation at 8 / 4 / 2)
+            auto sweeps = [&](auto tag) {
+                constexpr int L = decltype(tag)::value;
+                if (fuse0) LAUNCH(KK_GATHER_SCALE, k_abs_rowview_sweep0<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, V.scale2);
+                else LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)nullptr, V.scale2, (double*)nullptr);
+                LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, (double*)nullptr);
+                LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2, (double*)nullptr);
+                LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, V.cnorm);
+            };
+            if (lpr == 1) sweeps(std::integral_constant<int, 1>()); else if (lpr == 2) sweeps(std::integral_constant<int, 2>()); else if (lpr == 4) sweeps(std::integral_constant<int, 4>()); else sweeps(std::integral_constant<int, 8>());
         } else LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (opt.scaling != 1) LAUNCH(KK_GATHER_SCALE, k_colnorm, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, opt.scaling ? 1 : 0);      // (Ruiz: ~1 by construction, written by the last sweep)
         if (opt.scaling) LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
