@@ -1456,7 +1456,7 @@ public:
                 LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2, (double*)nullptr);
                 LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, V.cnorm);
             };
-            if (lpr == 1) sweeps(std::integral_constant<int, 1>()); else if (lpr == 2) sweeps(std::integral_constant<int, 2>()); else if (lpr == 4) sweeps(std::integral_constant<int, 4>()); else sweeps(std::integral_constant<int, 8>());
+            if (lpr == 2) sweeps(std::integral_constant<int, 2>()); else if (lpr == 4) sweeps(std::integral_constant<int, 4>()); else sweeps(std::integral_constant<int, 8>());
         } else LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (opt.scaling != 1) LAUNCH(KK_GATHER_SCALE, k_colnorm, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, opt.scaling ? 1 : 0);      // (Ruiz: ~1 by construction, written by the last sweep)
         if (opt.scaling) LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
