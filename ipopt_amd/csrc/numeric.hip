@@ -141,7 +141,9 @@ public:
     MatchView MV{};
     int match_unmatched = 0, match_rounds = 0, match_launches = 0;
     float match_ms = 0.f;
-    void match_free() { for (void* p : match_allocs) (void)hipFree(p); match_allocs.clear(); MV = MatchView{}; }
+    hipEvent_t match_e0 = nullptr, match_e1 = nullptr;
+    void match_free() { for (void* p : match_allocs) (void)hipFree(p); match_allocs.clear(); MV = MatchView{};
+                        if (match_e0) { (void)hipEventDestroy(match_e0); match_e0 = nullptr; } if (match_e1) { (void)hipEventDestroy(match_e1); match_e1 = nullptr; } }
     template <class T> bool match_alloc(T** d, size_t count) { T* p = nullptr; HIPCHK(hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(T))); match_allocs.push_back(p); *d = p; return true; }
     bool compute_matching_device() {
         const Symbolic& Sy = *S; const int n = Sy.n;
@@ -154,8 +156,8 @@ public:
             MV.n = n; MV.len = V.rslot_len;
         }
         MV.ptr = V.rslot_ptr; MV.col = V.rslot_col; MV.arv = V.arv; MV.perm = V.perm;       // (a structure edit for delayed pivots relabels the row view)
-        hipEvent_t e0 = nullptr, e1 = nullptr;
-        HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+        if (!match_e0) { HIPCHK(hipEventCreate(&match_e0)); HIPCHK(hipEventCreate(&match_e1)); }      // (members: an error return below must not leak them)
+        hipEvent_t e0 = match_e0, e1 = match_e1;
         HIPCHK(hipEventRecord(e0, stream));
         hipLaunchKernelGGL(k_gather_values, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
         hipLaunchKernelGGL(k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
@@ -202,7 +204,6 @@ public:
         if (!read_cnt()) return false;
         match_unmatched = hc[2];
         (void)hipEventElapsedTime(&match_ms, e0, e1);
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         if (opt.verbose) fprintf(stderr, "[mi355x_kkt] matching scaling on the device: %d rounds, %d launches, %.3f ms, %d unmatched columns\n", match_rounds, match_launches, match_ms, match_unmatched);
         return true;
     }
