@@ -69,6 +69,15 @@ def _case_hostile():
 _case_hostile.opts = dict(pivtol=0.01, pivtolmax=0.01, scaling=0, delay_rounds=12)
 
 
+def _case_grid_device_matching():
+    # scaling mode 5: every rank runs the device auction on the whole matrix -- the outcome does not depend on the order in which threads arrive, so all
+    # ranks hold the same factors (the check `same` below: identical solutions on every rank)
+    return kktgen.grid_kkt(40, 36, dof=2, ncon=1, seed=8, sigma_exp=6.0)
+
+
+_case_grid_device_matching.opts = dict(scaling=5)
+
+
 @pytest.mark.parametrize("world", [2, 4])
 @pytest.mark.parametrize("case", [_case_grid, _case_band], ids=["grid", "band"])
 def test_hip_multigpu_path_matches_single_gpu(world, case):
@@ -125,8 +134,8 @@ def _worker_comm(rank, world, port, case, subcube, ret):
 
 
 @pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (4, 0, _case_grid), (4, 1, _case_grid), (3, 1, _case_grid), (4, 1, _case_band),
-                                                (8, 1, _case_grid), (2, 0, _case_hostile), (4, 1, _case_hostile)],
-                         ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band", "8-subcube", "2-delayed-pivots", "4-subcube-delayed-pivots"])
+                                                (8, 1, _case_grid), (2, 0, _case_hostile), (4, 1, _case_hostile), (4, 1, _case_grid_device_matching)],
+                         ids=["2", "4", "4-subcube", "3-subcube", "4-subcube-band", "8-subcube", "2-delayed-pivots", "4-subcube-delayed-pivots", "4-subcube-device-matching"])
 @pytest.mark.parametrize("range_local", [True, False], ids=["range-local", "whole-machine"])
 def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, case, range_local, monkeypatch):
     """... with the classic mapping (one top replicated on every rank) and with the subtree-to-subcube mapping: replicated fronts held by the
@@ -136,7 +145,7 @@ def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, c
     everybody per step, zeros from the ranks outside a range (the fall-back without ncclCommSplit).  The hostile case has every rank move
     the same failed columns to their parent fronts (marks summed over the ranks) and refactor."""
     if not range_local:
-        if world < 3 or case is _case_band:
+        if world < 3 or case is _case_band or case is _case_grid_device_matching:
             pytest.skip("the fall-back differs from the range-local exchange only with sub-ranges; one band case is enough")
         monkeypatch.setenv("MI355X_KKT_NO_SUBCOMM", "1")
     ctx = mp.get_context("spawn")
