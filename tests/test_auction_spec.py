@@ -53,3 +53,41 @@ def test_auction_on_a_structurally_deficient_pattern_reports_the_columns_it_coul
     assert unmatched >= 1 and np.all(np.isfinite(s)) and np.all(s > 0)
     B = A.multiply(s[:, None]).multiply(s[None, :])
     assert B.max() <= 1.0 + 1e-12
+
+
+def random_symmetric_pattern(rng, n, density, zero_diag_frac, singletons=0):
+    """random sparse symmetric matrix (1-based lower triplets) with entries over 12 orders of magnitude, some zero diagonals and -- optionally -- pairs of
+    columns whose only entry is in the same row (structural deficiency)"""
+    import scipy.sparse as sp
+    A = sp.random(n, n, density=density, random_state=np.random.RandomState(int(rng.integers(1 << 30))), format="coo")
+    r, c = np.maximum(A.row, A.col), np.minimum(A.row, A.col)
+    keep = r != c
+    r, c = r[keep], c[keep]
+    v = 10.0 ** rng.uniform(-6, 6, len(r)) * rng.choice([-1.0, 1.0], len(r))
+    d = np.where(rng.random(n) < zero_diag_frac, 0.0, 10.0 ** rng.uniform(-6, 6, n))
+    rows = np.concatenate([r, np.arange(n)]); cols = np.concatenate([c, np.arange(n)]); vals = np.concatenate([v, d])
+    if singletons:                       # columns s, s + 1 get zero diagonals and ONE off-diagonal each, both in row t: at most one of them can be matched
+        for q in range(singletons):
+            s0, t = 2 * q, n - 1 - q
+            m = ~(((rows == s0) | (cols == s0) | (rows == s0 + 1) | (cols == s0 + 1)))
+            rows, cols, vals = rows[m], cols[m], vals[m]
+            rows = np.concatenate([rows, [s0, s0 + 1, t, t]]); cols = np.concatenate([cols, [s0, s0 + 1, s0, s0 + 1]]); vals = np.concatenate([vals, [0.0, 0.0, 3.0, 7.0]])
+    return n, (rows + 1).astype(np.int32), (cols + 1).astype(np.int32), vals.astype(np.float64)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_auction_fuzz_random_patterns(seed):
+    """random patterns with zero diagonals (and, on odd seeds, structurally deficient pairs of columns): the factors are finite and positive, no scaled entry
+    exceeds 1, and the columns left unmatched are at least the structural deficiency of the pattern"""
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    rng = np.random.default_rng(100 + seed)
+    n, r, c, v = random_symmetric_pattern(rng, int(rng.integers(40, 400)), 0.02 + 0.05 * rng.random(), 0.4, singletons=(seed % 2) * int(rng.integers(1, 4)))
+    A = column_view(n, r, c, v); A.eliminate_zeros()
+    s, unmatched = auction_spec.auction_scaling(n, A.indptr, A.indices, A.data, max_rounds=4000, phase_rounds=256)
+    assert np.all(np.isfinite(s)) and np.all(s > 0)
+    B = A.multiply(s[:, None]).multiply(s[None, :])
+    assert B.nnz == 0 or B.max() <= 1.0 + 1e-12
+    deficiency = n - int((maximum_bipartite_matching(A.tocsr(), perm_type="column") >= 0).sum())
+    assert unmatched >= deficiency
+    if deficiency == 0 and seed % 2 == 0:
+        assert unmatched <= max(2, n // 50)          # (the round limit may leave a straggler; the bound on the entries does not depend on it)

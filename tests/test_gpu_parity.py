@@ -428,6 +428,32 @@ def test_device_matching_scaling_is_reused_until_quality_is_asked_for():
     _device_matching_checks(n, r, c, v2, f3)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_device_matching_fuzz_random_patterns(seed):
+    """the device auction on random patterns with zero diagonals and (odd seeds) structurally deficient pairs of columns -- the cases of
+    tests/test_auction_spec.py::test_auction_fuzz_random_patterns through the C ABI: finite positive factors, no scaled entry above 1, at least as many
+    unmatched columns as the pattern's structural deficiency, and the same answer when asked twice"""
+    from scipy.sparse.csgraph import maximum_bipartite_matching
+    from tests.test_auction_spec import random_symmetric_pattern, column_view
+    rng = np.random.default_rng(100 + seed)
+    n, r, c, v = random_symmetric_pattern(rng, int(rng.integers(40, 400)), 0.02 + 0.05 * rng.random(), 0.4, singletons=(seed % 2) * int(rng.integers(1, 4)))
+    s = ipopt_amd.KKTSolver(scaling=5, delay_rounds=0)
+    s.initialize_structure(n, r, c, vals=v)
+    s.values()[:] = v
+    x = np.ones(n)
+    st = s.multi_solve(True, x, False, 0)
+    assert st in (kkt.SUCCESS, kkt.SINGULAR)
+    f = s.get_scaling().copy()
+    info = s.info()
+    A = column_view(n, r, c, v); A.eliminate_zeros()
+    B = A.multiply(f[:, None]).multiply(f[None, :])
+    assert np.all(np.isfinite(f)) and np.all(f > 0) and (B.nnz == 0 or B.max() <= 1.0 + 1e-12)
+    deficiency = n - int((maximum_bipartite_matching(A.tocsr(), perm_type="column") >= 0).sum())
+    assert info.matching_unmatched >= deficiency
+    x = np.ones(n); s.multi_solve(True, x, False, 0)
+    assert np.array_equal(s.get_scaling(), f)
+
+
 def test_device_matching_on_a_structurally_deficient_pattern():
     """a pattern without a perfect matching (two columns whose only entries share a row): the auction ends (a column whose best value has fallen below
     -300 stops bidding), reports the columns it left unmatched, and the factors are finite with every scaled entry <= 1; the factorisation reports SINGULAR as without scaling"""
