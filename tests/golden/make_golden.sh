@@ -44,3 +44,5 @@ ls -la
 # PDFullSpaceSolver::Solve, every call of hs071 and the first 8 of LukVlI1 n = 20 (bounds on every variable); reader: oracle/pd_oracle.py
 $D/ref_driver hs071 0 --record-pd hs071.pdrec --quiet > /dev/null
 $D/ref_driver LukVlI1 20 --record-pd lukvli1_20.pdrec --max-records 8 --quiet > /dev/null
+# SURVEY 8(d)-5's MFMA-bound 3-D family at a larger size (n = 125 000, m = 110 592, KKT dimension 235 592; fronts up to ~5 600 rows): one minute on 8 MKL threads
+MKL_NUM_THREADS=8 OMP_NUM_THREADS=8 run mbndry3d_50 MBndryCntrl_3D 50 norec
