@@ -87,6 +87,22 @@ def per_kind_work(solver):
     return out
 
 
+def schur_roofline(w, dms):
+    """Both roofs of k_big_schur, and the one that binds: a rank-k update of a contribution block reads and writes the block once (16 B per entry) for
+    2k flops per entry -- at k <= 64 (most fronts of this tree) that is <= 8 flop/B, and 8 TB/s x the launch-averaged intensity is a LOWER ceiling
+    than the fp64 MFMA peak.  `bound` = the lower of the two ceilings at the measured intensity; the other roof rides along under `other_roof`.
+    w: algorithmic {bytes, flops} of the kernel per factorisation (per_kind_work), dms: its time per factorisation in ms."""
+    ach_f = w["flops"] / (dms * 1e-3) / 1e12
+    ach_b = w["bytes"] / (dms * 1e-3) / 1e9
+    ai = w["flops"] / max(w["bytes"], 1)
+    hbm_ceiling_tflops = HBM_PEAK_GBS * 1e9 * ai / 1e12
+    mf = dict(bound="mfma", achieved=ach_f, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_f / MFMA_F64_PEAK_TFLOPS,
+              peak_sustained_measured=MFMA_F64_SUSTAINED_TFLOPS, frac_of_sustained=ach_f / MFMA_F64_SUSTAINED_TFLOPS)
+    hb = dict(bound="hbm", achieved=ach_b, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_b / HBM_PEAK_GBS)
+    first, second = (hb, mf) if hbm_ceiling_tflops < MFMA_F64_PEAK_TFLOPS else (mf, hb)
+    return dict(first, kernel="k_big_schur", arithmetic_intensity_flop_per_byte=ai, hbm_ceiling_tflops_at_this_intensity=hbm_ceiling_tflops, other_roof=second)
+
+
 def source_hash():
     """sha256 over the kernel + host sources: profiles/traffic_latest.json records the hash it was measured with, and
     `roofline.traffic` is only emitted while it still matches (a cached PMC figure must not outlive the kernels)."""
@@ -330,18 +346,7 @@ def main():
     dms, dlaunch = per_rep[dom]
     w = work.get(dom, dict(bytes=0, flops=0))
     if dom == "big_schur":
-        # Both roofs of the kernel, and the one that binds: a rank-k update of a contribution block reads and writes the block once (16 B per entry) for
-        # 2k flops per entry -- at k <= 64 (most fronts of this tree) that is <= 8 flop/B, and 8 TB/s x the launch-averaged intensity is a LOWER ceiling
-        # than the fp64 MFMA peak.  `bound` = the lower of the two ceilings at the measured intensity; the other roof rides along under `other_roof`.
-        ach_f = w["flops"] / (dms * 1e-3) / 1e12
-        ach_b = w["bytes"] / (dms * 1e-3) / 1e9
-        ai = w["flops"] / max(w["bytes"], 1)
-        hbm_ceiling_tflops = HBM_PEAK_GBS * 1e9 * ai / 1e12
-        mf = dict(bound="mfma", achieved=ach_f, peak=MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach_f / MFMA_F64_PEAK_TFLOPS,
-                  peak_sustained_measured=MFMA_F64_SUSTAINED_TFLOPS, frac_of_sustained=ach_f / MFMA_F64_SUSTAINED_TFLOPS)
-        hb = dict(bound="hbm", achieved=ach_b, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach_b / HBM_PEAK_GBS)
-        first, second = (hb, mf) if hbm_ceiling_tflops < MFMA_F64_PEAK_TFLOPS else (mf, hb)
-        roof = dict(first, kernel="k_big_schur", arithmetic_intensity_flop_per_byte=ai, hbm_ceiling_tflops_at_this_intensity=hbm_ceiling_tflops, other_roof=second)
+        roof = schur_roofline(w, dms)
     else:
         ach = w["bytes"] / (dms * 1e-3) / 1e9
         kn = {"front_wave": "k_front_dpp16 + k_front_reg<64,2|4>", "front_lds64": "k_front_reg<64,8>", "front_lds128": "k_front_reg<256,6|8>(fast + strict)", "big_diag": "k_big_diag_reg<4> / k_grp_fused / k_big_diag_trsm",

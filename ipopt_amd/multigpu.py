@@ -311,8 +311,7 @@ def bench_main(args, rank, world, local):
         dom = max(per_rep, key=per_rep.get)
         w = work.get(dom, dict(bytes=0, flops=0))
         if dom == "big_schur":
-            ach = w["flops"] / (per_rep[dom] * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel="k_big_schur", achieved=ach, peak=B.MFMA_F64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / B.MFMA_F64_PEAK_TFLOPS, traffic=None)
+            roof = dict(B.schur_roofline(w, per_rep[dom]), traffic=None)      # (both roofs; `bound` = the lower ceiling at the measured intensity, as on the one-GPU line)
         else:
             ach = w["bytes"] / (per_rep[dom] * 1e-3) / 1e9
             roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=B.HBM_PEAK_GBS, unit="GB/s", frac=ach / B.HBM_PEAK_GBS, traffic=None)
