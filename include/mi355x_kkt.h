@@ -269,9 +269,10 @@ const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
  *       duplicates) */
 int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t capacity);
 
-/* ---- measurement: device time per kernel kind (hip events on the solver's stream around every launch of an
- * eager, graph-less factor + one solve, accumulated over `reps` repetitions).  ms/launches need
- * MI355X_KKT_KERNEL_COUNT entries.  Used by bench.py for the roofline of the dominant kernel. ---- */
+/* ---- measurement: device time per kernel kind (hip events around every launch of an eager, graph-less factor + one
+ * solve -- on the stream the kernel is launched on: the look-ahead parts of the largest trailing updates run, and are
+ * measured, on the solver's second stream exactly as in a timed factorisation --, accumulated over `reps` repetitions).
+ * ms/launches need MI355X_KKT_KERNEL_COUNT entries.  Used by bench.py for the roofline of the dominant kernel. ---- */
 #define MI355X_KKT_KERNEL_GATHER_SCALE  0   /* value gather + Ruiz equilibration                                   */
 #define MI355X_KKT_KERNEL_FRONT_WAVE    1   /* k_front_dpp16 + k_front_reg<64,*> : fronts of order <= 32            */
 #define MI355X_KKT_KERNEL_FRONT_LDS64   2   /* k_front_reg<64,8>  : order <= 64, one wavefront each                */
@@ -322,6 +323,17 @@ int  mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn 
 typedef int (*mi355x_kkt_allreduce_range_fn)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream, int rank_lo, int nranks_in_range);
 int  mi355x_kkt_set_comm_range_callback(mi355x_kkt_handle h, mi355x_kkt_allreduce_range_fn fn);
 int  mi355x_kkt_exchange_bytes(mi355x_kkt_handle h, int64_t* arena_bytes, int64_t* rhs_bytes);
+/* What ONE rank of the handle's nranks will ask of its communicator, in order, for one factorisation + one solve -- and the ncclCommSplit calls
+ * _set_comm_rccl makes before them.  HOST ONLY (needs _analyse, not a device): a launcher or a test can check on any machine that all ranks
+ * issue matching sequences (same communicator, same count, same order) before an 8-GPU job is started; the reference's only counterpart is
+ * MUMPS' own MPI layer behind IpMumpsSolverInterface.cpp:191-245.  Records of 6 ints {what, step, colour, range size, count, dtype}:
+ *   what 0 = ncclCommSplit(colour, key = rank) (colour -1 = NCCL_SPLIT_NOCOLOR), 1 = sum of arena squares, 2 = inertia / pivot statistics,
+ *        3 = sum of top right-hand sides, 4 = sum of the solution pieces;  colour = first rank of the range whose sub-communicator carries the
+ *        collective, -2 = the whole communicator;  dtype 0 = fp64, 1 = int32;  range_local = 0: the fall-back of one whole-communicator sum per step.
+ *   _comm_info   the communicator in use: kind 0 none / 1 callbacks / 2 RCCL, the size the communicator itself reports (ncclCommCount), whether
+ *                range-local collectives are on (ncclCommSplit succeeded everywhere / a range callback is set), exchange steps of the structure */
+int  mi355x_kkt_comm_plan(mi355x_kkt_handle h, int rank, int range_local, int* records6, int capacity_records, int* count);
+int  mi355x_kkt_comm_info(mi355x_kkt_handle h, int* kind, int* ranks_seen, int* range_local, int* exchange_steps);
 /* The phases are also exposed one by one (a caller that wants to overlap or replace the collectives): */
 /* The top-of-tree fronts live in one contiguous device buffer ("top arena").  After
  * factor_local() each rank holds its own subtrees' Schur contributions there; the caller

@@ -27,6 +27,10 @@ struct mi355x_kkt_handle_s {
     int num_delayed = 0;           // columns moved to a parent front since analyse() (a column that moved twice counts twice), MA97's num_delay
     int num_restructures = 0;      // structure edits since analyse()
     std::vector<unsigned char> delay_count;   // per column (caller's numbering, 0-based): how often it has been moved up
+    // latches of the delayed-pivot loop, cleared by analyse():
+    bool delays_exhausted = false; // an edit ran into the growth cap (or nothing could move any more): static pivoting from here on, no more edits are built
+    bool zero_delay_futile = false;// a round driven by ZERO pivots alone did not lower their number: the matrix is singular (a dependent row is a zero pivot
+                                   // wherever it is eliminated) -- later factorisations whose only complaint is zero pivots answer SINGULAR at once
     std::string err;
     std::vector<double> host_vals_nodev;   // plain host staging buffer handed out when no device exists (values only, never computed on)
 };
@@ -68,7 +72,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
     try {
         h->analysed = false; h->numeric_ready = false; h->factored = false;
         delete h->num; h->num = nullptr;
-        h->num_delayed = 0; h->num_restructures = 0; h->delay_count.clear();
+        h->num_delayed = 0; h->num_restructures = 0; h->delay_count.clear(); h->delays_exhausted = false; h->zero_delay_futile = false;
         SymbolicOptions& so = h->so; so = SymbolicOptions();
         so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
@@ -135,7 +139,11 @@ static bool apply_delays(mi355x_kkt_handle h, const std::vector<int>& marks_perm
     for (size_t q = 0; q < marks_perm.size(); ++q) hops[q] = 1 << std::min<int>(h->delay_count[h->sym.perm[marks_perm[q]]], 6);
     std::vector<char> acted;
     if (!restructure_delays(h->sym, h->so, marks_perm, hops, ns, moved, &acted)) return false;
-    if (ns.nnz_l > 4 * h->base_nnz_l + 4000000) { *moved = 0; return false; }      // the factor may grow, not explode: static pivoting from here on
+    if (ns.nnz_l > 4 * h->base_nnz_l + 4000000) {      // the factor may grow, not explode: static pivoting from here on -- and no more edits are BUILT
+        *moved = 0; h->delays_exhausted = true;         // (a complete host re-analysis each, 0.1-1 s at n = 10^6, only to be thrown away: ADVICE r04)
+        if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: the delayed-pivot edit would grow nnz(L) to %lld (> 4 x %lld + 4e6): static pivoting from here on\n", (long long)ns.nnz_l, (long long)h->base_nnz_l);
+        return false;
+    }
     for (size_t q = 0; q < marks_perm.size(); ++q) if (acted[q]) { unsigned char& c = h->delay_count[h->sym.perm[marks_perm[q]]]; if (c < 255) ++c; }
     h->sym = std::move(ns);
     h->num_delayed += *moved; h->num_restructures++;
@@ -143,14 +151,26 @@ static bool apply_delays(mi355x_kkt_handle h, const std::vector<int>& marks_perm
 }
 static bool delay_and_refactor(mi355x_kkt_handle h, FactorStats& st)
 {
-    // (a forced candidate with nothing usable in its column is counted as a ZERO pivot, not in num_small: both can carry marks)
-    for (int round = 0; round < h->opts.delay_rounds && (st.num_small > 0 || st.num_zero > 0); ++round) {
+    // (a forced candidate with nothing usable in its column is counted as a ZERO pivot, not in num_small: both can carry marks -- the hostile
+    // band system's 234-270 static zero pivots all disappear once their columns have moved up.)  But a SINGULAR matrix -- Ipopt's rank-deficient
+    // Jacobian before the delta_c perturbation -- has zero pivots wherever its dependent rows are eliminated: a round that was driven by zero
+    // pivots alone and did not lower their number ends the loop and is remembered for the handle (zero_delay_futile), so that every later SINGULAR
+    // answer of the run costs one factorisation, not up to delay_rounds re-analyses with their fill.
+    if (h->delays_exhausted) return true;
+    for (int round = 0; round < h->opts.delay_rounds && (st.num_small > 0 || (st.num_zero > 0 && !h->zero_delay_futile)); ++round) {
+        const bool zero_only = st.num_small == 0;
+        const int zero_before = st.num_zero;
         std::vector<int> marks; int moved = 0;
         if (!h->num->failed_pivots(marks)) { h->err = h->num->error(); return false; }
         if (!apply_delays(h, marks, &moved)) break;                      // nothing that can move (root fronts) or the growth cap: keep the static result
         if (!h->num->restructure(h->sym)) { h->err = h->num->error(); h->numeric_ready = false; return false; }
-        if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: %d failed pivots, %d columns delayed to their parent fronts (round %d), refactoring\n", st.num_small, moved, round + 1);
+        if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: %d failed + %d zero pivots, %d columns delayed to their parent fronts (round %d), refactoring\n", st.num_small, st.num_zero, moved, round + 1);
         if (!h->num->factor(nullptr, true, st)) { h->err = h->num->error(); return false; }
+        if (zero_only && st.num_small == 0 && st.num_zero >= zero_before) {
+            h->zero_delay_futile = true;
+            if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: %d zero pivots stay after the delay (singular matrix): no further delays for zero pivots on this structure\n", st.num_zero);
+            break;
+        }
     }
     return true;
 }
@@ -494,6 +514,27 @@ int mi355x_kkt_set_comm_range_callback(mi355x_kkt_handle h, mi355x_kkt_allreduce
     if (!h) return MI355X_KKT_FATAL;
     if (!h->numeric_ready) { h->err = "set_comm_range_callback: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
     try { return h->num->set_comm_range_callback(fn) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
+}
+/* host only: the collectives one rank issues (see include/mi355x_kkt.h) -- needs the analysis, not a device */
+int mi355x_kkt_comm_plan(mi355x_kkt_handle h, int rank, int range_local, int* records6, int capacity_records, int* count)
+{
+    if (!h || !count) return MI355X_KKT_FATAL;
+    if (!h->analysed) { h->err = "comm_plan: analyse() first"; return MI355X_KKT_FATAL; }
+    try {
+        const int P = h->so.nranks > 0 ? h->so.nranks : 1;
+        if (rank < 0 || rank >= P) { h->err = "comm_plan: no such rank"; return MI355X_KKT_FATAL; }
+        std::vector<int> out;
+        Numeric::comm_plan(h->sym, P, rank, range_local != 0, out);
+        *count = (int)(out.size() / 6);
+        if (records6) for (int i = 0; i < *count && i < capacity_records; ++i) for (int j = 0; j < 6; ++j) records6[6 * i + j] = out[6 * (size_t)i + j];
+        return MI355X_KKT_SUCCESS;
+    } catch (...) { h->err = "comm_plan: unexpected exception"; return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_comm_info(mi355x_kkt_handle h, int* kind, int* ranks_seen, int* range_local, int* exchange_steps)
+{
+    if (!h) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready) { h->err = "comm_info: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    try { h->num->comm_info(kind, ranks_seen, range_local, exchange_steps); return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
 int mi355x_kkt_exchange_bytes(mi355x_kkt_handle h, int64_t* arena_bytes, int64_t* rhs_bytes)
 {

@@ -505,6 +505,12 @@ bool Mi355xSolverInterface::SetupCommunicator()
    const unsigned long long job = comm_job_tag();
    const unsigned int generation = ++comm_generation_;
    const std::string path = comm_file_.empty() ? comm_default_path(job) : comm_file_;
+   if( job == 0ull && kopts_.nranks > 1 && generation == 1 )
+   {
+      Jnlst().Printf(J_WARNING, J_LINEAR_ALGEBRA, "mi355x: rank %d found no job tag in the environment (MI355X_KKT_JOB_ID, TORCHELASTIC_RUN_ID, SLURM_JOB_ID, "
+                     "PMIX_NAMESPACE, OMPI_MCA_ess_base_jobid, MASTER_PORT): the communicator id file %s is only protected by its age; set MI355X_KKT_JOB_ID on every rank\n",
+                     kopts_.rank, path.c_str());
+   }
    if( kopts_.rank == 0 )
    {
       if( mi355x_kkt_comm_unique_id(rec.id) != MI355X_KKT_SUCCESS )
@@ -547,9 +553,11 @@ bool Mi355xSolverInterface::SetupCommunicator()
             CommRecord in;
             const bool whole = fread(&in, 1, sizeof(in), f) == sizeof(in);
             // without any job tag the only protection against a stale file of an earlier job is its age: written no more than
-            // MI355X_KKT_COMM_FRESH_S seconds (default 600: staggered starts, slow imports, clock skew on a shared file system) before this
-            // rank loaded the library
-            static const long fresh_s = getenv("MI355X_KKT_COMM_FRESH_S") ? atol(getenv("MI355X_KKT_COMM_FRESH_S")) : 600;
+            // MI355X_KKT_COMM_FRESH_S seconds before this rank loaded the library.  The default is SHORT (30 s): rank 0 unlinks what an earlier
+            // run left behind and writes its record after its own start, so a record that is older than this rank's start by more than the
+            // launcher's stagger is a leftover of a run that died between its write and its join -- accepting it would hang ncclCommInitRank.
+            // Launchers with a larger stagger set a job tag (then no age test at all) or the window.
+            static const long fresh_s = getenv("MI355X_KKT_COMM_FRESH_S") ? atol(getenv("MI355X_KKT_COMM_FRESH_S")) : 30;
             const bool have_stat = fstat(fileno(f), &sb) == 0;
             const bool fresh = job != 0ull || (have_stat && sb.st_mtime + fresh_s >= g_process_start);
             if( whole && !fresh && tries % 100 == 0 )

@@ -91,6 +91,11 @@ public:
     // with it a range of ranks sums its part of an exchange step among itself instead of the whole machine summing everything
     bool   set_comm_range_callback(int (*allreduce_range)(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream, int rank_lo, int nranks_in_range));
     long long exchange_bytes(int what) const;        // bytes of the arena squares (0) / top right-hand sides (1) of all exchange steps
+    // host only (no device): the collectives rank `rank` of `nranks` issues for one factorisation + one solve of the structure S, and the ncclCommSplit calls
+    // before them -- records of 6 ints, see NumericImpl::comm_plan.  What a CPU test walks to show that every rank issues matching sequences.
+    static void comm_plan(const Symbolic& S, int nranks, int rank, bool range_local, std::vector<int>& out6);
+    // the communicator in use: kind 0 none / 1 callbacks / 2 RCCL; ranks the communicator itself reports (ncclCommCount; nranks for callbacks); range-local collectives on
+    void comm_info(int* kind, int* ranks_seen, int* range_local, int* exchange_steps) const;
     static bool rccl_unique_id(void* out128, std::string& err);                       // ncclGetUniqueId (rank 0 creates, the launcher distributes)
 private:
     NumericImpl* p_;

@@ -48,6 +48,7 @@ enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_L
 #define DBGSTAMP(slot) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { V.dbg[2 * (slot)] = clock64(); V.dbg[2 * (slot) + 1] = wall_clock64(); } } while (0)
 #define DBGT(i) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) V.dbg[16 + (i)] = clock64(); } while (0)
 #define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); } while (0)
+#define LAUNCH_ON(kind, strm, ...) do { prof_begin(kind, strm); hipLaunchKernelGGL(__VA_ARGS__); prof_end(strm); } while (0)      // (a launch on the look-ahead stream: its events are recorded there)
 
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
 static constexpr double BK_ALPHA0 = 0.1;                 // a diagonal within this factor of its whole remaining column is taken as it comes (no partner search)
@@ -325,6 +326,7 @@ public:
         ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
         ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
         ncclResult_t (*CommSplit)(ncclComm_t, int, int, ncclComm_t*, void*) = nullptr;      // (RCCL >= 2.18; optional)
+        ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;                         // (optional: what the communicator itself says its size is)
         const char* (*GetErrorString)(ncclResult_t) = nullptr;
         std::vector<ncclComm_t> sub;       // per exchange step: the communicator of the range of ranks this rank belongs to there (null: none / the whole machine)
         bool sub_ok = false;
@@ -346,6 +348,7 @@ public:
         R.AllReduce = (decltype(R.AllReduce))dlsym(R.lib, "ncclAllReduce");
         R.CommDestroy = (decltype(R.CommDestroy))dlsym(R.lib, "ncclCommDestroy");
         R.CommSplit = (decltype(R.CommSplit))dlsym(R.lib, "ncclCommSplit");
+        R.CommCount = (decltype(R.CommCount))dlsym(R.lib, "ncclCommCount");
         R.GetErrorString = (decltype(R.GetErrorString))dlsym(R.lib, "ncclGetErrorString");
         if (!R.GetUniqueId || !R.CommInitRank || !R.AllReduce || !R.CommDestroy) { err = "librccl.so lacks the nccl* entry points"; return false; }
         return true;
@@ -449,12 +452,12 @@ public:
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kind; size_t prof_used = 0;
     double prof_ms[KK_COUNT] = {0}; int prof_launches[KK_COUNT] = {0};
-    void prof_begin(int kind) {
+    void prof_begin(int kind, hipStream_t strm = nullptr) {
         if (!prof_on) return;
         if (prof_used + 2 > prof_ev.size()) { size_t old = prof_ev.size(); prof_ev.resize(old + 64); for (size_t i = old; i < prof_ev.size(); ++i) (void)hipEventCreate(&prof_ev[i]); }
-        (void)hipEventRecord(prof_ev[prof_used], stream); prof_kind.push_back(kind);
+        (void)hipEventRecord(prof_ev[prof_used], strm ? strm : stream); prof_kind.push_back(kind);
     }
-    void prof_end() { if (!prof_on) return; (void)hipEventRecord(prof_ev[prof_used + 1], stream); prof_used += 2; }
+    void prof_end(hipStream_t strm = nullptr) { if (!prof_on) return; (void)hipEventRecord(prof_ev[prof_used + 1], strm ? strm : stream); prof_used += 2; }
     void prof_collect() {
         (void)hipStreamSynchronize(stream);
         for (size_t i = 0; i < prof_used; i += 2) { float ms = 0; (void)hipEventElapsedTime(&ms, prof_ev[i], prof_ev[i + 1]); int kd = prof_kind[i / 2]; prof_ms[kd] += ms; prof_launches[kd]++; }
@@ -521,6 +524,75 @@ public:
         *d = p; return true;
     }
 
+    // The layout of the exchange steps (a function of the symbolic structure only, the same on every rank; no device needed -- the C ABI's
+    // mi355x_kkt_comm_plan walks it on a machine without a GPU): top-rhs accumulators for every replicated front; arena squares only for those
+    // with a child from outside their range (the joins): that is all the all-reduce has to carry (A is replicated input, not reduced).  Only the
+    // LOWER triangle of a square travels (packed by columns, the layout the front kernels assemble into), and inside a step the squares are
+    // grouped by the range of ranks that holds their front: what a front receives comes from ranks of its own range only, so a range sums its
+    // part among its own ranks (sub-communicator / range callback) -- the other ranks neither send nor receive it.
+    static void exchange_layout(const Symbolic& Sy, int ndepth, std::vector<long long>& aoff, std::vector<long long>& troff, std::vector<long long>& abeg, std::vector<long long>& aend,
+                                std::vector<long long>& tbeg, std::vector<long long>& tend, std::vector<RangeSeg>& rsegs, long long& arena_doubles, long long& toprhs_doubles) {
+        auto same_range = [&](int a, int b) { return Sy.sn_owner[a] < 0 && Sy.sn_owner[b] < 0 && Sy.sn_glo[a] == Sy.sn_glo[b] && Sy.sn_gsz[a] == Sy.sn_gsz[b]; };
+        auto crosses = [&](int c) { const int pa = Sy.sn_parent[c]; return pa >= 0 && Sy.sn_owner[pa] < 0 && !same_range(c, pa); };
+        aoff.assign(Sy.num_sn, -1); troff.assign(Sy.num_sn, -1);
+        arena_doubles = 0; toprhs_doubles = 0;
+        std::vector<char> is_join(Sy.num_sn, 0);
+        for (int c = 0; c < Sy.num_sn; ++c) if (crosses(c)) is_join[Sy.sn_parent[c]] = 1;
+        abeg.assign(ndepth, 0); aend.assign(ndepth, 0); tbeg.assign(ndepth, 0); tend.assign(ndepth, 0);
+        rsegs.clear();
+        for (int d = 0; d < ndepth; ++d) {
+            abeg[d] = arena_doubles; tbeg[d] = toprhs_doubles;
+            std::vector<std::pair<int, int>> ranges;
+            for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && Sy.sn_gdepth[s] == d) {
+                const std::pair<int, int> rg(Sy.sn_glo[s], Sy.sn_gsz[s]);
+                if (std::find(ranges.begin(), ranges.end(), rg) == ranges.end()) ranges.push_back(rg);
+            }
+            std::sort(ranges.begin(), ranges.end());
+            for (const auto& rg : ranges) {
+                RangeSeg sg{d, rg.first, rg.second, arena_doubles, 0, toprhs_doubles, 0};
+                for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && Sy.sn_gdepth[s] == d && Sy.sn_glo[s] == rg.first && Sy.sn_gsz[s] == rg.second) {
+                    const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
+                    troff[s] = toprhs_doubles; toprhs_doubles += m;
+                    if (is_join[s]) { aoff[s] = arena_doubles; arena_doubles += m * (m + 1) / 2; }
+                }
+                sg.aend = arena_doubles; sg.tend = toprhs_doubles;
+                rsegs.push_back(sg);
+            }
+            aend[d] = arena_doubles; tend[d] = toprhs_doubles;
+        }
+    }
+    // The collectives ONE rank issues, in order, for a factorisation and for one solve -- and the ncclCommSplit calls of make_subcomms() before them:
+    // records of 6 ints {what, depth, colour, range size, count, dtype}; what: 0 = ncclCommSplit (colour -1: NCCL_SPLIT_NOCOLOR, key = rank), 1 = all-reduce of
+    // arena squares, 2 = inertia / pivot statistics, 3 = all-reduce of top right-hand sides, 4 = solution pieces; colour = first rank of the range (sub-communicator
+    // of that step) or -2 = the whole communicator.  The SAME walk as factor_dist / solve_dist / make_subcomms / exchange_step, without a device.
+    static void comm_plan(const Symbolic& Sy, int nranks, int rank, bool range_local, int n, std::vector<int>& out) {
+        const int ndepth = std::max(1, Sy.num_gdepths);
+        std::vector<long long> aoff, troff, abeg, aend, tbeg, tend; std::vector<RangeSeg> rsegs; long long ad = 0, td = 0;
+        exchange_layout(Sy, ndepth, aoff, troff, abeg, aend, tbeg, tend, rsegs, ad, td);
+        auto rec = [&](int what, int d, int colour, int gsz, long long count, int dtype) { out.push_back(what); out.push_back(d); out.push_back(colour); out.push_back(gsz); out.push_back((int)std::min<long long>(count, 0x7fffffffll)); out.push_back(dtype); };
+        if (range_local)
+            for (int d = 0; d < ndepth; ++d) {
+                bool partial = false; int color = -1;
+                for (const RangeSeg& sg : rsegs) if (sg.d == d && sg.gsz < nranks) { partial = true; if (sg.glo <= rank && rank < sg.glo + sg.gsz) color = sg.glo; }
+                if (partial) rec(0, d, color, 0, 0, 1);
+            }
+        auto step = [&](int d, int what) {
+            if (range_local) {
+                for (const RangeSeg& sg : rsegs) {
+                    if (sg.d != d || !(sg.glo <= rank && rank < sg.glo + sg.gsz)) continue;
+                    const long long cnt = what == 1 ? sg.aend - sg.abeg : sg.tend - sg.tbeg;
+                    if (cnt > 0) rec(what, d, sg.gsz >= nranks ? -2 : sg.glo, sg.gsz, cnt, 0);
+                }
+            } else {
+                const long long cnt = what == 1 ? aend[d] - abeg[d] : tend[d] - tbeg[d];
+                if (cnt > 0) rec(what, d, -2, nranks, cnt, 0);
+            }
+        };
+        for (int d = ndepth - 1; d >= 0; --d) step(d, 1);
+        rec(2, 0, -2, nranks, 8, 1);
+        for (int d = ndepth - 1; d >= 0; --d) step(d, 3);
+        if (n > 0) rec(4, 0, -2, nranks, n, 0);
+    }
     // Delayed pivots changed the structure (symbolic.cpp restructure_delays): everything derived from it is rebuilt, the rest (see release) stays
     bool restructure(const Symbolic& Sy) {
         if (!have_device || !stream) { err_ = "restructure: solver not set up"; return false; }
@@ -612,35 +684,7 @@ public:
             // a child goes through the arena / the top-rhs accumulators when its parent is a replicated front of ANOTHER range of ranks
             auto same_range = [&](int a, int b) { return Sy.sn_owner[a] < 0 && Sy.sn_owner[b] < 0 && Sy.sn_glo[a] == Sy.sn_glo[b] && Sy.sn_gsz[a] == Sy.sn_gsz[b]; };
             auto crosses = [&](int c) { const int pa = Sy.sn_parent[c]; return pa >= 0 && Sy.sn_owner[pa] < 0 && !same_range(c, pa); };
-            // top-rhs accumulators for every replicated front; arena squares only for those with a child from outside their range (the joins):
-            // that is all the all-reduce has to carry (A is replicated input, not reduced).  Both laid out step by step, the same on every rank.
-            std::vector<char> is_join(Sy.num_sn, 0);
-            for (int c = 0; c < Sy.num_sn; ++c) if (crosses(c)) is_join[Sy.sn_parent[c]] = 1;
-            // Only the LOWER triangle of a square travels (packed by columns, the layout the front kernels assemble into), and inside a step the
-            // squares are grouped by the range of ranks that holds their front: what a front receives comes from ranks of its own range only, so
-            // a range sums its part among its own ranks (sub-communicator / range callback) -- the other ranks neither send nor receive it.
-            abeg.assign(ndepth, 0); aend.assign(ndepth, 0); tbeg.assign(ndepth, 0); tend.assign(ndepth, 0);
-            rsegs.clear();
-            for (int d = 0; d < ndepth; ++d) {
-                abeg[d] = arena_doubles; tbeg[d] = toprhs_doubles;
-                std::vector<std::pair<int, int>> ranges;
-                for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && Sy.sn_gdepth[s] == d) {
-                    const std::pair<int, int> rg(Sy.sn_glo[s], Sy.sn_gsz[s]);
-                    if (std::find(ranges.begin(), ranges.end(), rg) == ranges.end()) ranges.push_back(rg);
-                }
-                std::sort(ranges.begin(), ranges.end());
-                for (const auto& rg : ranges) {
-                    RangeSeg sg{d, rg.first, rg.second, arena_doubles, 0, toprhs_doubles, 0};
-                    for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_owner[s] < 0 && Sy.sn_gdepth[s] == d && Sy.sn_glo[s] == rg.first && Sy.sn_gsz[s] == rg.second) {
-                        const long long m = Sy.sn_rowptr[s + 1] - Sy.sn_rowptr[s];
-                        troff[s] = toprhs_doubles; toprhs_doubles += m;
-                        if (is_join[s]) { aoff[s] = arena_doubles; arena_doubles += m * (m + 1) / 2; }
-                    }
-                    sg.aend = arena_doubles; sg.tend = toprhs_doubles;
-                    rsegs.push_back(sg);
-                }
-                aend[d] = arena_doubles; tend[d] = toprhs_doubles;
-            }
+            exchange_layout(Sy, ndepth, aoff, troff, abeg, aend, tbeg, tend, rsegs, arena_doubles, toprhs_doubles);
             // what this rank reports: its own subtree roots (kind 0), and -- as the first rank of its depth-d range -- that range's fronts (kind 1 + d)
             join.assign(ndepth + 1, JoinList());
             for (int c = 0; c <= ndepth; ++c) {
@@ -1279,7 +1323,10 @@ public:
             int fl = top_mode;
             if (V.fastpiv && wave_mmin[lv] <= 16) {      // fronts of order <= 16: four per wavefront on the static-order path first; what it accepts is skipped below
                 const int n16 = sg ? tiny16[lv] : nb;
-                if (n16 > 0) { LAUNCH(KK_FRONT_WAVE, k_front_dpp16, dim3((n16 + 3) / 4), dim3(64), 0, stream, V, b0, n16, top_mode); fl |= 2; }
+                // (the kernel raises qstat[4] for a front it rejects only when NO strict launch follows -- optimistic && n16 == nb: behind a strict
+                // launch the rejected front is simply the strict kernel's, and raising the flag there made factor() repeat the whole factorisation
+                // with the full schedule and drop the optimistic one for the life of the handle: ADVICE r04)
+                if (n16 > 0) { LAUNCH(KK_FRONT_WAVE, k_front_dpp16, dim3((n16 + 3) / 4), dim3(64), 0, stream, V, b0, n16, top_mode, (optimistic && n16 == nb) ? 1 : 0); fl |= 2; }
                 // OPTIMISTIC schedule: every front of the bucket has order <= 16 and the static-order kernel accepts (nearly) everything it is given
                 // (LukVlE1 10^6: all 164 000 fronts) -- the strict launch behind it would find nothing to do, 4-8 us each, 21 of them per
                 // factorisation.  It is left out; a front the kernel rejects raises qstat[4] and factor() runs the full schedule again.
@@ -1368,7 +1415,7 @@ public:
         if (b1 == bs) return true;
         const int nb = b1 - bs;
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }      // a full update may touch what an earlier part 2 is still writing
-        if (G.la2[lv] > 0 && !prof_on) {
+        if (G.la2[lv] > 0) {      // (also while profile() records its events: the per-kernel times are those of the TIMED schedule, look-ahead stream included)
             // part 1 in 64 x 64 tiles where the 128 x 128 ones would leave most of the chip idle (k_big_schur_p1); the fronts of the list that are not split
             // get their whole update from a launch of their own then
             if (p1_small_tiles && G.la1[lv] * nb <= 512) {
@@ -1377,7 +1424,7 @@ public:
             } else LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(G.la1[lv]), nb), dim3(SCHUR_NT), 0, stream, V, bs, 1, 0, 0);
             HIPCHK(hipEventRecord(G.evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, G.evA[lv], 0));
-            hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(std::min(G.la2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, bs, 2, G.la2[lv], 0);
+            LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur, dim3(schur_grid(std::min(G.la2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, bs, 2, G.la2[lv], 0);
             HIPCHK(hipEventRecord(G.evB[lv], stream2));
             la_last = G.evB[lv]; la_pending = true;
         } else if (G.tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(G.tiles[lv]), nb), dim3(SCHUR_NT), 0, stream, V, bs, 0, 0, 0);
@@ -1394,10 +1441,12 @@ public:
     // children, no arena): measured 4.1 -> 2.0 ms per factorisation on synth_1e6, but 3.4 -> 8.7 ms on MBndryCntrl_3D 30, whose levels are a
     // handful of fronts of ~1000 rows with a dozen children each -- there the column kernel has four times the workgroups and no preamble.
     void launch_assemble(int mm, int nfronts, int b0, int top_mode) {
-        bool v2 = !asm_v1 && nfronts >= 32 && !top_mode;
+        const int ldi = (mm + 15) & ~15;                    // the children's inverse row maps of one front in LDS: ASM_MAXCH x ldi ints (78 KiB at the largest front of synth_1e6)
+        // (... which has to FIT: a level of >= 32 fast-path fronts whose largest order exceeds ~6 780 -- a 3-D problem, or fronts enlarged by a
+        // delayed-pivot edit -- would make the launch fail instead of falling back to the column kernel: ADVICE r04)
+        bool v2 = !asm_v1 && nfronts >= 32 && !top_mode && (size_t)ASM_MAXCH * ldi * sizeof(int) <= (size_t)159 * 1024;
         for (int q = b0; q < b0 + nfronts && v2; ++q) v2 = asm_fast_ok[q] != 0;
         if (!v2) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
-        const int ldi = (mm + 15) & ~15;                    // the children's inverse row maps of one front in LDS: ASM_MAXCH x ldi ints (<= 78 KiB at the largest front)
         LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble2, dim3((mm + ASM_CH - 1) / ASM_CH, nfronts), dim3(256), (size_t)ASM_MAXCH * ldi * sizeof(int), stream, V, b0, top_mode, ldi);
     }
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
@@ -1427,11 +1476,11 @@ public:
         if (single && la_full[lv] && la_pending) {       // a full update may touch what an earlier part 2 is still writing
             HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false;
         }
-        if (single && la_tiles2[lv] > 0 && !prof_on) {
+        if (single && la_tiles2[lv] > 0) {
             LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(la_tiles1[lv]), nb), dim3(SCHUR_NT), 0, stream, V, b0, 1, 0, 0);
             HIPCHK(hipEventRecord(la_evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, la_evA[lv], 0));
-            hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(std::min(la_tiles2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, b0, 2, la_tiles2[lv], 0);
+            LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur, dim3(schur_grid(std::min(la_tiles2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, b0, 2, la_tiles2[lv], 0);
             HIPCHK(hipEventRecord(la_evB[lv], stream2));
             la_last = la_evB[lv]; la_pending = true;
         } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(tiles), nb), dim3(SCHUR_NT), 0, stream, V, b0, 0, 0, 0);
@@ -2219,6 +2268,16 @@ bool Numeric::ruiz_triplet(int device, int n, int nnz, const int* irn, const int
 bool Numeric::set_comm_rccl(const void* unique_id128) { return p_->set_comm_rccl(unique_id128); }
 bool Numeric::set_comm_callback(int (*fn)(void*, void*, int64_t, int, void*), void* ctx) { return p_->set_comm_callback(fn, ctx); }
 bool Numeric::set_comm_range_callback(int (*fn)(void*, void*, int64_t, int, void*, int, int)) { return p_->set_comm_range_callback(fn); }
+void Numeric::comm_plan(const Symbolic& S, int nranks, int rank, bool range_local, std::vector<int>& out6) { NumericImpl::comm_plan(S, nranks, rank, range_local, S.n, out6); }
+void Numeric::comm_info(int* kind, int* ranks_seen, int* range_local, int* exchange_steps) const
+{
+    int seen = p_->comm_kind == 0 ? 0 : p_->opt.nranks;
+    if (p_->comm_kind == 2 && p_->rccl.comm && p_->rccl.CommCount) { int c = 0; if (p_->rccl.CommCount(p_->rccl.comm, &c) == ncclSuccess) seen = c; }
+    if (kind) *kind = p_->comm_kind;
+    if (ranks_seen) *ranks_seen = seen;
+    if (range_local) *range_local = p_->range_local() ? 1 : 0;
+    if (exchange_steps) *exchange_steps = p_->ndepth;
+}
 long long Numeric::exchange_bytes(int what) const { long long b = 0; for (const auto& sg : p_->rsegs) b += 8 * (what == 0 ? sg.aend - sg.abeg : sg.tend - sg.tbeg); return b; }
 bool Numeric::rccl_unique_id(void* out128, std::string& err)
 {

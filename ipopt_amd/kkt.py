@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
-    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks", "mi355x_kkt_set_comm_range_callback", "mi355x_kkt_exchange_bytes",
+    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks", "mi355x_kkt_set_comm_range_callback", "mi355x_kkt_exchange_bytes", "mi355x_kkt_comm_plan", "mi355x_kkt_comm_info",
     "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_failed_pivots", "mi355x_kkt_delay_columns", "mi355x_kkt_set_delay_rounds", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
     "mi355x_kkt_pd_define", "mi355x_kkt_pd_put_data", "mi355x_kkt_pd_put", "mi355x_kkt_pd_get", "mi355x_kkt_pd_solve_once", "mi355x_kkt_pd_residual",
 ]
@@ -141,6 +141,8 @@ def load_library():
     lib.mi355x_kkt_set_comm_callbacks.argtypes = [vp, ALLREDUCE_FN, vp]
     lib.mi355x_kkt_set_comm_range_callback.argtypes = [vp, ALLREDUCE_RANGE_FN]
     lib.mi355x_kkt_exchange_bytes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    lib.mi355x_kkt_comm_plan.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, ip]
+    lib.mi355x_kkt_comm_info.argtypes = [vp, ip, ip, ip, ip]
     _LIB = lib
     return lib
 
@@ -352,6 +354,24 @@ class KKTSolver:
         if self.lib.mi355x_kkt_exchange_bytes(self._h, C.byref(a), C.byref(t)) != 0:
             raise KKTError("exchange_bytes: no device-side set-up")
         return a.value, t.value
+
+    def comm_plan(self, rank, range_local=True):
+        """host only: the collectives rank `rank` issues for one factorisation + one solve (and the ncclCommSplit calls before them) as an (k, 6) int array
+        {what, step, colour, range size, count, dtype} -- include/mi355x_kkt.h mi355x_kkt_comm_plan.  Needs the analysis, not a device."""
+        cnt = C.c_int(0)
+        if self.lib.mi355x_kkt_comm_plan(self._h, int(rank), int(bool(range_local)), None, 0, C.byref(cnt)) != 0:
+            raise KKTError("comm_plan: " + self.last_error())
+        out = np.zeros((max(cnt.value, 1), 6), dtype=np.int32)
+        if self.lib.mi355x_kkt_comm_plan(self._h, int(rank), int(bool(range_local)), out.ctypes.data, cnt.value, C.byref(cnt)) != 0:
+            raise KKTError("comm_plan: " + self.last_error())
+        return out[:cnt.value]
+
+    def comm_info(self):
+        """{kind: 0 none / 1 callbacks / 2 rccl, ranks_seen (ncclCommCount), range_local, exchange_steps} of the communicator in use"""
+        k, r, l, e = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+        if self.lib.mi355x_kkt_comm_info(self._h, C.byref(k), C.byref(r), C.byref(l), C.byref(e)) != 0:
+            raise KKTError("comm_info: " + self.last_error())
+        return {"kind": ("none", "callbacks", "rccl")[k.value], "ranks_seen": r.value, "range_local": bool(l.value), "exchange_steps": e.value}
 
     _refactor = False
 

@@ -191,6 +191,66 @@ class CommKKT:
             self.s.set_comm_callback(fn, fn_range if not os.environ.get("MI355X_KKT_NO_SUBCOMM") else None)
 
 
+def play_comm_plans(plans):
+    """plans[rank] = KKTSolver.comm_plan(rank): play the ranks' collective lists against each other -- a collective completes when EVERY member of its
+    communicator has it at the head of its list with the same (what, step, count, dtype).  Returns (collectives completed, {(step, colour): members}) or
+    raises AssertionError on a mismatch / when nothing can complete although a list is not empty (= a deadlock).  The property that makes an N-rank run
+    of factor_dist / solve_dist hang-free, checkable on a machine without a GPU (tests/test_comm_plan.py; bench.py --gpus N dry run)."""
+    SPLIT, WHOLE, NOCOLOR = 0, -2, -1
+    world = len(plans)
+    subcomm = {}
+    for rk in range(world):
+        for what, d, colour, gsz, cnt, dt in plans[rk]:
+            if what == SPLIT and colour != NOCOLOR:
+                subcomm.setdefault((int(d), int(colour)), []).append(rk)
+    queues = [[tuple(int(x) for x in rec) for rec in plans[rk] if rec[0] != SPLIT] for rk in range(world)]
+    done = 0
+    while any(queues):
+        progress = False
+        for rk in range(world):
+            if not queues[rk]:
+                continue
+            what, d, colour, gsz, cnt, dt = queues[rk][0]
+            members = list(range(world)) if colour == WHOLE else subcomm[(d, colour)]
+            assert rk in members, (rk, what, d, colour)
+            heads = [queues[m][0] if queues[m] else None for m in members]
+            if all(h is not None and h[2] == colour and h[1] == d for h in heads):
+                assert len(set(heads)) == 1, f"members of communicator (step {d}, colour {colour}) disagree: {set(heads)}"
+                for m in members:
+                    queues[m].pop(0)
+                done += 1
+                progress = True
+        assert progress, f"deadlock: heads {[q[0] if q else None for q in queues]}"
+    return done, subcomm
+
+
+def bench_dry_run(args, rank, world):
+    """bench.py --gpus N with MI355X_KKT_BENCH_DRYRUN=1: everything of the N-rank launch that needs no device -- the launcher, the rendezvous (gloo), the
+    analysis with (nranks, rank) on every rank, the collective plan of every rank gathered and played against each other -- and a JSON line that says so.
+    What a CPU-only box can prove about first contact with N GPUs (tests/test_bench_tools.py runs it with two ranks)."""
+    import torch.distributed as dist
+    import bench as B
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wl = "grid_1e5" if args.workload == "auto" else args.workload
+    n, r, c, v, neg = B.make_workload(wl)
+    subcube = int(os.environ.get("MI355X_KKT_SUBCUBE", "1" if world > 2 else "0"))
+    s = _kkt.KKTSolver(device=-1, nranks=world, rank=rank, subcube=subcube)
+    s.initialize_structure(n, r, c, vals=v)
+    range_local = not bool(os.environ.get("MI355X_KKT_NO_SUBCOMM"))
+    mine = s.comm_plan(rank, range_local).tolist()
+    box = [None] * world
+    dist.all_gather_object(box, mine)
+    I = s.info()
+    if rank == 0:
+        done, subcomm = play_comm_plans([np.array(p, dtype=np.int64).reshape(-1, 6) for p in box])
+        print(json.dumps({"dry_run": True, "what": "launcher + rendezvous + per-rank analysis + collective plans of all ranks played against each other; no HIP call was made",
+                          "n_gpus": world, "ranks_seen": len(box), "workload": wl, "kkt_dim": n, "subcube": subcube, "range_local_collectives": range_local,
+                          "collectives_per_factor_plus_solve": done, "sub_communicators": [[int(d), members] for (d, col), members in sorted(subcomm.items())],
+                          "supernodes": I.num_sn, "plan_ok": True}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def partition_model(s, I, own, world):
     """What the partition itself allows (work only, no latency, no communication): every rank does the flops of its own subtrees and of the
     replicated fronts it holds (all of them with the classic mapping, those above its subtrees with the subtree-to-subcube mapping);
@@ -248,6 +308,8 @@ def bench_main(args, rank, world, local):
     import bench as B
     from tests.support import kktgen
 
+    if os.environ.get("MI355X_KKT_BENCH_DRYRUN"):
+        return bench_dry_run(args, rank, world)
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world)
     wl = "synth_1e6" if args.workload == "auto" else args.workload
@@ -287,6 +349,7 @@ def bench_main(args, rank, world, local):
     dt = float(el[0]) / args.steps
     own = s.symbolic(11, I.num_sn)
     flops_step = I.flops_factor + NSOLVE * I.flops_solve
+    cinfo = s.comm_info()      # what the communicator itself says: ncclCommCount, whether ncclCommSplit gave every range its sub-communicator
     line = None
     if rank == 0:
         # the same workload on ONE GPU of this node, so that the line carries its own strong-scaling reference
@@ -328,7 +391,8 @@ def bench_main(args, rank, world, local):
                        "supernodes": I.num_sn, "replicated_top_supernodes": int((own < 0).sum()), "num_neg": nneg, "scaled_residual": res},
             "same_workload_1gpu": {"ms_per_step": dt1 * 1e3, "value": flops_step / dt1 / 1e9, "speedup": dt1 / dt},
             "partition_model": partition_model(s, I, own, world),
-            "range_local_collectives": not bool(os.environ.get("MI355X_KKT_NO_SUBCOMM")),
+            "range_local_collectives": cinfo["range_local"], "rccl_ranks_seen": cinfo["ranks_seen"], "subcomm": "on" if cinfo["range_local"] else "off",
+            "communicator": cinfo,
             "roofline": roof,
         }
     if rank == 0:
