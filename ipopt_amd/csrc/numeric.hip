@@ -1233,6 +1233,25 @@ public:
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
             !upload(Sy.perm, &V.perm)) return false;
         lap("uploads");
+        {   // Everything numeric is allocated once, here; the bulk is ONE pool  L | cb  (every contribution block resident: DESIGN.md "Data layout").  A structure
+            // whose pool does not fit -- a 3-D problem beyond MBndryCntrl_3D N ~ 120 on 288 GB, or a device shared with another process -- is refused with
+            // the numbers, before the allocation is attempted: factor() / solve() then answer MI355X_KKT_FATAL with this message (no partial set-up, no
+            // fallback).  MI355X_KKT_POOL_LIMIT_GIB caps what one handle may take (a GPU shared by several ranks or applications).
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            const double gib = 1.0 / (1024.0 * 1024.0 * 1024.0);
+            const double need = 8.0 * ((double)Sy.l_doubles + (double)Sy.cb_doubles + (double)Sy.wbuf_doubles + (double)Sy.minv_doubles + (double)Sy.cvec_doubles + (double)Sy.gpart_doubles) +
+                                12.0 * (double)Sy.nnz_a + 16.0 * (double)Sy.nnz_in + 12.0 * (double)Sy.rslot_idx.size() + 200.0 * (double)Sy.n;
+            double cap = (double)fr;
+            if (const char* e = getenv("MI355X_KKT_POOL_LIMIT_GIB")) cap = std::min(cap, atof(e) / gib);
+            if (need > cap) {
+                char msg[512];
+                snprintf(msg, sizeof msg, "the factor + contribution-block pool of this structure does not fit the device: %.2f GiB needed (L %.2f + contribution blocks %.2f + work space), "
+                                          "%.2f GiB available (%.2f GiB free of %.2f%s); no out-of-core path, no CPU fallback", need * gib, 8.0 * (double)Sy.l_doubles * gib, 8.0 * (double)Sy.cb_doubles * gib,
+                         cap * gib, (double)fr * gib, (double)tot * gib, getenv("MI355X_KKT_POOL_LIMIT_GIB") ? ", capped by MI355X_KKT_POOL_LIMIT_GIB" : "");
+                err_ = msg; return false;
+            }
+        }
         double* tv = keep ? keep_tvals : nullptr;
         if (!tv && !dalloc(&tv, Sy.nnz_in)) return false;
         V.tvals = tv;
@@ -2156,17 +2175,19 @@ public:
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
         const size_t n = S->n;
-        if (d_rhs_cap < n) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(n, 1) * sizeof(double))); d_rhs_cap = n;
-                             if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
-        double total = 0;
-        for (int r = 0; r < nrhs; ++r) {
-            HIPCHK(hipMemcpyAsync(d_rhs, rhs + (size_t)r * ld, n * sizeof(double), hipMemcpyHostToDevice, stream));
-            if (!solve_device(1, d_rhs, (int)n, d_rhs, (int)n, true)) return false;
-            total += solve_ms;
-            HIPCHK(hipMemcpyAsync(rhs + (size_t)r * ld, d_rhs, n * sizeof(double), hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-        }
-        solve_ms = total;
+        // nrhs > 1 (IpLowRankAugSystemSolver.cpp:435-487, sIPOPT): ALL columns go up in one stream-ordered batch, the sweeps of the columns run back to back
+        // on the device with no host synchronisation between them, all solutions come down behind the last one -- one PCIe round trip and one wait per
+        // call instead of one per column (round 4: upload, solve, download, synchronise per column).  L is still streamed once per column: the sweeps are
+        // written for one vector (panel rows in registers, 16-lane DPP rows); a blocked multi-vector version of them is not built.
+        const size_t need = n * (size_t)std::max(nrhs, 1);
+        if (d_rhs_cap < need) { if (d_rhs) (void)hipFree(d_rhs); d_rhs = nullptr; HIPCHK(hipMalloc((void**)&d_rhs, std::max<size_t>(need, 1) * sizeof(double))); d_rhs_cap = need;
+                                if (g_solve) { (void)hipGraphExecDestroy(g_solve); g_solve = nullptr; } }
+        if ((size_t)ld == n || nrhs == 1) HIPCHK(hipMemcpyAsync(d_rhs, rhs, n * (size_t)nrhs * sizeof(double), hipMemcpyHostToDevice, stream));
+        else for (int r = 0; r < nrhs; ++r) HIPCHK(hipMemcpyAsync(d_rhs + (size_t)r * n, rhs + (size_t)r * ld, n * sizeof(double), hipMemcpyHostToDevice, stream));
+        if (!solve_device(nrhs, d_rhs, (int)n, d_rhs, (int)n, true)) return false;          // (synchronises once, behind the last column; solve_ms = all columns)
+        if ((size_t)ld == n || nrhs == 1) HIPCHK(hipMemcpyAsync(rhs, d_rhs, n * (size_t)nrhs * sizeof(double), hipMemcpyDeviceToHost, stream));
+        else for (int r = 0; r < nrhs; ++r) HIPCHK(hipMemcpyAsync(rhs + (size_t)r * ld, d_rhs + (size_t)r * n, n * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
         return true;
     }
 };

@@ -46,3 +46,6 @@ $D/ref_driver hs071 0 --record-pd hs071.pdrec --quiet > /dev/null
 $D/ref_driver LukVlI1 20 --record-pd lukvli1_20.pdrec --max-records 8 --quiet > /dev/null
 # SURVEY 8(d)-5's MFMA-bound 3-D family at a larger size (n = 125 000, m = 110 592, KKT dimension 235 592; fronts up to ~5 600 rows): one minute on 8 MKL threads
 MKL_NUM_THREADS=8 OMP_NUM_THREADS=8 run mbndry3d_50 MBndryCntrl_3D 50 norec
+# SURVEY 8(d)-5's 3-D instance itself: MBndryCntrl_3D N = 78 (n = 80^3 = 512 000, m = 78^3 = 474 552, KKT dimension 986 552; examples/ScalableProblems/solve_problem.cpp:56):
+# 16 iterations, 13 minutes on 8 MKL threads (PDSystemSolverTotal 727 s of the 775 s)
+MKL_NUM_THREADS=8 OMP_NUM_THREADS=8 run mbndry3d_78 MBndryCntrl_3D 78 norec

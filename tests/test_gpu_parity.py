@@ -139,6 +139,47 @@ def test_edge_cases_tiny_empty_diagonal_multirhs():
     assert st == 0 and s.number_of_neg_evals() == 2 and np.allclose(x, [[1] * 5, [2] * 5, [-1] * 5], rtol=1e-15)
 
 
+def test_a_pool_that_does_not_fit_the_device_is_refused_with_the_numbers(monkeypatch):
+    """Every contribution block is resident (one pool L | cb, DESIGN.md "Data layout"; MBndryCntrl_3D N = 78 takes 74 GiB of the 288): a structure whose pool
+    does not fit is refused at set-up with the sizes in the message, and factor / solve answer MI355X_KKT_FATAL -- no partial set-up, no CPU fallback.
+    MI355X_KKT_POOL_LIMIT_GIB (a cap for a device shared by several handles) stands in for a structure of hundreds of GiB."""
+    n, r, c, v, neg = kktgen.grid_kkt(60, 50, dof=3, ncon=2, seed=3)
+    monkeypatch.setenv("MI355X_KKT_POOL_LIMIT_GIB", "0.01")
+    s = ipopt_amd.KKTSolver()
+    assert s.initialize_structure(n, r, c, vals=v) == 0             # the analysis itself succeeds (host) and stays queryable
+    assert s.info().nnz_l > 0
+    with pytest.raises(kkt.KKTError, match="does not fit the device.*GiB needed.*MI355X_KKT_POOL_LIMIT_GIB"):
+        s.multi_solve(True, np.ones(n))
+    neg_, zero_ = kkt.C.c_int(0), kkt.C.c_int(0)
+    assert s.lib.mi355x_kkt_factor(s._h, None, kkt.C.byref(neg_), kkt.C.byref(zero_)) == kkt.FATAL
+    monkeypatch.delenv("MI355X_KKT_POOL_LIMIT_GIB")
+    s2, st, x = gpu_factor_solve(n, r, c, v, np.ones(n), check=True, required=neg)      # the same structure without the cap
+    assert st == 0
+
+
+def test_eight_right_hand_sides_in_one_call_equal_eight_single_solves_bitwise():
+    """nrhs > 1 (what IpLowRankAugSystemSolver.cpp:435-487 and sIPOPT ask of MultiSolve): all columns go up in one batch, their sweeps run back to back with no
+    host synchronisation in between, all solutions come down behind the last one -- and every column is bitwise the solution of a single solve, with a
+    leading dimension larger than n as well (the C ABI's `ld`)."""
+    n, r, c, v, neg = kktgen.grid_kkt(48, 40, dof=3, ncon=2, seed=23)
+    K = kktgen.to_scipy(n, r, c, v)
+    rng = np.random.default_rng(5)
+    B = np.ascontiguousarray(rng.standard_normal((8, n)))
+    s, st, x0 = gpu_factor_solve(n, r, c, v, B[0].copy(), check=True, required=neg)
+    assert st == 0
+    singles = []
+    for q in range(8):
+        x = B[q].copy(); assert s.multi_solve(False, x) == 0; singles.append(x)
+    X = B.copy(); assert s.multi_solve(False, X) == 0
+    assert all(np.array_equal(X[q], singles[q]) for q in range(8))
+    assert max(sres(K, X[q], B[q]) for q in range(8)) <= RES_TOL
+    # ld > n through the C ABI directly
+    ld = n + 37
+    W = np.zeros((8, ld)); W[:, :n] = B
+    assert s.lib.mi355x_kkt_solve(s._h, 8, W.ctypes.data, ld) == 0
+    assert all(np.array_equal(W[q, :n], singles[q]) for q in range(8)) and not W[:, n:].any()
+
+
 def test_full_size_properties_config_sized():
     """BASELINE.json sizes without the oracle: LukVlE1-shaped KKT with n = 10^6 variables (dim 1 999 998):
     by-construction inertia, residual, linearity of the solve, idempotence."""
