@@ -1553,6 +1553,7 @@ public:
         return true;
     }
 
+    bool norestore_on = getenv("MI355X_KKT_RESTORE") == nullptr;      // (development knob: keep the safety copies of the pivot blocks in the optimistic schedule too)
     bool optimistic = false;                 // (set per factorisation: see launch_bucket)
     bool optimistic_ok = true;               // no factorisation of this handle has needed a strict launch the optimistic schedule leaves out
     hipGraphExec_t g_factor_full = nullptr;  // the schedule with every strict launch (g_factor: the optimistic one)
@@ -1563,7 +1564,7 @@ public:
         static const bool opt_off = getenv("MI355X_KKT_NO_OPTIMISTIC") != nullptr;
         optimistic = V.fastpiv && !opt_off && !prof_on && optimistic_ok;
         if (!factor_once(dvals, reuse, st)) return false;
-        if (optimistic && h_stats[8] != 0) {                      // some front was left for a strict launch that was not there: the full schedule, same values
+        if (optimistic && (h_stats[8] != 0 || h_stats[9] != 0)) { // some front was left for a strict launch that was not there / a pivot block without a safety copy was rejected: the full schedule, same values
             optimistic = false; optimistic_ok = false;            // ... and from now on for this structure: a matrix family that needs the strict kernels once needs them again
             if (opt.verbose) fprintf(stderr, "[mi355x_kkt] factor: the optimistic schedule met a front for the strict kernels, running the full one\n");
             return factor_once(nullptr, true, st);
@@ -1573,6 +1574,7 @@ public:
     bool factor_once(const double* dvals, bool reuse, FactorStats& st) {
         const Symbolic& Sy = *S;
         V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small;
+        V.norestore = (optimistic && norestore_on) ? 1 : 0;
         if (!reuse) {
             if (dvals) HIPCHK(hipMemcpyAsync((void*)V.tvals, dvals, Sy.nnz_in * sizeof(double), hipMemcpyDeviceToDevice, stream));
             else       HIPCHK(hipMemcpyAsync((void*)V.tvals, h_vals, Sy.nnz_in * sizeof(double), hipMemcpyHostToDevice, stream));
