@@ -23,6 +23,7 @@ __global__ __launch_bounds__(256) void k_probe(const double* A, unsigned long lo
         for (int idx = tid; idx < k * k; idx += 256) { const int i = idx % k, c = idx / k; Lb[i + c * ld] = A[i + c * k]; }
         __syncthreads();
         int nneg = 0;
+        if (variant == 1) { asm volatile("s_icache_inv\n\ts_nop 7\n\ts_nop 7" ::: "memory"); __syncthreads(); }      // (every pass starts with a cold instruction cache, as in k_grp_fused where a workgroup runs this code ONCE)
         const unsigned long long t0 = clock64();
         const bool ok = ldlt_blocked_static(Lb, ld, k, Wp, dinv_s, Isb, shflag, 1e-300, 1e8, nneg, nullptr, ts);
         const unsigned long long t1 = clock64();
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(256) void k_probe(const double* A, unsigned long lo
 }
 int main(int argc, char** argv)
 {
-    const int k = argc > 1 ? atoi(argv[1]) : 64, reps = 21;
+    const int k = argc > 1 ? atoi(argv[1]) : 64, reps = 21, variant = argc > 2 ? atoi(argv[2]) : 0;
     std::vector<double> A((size_t)k * k);
     for (int c = 0; c < k; ++c) for (int i = 0; i < k; ++i) A[i + (size_t)c * k] = (i == c) ? (4.0 + 0.01 * i) * ((i % 3) ? 1.0 : -1.0) : 0.3 / (1.0 + abs(i - c));
     double *dA, *dL; unsigned long long* dout;
@@ -49,7 +50,7 @@ int main(int argc, char** argv)
     hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice);
     hipFuncSetAttribute((const void*)mi355x::k_probe, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(mi355x::k_probe, dim3(1), dim3(256), 120 * 1024, 0, dA, dout, dL, k, reps, 0);
+        hipLaunchKernelGGL(mi355x::k_probe, dim3(1), dim3(256), 120 * 1024, 0, dA, dout, dL, k, reps, variant);
         hipDeviceSynchronize();
     }
     unsigned long long out[64]; hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost);
