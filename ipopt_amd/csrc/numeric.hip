@@ -1261,7 +1261,7 @@ public:
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 12) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
-            !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
+            !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_p, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         if (opt.scaling >= 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2 && !d_user_scale) opt.scaling = 1;       // (user factors can only come through set_scaling)
