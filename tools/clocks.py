@@ -40,7 +40,7 @@ ps = o[40:48]
 print("sub-block 0, wavefront 0 (cycles): load %d  factor %d  checks %d  inverse %d  store %d | to barrier B %d, to barrier C %d" % (ps[1]-ps[0], ps[2]-ps[1], ps[3]-ps[2], ps[4]-ps[3], ps[5]-ps[4], ps[6]-ps[5], ps[7]-ps[6]))
 
 r = o[64:92]
-if r[4]:
+if r[4] and r[0]:
     base = r[4]
     names = {4: "flag seen", 0: "L11/D/Is loaded", 1: "rows permuted (+inverses)", 2: "substitution done", 3: "W/L stored", 5: "S flag raised", 6: "other links' columns updated", 7: "own block updated",
              8: "pivot block: entered colmax", 9: "colmax done", 10: "blocked LDL^T done", 11: "L11 / D / Is written", 12: "F flag raised"}
@@ -49,6 +49,12 @@ if r[4]:
     for i in (4, 0, 1, 2, 3, 5, 6, 13, 14, 15, 7, 8, 9, 10, 11, 12):
         print("  %-34s %8d" % (names[i], r[i] - base))
 
+if r[4] and not r[0] and r[8]:      # optimistic schedule: the panel solve ran in step with the pivot block before (trsm_rows_pipe) -- what is left behind its LAST sub-block
+    base = r[4]
+    print("role 1 of group 0 (last launch), last link, panel solve in step with the pivot block: shader cycles after the LAST 16-column sub-block of the pivot block before was seen")
+    for i, nm in ((4, "last sub-block seen"), (2, "last step solved, scaled, stored"), (7, "own block updated (+ S flag)"), (8, "pivot block: entered colmax"), (9, "colmax done"), (10, "blocked LDL^T done"),
+                  (11, "L11 / D / Is written"), (12, "F flag raised")):
+        print("  %-34s %8d" % (nm, r[i] - base))
 if r[4] and r[16]:
     print("  blocked LDL^T of role 1's pivot block, per 16-column sub-block (cycles): diagonal block + inverse | rows below | trailing tiles")
     prev = r[9]
