@@ -1222,6 +1222,48 @@ public:
             if (lcl.empty()) lcl.push_back(LeafLink());
             if (!upload(lcp, &V.lc_ptr) || !upload(lcl, &V.lc_link)) return false;
         }
+        {   // k_front_df: maximal runs of >= 2 consecutive levels (above the leaf chains) whose fronts are all one-wavefront fronts
+            df_runs.clear(); df_run_at.assign(Sy.num_levels, -1);
+            std::vector<DfLevel> tab; std::vector<long long> cto(std::max(Sy.num_sn, 1), -1); std::vector<int> run_of(std::max(Sy.num_sn, 1), -1); long long cbt_len = 0;
+            if (!multi && V.fastpiv && df_on) {
+                auto pure = [&](int lv) {
+                    const int w0 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE], w1 = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_WAVE + 1];
+                    return w1 > w0 && w1 - w0 == Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)lv * FC_COUNT];
+                };
+                for (int lv = lc_levels; lv < Sy.num_levels; ) {
+                    if (!pure(lv)) { ++lv; continue; }
+                    int e = lv; while (e + 1 < Sy.num_levels && pure(e + 1)) ++e;
+                    if (e > lv) {
+                        DfRun R{lv, e, (int)tab.size(), e - lv + 1, 0};
+                        for (int l = lv; l <= e; ++l) {
+                            const int w0 = Sy.level_ptr[(size_t)l * FC_COUNT + FC_WAVE], w1 = Sy.level_ptr[(size_t)l * FC_COUNT + FC_WAVE + 1];
+                            tab.push_back(DfLevel{w0, tiny16[l], w1 - w0, R.nq});
+                            R.nq += (tiny16[l] + 3) / 4 + (w1 - w0 - tiny16[l]);
+                            for (int q = w0; q < w1; ++q) run_of[lvl_list[q]] = (int)df_runs.size();
+                        }
+                        df_run_at[lv] = (int)df_runs.size(); df_runs.push_back(R);
+                    }
+                    lv = e + 1;
+                }
+                int per_cu = 0, ncu = 0;
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_front_df, 64, 0);
+                (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+                df_grid_cap = std::max(1, per_cu) * std::max(1, ncu);      // every workgroup of the launch must be resident (they wait for each other)
+                if (opt.verbose && !df_runs.empty()) { int nl = 0; for (auto& R : df_runs) nl += R.nlev; fprintf(stderr, "[mi355x_kkt] small fronts: %d runs covering %d of %d levels in one data-flow launch each (grid <= %d workgroups)\n", (int)df_runs.size(), nl, Sy.num_levels, df_grid_cap); }
+            }
+            // tagged contribution blocks: for every front of a run whose PARENT is a front of the same run
+            for (int sn = 0; sn < Sy.num_sn; ++sn) {
+                const int pa = Sy.sn_parent[sn];
+                if (run_of[sn] < 0 || pa < 0 || run_of[pa] != run_of[sn]) continue;
+                const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
+                if (mu <= 0) continue;
+                cto[sn] = cbt_len; cbt_len += mu <= 16 ? 256 : 1024;
+            }
+            if (tab.empty()) tab.push_back(DfLevel{0, 0, 0, 0});
+            if (!upload(tab, &d_dftab)) return false;
+            if (!upload(cto, &V.cbt_off)) return false;
+            if (!dalloc(&V.cbt, (size_t)std::max<long long>(cbt_len, 1))) return false;
+        }
         // the inertia / pivot counts are summed over the ranks: a replicated front is counted by the first rank of its range (-1 in this rank's view), -3 = not here
         std::vector<int> stat_owner(Sy.sn_owner.begin(), Sy.sn_owner.end());
         if (multi) for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_owner[sn] < 0) stat_owner[sn] = Sy.sn_glo[sn] == opt.rank ? -1 : -3;
@@ -1358,6 +1400,9 @@ public:
         } else if (fc == FC_LDS128) {
             const int nm = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_LDS128]) ? mid_split[lv] : 0;    // single-GPU schedule only
             const int fl = top_mode | (V.fastpiv ? 2 : 0);
+            // (measured and not kept, r05: in the optimistic schedule the strict launch only on the fronts with > 16 pivots and on a device-built list of
+            // the fronts the static-order launch rejected -- 342 of them on synth_1e6 -- instead of the whole bucket: 18.21 against 18.16 ms.  The
+            // 60-150 us of the strict launches are those fronts' own latency chains, not the workgroups that find nothing to do.)
             if (V.fastpiv) {      // fronts with <= 16 pivots: static-order path first; what it accepts is skipped by the launch behind it
                 if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
                 if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
@@ -1451,6 +1496,10 @@ public:
     }
     int grp_rbw_max = 8;
     int ntfuse = 0;
+    // runs of consecutive tree levels that hold nothing but one-wavefront fronts (order <= 32): one persistent data-flow launch each (k_front_df)
+    struct DfRun { int lv0, lv1, tab0, nlev, nq; };
+    std::vector<DfRun> df_runs; std::vector<int> df_run_at; const DfLevel* d_dftab = nullptr; int df_grid_cap = 0;
+    bool df_on = getenv("MI355X_KKT_NO_FRONT_DF") == nullptr;
     int lc_levels = 0, lc_nchains = 0;      // leaf chains: the tree levels below lc_levels are lc_nchains chains of fronts of order <= 16 (k_leaf_chain)
     bool p1_small_tiles = getenv("MI355X_KKT_NO_P1_SMALL") == nullptr;
     std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path
@@ -1539,6 +1588,11 @@ public:
         const int lc = (optimistic && lc_levels > 0) ? lc_levels : 0;      // the leaf chains: one launch for their levels (optimistic schedule only: no strict kernel behind it)
         if (lc > 0) LAUNCH(KK_FRONT_WAVE, k_leaf_chain, dim3((lc_nchains + 3) / 4), dim3(64), 0, stream, V, lc_nchains);
         for (int lv = lc; lv < Sy.num_levels; ++lv) {
+            if (optimistic && df_run_at[lv] >= 0) {      // a run of levels of one-wavefront fronts: one persistent data-flow launch (optimistic schedule only: no strict kernels behind it)
+                const DfRun& R = df_runs[df_run_at[lv]];
+                LAUNCH(KK_FRONT_WAVE, k_front_df, dim3(std::min(R.nq, df_grid_cap)), dim3(64), 0, stream, V, d_dftab + R.tab0, R.nlev, R.nq);
+                lv = R.lv1; continue;
+            }
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
@@ -1566,7 +1620,8 @@ public:
         if (!factor_once(dvals, reuse, st)) return false;
         if (optimistic && (h_stats[8] != 0 || h_stats[9] != 0)) { // some front was left for a strict launch that was not there / a pivot block without a safety copy was rejected: the full schedule, same values
             optimistic = false; optimistic_ok = false;            // ... and from now on for this structure: a matrix family that needs the strict kernels once needs them again
-            if (opt.verbose) fprintf(stderr, "[mi355x_kkt] factor: the optimistic schedule met a front for the strict kernels, running the full one\n");
+            if (opt.verbose) fprintf(stderr, h_stats[10] ? "[mi355x_kkt] factor: a wait of the data-flow launch over the small-front levels timed out (device shared?), running the full schedule\n"
+                                                           : "[mi355x_kkt] factor: the optimistic schedule met a front for the strict kernels, running the full one\n");
             return factor_once(nullptr, true, st);
         }
         return true;

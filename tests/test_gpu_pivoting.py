@@ -267,3 +267,34 @@ def test_delayed_pivots_keep_the_callers_buffers_and_the_device_state():
     x3 = b.copy()
     assert st == kkt.SUCCESS and s.multi_solve(False, x3) == kkt.SUCCESS
     assert np.abs(2.0 * x3 - x).max() <= 1e-9 * max(1.0, np.abs(x).max())
+
+
+def test_a_rejected_optimistic_run_leaves_nothing_behind_for_the_full_schedule():
+    """One handle, three matrices of one structure: a friendly one (the optimistic schedule: leaf chains + the data-flow launch over the runs of
+    small-front levels, k_front_df, accept everything), a hostile one (multipliers of 1e5 .. 1e6 against the static path's bound of 1e4, fronts rejected: factor() repeats with the full schedule and keeps it for the
+    life of the handle), another friendly one.  Every solve must be as good as a fresh handle's: a front of order 17 .. 32 that k_front_df had
+    marked "done by the static-order kernel" was skipped by the strict kernel of the full schedule ever after (found on LukVlE5, iteration 8)."""
+    N = 20000
+    n, r, c, vh = kktgen.hostile_band_kkt(N, frac=0.15, tiny=1e-5, seed=4)
+    _, r1, c1, v1, _ = kktgen.lukvl_like(N, seed=4)
+    _, _, _, v2, _ = kktgen.lukvl_like(N, seed=4, sigma_scale=0.5)
+    assert np.array_equal(r, r1) and np.array_equal(c, c1)
+    s = ipopt_amd.KKTSolver(pivtol=1e-8, scaling=0, delay_rounds=0)
+    s.initialize_structure(n, r, c, vals=v1)
+    xt = np.ones(n)
+    for v in (v1, vh, v2, v1):
+        K = kktgen.to_scipy(n, r, c, v)
+        b = K @ xt
+        s.values()[:] = v
+        x = b.copy()
+        st = s.multi_solve(True, x)
+        if v is vh:      # (without delayed pivots this matrix may be answered "singular": what matters is that the full schedule has run on this handle)
+            assert st in (kkt.SUCCESS, kkt.SINGULAR)
+            continue
+        assert st == kkt.SUCCESS
+        f = ipopt_amd.KKTSolver(pivtol=1e-8, scaling=0, delay_rounds=0)
+        f.initialize_structure(n, r, c, vals=v); f.values()[:] = v
+        xf = b.copy()
+        assert f.multi_solve(True, xf) == kkt.SUCCESS
+        assert s.number_of_neg_evals() == f.number_of_neg_evals() == N - 2
+        assert np.abs(x - xt).max() <= 1e-7 and np.abs(x - xf).max() <= 1e-7, (np.abs(x - xt).max(), np.abs(x - xf).max())
