@@ -9,7 +9,7 @@ import bench, ipopt_amd
 
 wl = sys.argv[1] if len(sys.argv) > 1 else "synth_1e6"
 n, r, c, v, _ = bench.make_workload(wl)
-s = ipopt_amd.KKTSolver()
+s = ipopt_amd.KKTSolver(device=-1)
 s.initialize_structure(n, r, c, vals=v)
 I = s.info(); g = s.symbolic
 colptr, rowptr = g(1, I.num_sn + 1).astype(np.int64), g(2, I.num_sn + 1).astype(np.int64)
