@@ -848,6 +848,11 @@ static bool finish_analysis(Symbolic& S, const SymbolicOptions& opt, const std::
     {
         auto K = [&](int s) { return (int64_t)(S.sn_colptr[s + 1] - S.sn_colptr[s]); };
         auto Mf = [&](int s) { return (int64_t)(S.sn_rowptr[s + 1] - S.sn_rowptr[s]); };
+        // (measured and not kept, r05: the TAIL links of the root chain -- synth_1e6: (146, 63) -> (83, 63) -> (20, 20), strict pivot loops of one workgroup
+        // at the very end, 104 + 29 us; MBndryCntrl1 N = 100: 141 + 82 us of 1 350 -- classed BIG so that they join their predecessor's chain group.  A
+        // BIG front's pivot block only sees its own k x k block (the rows below are tested a posteriori), a small front's strict loop the whole column:
+        // on the dense hostile grid at u = 0.01 the delayed-pivot loop then needed a ninth edit for one column of the tail.  The pivoting of the last
+        // fronts of the tree is not worth 0.5 % of a factorisation.)
         for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG)
             for (int q = S.child_ptr[s]; q < S.child_ptr[s + 1]; ++q) {
                 const int c = S.child_idx[q];

@@ -14,7 +14,7 @@ def fetch(solver):
     return dict(info=I, perm=g(0, I.n), colptr=g(1, I.num_sn + 1), rowptr=g(2, I.num_sn + 1), rows=g(3, I.sum_sn_rows),
                 parent=g(4, I.num_sn), level=g(5, I.num_sn), rel=g(6, I.sum_sn_rows), acolptr=g(7, I.n + 1),
                 arow=g(8, I.nnz_a), t2s=g(9, I.nnz_in), pair=g(10, I.n), owner=g(11, I.num_sn), apos=g(12, I.nnz_a),
-                glo=g(18, I.num_sn), gsz=g(19, I.num_sn), gdepth=g(20, I.num_sn))
+                glo=g(18, I.num_sn), gsz=g(19, I.num_sn), gdepth=g(20, I.num_sn), cls=g(23, I.num_sn))
 
 
 def factor_solve(sym, vals, rhs, only=None):
@@ -208,6 +208,12 @@ def ldlt_front(F, k, u, u2, small=1e-20, see_update_rows=True, cnorm=None):
 
 
 BIG_FRONT = 128      # fronts above this order take the blocked path: in-block test + a posteriori test on the rows below
+
+
+def is_big(sym, s, m):
+    """The blocked path: class 3 in the library's own classification (symbolic.cpp: order > 128)."""
+    return sym["cls"][s] == 3 if "cls" in sym else m > BIG_FRONT
+
 FAST_U = 1e-4        # a pivot block taken in natural order is accepted iff every multiplier is <= 1 / max(u, u2, FAST_U)
 
 
@@ -312,7 +318,7 @@ def factor_solve_pivoted(sym, vals, rhs, u=1e-8, u2=1e-4, small=1e-20, fast_bloc
             F[np.ix_(rl, rl)] += cbs[ch]
             bs[rl] += cvec[ch]
             cbs[ch] = None
-        if m <= BIG_FRONT:
+        if not is_big(sym, s, m):
             # static-order path first: fronts of order <= 16 (k_front_dpp16) and of order 65 .. 128 with <= 16 pivots (front_fast16)
             st = ldlt_front_static(F, k, u, u2, small, cnorm=cn[c0:c1]) if (fast_blocks and (m <= 16 or (m >= FAST16_MIN_M and k <= 16))) else None
             if st is None:

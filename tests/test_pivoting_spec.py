@@ -120,7 +120,7 @@ def test_blocked_a_posteriori_rule_of_the_big_pivot_blocks():
     s = ipopt_amd.KKTSolver(scaling=0)
     s.initialize_structure(n, r, c, vals=v)
     sym = mirror.fetch(s)
-    nbig = int(((sym["rowptr"][1:] - sym["rowptr"][:-1]) > mirror.BIG_FRONT).sum())
+    nbig = int((sym["cls"] == 3).sum())
     assert nbig > 5
     out = {}
     for fast in (True, False):
@@ -155,7 +155,7 @@ def test_hostile_grid_specification_against_the_delaying_oracle(u):
     xo, oneg, ozero, _ = ko.factor_solve(n, r, c, v, b, u=u)
     assert st["num_neg"] == oneg == true_neg and st["num_zero"] == ozero == 0
     assert np.abs(xo - xt).max() <= 1e-6 and np.abs(x - xt).max() <= 1e-6
-    nbig = int((np.diff(sym["rowptr"]) > mirror.BIG_FRONT).sum())
+    nbig = int((sym["cls"] == 3).sum())
     assert nbig >= 10 and st["num_fast"] < nbig              # some pivot blocks of the big fronts need the strict rule at either u
     assert st["num_two"] >= 20 and st["u_sensitive"] == 1
     if u == 0.01:

@@ -256,16 +256,17 @@ def test_chain_groups_are_consistent():
     I = s.info(); nsn = I.num_sn
     cp, rp = s.symbolic(1, nsn + 1), s.symbolic(2, nsn + 1)
     rows, par, lev = s.symbolic(3, rp[-1]), s.symbolic(4, nsn), s.symbolic(5, nsn)
-    gpos, grem, alias = s.symbolic(15, nsn), s.symbolic(16, nsn), s.symbolic(17, nsn)
+    gpos, grem, alias, cls = s.symbolic(15, nsn), s.symbolic(16, nsn), s.symbolic(17, nsn), s.symbolic(23, nsn)
     k, m = np.diff(cp), np.diff(rp)
     assert (alias >= 0).sum() > 0 and gpos.max() >= 1, "the test matrix must produce separator chains"
+    assert np.array_equal(cls, np.where(m <= 32, 0, np.where(m <= 64, 1, np.where(m <= 128, 2, 3))))      # kernel class of a front = its order's
     nxt = {}
     for p in range(nsn):
         ch = alias[p]
         if ch < 0:
             assert gpos[p] == 0
             continue
-        assert par[ch] == p and m[p] > 128 and m[ch] > 128
+        assert par[ch] == p and cls[p] == 3 and cls[ch] == 3
         assert np.array_equal(rows[rp[ch] + k[ch]:rp[ch + 1]], rows[rp[p]:rp[p + 1]])       # the front IS the child's update block
         if gpos[p] > 0:
             assert gpos[p] == gpos[ch] + 1 and lev[p] == lev[ch] + 1
