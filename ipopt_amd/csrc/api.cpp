@@ -11,6 +11,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <chrono>
 #include <vector>
 
 using namespace mi355x;
@@ -83,18 +84,23 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         // out initialises the runtime -- a good part of what is to be overlapped -- so the CALLER does the warm-up and the helper thread the analysis,
         // which is plain host code.  The thread is joined on every path out of this scope, exceptions included (a joinable std::thread that is destroyed
         // terminates the process); what it threw comes back as its error.
+        auto wall_ = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double t_in = wall_();
         void* pre = nullptr;
         bool aok = false; std::string aerr;
         {
             struct Joiner { std::thread t; ~Joiner() { if (t.joinable()) t.join(); } } an;
             an.t = std::thread([&] {
-                try { aok = analyse(h->sym, so, n, nnz, row, col, format, vals); if (!aok) aerr = h->sym.error; }
+                try { aok = analyse(h->sym, so, n, nnz, row, col, format, vals); if (!aok) aerr = h->sym.error;
+                      if (h->opts.verbose >= 2) fprintf(stderr, "[mi355x_kkt]   analyse() returned %.3f s after the call\n", wall_() - t_in); }
                 catch (const std::bad_alloc&) { aok = false; aerr = "analyse: out of host memory"; }
                 catch (...) { aok = false; aerr = "analyse: unexpected exception"; }
             });
             try { pre = Numeric::prewarm(h->opts.device, (size_t)(nnz > 0 ? nnz : 1)); } catch (...) { pre = nullptr; }
+            if (h->opts.verbose >= 2) fprintf(stderr, "[mi355x_kkt]   device warm-up done %.3f s after the call\n", wall_() - t_in);
         }
         struct PreGuard { void*& p; bool taken; ~PreGuard() { if (!taken && p) { Numeric::prewarm_discard(p); p = nullptr; } } } pg{pre, false};      // (released on every path on which setup() does not take it)
+        if (h->opts.verbose >= 2) fprintf(stderr, "[mi355x_kkt]   analysis thread and device warm-up joined %.3f s after the call\n", wall_() - t_in);
         if (!aok) { h->err = aerr; return MI355X_KKT_FATAL; }
         h->analysed = true; h->base_nnz_l = h->sym.nnz_l;
         // device setup is attempted right away so that values_buffer() can hand out pinned memory;
@@ -109,6 +115,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         pg.taken = true;                       // (setup owns the buffer from here on, whether it succeeds or not)
         h->numeric_ready = h->num->setup(h->sym, no);
         if (!h->numeric_ready) h->err = h->num->error();
+        if (h->opts.verbose >= 2) fprintf(stderr, "[mi355x_kkt]   device set-up done %.3f s after the call\n", wall_() - t_in);
         return MI355X_KKT_SUCCESS;
     } catch (const std::bad_alloc&) { h->err = "analyse: out of host memory"; return MI355X_KKT_FATAL; }
     catch (...) { h->err = "analyse: unexpected exception"; return MI355X_KKT_FATAL; }

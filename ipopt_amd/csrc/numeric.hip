@@ -1305,6 +1305,7 @@ public:
             !dalloc(&d_stats, 12) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
             !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_p, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
+        lap("device allocations");
         if (opt.scaling >= 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
         else if (opt.scaling == 2 && !d_user_scale) opt.scaling = 1;       // (user factors can only come through set_scaling)
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
@@ -1350,6 +1351,7 @@ public:
         // sweeps of a small system could meet flags / tagged messages left in recycled device memory by an earlier handle (or process) before
         // the zero fill has landed
         HIPCHK(hipDeviceSynchronize());
+        lap("kernel attributes, zero fills landed");
         ready = true;
         if (keep && comm_kind == 2) make_subcomms();
         return true;

@@ -34,10 +34,11 @@ names = ["start", "F(q-1) seen", "solved", "S flag", "updated", "F start", "F fl
 for q in range(4):
     row = g[8 * q:8 * q + 8]
     if row[0] == 0: continue
-    print("  role %d: " % q + "  ".join("%s %.1f" % (names[i], (row[i] - t0) / 100.0) for i in range(8) if row[i] >= t0))
+    print("  role %d: " % q + "  ".join("%s %.1f" % (names[i], (row[i] - t0) / 100.0) for i in range(8) if t0 <= row[i] < t0 + 10**8))      # (a stamp that this schedule does not take stays 0 or keeps an old value)
 
 ps = o[40:48]
-print("sub-block 0, wavefront 0 (cycles): load %d  factor %d  checks %d  inverse %d  store %d | to barrier B %d, to barrier C %d" % (ps[1]-ps[0], ps[2]-ps[1], ps[3]-ps[2], ps[4]-ps[3], ps[5]-ps[4], ps[6]-ps[5], ps[7]-ps[6]))
+if all(0 <= ps[i + 1] - ps[i] < 10**8 for i in range(7)):
+    print("sub-block 0, wavefront 0 (cycles): load %d  factor %d  checks %d  inverse %d  store %d | to barrier B %d, to barrier C %d" % (ps[1]-ps[0], ps[2]-ps[1], ps[3]-ps[2], ps[4]-ps[3], ps[5]-ps[4], ps[6]-ps[5], ps[7]-ps[6]))
 
 r = o[64:92]
 if r[4] and r[0]:
