@@ -503,6 +503,7 @@ public:
         { std::vector<GrpSched*> all{&gs_single, &gs_local}; for (auto& g : gs_stage) all.push_back(&g);
           for (GrpSched* g : all) { for (auto e : g->evA) if (e) (void)hipEventDestroy(e); for (auto e : g->evB) if (e) (void)hipEventDestroy(e); g->evA.clear(); g->evB.clear(); } }
         for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
+        for (auto* v : {&side_evF, &side_evJ}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
         ch_bulk_last = ch_far_last = la_last = nullptr; ch_bulk_pending = ch_far_pending = la_pending = false;
         if (!keep) {
             if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
@@ -1312,7 +1313,7 @@ public:
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
         if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 128)) return false; }
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
-        V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn;
+        V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn; V.xcd_affine = getenv("MI355X_KKT_NO_XCD_AFFINE") ? 0 : 1;
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_big_diag_reg<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1498,6 +1499,10 @@ public:
     }
     int grp_rbw_max = 8;
     int ntfuse = 0;
+    // A handful of small fronts on a level whose bulk is elsewhere (synth_1e6: 3 fronts of order <= 128 next to 2 045 big ones; one front of order <= 64
+    // next to 943 of order <= 128) is a launch of 1-3 workgroups running their strict pivot loops for 40-90 us with the chip idle.  The buckets of one level
+    // are independent: in the eager (multi-stream) schedule such a bucket goes to the third stream, next to the level's main launches.
+    std::vector<hipEvent_t> side_evF, side_evJ; bool side_on = getenv("MI355X_KKT_NO_SIDE_SMALL") == nullptr; static constexpr int SIDE_MAX_FRONTS = 16;
     // runs of consecutive tree levels that hold nothing but one-wavefront fronts (order <= 32): one persistent data-flow launch each (k_front_df)
     struct DfRun { int lv0, lv1, tab0, nlev, nq; };
     std::vector<DfRun> df_runs; std::vector<int> df_run_at; const DfLevel* d_dftab = nullptr; int df_grid_cap = 0;
@@ -1595,11 +1600,24 @@ public:
                 LAUNCH(KK_FRONT_WAVE, k_front_df, dim3(std::min(R.nq, df_grid_cap)), dim3(64), 0, stream, V, d_dftab + R.tab0, R.nlev, R.nq);
                 lv = R.lv1; continue;
             }
+            int lvl_fronts = 0, lvl_max = 0;
+            for (int fc = 0; fc < FC_COUNT; ++fc) { const int nb = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1] - Sy.level_ptr[(size_t)lv * FC_COUNT + fc]; lvl_fronts += nb; lvl_max = std::max(lvl_max, nb); }
+            bool side_open = false;
             for (int fc = 0; fc < FC_COUNT; ++fc) {
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
-                launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv], big_tiles64[lv]);
+                // (the eager schedule only: a multi-stream hipGraph is what factor_once() avoids; not next to the three-stream chain look-ahead)
+                const bool side = side_on && la_any && !chain_la && !multi && fc != FC_BIG && b1 - b0 <= SIDE_MAX_FRONTS && lvl_max >= 8 * (b1 - b0) && lvl_fronts > b1 - b0;
+                if (!side) { launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv], big_tiles64[lv]); continue; }
+                if ((int)side_evF.size() < Sy.num_levels) { side_evF.resize(Sy.num_levels, nullptr); side_evJ.resize(Sy.num_levels, nullptr); }
+                if (!side_evF[lv]) { HIPCHK(hipEventCreateWithFlags(&side_evF[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&side_evJ[lv], hipEventDisableTiming)); }
+                if (!side_open) { HIPCHK(hipEventRecord(side_evF[lv], stream)); HIPCHK(hipStreamWaitEvent(stream3, side_evF[lv], 0)); side_open = true; }      // behind the level below
+                std::swap(stream, stream3);
+                const bool ok = launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv], big_tiles64[lv]);
+                std::swap(stream, stream3);
+                if (!ok) return false;
             }
+            if (side_open) { HIPCHK(hipEventRecord(side_evJ[lv], stream3)); HIPCHK(hipStreamWaitEvent(stream, side_evJ[lv], 0)); }      // the level above reads what they wrote
         }
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
         if (!drain_chain()) return false;
