@@ -238,7 +238,7 @@ public:
     // grouped schedule (single GPU): per level the chain groups whose FIRST link sits there (entries = FrontMeta of the LAST link, sorted by
     // order, split at 1024 rows like the BIG buckets), launch geometry, look-ahead tiles
     bool grouped = false;
-    struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2, p1t, la3, nsplit; std::vector<hipEvent_t> evA, evB; };      // p1t: 64 x 64 tiles of a split front's part 1, la3: tiles of the fronts not split, nsplit: split fronts (among the large ones)
+    struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2, p1t, la3, nsplit; std::vector<hipEvent_t> evA, evB, evC, evD; };      // evC / evD: fork / join of the row blocks launched next to the pivot-row blocks (k_grp_rows); p1t: 64 x 64 tiles of a split front's part 1, la3: tiles of the fronts not split, nsplit: split fronts (among the large ones)
     GrpSched gs_single, gs_local;              // one-GPU schedule; multi-GPU: the rank's own subtrees
     std::vector<GrpSched> gs_stage;            // multi-GPU: the replicated fronts this rank holds, per exchange step (sn_gdepth)
     GrpSched* gs_cur = nullptr;                // ... the step launch_fronts is working on
@@ -501,7 +501,7 @@ public:
         for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
         la_evA.clear(); la_evB.clear();
         { std::vector<GrpSched*> all{&gs_single, &gs_local}; for (auto& g : gs_stage) all.push_back(&g);
-          for (GrpSched* g : all) { for (auto e : g->evA) if (e) (void)hipEventDestroy(e); for (auto e : g->evB) if (e) (void)hipEventDestroy(e); g->evA.clear(); g->evB.clear(); } }
+          for (GrpSched* g : all) { for (auto* v : {&g->evA, &g->evB, &g->evC, &g->evD}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); } } }
         for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
         for (auto* v : {&side_evF, &side_evJ}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
         ch_bulk_last = ch_far_last = la_last = nullptr; ch_bulk_pending = ch_far_pending = la_pending = false;
@@ -1057,7 +1057,7 @@ public:
             // in-place chain never crosses an ownership boundary -- symbolic.cpp only aliases fronts of one owner and one range of ranks -- so neither does a group)
             auto build_groups = [&](GrpSched& G, int which) -> bool {
                 for (auto* v : {&G.g0, &G.g1, &G.split, &G.nrb, &G.tiles64, &G.tiles, &G.la1, &G.la2, &G.p1t, &G.la3, &G.nsplit}) v->assign(Sy.num_levels, 0);
-                G.evA.assign(Sy.num_levels, nullptr); G.evB.assign(Sy.num_levels, nullptr);
+                G.evA.assign(Sy.num_levels, nullptr); G.evB.assign(Sy.num_levels, nullptr); G.evC.assign(Sy.num_levels, nullptr); G.evD.assign(Sy.num_levels, nullptr);
                 if (!grouped) return true;
                 std::vector<std::vector<int>> at(Sy.num_levels);
                 for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
@@ -1087,6 +1087,7 @@ public:
                     }
                     G.split[lv] = nsmall; G.g1[lv] = (int)lvl_list.size();
                     if (G.la2[lv] > 0) { HIPCHK(hipEventCreateWithFlags(&G.evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&G.evB[lv], hipEventDisableTiming)); }
+                    if (G.g1[lv] > G.g0[lv]) { HIPCHK(hipEventCreateWithFlags(&G.evC[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&G.evD[lv], hipEventDisableTiming)); }
                 }
                 if (opt.verbose) fprintf(stderr, "[mi355x_kkt] grouped schedule%s: %d chain groups factored in one launch each (tree levels >= %d)\n",
                                          which == 0 ? "" : (which == 1 ? " (own subtrees)" : " (replicated fronts of one exchange step)"), ng, Sy.grp_cut_level);
@@ -1324,6 +1325,8 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // exact LDS need of the register-tiled front kernel per (level, class) bucket
         reg_lds.assign((size_t)Sy.num_levels * FC_COUNT, 0);
         for (int s = 0; s < Sy.num_sn; ++s) {
@@ -1338,6 +1341,7 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_grp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        HIPCHK(hipFuncSetAttribute((const void*)k_grp_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_assemble2, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));      // (+ 80 bytes of static LDS)
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
@@ -1407,8 +1411,10 @@ public:
             // the fronts the static-order launch rejected -- 342 of them on synth_1e6 -- instead of the whole bucket: 18.21 against 18.16 ms.  The
             // 60-150 us of the strict launches are those fronts' own latency chains, not the workgroups that find nothing to do.)
             if (V.fastpiv) {      // fronts with <= 16 pivots: static-order path first; what it accepts is skipped by the launch behind it
-                if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
-                if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
+                if (nm > 0) { if (fast_occ & 1) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true, 4>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
+                              else LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode); }
+                if (nb - nm > 0) { if (fast_occ & 2) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true, 3>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
+                                   else LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode); }
             }
             if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, fl);
             if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, fl);
@@ -1475,8 +1481,24 @@ public:
             int rbw = 1;
             while (rbw < grp_rbw_max && (b1 - b0) * (4 + (G.nrb[lv] + rbw - 1) / rbw) > 256) rbw *= 2;
             const int nrbw = (G.nrb[lv] + rbw - 1) / rbw;
-            const int st = (b1 - b0) * (4 + nrbw) <= 256 ? 1 : 0;
-            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + nrbw), dim3(256), std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0)), stream, V, b0, st, rbw);
+            const int st = ((b1 - b0) * (4 + nrbw) <= 256 && !grp_nostage) ? 1 : 0;
+            const size_t lds = std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0));
+            // next to a part-2 update still running on the second stream: the pivot-row blocks first (4 workgroups per chain), the row blocks below in a second
+            // launch (see k_grp_fused) -- where that update is the longer of the two (grp_split_min: workgroups of the fused launch from which it pays)
+            const bool cut = la_pending && grp_split_min > 0 && (b1 - b0) * (4 + nrbw) >= grp_split_min && nrbw > 0;
+            // ... or the row blocks NEXT TO the pivot-row blocks, as a launch of the light kernel (k_grp_rows) on the third stream: an update workgroup shares a CU with those
+            const bool rows = la_pending && !multi && !prof_on && grp_rows_min > 0 && (b1 - b0) * (4 + nrbw) >= grp_rows_min && nrbw > 0 && G.evC[lv];
+            if (rows) {
+                HIPCHK(hipEventRecord(G.evC[lv], stream)); HIPCHK(hipStreamWaitEvent(stream3, G.evC[lv], 0));
+                LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4), dim3(256), lds, stream, V, b0, st, 1, 0);
+                hipLaunchKernelGGL(k_grp_rows, dim3(b1 - b0, G.nrb[lv]), dim3(256), trsm_lds_bytes(64, false), stream3, V, b0, 0, 1);
+                HIPCHK(hipEventRecord(G.evD[lv], stream3)); HIPCHK(hipStreamWaitEvent(stream, G.evD[lv], 0));
+            } else if (cut) {
+                const int nrb1 = G.nrb[lv];
+                LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4), dim3(256), lds, stream, V, b0, st, 1, 0);
+                LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, nrb1), dim3(256), lds, stream, V, b0, st, 1, 4);
+            } else
+            LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + nrbw), dim3(256), lds, stream, V, b0, st, rbw, 0);
         }
         if (bs > b0 && G.tiles64[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(G.tiles64[lv], bs - b0), dim3(256), 0, stream, V, b0, 0);
         if (b1 == bs) return true;
@@ -1491,7 +1513,7 @@ public:
             } else LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(G.la1[lv]), nb), dim3(SCHUR_NT), 0, stream, V, bs, 1, 0, 0);
             HIPCHK(hipEventRecord(G.evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, G.evA[lv], 0));
-            LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur, dim3(schur_grid(std::min(G.la2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, bs, 2, G.la2[lv], 0);
+            launch_part2(bs, nb, G.la2[lv]);
             HIPCHK(hipEventRecord(G.evB[lv], stream2));
             la_last = G.evB[lv]; la_pending = true;
         } else if (G.tiles[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(G.tiles[lv]), nb), dim3(SCHUR_NT), 0, stream, V, bs, 0, 0, 0);
@@ -1509,6 +1531,20 @@ public:
     bool df_on = getenv("MI355X_KKT_NO_FRONT_DF") == nullptr;
     int lc_levels = 0, lc_nchains = 0;      // leaf chains: the tree levels below lc_levels are lc_nchains chains of fronts of order <= 16 (k_leaf_chain)
     bool p1_small_tiles = getenv("MI355X_KKT_NO_P1_SMALL") == nullptr;
+    // part 2 of the split updates (second stream, next to the following group's pivot chain): 128 x 128 tiles on 16 wavefronts, or quarter tiles on 4
+    // wavefronts that fit on the CUs a k_grp_fused workgroup occupies (kernels_big.hip.inc: k_big_schur_q / _w)
+    int p2_kernel = getenv("MI355X_KKT_P2_KERNEL") ? atoi(getenv("MI355X_KKT_P2_KERNEL")) : 1;      // default: quarter tiles through LDS (synth_1e6 17.85 -> 17.70 ms, bitwise identical; 2 = straight from L2: 17.92)
+    int grp_split_min = getenv("MI355X_KKT_GRP_SPLIT") ? atoi(getenv("MI355X_KKT_GRP_SPLIT")) : 0;
+    int fast_occ = getenv("MI355X_KKT_FAST_OCC") ? atoi(getenv("MI355X_KKT_FAST_OCC")) : 1;      // bit 0: <256, 6, true> cut to 128 VGPRs (4 workgroups per CU: 2.24 -> 2.13 ms of front_lds128 on synth_1e6), bit 1: <256, 8, true> to 168 (no gain)
+    int grp_rows_min = getenv("MI355X_KKT_GRP_ROWS") ? atoi(getenv("MI355X_KKT_GRP_ROWS")) : 0;
+    bool grp_nostage = getenv("MI355X_KKT_GRP_NOSTAGE") != nullptr;      // (development: 110 KB instead of 143 KB of LDS per k_grp_fused workgroup -- room for a k_big_schur_q workgroup next to it)
+    void launch_part2(int b0, int nb, int ntiles) {
+        const int nvirt = ((ntiles + 7) / 8) * 32;
+        const int wgs = (int)std::min<long long>(nvirt, 4ll * la_wgs);
+        if (p2_kernel == 1)      LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur_q, dim3(wgs, nb), dim3(256), 0, stream2, V, b0, ntiles);
+        else if (p2_kernel == 2) LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur_w, dim3(wgs, nb), dim3(256), 0, stream2, V, b0, ntiles);
+        else LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur, dim3(schur_grid(std::min(ntiles, la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, b0, 2, ntiles, 0);
+    }
     std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path
     bool asm_v1 = false;
     // The column-chunk kernel pays where a level is MANY fronts of a few hundred rows (short columns: the one-wavefront-per-column kernel runs at the
@@ -1555,7 +1591,7 @@ public:
             LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(la_tiles1[lv]), nb), dim3(SCHUR_NT), 0, stream, V, b0, 1, 0, 0);
             HIPCHK(hipEventRecord(la_evA[lv], stream));
             HIPCHK(hipStreamWaitEvent(stream2, la_evA[lv], 0));
-            LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur, dim3(schur_grid(std::min(la_tiles2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, b0, 2, la_tiles2[lv], 0);
+            launch_part2(b0, nb, la_tiles2[lv]);
             HIPCHK(hipEventRecord(la_evB[lv], stream2));
             la_last = la_evB[lv]; la_pending = true;
         } else if (tiles > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur, dim3(schur_grid(tiles), nb), dim3(SCHUR_NT), 0, stream, V, b0, 0, 0, 0);

@@ -649,6 +649,43 @@ static bool finish_analysis(Symbolic& S, const SymbolicOptions& opt, const std::
         }
     }
     S.sum_sn_rows = (int64_t)S.sn_rows.size();
+    // ---- 9b. the side children of in-place chain links go DOWN the chain ----
+    // A separator of a 3-D problem is a chain of 64-column supernodes; link j + 1 is factored IN PLACE in the contribution block of link j (its front IS
+    // link j's update rows) and up to four consecutive links are one launch with ONE rank-256 update (step 12 below) -- if the links after the first have
+    // no other child.  On the MBndryCntrl_3D family 2 of 3 chain links do have one: a dangling subtree whose contribution block is a handful of rows
+    // (median 2), finished many levels below.  Its rows lie in the link's front, hence in the update part of EVERY link below it in the chain: the block
+    // can be extend-added into any of those instead and rides up inside the chain's contribution blocks (the assembly tree may hang a child on any front
+    // down the chain that holds its rows; the elimination order is untouched).  So such a child is handed to the LOWEST link of the chain that still lies
+    // above it in the level order (no level changes: the child is lower than its new parent was already) -- normally the chain's first link, which is
+    // assembled from its children anyway.  The links above come out pure: the chain groups form (N = 50: 212 of 285 GFlop of trailing updates at rank
+    // 193-256, 31 before), their k_big_assemble launches disappear, and a group-end update may be split for the look-ahead (which needs the NEXT group
+    // pure: handing the children to the first link of their own GROUP instead was measured -- no split anywhere, 36.9 ms against 32.7).
+    // Sums are formed in a different order than without the pass.
+    S.num_rehung = 0;
+    if (opt.chain_purify && opt.nranks <= 1) {      // (one GPU only: a rehung child may carry a LARGER index than its new parent, which the subtree-to-rank mapping of step 11 does not expect)
+        vector<int> head(nsn, -1), nxt(nsn, -1), height(nsn, 0), below(nsn, -1);
+        for (int s = nsn - 1; s >= 0; --s) { const int p = S.sn_parent[s]; if (p >= 0) { nxt[s] = head[p]; head[p] = s; } }      // natural children, ascending
+        for (int s = 0; s < nsn; ++s) {
+            const int ms = S.sn_rowptr[s + 1] - S.sn_rowptr[s];
+            int ac = -1;
+            if (ms > 128)
+                for (int c = head[s]; c != -1; c = nxt[c]) {
+                    const int mc = S.sn_rowptr[c + 1] - S.sn_rowptr[c], kc = S.sn_colptr[c + 1] - S.sn_colptr[c];
+                    if (mc > 128 && mc - kc == ms) { ac = c; break; }      // (the structural part of the alias condition of step 12)
+                }
+            below[s] = ac;
+            int h = 0;
+            for (int c = head[s]; c != -1; c = nxt[c]) {
+                if (ac >= 0 && c != ac) {
+                    int b = s, x = ac;
+                    while (x >= 0 && height[x] > height[c]) { b = x; x = below[x]; }
+                    if (b != s) { S.sn_parent[c] = b; ++S.num_rehung; continue; }      // (height[b] > height[c]: the level of b stays what it is)
+                }
+                h = std::max(h, height[c] + 1);
+            }
+            height[s] = h;
+        }
+    }
     // children lists (ascending)
     S.child_ptr.assign(nsn + 1, 0);
     for (int s = 0; s < nsn; ++s) if (S.sn_parent[s] >= 0) S.child_ptr[S.sn_parent[s] + 1]++;
@@ -1343,8 +1380,8 @@ bool analyse(Symbolic& S, const SymbolicOptions& opt, int n, int nnz, const int*
     if (!finish_analysis(S, opt, lap)) return false;
     S.time_analyse = now_s() - t0;
     if (opt.verbose)
-        fprintf(stderr, "[mi355x_kkt] analyse: n=%d nnzA=%d pairs=%d nsn=%d levels=%d maxfront=%d maxsn=%d nnzL=%lld flops=%.3g big=%d  %.3fs\n",
-                n, S.nnz_a, S.num_pairs, S.num_sn, S.num_levels, S.maxfront, S.maxsupernode, (long long)S.nnz_l, (double)S.flops_factor, S.num_big, S.time_analyse);
+        fprintf(stderr, "[mi355x_kkt] analyse: n=%d nnzA=%d pairs=%d nsn=%d levels=%d maxfront=%d maxsn=%d nnzL=%lld flops=%.3g big=%d rehung=%d  %.3fs\n",
+                n, S.nnz_a, S.num_pairs, S.num_sn, S.num_levels, S.maxfront, S.maxsupernode, (long long)S.nnz_l, (double)S.flops_factor, S.num_big, S.num_rehung, S.time_analyse);
     return true;
 }
 
@@ -1387,13 +1424,16 @@ bool restructure_delays(const Symbolic& C, const SymbolicOptions& opt, const std
     }
     vector<int> incount(nsn0 + 1, 0);
     int moved = 0;
+    // the parent in the ELIMINATION tree: the front that holds the first update row (finish_analysis 9b may have hung a side child of a chain link on a
+    // lower link of the chain for the assembly; a delayed column must go where it is eliminated later than its siblings)
+    auto nat_parent = [&](int s) { const int k = C.sn_colptr[s + 1] - C.sn_colptr[s]; return C.sn_rowptr[s] + k < C.sn_rowptr[s + 1] ? C.sn_of[C.sn_rows[C.sn_rowptr[s] + k]] : -1; };
     for (int s = 0; s < nsn0; ++s) {
-        const int p = C.sn_parent[s];
         if (nmark[s] == 0) continue;
+        const int p = nat_parent(s);
         for (int j = C.sn_colptr[s]; j < C.sn_colptr[s + 1]; ++j) if (mk[j]) {
             if (p < 0) { mk[j] = 0; continue; }                                             // a root front has nowhere to delay to
             int t = p;                                                                      // a column that failed before climbs several levels at once
-            for (int h = target[j]; h > 1 && C.sn_parent[t] >= 0; --h) t = C.sn_parent[t];
+            for (int h = target[j]; h > 1 && nat_parent(t) >= 0; --h) t = nat_parent(t);
             target[j] = t; incount[t + 1]++; ++moved;
         }
     }

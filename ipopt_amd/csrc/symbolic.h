@@ -52,6 +52,7 @@ struct SymbolicOptions {
     int    tree_merge  = 0;    // merge small non-contiguous child supernodes into the parent: 1 on, 0 off (default), -1 auto (n <= 4e5)
     int    solve_group = 0;    // 1: the triangular solves also work per chain group (default: per link, measured faster)
     int    chain_group = 4;    // links of an in-place separator chain handled as one unit (1 = off, max 4)
+    int    chain_purify = 1;   // the small side children of in-place chain links are assembled into the chain's first link instead (symbolic.cpp 9b): pure chains => chain groups
     int    wide_panels = 0;    // 1: separator fronts of order >= 512 get 128-column panels (kernels support it; default off)
     int    nranks      = 1;
     int    subcube     = 0;    // multi-GPU: 1 = subtree-to-subcube mapping (a top front is replicated on the ranks beneath it only), 0 = one replicated top
@@ -126,6 +127,7 @@ struct Symbolic {
     int num_gdepths = 1;
     // statistics
     int64_t nnz_l = 0, flops_factor = 0, sum_sn_rows = 0, cb_doubles = 0, l_doubles = 0;
+    int num_rehung = 0;        // side children of chain links assembled further down their chain (SymbolicOptions::chain_purify)
     int maxfront = 0, maxsupernode = 0, num_big = 0;
     double time_analyse = 0;
     std::string error;
