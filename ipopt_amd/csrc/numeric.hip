@@ -1106,25 +1106,36 @@ public:
             const bool chain_only = Sy.alias_child[sn] >= 0 && nch == 0;      // (pure in-place link: nothing to assemble either way)
             asm_fast_ok[q] = (chain_only || (Sy.alias_child[sn] < 0 && nch <= 6)) ? 1 : 0;
         }
-        // tfuse: the contribution block of a front is formed by its trailing update (k_big_schur64: T = sum of the children's contributions - L21 W21^T, written
-        // once) instead of being assembled, read back and written again.  For the fronts whose whole update is ONE k_big_schur64 launch of the single-GPU
-        // schedule: assembled (not in place on a child), order <= 1024, a unit of their own (no chain group), below the grouped top of the tree.
+        // tfuse: the contribution block of a front is formed by its trailing update (T = sum of the children's contributions - L21 W21^T, written once) instead of
+        // being assembled, read back and written again.  A front that is a unit of its own -- assembled (not in place on a child), its update one launch of
+        // k_big_schur64 / k_big_schur -- or (round 5) a whole CHAIN GROUP whose first link is assembled: that link's assembly stops at the group's columns
+        // (asmcut: the panels of all the group's links), the trailing block of the LAST link is formed by the group-end update out of the FIRST link's children.
+        // MI355X_KKT_TFUSE_SMALL: the scope of round 4 (fronts of order <= 1024 below the grouped top that are no chain group).
         std::vector<char> tfuse_of(Sy.num_sn, 0);
+        std::vector<int> asmcut_of(Sy.num_sn, 0);
         ntfuse = 0;
-        if (!multi && getenv("MI355X_KKT_NO_TFUSE") == nullptr)
+        if (!multi && getenv("MI355X_KKT_NO_TFUSE") == nullptr) {
+            const bool wide = getenv("MI355X_KKT_TFUSE_SMALL") == nullptr && !chain_la;
             for (int sn = 0; sn < Sy.num_sn; ++sn) {
-                const int m = Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn], k = Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn], nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
-                if (Sy.sn_class[sn] != FC_BIG || Sy.alias_child[sn] >= 0 || m > 1024 || m <= k || nch > 16) continue;
-                if (Sy.grp_pos[sn] != 0 || Sy.grp_rem[sn] != 0) continue;
-                if (grouped && Sy.sn_level[sn] >= Sy.grp_cut_level) continue;
+                if (Sy.sn_class[sn] != FC_BIG || Sy.grp_rem[sn] != 0) continue;      // (the last link of its group, or a front of its own)
+                int first = sn;
+                for (int j = 0; j < Sy.grp_pos[sn]; ++j) first = Sy.alias_child[first];
+                const int m = Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn], k = Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn], nch = Sy.child_ptr[first + 1] - Sy.child_ptr[first];
+                if (Sy.alias_child[first] >= 0 || m <= k) continue;
+                if (!wide) {
+                    if (m > 1024 || nch > 16 || Sy.grp_pos[sn] != 0) continue;
+                    if (grouped && Sy.sn_level[sn] >= Sy.grp_cut_level) continue;
+                } else if (nch > 96) continue;
                 tfuse_of[sn] = 1; ++ntfuse;
+                asmcut_of[first] = (Sy.sn_rowptr[first + 1] - Sy.sn_rowptr[first]) - (m - k);      // (= k of a front of its own, the group's columns otherwise)
             }
+        }
         if (opt.verbose) fprintf(stderr, "[mi355x_kkt] contribution blocks formed by their update (not assembled): %d of %d big fronts\n", ntfuse, Sy.num_big);
         std::vector<FrontMeta> fm(lvl_list.size());
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
             FrontMeta& M = fm[q];
-            M.tfuse = tfuse_of[sn];
+            M.tfuse = tfuse_of[sn]; M.asmcut = asmcut_of[sn];
             M.s = sn; M.c0 = Sy.sn_colptr[sn]; M.k = Sy.sn_colptr[sn + 1] - M.c0; M.r0 = Sy.sn_rowptr[sn]; M.m = Sy.sn_rowptr[sn + 1] - M.r0;
             M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.alias = Sy.alias_child[sn] >= 0 ? 1 : 0;
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
@@ -1156,6 +1167,7 @@ public:
             const int ch = Sy.child_idx[q]; const int kc = Sy.sn_colptr[ch + 1] - Sy.sn_colptr[ch];
             cm[q].ch = ch; cm[q].relbase = Sy.sn_rowptr[ch] + kc; cm[q].mc = Sy.sn_rowptr[ch + 1] - cm[q].relbase;
             cm[q].owner = child_code(ch); cm[q].cb_off = Sy.cb_off[ch]; cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0; cm[q].cvbase = Sy.cv_off[ch] + kc;
+            cm[q].rlo = cm[q].mc > 0 ? Sy.rel[cm[q].relbase] : (1 << 30); cm[q].rhi = cm[q].mc > 0 ? Sy.rel[cm[q].relbase + cm[q].mc - 1] : -1;      // (rel is ascending)
         }
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0)
             for (int q = Sy.child_ptr[sn]; q < Sy.child_ptr[sn + 1]; ++q) if (Sy.child_idx[q] == Sy.alias_child[sn]) cm[q].aliased = 1;
