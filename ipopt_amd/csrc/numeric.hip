@@ -1098,13 +1098,13 @@ public:
                    gs_stage.assign(ndepth, GrpSched());
                    for (int d = 0; d < ndepth; ++d) if (!build_groups(gs_stage[d], 2 + d)) return false; }
         }
-        asm_fast_ok.assign(lvl_list.size(), 0);
+        asm_fast_ok.assign(lvl_list.size(), 0); h_asmcut.assign(lvl_list.size(), 0);
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
             int nch = 0;
             for (int c = Sy.child_ptr[sn]; c < Sy.child_ptr[sn + 1]; ++c) if (Sy.child_idx[c] != Sy.alias_child[sn]) ++nch;
             const bool chain_only = Sy.alias_child[sn] >= 0 && nch == 0;      // (pure in-place link: nothing to assemble either way)
-            asm_fast_ok[q] = (chain_only || (Sy.alias_child[sn] < 0 && nch <= 6)) ? 1 : 0;
+            asm_fast_ok[q] = chain_only ? 1 : (Sy.alias_child[sn] < 0 ? (nch <= 6 ? std::max(nch, 1) : (asm2_wide ? std::min(nch, (int)ASM_MAXCH) : 0)) : 0);      // (the number of children the front brings to k_big_assemble2's row maps -- a front with more than ASM_MAXCH falls back to the column routine inside the kernel; 0: not for that kernel)
         }
         // tfuse: the contribution block of a front is formed by its trailing update (T = sum of the children's contributions - L21 W21^T, written once) instead of
         // being assembled, read back and written again.  A front that is a unit of its own -- assembled (not in place on a child), its update one launch of
@@ -1135,7 +1135,7 @@ public:
         for (size_t q = 0; q < lvl_list.size(); ++q) {
             const int sn = lvl_list[q];
             FrontMeta& M = fm[q];
-            M.tfuse = tfuse_of[sn]; M.asmcut = asmcut_of[sn];
+            M.tfuse = tfuse_of[sn]; M.asmcut = asmcut_of[sn]; h_asmcut[q] = M.asmcut;      // (-1 below: a pure in-place link, nothing to assemble)
             M.s = sn; M.c0 = Sy.sn_colptr[sn]; M.k = Sy.sn_colptr[sn + 1] - M.c0; M.r0 = Sy.sn_rowptr[sn]; M.m = Sy.sn_rowptr[sn + 1] - M.r0;
             M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.alias = Sy.alias_child[sn] >= 0 ? 1 : 0;
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
@@ -1148,6 +1148,7 @@ public:
                 const int nch = Sy.child_ptr[sn + 1] - Sy.child_ptr[sn];
                 M.solo = (Sy.alias_child[sn] >= 0 && nch == 1) ? 1 : ((Sy.alias_child[sn] < 0 && nch == 0) ? 2 : 0);
             }
+            if (M.selfasm && !M.asmcut) h_asmcut[q] = -1;
             if (q < solve_entry.size() && solve_entry[q] && !Sy.solve_group) {     // per-link solves: every front is its own unit
                 M.gbase += M.gpos; M.gpos = 0; M.grem = 0; M.gcols = M.k;
             }
@@ -1354,7 +1355,7 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_grp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_grp_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_big_assemble2, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));      // (+ 80 bytes of static LDS)
+        HIPCHK(hipFuncSetAttribute((const void*)k_big_assemble2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));      // (+ 1.3 KB of static LDS: the per-child tables)
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
         for (int s = 0; s < Sy.num_sn; ++s) if (Sy.sn_class[s] == FC_BIG) {
@@ -1557,7 +1558,9 @@ public:
         else if (p2_kernel == 2) LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur_w, dim3(wgs, nb), dim3(256), 0, stream2, V, b0, ntiles);
         else LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur, dim3(schur_grid(std::min(ntiles, la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, b0, 2, ntiles, 0);
     }
-    std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path
+    std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path (the number of children it pulls; 0: it cannot)
+    std::vector<int> h_asmcut;              // per launch-list entry: FrontMeta::asmcut
+    bool asm2_wide = getenv("MI355X_KKT_ASM2_WIDE") != nullptr;      // (default off: measured on the MBndryCntrl_3D 50 system, big_assemble 7.16 -> 7.65 ms with the wide scope)
     bool asm_v1 = false;
     // The column-chunk kernel pays where a level is MANY fronts of a few hundred rows (short columns: the one-wavefront-per-column kernel runs at the
     // latency of its load chain there) and every front can take its fast path (at most ASM_MAXCH children to pull, not an in-place link with other
@@ -1567,10 +1570,16 @@ public:
         const int ldi = (mm + 15) & ~15;                    // the children's inverse row maps of one front in LDS: ASM_MAXCH x ldi ints (78 KiB at the largest front of synth_1e6)
         // (... which has to FIT: a level of >= 32 fast-path fronts whose largest order exceeds ~6 780 -- a 3-D problem, or fronts enlarged by a
         // delayed-pivot edit -- would make the launch fail instead of falling back to the column kernel: ADVICE r04)
-        bool v2 = !asm_v1 && nfronts >= 32 && !top_mode && (size_t)ASM_MAXCH * ldi * sizeof(int) <= (size_t)159 * 1024;
-        for (int q = b0; q < b0 + nfronts && v2; ++q) v2 = asm_fast_ok[q] != 0;
+        // Round 5: a front whose contribution block is formed by its update (asmcut) has only its panel columns assembled; a launch of such fronts has no
+        // workgroups behind the largest asmcut.  (MI355X_KKT_ASM2_WIDE: this kernel also for levels of a few dozen fronts with up to ASM_MAXCH = 16 children each
+        // once only their panel columns are assembled -- the MBndryCntrl_3D family; measured slower there than the column kernel, 7.65 against 7.16 ms.)
+        bool v2 = !asm_v1 && !top_mode;
+        int maxch = 1, ncut = 0, cutmax = 0;
+        for (int q = b0; q < b0 + nfronts && v2; ++q) { v2 = asm_fast_ok[q] != 0; maxch = std::max(maxch, (int)asm_fast_ok[q]); if (h_asmcut[q]) { ++ncut; cutmax = std::max(cutmax, h_asmcut[q] > 0 ? h_asmcut[q] : 0); } }
+        v2 = v2 && (size_t)maxch * ldi * sizeof(int) <= (size_t)158 * 1024 && ((nfronts >= 32 && maxch <= 6) || (asm2_wide && ncut == nfronts && cutmax <= 4 * ASM_CH));
         if (!v2) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
-        LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble2, dim3((mm + ASM_CH - 1) / ASM_CH, nfronts), dim3(256), (size_t)ASM_MAXCH * ldi * sizeof(int), stream, V, b0, top_mode, ldi);
+        const int ncols = (ncut == nfronts) ? std::min(mm, cutmax) : mm;      // (every front stops at its asmcut: no workgroups for the columns behind the largest of them)
+        LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble2, dim3((ncols + ASM_CH - 1) / ASM_CH, nfronts), dim3(256), (size_t)maxch * ldi * sizeof(int), stream, V, b0, top_mode, ldi, maxch);
     }
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
         if (single && lv_chain[lv] && !prof_on && !top_mode) return launch_big_chain(lv, b0, bs, b1, mm, kk, tiles_small, tiles);
