@@ -34,6 +34,9 @@ run lukvle5_10000 LukVlE5 10000 norec
 run mbndry2_100 MBndryCntrl2 100 norec
 run mdist1_100 MDistCntrl1 100 norec
 run mbndry3d_12 MBndryCntrl_3D 12 norec
+# the first boundary call of a small 3-D instance: its separator chains have the dangling side children that finish_analysis 9b hangs down the chain
+# (tests/test_symbolic.py::test_side_children_of_chain_links_hang_down_the_chain)
+run mbndry3d_14 MBndryCntrl_3D 14 rec1
 run mbndry3d_30 MBndryCntrl_3D 30 norec      # 3-D separators (fronts of ~2 000 rows at KKT dimension 50 600): SURVEY 8(d)-5's MFMA-bound family at a size the CPU run takes 17 s for
 run mbndry1_300 MBndryCntrl1 300 norec
 # the CUTEst-style ~10^6 stand-in of BASELINE.json configs[4] (n = 492 800, m = 490 000; examples/ScalableProblems/solve_problem.cpp:28-91),

@@ -304,3 +304,73 @@ def test_analysis_is_independent_of_the_thread_count(monkeypatch, shape):
         s.initialize_structure(n, r, c, vals=v)
         perms.append(s.symbolic(0, n).copy())
     assert all(np.array_equal(perms[0], q) for q in perms[1:])
+
+
+def test_side_children_of_chain_links_hang_down_the_chain(monkeypatch, golden_dir):
+    """finish_analysis 9b (DESIGN "Round 5, second half"): on the MBndryCntrl_3D family two of three links of the in-place separator chains have a dangling side
+    child of a few rows; the assembly tree hangs it on a lower link of the chain (the links above come out pure: chain groups, rank-256 updates).  The
+    elimination order, the row structures and the levels must not change, every child's update rows must lie in its (new) parent's front, and the
+    numpy block-multifrontal that walks the exported structures must still factor and solve the system -- here the first KKT matrix of the reference's own
+    MBndryCntrl_3D N = 14 run (tests/golden/mbndry3d_14.kktrec, tests/golden/make_golden.sh)."""
+    import os
+    n, r, c, v, neg = kktgen.recorded_kkt(os.path.join(golden_dir, "mbndry3d_14.kktrec"), which=0)
+    syms = {}
+    for off in (False, True):
+        if off: monkeypatch.setenv("MI355X_KKT_NO_PURIFY", "1")
+        else: monkeypatch.delenv("MI355X_KKT_NO_PURIFY", raising=False)
+        s = ipopt_amd.KKTSolver()
+        s.initialize_structure(n, r, c, vals=v)
+        syms[off] = mirror.fetch(s)
+    a, b = syms[False], syms[True]
+    for key in ("perm", "colptr", "rowptr", "rows", "level"):
+        assert np.array_equal(a[key], b[key]), key
+    moved = np.where(a["parent"] != b["parent"])[0]
+    assert len(moved) >= 20                                   # (51 at the time of writing)
+    colptr, rowptr, rows, par, lev = a["colptr"], a["rowptr"], a["rows"], a["parent"], a["level"]
+    m = np.diff(rowptr); k = np.diff(colptr)
+    for ch in moved:
+        p_new, p_nat = par[ch], b["parent"][ch]
+        assert lev[ch] < lev[p_new] <= lev[p_nat] and m[p_new] > 128          # a lower link of a chain of BIG fronts, still above the child
+        upd = rows[rowptr[ch] + k[ch]:rowptr[ch + 1]]
+        prow = rows[rowptr[p_new] + k[p_new]:rowptr[p_new + 1]]
+        assert np.isin(upd, prow).all()                          # the child's rows lie in the UPDATE part of its new parent: it rides up inside the chain's blocks
+    # the natural parents of the moved children have come out pure where they continue a chain: fewer links with more than one child
+    nch = lambda sym: np.bincount(sym["parent"][sym["parent"] >= 0], minlength=len(m))
+    big = m > 128
+    assert (nch(a)[big] > 1).sum() < (nch(b)[big] > 1).sum()
+    K = kktgen.to_scipy(n, r, c, v)
+    rhs = K @ np.linspace(1.0, 2.0, n)
+    x, nneg = mirror.factor_solve(a, v, rhs)
+    assert nneg == neg
+    assert np.abs(K @ x - rhs).max() <= 1e-9 * np.abs(rhs).max()
+
+
+def test_delays_out_of_rehung_children_follow_the_elimination_tree(golden_dir):
+    """A failed pivot of a side child that 9b has hung on a lower chain link must still be delayed to the front that ELIMINATES later than the child (its parent in
+    the elimination tree), not to the assembly parent: the edited structure is walked by the numpy multifrontal, which must factor and solve the system."""
+    import os
+    n, r, c, v, neg = kktgen.recorded_kkt(os.path.join(golden_dir, "mbndry3d_14.kktrec"), which=0)
+    s = ipopt_amd.KKTSolver()
+    s.initialize_structure(n, r, c, vals=v)
+    a = mirror.fetch(s)
+    colptr, rowptr, rows, par = a["colptr"], a["rowptr"], a["rows"], a["parent"]
+    k = np.diff(colptr)
+    # rehung children: the parent does not hold the child's first update row among its own columns
+    first_upd = np.array([rows[rowptr[i] + k[i]] if rowptr[i] + k[i] < rowptr[i + 1] else -1 for i in range(len(k))])
+    snof = np.repeat(np.arange(len(k)), k)
+    rehung = [i for i in range(len(k)) if par[i] >= 0 and first_upd[i] >= 0 and snof[first_upd[i]] != par[i]]
+    assert len(rehung) >= 20
+    cols = np.array([a["perm"][colptr[i]] for i in rehung[:12]], dtype=np.int32) + 1        # one column of each, caller's (1-based) numbering
+    assert s.delay_columns(cols) == len(cols)
+    e = mirror.fetch(s)
+    assert sorted(e["perm"].tolist()) == list(range(n))
+    for sn in range(e["info"].num_sn):
+        if e["parent"][sn] >= 0:
+            assert e["level"][sn] < e["level"][e["parent"][sn]]
+    # every delayed column now sits in the supernode that held its child's first update row (or a piece of it, if that supernode was cut at 64 columns)
+    iperm = np.empty(n, dtype=np.int64); iperm[e["perm"]] = np.arange(n)
+    K = kktgen.to_scipy(n, r, c, v)
+    rhs = K @ np.linspace(1.0, 2.0, n)
+    x, nneg = mirror.factor_solve(e, v, rhs)
+    assert nneg == neg
+    assert np.abs(K @ x - rhs).max() <= 1e-9 * np.abs(rhs).max()
