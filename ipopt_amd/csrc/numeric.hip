@@ -638,7 +638,67 @@ public:
         }
         opt.prewarmed_vals = nullptr;
         lap("device, streams, pinned buffer");
-        std::vector<long long> poff(Sy.panel_off.begin(), Sy.panel_off.end()), coff(Sy.cb_off.begin(), Sy.cb_off.end()), moff(Sy.minv_off.begin(), Sy.minv_off.end());
+        {   // Everything numeric is allocated once, here; the bulk is ONE pool  L | cb  (every contribution block resident: DESIGN.md "Data layout").  A structure
+            // whose pool does not fit -- a 3-D problem beyond MBndryCntrl_3D N ~ 120 on 288 GB, or a device shared with another process -- is refused with
+            // the numbers, before the allocation is attempted: factor() / solve() then answer MI355X_KKT_FATAL with this message (no partial set-up, no
+            // fallback).  MI355X_KKT_POOL_LIMIT_GIB caps what one handle may take (a GPU shared by several ranks or applications).
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            const double gib = 1.0 / (1024.0 * 1024.0 * 1024.0);
+            const double need = 8.0 * ((double)Sy.l_doubles + (double)Sy.cb_doubles + (double)Sy.wbuf_doubles + (double)Sy.minv_doubles + (double)Sy.cvec_doubles + (double)Sy.gpart_doubles) +
+                                12.0 * (double)Sy.nnz_a + 16.0 * (double)Sy.nnz_in + 12.0 * (double)Sy.rslot_idx.size() + 200.0 * (double)Sy.n;
+            double cap = (double)fr;
+            if (const char* e = getenv("MI355X_KKT_POOL_LIMIT_GIB")) cap = std::min(cap, atof(e) / gib);
+            if (need > cap) {
+                char msg[512];
+                snprintf(msg, sizeof msg, "the factor + contribution-block pool of this structure does not fit the device: %.2f GiB needed (L %.2f + contribution blocks %.2f + work space), "
+                                          "%.2f GiB available (%.2f GiB free of %.2f%s); no out-of-core path, no CPU fallback", need * gib, 8.0 * (double)Sy.l_doubles * gib, 8.0 * (double)Sy.cb_doubles * gib,
+                         cap * gib, (double)fr * gib, (double)tot * gib, getenv("MI355X_KKT_POOL_LIMIT_GIB") ? ", capped by MI355X_KKT_POOL_LIMIT_GIB" : "");
+                err_ = msg; return false;
+            }
+        }
+        // The pool in PIECES (round 5; MI355X_KKT_POOL_PIECE_MIB, default: one block).  hipMalloc of ONE block takes 0.5 s at 16 GiB, 1.4 s at 32, 2.2-2.7 s at the 74 GiB
+        // of MBndryCntrl_3D 78 (tools/micro/malloc_time.hip) -- the largest item of that run's whole set-up -- and ten blocks of 7.4 GiB took 3 ms in the micro benchmark,
+        // but only because the process had held and freed that memory before: in a fresh process twelve pieces cost what the one block costs (1.6-2.1 s: the price is per
+        // byte mapped, whoever asks; a virtual range backed by hipMemCreate / hipMemMap pieces: 4.3 s).  Kept as an option for a device too fragmented for one block.
+        // The layout  L | cb  stays ONE linear offset space (symbolic.cpp step 12); it is cut between the blocks of two fronts (the panel or the contribution block of
+        // a front that is not in place on a child: everything an in-place chain touches lies inside its first link's block) into segments of at most `piece` doubles,
+        // every segment is its own allocation, and an offset of the symbolic structure becomes  offset + (address of its segment - address of segment 0) / 8 - (start
+        // of the segment):  V.L + offset then points into the right allocation; every table the kernels read is built from PO() / CO() below.
+        std::vector<long long> pool_cut, pool_delta;
+        {
+            const long long total = Sy.l_doubles + Sy.cb_doubles;
+            long long piece = 1ll << 60;      // default: ONE block (see above: pieces do not make the allocation faster)
+            if (const char* e = getenv("MI355X_KKT_POOL_PIECE_MIB")) piece = std::max(1ll, atoll(e)) << 17;      // (MiB -> doubles; a device too fragmented for one block, tests)
+            std::vector<long long> starts;
+            starts.reserve(2 * (size_t)Sy.num_sn + 1);
+            for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] < 0) { starts.push_back(Sy.panel_off[sn]); starts.push_back(Sy.l_doubles + Sy.cb_off[sn]); }
+            starts.push_back(total);
+            std::sort(starts.begin(), starts.end());
+            long long cur = 0, last_ok = 0;
+            pool_cut.push_back(0);
+            for (long long b : starts) {
+                if (b <= cur) continue;
+                while (b - cur > piece && last_ok > cur) { cur = last_ok; pool_cut.push_back(cur); }      // (a single block larger than a piece gets a segment of its own size)
+                last_ok = b;
+            }
+            std::vector<char*> base(pool_cut.size(), nullptr);
+            for (size_t i = 0; i < pool_cut.size(); ++i) {
+                const long long end = i + 1 < pool_cut.size() ? pool_cut[i + 1] : total;
+                double* pp = nullptr;
+                if (!dalloc(&pp, (size_t)std::max<long long>(end - pool_cut[i], 1))) return false;
+                base[i] = (char*)pp;
+                pool_delta.push_back((long long)((base[i] - base[0]) / (ptrdiff_t)sizeof(double)) - pool_cut[i]);
+            }
+            V.L = (double*)base[0];
+            if (opt.verbose >= 2) fprintf(stderr, "[mi355x_kkt]   pool: %.2f GiB in %zu pieces\n", 8.0 * (double)total / (1024.0 * 1024.0 * 1024.0), pool_cut.size());
+        }
+        auto pool_remap = [&](long long lin) { const size_t i = (size_t)(std::upper_bound(pool_cut.begin(), pool_cut.end(), lin) - pool_cut.begin()) - 1; return lin + pool_delta[i]; };
+        auto PO = [&](int sn) { return pool_remap(Sy.panel_off[sn]); };                                   // panel of a front, relative to V.L
+        auto CO = [&](int sn) { return pool_remap(Sy.l_doubles + Sy.cb_off[sn]) - Sy.l_doubles; };        // contribution block, relative to V.cb = V.L + l_doubles
+        lap("pool");
+        std::vector<long long> poff(Sy.num_sn), coff(Sy.num_sn), moff(Sy.minv_off.begin(), Sy.minv_off.end());
+        for (int sn = 0; sn < Sy.num_sn; ++sn) { poff[sn] = PO(sn); coff[sn] = CO(sn); }
         multi = opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") != nullptr;   // (1-rank multi path: plumbing tests on a 1-GPU box)
         std::vector<int> lvl_list(Sy.level_sn.begin(), Sy.level_sn.end());
         std::vector<char> solve_entry;      // parallel to lvl_list: 1 = entry of a solve-unit list
@@ -824,7 +884,7 @@ public:
                         for (int q = Sy.level_ptr[(size_t)l * FC_COUNT]; q < Sy.level_ptr[(size_t)l * FC_COUNT + FC_COUNT]; ++q) {
                             const int sn = Sy.level_sn[q], ac = Sy.alias_child[sn];
                             in_seg[sn] = 1;
-                            ChainLink L{}; L.panel_off = Sy.panel_off[sn]; L.minv_off = Sy.minv_off[sn]; L.c0 = Sy.sn_colptr[sn]; L.k = Kc(sn); L.ldp = Sy.sn_ldp[sn];
+                            ChainLink L{}; L.panel_off = PO(sn); L.minv_off = Sy.minv_off[sn]; L.c0 = Sy.sn_colptr[sn]; L.k = Kc(sn); L.ldp = Sy.sn_ldp[sn];
                             L.s = sn; L.r0 = Sy.sn_rowptr[sn];
                             const int cprev = (ac >= 0 && nchild(sn) == 1 && Sy.sn_level[ac] >= lv) ? chain_of[ac] : -1;
                             if (cprev >= 0) {          // next link of its child's chain (the child is that chain's last link so far)
@@ -922,10 +982,10 @@ public:
             gbase_of[sn] = (int)gt.size(); gcols_of[sn] = 0;
             for (int l : links) {
                 GroupLink G;
-                G.panel_off = Sy.panel_off[l]; G.wb = Sy.wb_off[l]; G.minv_off = Sy.minv_off[l]; G.cv = Sy.cv_off[l]; G.tr = troff[l];
+                G.panel_off = PO(l); G.wb = Sy.wb_off[l]; G.minv_off = Sy.minv_off[l]; G.cv = Sy.cv_off[l]; G.tr = troff[l];
                 G.c0 = Sy.sn_colptr[l]; G.k = Sy.sn_colptr[l + 1] - G.c0; G.r0 = Sy.sn_rowptr[l]; G.m = Sy.sn_rowptr[l + 1] - G.r0;
                 G.ldp = Sy.sn_ldp[l]; G.ch0 = Sy.child_ptr[l]; G.ch1 = Sy.child_ptr[l + 1]; G.alias = Sy.alias_child[l] >= 0 ? 1 : 0;
-                G.t_off = Sy.cb_off[l]; G.ldt = Sy.sn_ldt[l]; G.s = l; G.aq0 = Sy.acolptr[G.c0]; G.aq1 = Sy.acolptr[G.c0 + G.k]; G.bigidx = bigidx_of[l];
+                G.t_off = CO(l); G.ldt = Sy.sn_ldt[l]; G.s = l; G.aq0 = Sy.acolptr[G.c0]; G.aq1 = Sy.acolptr[G.c0 + G.k]; G.bigidx = bigidx_of[l];
                 G.selfasm = ((!multi || aoff[l] < 0) && getenv("MI355X_KKT_NO_SELFASM") == nullptr && Sy.alias_child[l] >= 0 && Sy.child_ptr[l + 1] - Sy.child_ptr[l] == 1) ? 1 : 0;
                 gt.push_back(G); gcols_of[sn] += G.k;
             }
@@ -1139,7 +1199,7 @@ public:
             M.s = sn; M.c0 = Sy.sn_colptr[sn]; M.k = Sy.sn_colptr[sn + 1] - M.c0; M.r0 = Sy.sn_rowptr[sn]; M.m = Sy.sn_rowptr[sn + 1] - M.r0;
             M.aq0 = Sy.acolptr[M.c0]; M.aq1 = Sy.acolptr[M.c0 + M.k]; M.ch0 = Sy.child_ptr[sn]; M.ch1 = Sy.child_ptr[sn + 1]; M.alias = Sy.alias_child[sn] >= 0 ? 1 : 0;
             M.ldp = Sy.sn_ldp[sn]; M.ldt = Sy.sn_ldt[sn];
-            M.panel_off = Sy.panel_off[sn]; M.cb_off = Sy.cb_off[sn]; M.minv_off = Sy.minv_off[sn];
+            M.panel_off = PO(sn); M.cb_off = CO(sn); M.minv_off = Sy.minv_off[sn];
             M.cv = Sy.cv_off[sn]; M.wb = Sy.wb_off[sn]; M.gpart = Sy.gpart_off[sn];
             M.gbase = gbase_of[sn]; M.gpos = Sy.grp_pos[sn]; M.grem = Sy.grp_rem[sn]; M.gcols = gcols_of[sn]; M.split = split_of[sn]; M.ttab = ttab_of[sn]; M.ttab2 = ttab2_of[sn];
             // (multi-GPU: not for a front at a subtree join -- its square comes out of the all-reduced arena)
@@ -1167,7 +1227,7 @@ public:
         for (size_t q = 0; q < cm.size(); ++q) {
             const int ch = Sy.child_idx[q]; const int kc = Sy.sn_colptr[ch + 1] - Sy.sn_colptr[ch];
             cm[q].ch = ch; cm[q].relbase = Sy.sn_rowptr[ch] + kc; cm[q].mc = Sy.sn_rowptr[ch + 1] - cm[q].relbase;
-            cm[q].owner = child_code(ch); cm[q].cb_off = Sy.cb_off[ch]; cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0; cm[q].cvbase = Sy.cv_off[ch] + kc;
+            cm[q].owner = child_code(ch); cm[q].cb_off = CO(ch); cm[q].ldt = Sy.sn_ldt[ch]; cm[q].aliased = 0; cm[q].cvbase = Sy.cv_off[ch] + kc;
             cm[q].rlo = cm[q].mc > 0 ? Sy.rel[cm[q].relbase] : (1 << 30); cm[q].rhi = cm[q].mc > 0 ? Sy.rel[cm[q].relbase + cm[q].mc - 1] : -1;      // (rel is ascending)
         }
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.alias_child[sn] >= 0)
@@ -1290,31 +1350,12 @@ public:
             !upload(Sy.sn_parent, &V.sn_parent) || !upload(colown, &V.col_owner) || !upload(aoff, &V.arena_off) || !upload(troff, &V.top_rhs_off) ||
             !upload(Sy.perm, &V.perm)) return false;
         lap("uploads");
-        {   // Everything numeric is allocated once, here; the bulk is ONE pool  L | cb  (every contribution block resident: DESIGN.md "Data layout").  A structure
-            // whose pool does not fit -- a 3-D problem beyond MBndryCntrl_3D N ~ 120 on 288 GB, or a device shared with another process -- is refused with
-            // the numbers, before the allocation is attempted: factor() / solve() then answer MI355X_KKT_FATAL with this message (no partial set-up, no
-            // fallback).  MI355X_KKT_POOL_LIMIT_GIB caps what one handle may take (a GPU shared by several ranks or applications).
-            size_t fr = 0, tot = 0;
-            (void)hipMemGetInfo(&fr, &tot);
-            const double gib = 1.0 / (1024.0 * 1024.0 * 1024.0);
-            const double need = 8.0 * ((double)Sy.l_doubles + (double)Sy.cb_doubles + (double)Sy.wbuf_doubles + (double)Sy.minv_doubles + (double)Sy.cvec_doubles + (double)Sy.gpart_doubles) +
-                                12.0 * (double)Sy.nnz_a + 16.0 * (double)Sy.nnz_in + 12.0 * (double)Sy.rslot_idx.size() + 200.0 * (double)Sy.n;
-            double cap = (double)fr;
-            if (const char* e = getenv("MI355X_KKT_POOL_LIMIT_GIB")) cap = std::min(cap, atof(e) / gib);
-            if (need > cap) {
-                char msg[512];
-                snprintf(msg, sizeof msg, "the factor + contribution-block pool of this structure does not fit the device: %.2f GiB needed (L %.2f + contribution blocks %.2f + work space), "
-                                          "%.2f GiB available (%.2f GiB free of %.2f%s); no out-of-core path, no CPU fallback", need * gib, 8.0 * (double)Sy.l_doubles * gib, 8.0 * (double)Sy.cb_doubles * gib,
-                         cap * gib, (double)fr * gib, (double)tot * gib, getenv("MI355X_KKT_POOL_LIMIT_GIB") ? ", capped by MI355X_KKT_POOL_LIMIT_GIB" : "");
-                err_ = msg; return false;
-            }
-        }
         double* tv = keep ? keep_tvals : nullptr;
         if (!tv && !dalloc(&tv, Sy.nnz_in)) return false;
         V.tvals = tv;
         V.rslot_len = (int)Sy.rslot_idx.size();
         if (!dalloc(&V.arv, Sy.rslot_idx.size()) || !dalloc(&V.aval, Sy.nnz_a) || !dalloc(&V.scale, Sy.n) || !dalloc(&V.scale2, Sy.n) || !dalloc(&V.rowmax, Sy.n) ||
-            !dalloc(&V.L, (size_t)(Sy.l_doubles + Sy.cb_doubles)) || !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
+            !dalloc(&V.wbuf, (size_t)Sy.wbuf_doubles) || !dalloc(&V.minv, (size_t)Sy.minv_doubles) ||
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 12) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
