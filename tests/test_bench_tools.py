@@ -68,3 +68,23 @@ def test_kernel_code_hash_survives_a_rebuild_and_sees_a_changed_kernel(tmp_path)
     cuid = [[w for w in s.split() if w.startswith("__hip_cuid_")] for s in syms]
     assert cuid[0] and cuid[1] and cuid[0] != cuid[1]            # the two builds really differ where round 4's hash looked
     assert bench.kernel_code_hash("k_no_such_kernel", lib=a) is None
+
+
+def test_host_only_model_tools_run_without_a_device():
+    """tools/level_model.py (per-level work model) and tools/mem_plan.py (what a recycling plan of the contribution blocks would need) are host tools: they run
+    on a box without a GPU, and their totals are consistent with the analysis (every block resident = Info.cb_doubles)."""
+    import re
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mem_plan.py"), "grid_1e5", "0", "8"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    out = p.stdout
+    tot = float(re.search(r"every block resident: ([0-9.]+) GiB", out).group(1))
+    pools = [float(x) for x in re.findall(r"-> pool\s+([0-9.]+) GiB", out)]
+    assert len(pools) == 2 and 0.0 < pools[0] <= pools[1] <= tot + 0.01
+    sys.path.insert(0, ROOT)
+    import bench, ipopt_amd
+    n, r, c, v, _ = bench.make_workload("grid_1e5")
+    s = ipopt_amd.KKTSolver(device=-1)
+    s.initialize_structure(n, r, c, vals=v)
+    assert abs(8.0 * s.info().cb_doubles / 2 ** 30 - tot) <= 0.01
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "level_model.py"), "grid_1e5"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert p.returncode == 0 and "big fronts=" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]
