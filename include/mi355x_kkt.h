@@ -266,7 +266,10 @@ const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
  *       front, all ranks for the classic replicated top, the ranks beneath it with opts.subcube), 20 sn_gdepth[num_sn] (bisections of the
  *       machine above that range = the exchange step the front belongs to),
  *       21 dup_ptr[nnz_a + 1], 22 dup_src[nnz_in] (the triplets of every CSC slot in ascending order: the order in which the device sums
- *       duplicates), 23 sn_class[num_sn] (kernel class of the front: 0 order <= 32, 1 <= 64, 2 <= 128, 3 the blocked path, order > 128) */
+ *       duplicates), 23 sn_class[num_sn] (kernel class of the front: 0 order <= 32, 1 <= 64, 2 <= 128, 3 the blocked path, order > 128),
+ *       24 rslot_ptr[n + 1], 25 rslot_idx[rslot_ptr[n]], 26 rslot_col[rslot_ptr[n]] (the symmetric row view of the permuted pattern the equilibration
+ *       sweeps and the device refinement gather over: for every row its entries of both triangles -- CSC slot and the other index -- by ascending other index).
+ *       sn_parent (4) is the parent in the ASSEMBLY tree: a side child of an in-place chain link may hang on a lower link of that chain (finish_analysis 9b). */
 int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t capacity);
 
 /* ---- measurement: device time per kernel kind (hip events around every launch of an eager, graph-less factor + one

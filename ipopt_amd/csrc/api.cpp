@@ -468,6 +468,7 @@ int mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t cap
         case 15: v = &S.grp_pos; break;    case 16: v = &S.grp_rem; break;   case 17: v = &S.alias_child; break;
         case 18: v = &S.sn_glo; break;     case 19: v = &S.sn_gsz; break;    case 20: v = &S.sn_gdepth; break;
         case 21: v = &S.dup_ptr; break;    case 22: v = &S.dup_src; break;    case 23: v = &S.sn_class; break;
+        case 24: v = &S.rslot_ptr; break;  case 25: v = &S.rslot_idx; break;  case 26: v = &S.rslot_col; break;      // the symmetric row view (equilibration, refinement)
         default: h->err = "get_symbolic: unknown selector"; return MI355X_KKT_FATAL;
     }
     if ((int64_t)v->size() > cap) { h->err = "get_symbolic: buffer too small"; return MI355X_KKT_FATAL; }

@@ -374,3 +374,21 @@ def test_delays_out_of_rehung_children_follow_the_elimination_tree(golden_dir):
     x, nneg = mirror.factor_solve(e, v, rhs)
     assert nneg == neg
     assert np.abs(K @ x - rhs).max() <= 1e-9 * np.abs(rhs).max()
+
+
+def test_row_view_lists_every_entry_of_both_triangles_by_ascending_other_index():
+    """The symmetric row view (selectors 24-26): row i holds every entry (i, c) and (r, i) of the permuted lower pattern once, by ascending other index,
+    with the CSC slot it came from -- what the equilibration sweeps and the device refinement gather over."""
+    n, r, c, v, _ = kktgen.grid_kkt(9, 7, dof=2, ncon=1, seed=3)
+    s = ipopt_amd.KKTSolver()
+    s.initialize_structure(n, r, c, vals=v)
+    acolptr = s.symbolic(7, n + 1); arow = s.symbolic(8, int(acolptr[-1]))
+    acol = np.repeat(np.arange(n), np.diff(acolptr))
+    ptr = s.symbolic(24, n + 1); L = int(ptr[-1]); idx = s.symbolic(25, L); col = s.symbolic(26, L)
+    nd = int((arow != acol).sum())
+    assert L == len(arow) + nd
+    for i in range(n):
+        sl, oc = idx[ptr[i]:ptr[i + 1]], col[ptr[i]:ptr[i + 1]]
+        assert (np.diff(oc) > 0).all()                                         # ascending other index, each once
+        for q, o in zip(sl, oc):
+            assert {int(arow[q]), int(acol[q])} == {i, int(o)}
