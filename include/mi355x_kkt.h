@@ -316,6 +316,15 @@ typedef int (*mi355x_kkt_allreduce_fn)(void* ctx, void* dptr, int64_t count, int
 int  mi355x_kkt_comm_unique_id(void* out128);
 int  mi355x_kkt_set_comm_rccl(mi355x_kkt_handle h, const void* unique_id128);
 int  mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn fn, void* ctx);
+/*   _comm_shm_id           rank 0: creates a POSIX shared-memory segment for `nranks` ranks of ONE node and writes its name into out128 (handed to
+ *                          the other ranks like the RCCL id)
+ *   _set_comm_shm          every rank: attaches (rank 0 unlinks the name once all have) and installs a host-staged sum -- device -> slot, sum of
+ *                          the slots in rank order (bitwise the same on every rank), -> device -- for both collectives above.  For ranks that
+ *                          SHARE a device (RCCL refuses that), bring-up and the one-GPU test box; the production path is RCCL.  A peer that does
+ *                          not arrive within MI355X_KKT_SHM_TIMEOUT_S (300) fails the call: never a hang.  The communicator in the adapter has the
+ *                          reference's MPI_Init-inside-the-interface as its precedent (IpMumpsSolverInterface.cpp:58-75). */
+int  mi355x_kkt_comm_shm_id(void* out128, int nranks);
+int  mi355x_kkt_set_comm_shm(mi355x_kkt_handle h, const void* id128);
 /* Range-local exchange.  A replicated front is held by a RANGE of ranks [rank_lo, rank_lo + nranks_in_range) and what it receives comes from
  * ranks of that range only, so its arena square (lower triangle, packed) and its top right-hand side are summed among those ranks alone:
  * with RCCL through one sub-communicator per exchange step (ncclCommSplit, created by _set_comm_rccl; without it -- or with

@@ -4,6 +4,7 @@
 #include "symbolic.h"
 #include "numeric.h"
 #include "matching_scaling.h"
+#include "comm_shm.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -30,8 +31,10 @@ struct mi355x_kkt_handle_s {
     std::vector<unsigned char> delay_count;   // per column (caller's numbering, 0-based): how often it has been moved up
     // latches of the delayed-pivot loop, cleared by analyse():
     bool delays_exhausted = false; // an edit ran into the growth cap (or nothing could move any more): static pivoting from here on, no more edits are built
+    int  zero_futile_events = 0;   // consecutive rounds driven by ZERO pivots alone that did not lower their number (latched at 2: see zero_delay_futile)
     bool zero_delay_futile = false;// a round driven by ZERO pivots alone did not lower their number: the matrix is singular (a dependent row is a zero pivot
                                    // wherever it is eliminated) -- later factorisations whose only complaint is zero pivots answer SINGULAR at once
+    ShmComm* shm = nullptr;        // the shared-memory communicator of set_comm_shm (owned; the Numeric object only holds the callbacks' context)
     std::string err;
     std::vector<double> host_vals_nodev;   // plain host staging buffer handed out when no device exists (values only, never computed on)
 };
@@ -62,7 +65,7 @@ int mi355x_kkt_create(mi355x_kkt_handle* h, const mi355x_kkt_options* opts)
 void mi355x_kkt_destroy(mi355x_kkt_handle h)
 {
     if (!h) return;
-    try { delete h->num; delete h; } catch (...) {}
+    try { delete h->num; shm_comm_destroy(h->shm); delete h; } catch (...) {}
 }
 
 const char* mi355x_kkt_last_error(mi355x_kkt_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -73,7 +76,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
     try {
         h->analysed = false; h->numeric_ready = false; h->factored = false;
         delete h->num; h->num = nullptr;
-        h->num_delayed = 0; h->num_restructures = 0; h->delay_count.clear(); h->delays_exhausted = false; h->zero_delay_futile = false;
+        h->num_delayed = 0; h->num_restructures = 0; h->delay_count.clear(); h->delays_exhausted = false; h->zero_delay_futile = false; h->zero_futile_events = 0;
         SymbolicOptions& so = h->so; so = SymbolicOptions();
         so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
@@ -173,8 +176,11 @@ static bool delay_and_refactor(mi355x_kkt_handle h, FactorStats& st)
         if (!h->num->restructure(h->sym)) { h->err = h->num->error(); h->numeric_ready = false; return false; }
         if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: %d failed + %d zero pivots, %d columns delayed to their parent fronts (round %d), refactoring\n", st.num_small, st.num_zero, moved, round + 1);
         if (!h->num->factor(nullptr, true, st)) { h->err = h->num->error(); return false; }
+        if (zero_only && st.num_small == 0 && st.num_zero < zero_before) h->zero_futile_events = 0;
         if (zero_only && st.num_small == 0 && st.num_zero >= zero_before) {
-            h->zero_delay_futile = true;
+            // one futile round ends THIS call's loop; the latch for the handle needs two in a row (a delayed column's hop doubles each time it
+            // fails again, so the round after a futile one may still succeed: ADVICE r05) and is cleared by set_pivtol / set_delay_rounds / delay_columns
+            if (++h->zero_futile_events >= 2) h->zero_delay_futile = true;
             if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: %d zero pivots stay after the delay (singular matrix): no further delays for zero pivots on this structure\n", st.num_zero);
             break;
         }
@@ -390,6 +396,7 @@ int mi355x_kkt_set_pivtol(mi355x_kkt_handle h, double u)
     if (!h) return MI355X_KKT_FATAL;
     if (!(u > 0.0) || u > 0.5) { h->err = "set_pivtol: u must be in (0, 0.5]"; return MI355X_KKT_FATAL; }
     h->opts.pivtol = u;
+    h->zero_delay_futile = false; h->zero_futile_events = 0;   // (not delays_exhausted: the growth cap is a property of the structure)
     if (h->num) h->num->set_pivtol(u);
     return MI355X_KKT_SUCCESS;
 }
@@ -398,6 +405,7 @@ int mi355x_kkt_set_delay_rounds(mi355x_kkt_handle h, int rounds)
 {
     if (!h || rounds < 0) return MI355X_KKT_FATAL;
     h->opts.delay_rounds = rounds;
+    h->zero_delay_futile = false; h->zero_futile_events = 0; h->delays_exhausted = false;
     return MI355X_KKT_SUCCESS;
 }
 
@@ -516,6 +524,24 @@ int mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn f
     if (!h) return MI355X_KKT_FATAL;
     if (!h->numeric_ready) { h->err = "set_comm_callbacks: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
     try { if (!h->num->set_comm_callback(fn, ctx)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
+/* the host-staged communicator over POSIX shared memory (comm_shm.cpp): ranks of ONE node, which may share a device */
+int mi355x_kkt_comm_shm_id(void* out128, int nranks)
+{
+    if (!out128) return MI355X_KKT_FATAL;
+    try { std::string err; if (!shm_comm_create(nranks, out128, err)) { fprintf(stderr, "[mi355x_kkt] %s\n", err.c_str()); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
+}
+int mi355x_kkt_set_comm_shm(mi355x_kkt_handle h, const void* id128)
+{
+    if (!h || !id128) return MI355X_KKT_FATAL;
+    if (!h->numeric_ready) { h->err = "set_comm_shm: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    try {
+        ShmComm* c = shm_comm_attach(id128, h->opts.rank, h->opts.nranks > 0 ? h->opts.nranks : 1, h->err);
+        if (!c) return MI355X_KKT_FATAL;
+        if (!h->num->set_comm_callback(shm_comm_allreduce, c) || !h->num->set_comm_range_callback(shm_comm_allreduce_range)) { h->err = h->num->error(); shm_comm_destroy(c); return MI355X_KKT_FATAL; }
+        shm_comm_destroy(h->shm); h->shm = c;
+        return MI355X_KKT_SUCCESS;
+    } catch (...) { h->err = "set_comm_shm: unexpected exception"; return MI355X_KKT_FATAL; }
 }
 int mi355x_kkt_set_comm_range_callback(mi355x_kkt_handle h, mi355x_kkt_allreduce_range_fn fn)
 {

@@ -100,6 +100,9 @@ Mi355xAugSystemSolver::~Mi355xAugSystemSolver()
 bool Mi355xAugSystemSolver::InitializeImpl(const OptionsList& options, const std::string& prefix)
 {
    Mi355xSolverInterface::ReadNumericOptions(options, prefix, kopts_, pivtol_, pivtolmax_);
+   // several Ipopt processes may share the factorisation on this route too: device assembly and the 8-block kernels are replicated work on
+   // identical data, the factorisation / solves underneath are the distributed ones (IpMi355xCommBootstrap.hpp)
+   comm_.ReadOptions(options, prefix, kopts_);
    bool ws = false;
    try
    {
@@ -326,6 +329,10 @@ ESymSolverStatus Mi355xAugSystemSolver::EnsureFactorization(const SymMatrix* W, 
             IpData().TimingStats().LinearSystemSymbolicFactorization().Start();
          }
          int st = mi355x_kkt_analyse(handle_, dim_, nnz_, &irn_[0], &jcn_[0], MI355X_KKT_FMT_TRIPLET, &vals[0]);
+         if( st == MI355X_KKT_SUCCESS && comm_.Wanted(kopts_) && !comm_.Ready() && !comm_.Setup(handle_, kopts_, Jnlst()) )
+         {
+            st = MI355X_KKT_FATAL;
+         }
          if( st == MI355X_KKT_SUCCESS )
          {
             st = mi355x_kkt_assembly_define(handle_, NSEG, (const int64_t*) seg_off_, (const int64_t*) seg_len_);

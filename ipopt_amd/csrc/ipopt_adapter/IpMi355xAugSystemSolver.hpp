@@ -17,6 +17,7 @@
 #include "IpAugSystemSolver.hpp"
 #include "IpAlgBuilder.hpp"
 #include "mi355x_kkt.h"
+#include "IpMi355xCommBootstrap.hpp"
 #include <vector>
 #include <string>
 
@@ -102,6 +103,7 @@ private:
 
    mi355x_kkt_handle handle_;
    mi355x_kkt_options kopts_;
+   Mi355xCommBootstrap comm_;          // ranks sharing the factorisation (mi355x_nranks / mi355x_rank / mi355x_comm)
    bool structured_, analysed_, have_factor_, pivtol_changed_, warm_start_same_structure_;
    Number pivtol_, pivtolmax_;
    Index negevals_;

@@ -1,6 +1,7 @@
 // IpMi355xSolverInterface.cpp -- see the header.  Status protocol as in IpSymLinearSolver.hpp:19-33.
 #include "IpMi355xSolverInterface.hpp"
 #include "IpMi355xTSymScalingMethod.hpp"
+#include "IpMi355xCommBootstrap.hpp"
 #include "IpTSymLinearSolver.hpp"
 #include "IpIpoptData.hpp"
 #include "IpTimingStatistics.hpp"
@@ -20,7 +21,7 @@ namespace Ipopt
 
 Mi355xSolverInterface::Mi355xSolverInterface()
    : handle_(NULL), dim_(0), nonzeros_(0), ia_(NULL), ja_(NULL), analysed_(false), pivtol_changed_(false),
-     warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1), nranks_opt_(0), rank_opt_(-1), comm_ready_(false), comm_generation_(0)
+     warm_start_same_structure_(false), pivtol_(1e-8), pivtolmax_(1e-4), negevals_(-1)
 {
    mi355x_kkt_default_options(&kopts_);
 }
@@ -75,6 +76,10 @@ void Mi355xSolverInterface::RegisterOptions(SmartPtr<RegisteredOptions> roptions
                               "no", "one top of the elimination tree replicated on every rank, one exchange step per factorisation",
                               "yes", "subtree-to-subcube mapping: one exchange step per bisection of the machine (more than two ranks)",
                               "Multi-GPU partition of the KKT factorisation (load-balance knob; cf. IpSpralSolverInterface.cpp:55-67).");
+   roptions->AddStringOption2("mi355x_comm", "Communicator among the mi355x_nranks processes.", "rccl",
+                              "rccl", "RCCL over xGMI, one process per GPU (the production path)",
+                              "shm", "host-staged sums over POSIX shared memory: ranks of one node that may SHARE a device (bring-up, one-GPU test boxes)",
+                              "The reference's only distributed backend owns its communicator in the same place (IpMumpsSolverInterface.cpp:58-75).");
    roptions->AddStringOption1("mi355x_comm_file", "File through which rank 0 hands the RCCL unique id to the other ranks.", "",
                               "*", "any path on a file system all ranks see (default: $MI355X_KKT_COMM_FILE)");
 }
@@ -171,30 +176,6 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
          kopts_.scaling = 0;
       }
    }
-   try
-   {
-      Index iv;
-      std::string sv;
-      if( options.GetIntegerValue("mi355x_nranks", iv, prefix) )
-      {
-         nranks_opt_ = iv;
-      }
-      if( options.GetIntegerValue("mi355x_rank", iv, prefix) )
-      {
-         rank_opt_ = iv;
-      }
-      if( options.GetStringValue("mi355x_comm_file", sv, prefix) )
-      {
-         comm_file_ = sv;
-      }
-      if( options.GetStringValue("mi355x_subcube", sv, prefix) )
-      {
-         kopts_.subcube = sv == "yes" ? 1 : 0;
-      }
-   }
-   catch( ... )
-   {
-   }
    if( pivtolmax_ < pivtol_ )
    {
       pivtolmax_ = pivtol_;
@@ -202,30 +183,7 @@ bool Mi355xSolverInterface::InitializeImpl(const OptionsList& options, const std
    kopts_.pivtol = pivtol_;
    kopts_.pivtolmax = pivtolmax_;
    kopts_.index_base = 1;
-   {
-      // launcher conventions: torchrun (RANK / WORLD_SIZE / LOCAL_RANK), Open MPI (OMPI_COMM_WORLD_*)
-      const char* e;
-      int nranks = nranks_opt_, rank = rank_opt_;
-      if( nranks <= 0 )
-      {
-         nranks = (e = getenv("WORLD_SIZE")) ? atoi(e) : ((e = getenv("OMPI_COMM_WORLD_SIZE")) ? atoi(e) : 1);
-      }
-      if( rank < 0 )
-      {
-         rank = (e = getenv("RANK")) ? atoi(e) : ((e = getenv("OMPI_COMM_WORLD_RANK")) ? atoi(e) : 0);
-      }
-      kopts_.nranks = nranks > 0 ? nranks : 1;
-      kopts_.rank = rank;
-      if( kopts_.nranks > 1 && kopts_.device < 0 )
-      {
-         kopts_.device = (e = getenv("LOCAL_RANK")) ? atoi(e) : ((e = getenv("OMPI_COMM_WORLD_LOCAL_RANK")) ? atoi(e) : rank);
-      }
-      if( comm_file_.empty() && (e = getenv("MI355X_KKT_COMM_FILE")) )
-      {
-         comm_file_ = e;
-      }
-      comm_ready_ = false;
-   }
+   comm_.ReadOptions(options, prefix, kopts_);      // ranks, device, communicator kind (IpMi355xCommBootstrap.hpp)
 
    bool ws = false;
    try
@@ -317,9 +275,9 @@ ESymSolverStatus Mi355xSolverInterface::MultiSolve(bool new_matrix, const Index*
       std::vector<Number>().swap(staging_);
       analysed_ = true;
       new_matrix = true;
-      if( (kopts_.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI")) && !comm_ready_ )
+      if( comm_.Wanted(kopts_) && !comm_.Ready() )
       {
-         if( !SetupCommunicator() )
+         if( !comm_.Setup(handle_, kopts_, Jnlst()) )
          {
             return SYMSOLVER_FATAL_ERROR;
          }
@@ -447,154 +405,6 @@ ESymSolverStatus Mi355xSolverInterface::DetermineDependentRows(const Index* /*ia
       c_deps.push_back(idx[i] - 1);      // 0-based, as MUMPS' pivnul_list - 1 (IpMumpsSolverInterface.cpp:703-706)
    }
    return SYMSOLVER_SUCCESS;
-}
-
-// Rendez-vous of the ranks of one job: rank 0 creates the ncclUniqueId and hands it to the others through a small file.
-//   * the record is {magic, job tag, generation, id}: the job tag comes from the launcher's environment (MI355X_KKT_JOB_ID, or torchrun's
-//     TORCHELASTIC_RUN_ID / MASTER_PORT, SLURM_JOB_ID, or Open MPI's PMIX_NAMESPACE / OMPI_MCA_ess_base_jobid), the generation counts the communicators this process has set up (every rank
-//     sets them up in the same order) -- a reader only accepts the record of ITS job and ITS generation, a file left behind by an earlier
-//     run or by the previous set-up of the same run is ignored (and, without a launcher tag, so is any file older than this process);
-//   * rank 0 unlinks whatever is there first, writes a private temporary (O_EXCL, 0600) and renames it into place; it removes the file
-//     again once ncclCommInitRank has returned, i.e. once every rank has read it;
-//   * default location: a per-user directory (0700) under $XDG_RUNTIME_DIR or /tmp, not a fixed world-writable name.
-namespace
-{
-struct CommRecord
-{
-   unsigned int magic, generation;
-   unsigned long long job;
-   unsigned char id[128];
-};
-const unsigned int COMM_MAGIC = 0x4b4b4d49u;      // "IMKK"
-
-unsigned long long comm_job_tag()
-{
-   // (Open MPI's mpirun / PRRTE set none of the first three: OMPI_MCA_ess_base_jobid / PMIX_NAMESPACE identify the job there)
-   const char* names[6] = {"MI355X_KKT_JOB_ID", "TORCHELASTIC_RUN_ID", "SLURM_JOB_ID", "PMIX_NAMESPACE", "OMPI_MCA_ess_base_jobid", "MASTER_PORT"};
-   for( int q = 0; q < 6; ++q )
-   {
-      const char* e = getenv(names[q]);
-      if( e && *e )
-      {
-         unsigned long long h = 1469598103934665603ull;      // FNV-1a of "<name>=<value>"
-         for( const char* c = names[q]; *c; ++c ) { h = (h ^ (unsigned char) *c) * 1099511628211ull; }
-         for( const char* c = e; *c; ++c ) { h = (h ^ (unsigned char) *c) * 1099511628211ull; }
-         return h ? h : 1ull;
-      }
-   }
-   return 0ull;      // no launcher tag: readers fall back to "not older than this process"
-}
-
-std::string comm_default_path(unsigned long long job)
-{
-   const char* rt = getenv("XDG_RUNTIME_DIR");
-   char buf[64];
-   snprintf(buf, sizeof(buf), "/mi355x_kkt_%u", (unsigned) getuid());
-   const std::string dir = std::string((rt && *rt) ? rt : "/tmp") + buf;
-   (void) mkdir(dir.c_str(), 0700);
-   snprintf(buf, sizeof(buf), "/comm_id_%016llx", job);
-   return dir + buf;
-}
-const time_t g_process_start = time(NULL);
-}
-
-bool Mi355xSolverInterface::SetupCommunicator()
-{
-   CommRecord rec;
-   memset(&rec, 0, sizeof(rec));
-   const unsigned long long job = comm_job_tag();
-   const unsigned int generation = ++comm_generation_;
-   const std::string path = comm_file_.empty() ? comm_default_path(job) : comm_file_;
-   if( job == 0ull && kopts_.nranks > 1 && generation == 1 )
-   {
-      Jnlst().Printf(J_WARNING, J_LINEAR_ALGEBRA, "mi355x: rank %d found no job tag in the environment (MI355X_KKT_JOB_ID, TORCHELASTIC_RUN_ID, SLURM_JOB_ID, "
-                     "PMIX_NAMESPACE, OMPI_MCA_ess_base_jobid, MASTER_PORT): the communicator id file %s is only protected by its age; set MI355X_KKT_JOB_ID on every rank\n",
-                     kopts_.rank, path.c_str());
-   }
-   if( kopts_.rank == 0 )
-   {
-      if( mi355x_kkt_comm_unique_id(rec.id) != MI355X_KKT_SUCCESS )
-      {
-         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: could not create the RCCL unique id (librccl.so not loadable?)\n");
-         return false;
-      }
-      if( kopts_.nranks > 1 )
-      {
-         rec.magic = COMM_MAGIC; rec.generation = generation; rec.job = job;
-         char sfx[48];
-         snprintf(sfx, sizeof(sfx), ".tmp.%ld.%u", (long) getpid(), generation);
-         const std::string tmp = path + sfx;
-         (void) unlink(path.c_str());                       // whatever an earlier run or set-up left behind
-         (void) unlink(tmp.c_str());
-         const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL, 0600);
-         if( fd < 0 || write(fd, &rec, sizeof(rec)) != (ssize_t) sizeof(rec) )
-         {
-            Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: cannot write %s\n", tmp.c_str());
-            if( fd >= 0 ) close(fd);
-            return false;
-         }
-         close(fd);
-         if( rename(tmp.c_str(), path.c_str()) != 0 )
-         {
-            (void) unlink(tmp.c_str());
-            return false;
-         }
-      }
-   }
-   else
-   {
-      bool got = false;
-      for( int tries = 0; tries < 6000 && !got; ++tries )   // up to 10 minutes: rank 0 may still be in its (longer) start-up
-      {
-         struct stat sb;
-         FILE* f = fopen(path.c_str(), "rb");
-         if( f )
-         {
-            CommRecord in;
-            const bool whole = fread(&in, 1, sizeof(in), f) == sizeof(in);
-            // without any job tag the only protection against a stale file of an earlier job is its age: written no more than
-            // MI355X_KKT_COMM_FRESH_S seconds before this rank loaded the library.  The default is SHORT (30 s): rank 0 unlinks what an earlier
-            // run left behind and writes its record after its own start, so a record that is older than this rank's start by more than the
-            // launcher's stagger is a leftover of a run that died between its write and its join -- accepting it would hang ncclCommInitRank.
-            // Launchers with a larger stagger set a job tag (then no age test at all) or the window.
-            static const long fresh_s = getenv("MI355X_KKT_COMM_FRESH_S") ? atol(getenv("MI355X_KKT_COMM_FRESH_S")) : 30;
-            const bool have_stat = fstat(fileno(f), &sb) == 0;
-            const bool fresh = job != 0ull || (have_stat && sb.st_mtime + fresh_s >= g_process_start);
-            if( whole && !fresh && tries % 100 == 0 )
-            {
-               Jnlst().Printf(J_WARNING, J_LINEAR_ALGEBRA, "mi355x: rank %d ignores %s: no job tag in the environment and the file is older than %ld s "
-                              "(set MI355X_KKT_JOB_ID on every rank, or MI355X_KKT_COMM_FRESH_S)\n", kopts_.rank, path.c_str(), fresh_s);
-            }
-            fclose(f);
-            if( whole && fresh && in.magic == COMM_MAGIC && in.job == job && in.generation == generation )
-            {
-               rec = in;
-               got = true;
-            }
-         }
-         if( !got )
-         {
-            usleep(100000);
-         }
-      }
-      if( !got )
-      {
-         Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: rank %d never saw generation %u of the communicator id file %s\n", kopts_.rank, generation, path.c_str());
-         return false;
-      }
-   }
-   if( mi355x_kkt_set_comm_rccl(handle_, rec.id) != MI355X_KKT_SUCCESS )
-   {
-      Jnlst().Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x_kkt_set_comm_rccl failed: %s\n", mi355x_kkt_last_error(handle_));
-      return false;
-   }
-   if( kopts_.rank == 0 && kopts_.nranks > 1 )
-   {
-      (void) unlink(path.c_str());                          // ncclCommInitRank has returned: every rank has read the record
-   }
-   comm_ready_ = true;
-   Jnlst().Printf(J_DETAILED, J_LINEAR_ALGEBRA, "MI355X: rank %d of %d joined the RCCL communicator (device %d)\n", kopts_.rank, kopts_.nranks, kopts_.device);
-   return true;
 }
 
 Index Mi355xSolverInterface::NumberOfNegEVals() const

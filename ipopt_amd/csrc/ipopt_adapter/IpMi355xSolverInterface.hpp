@@ -15,6 +15,7 @@
 #include "IpAlgBuilder.hpp"
 #include "IpRegOptions.hpp"
 #include "mi355x_kkt.h"
+#include "IpMi355xCommBootstrap.hpp"
 #include <vector>
 #include <list>
 #include <string>
@@ -79,13 +80,9 @@ private:
    Number pivtol_, pivtolmax_;
    Index negevals_;
    std::vector<Number> staging_;   // values before the (lazy) analysis has produced the pinned buffer
-   // multi-GPU (options mi355x_nranks / mi355x_rank / mi355x_comm_file, or the launcher's environment)
-   Index nranks_opt_, rank_opt_;
-   std::string comm_file_;
-   bool comm_ready_;
+   // multi-GPU (options mi355x_nranks / mi355x_rank / mi355x_comm / mi355x_comm_file, or the launcher's environment)
+   Mi355xCommBootstrap comm_;
    bool no_internal_scaling_ = false;
-   unsigned int comm_generation_;      // communicators set up by this process so far (part of the rendez-vous record)
-   bool SetupCommunicator();
 };
 
 /** AlgorithmBuilder that injects the MI355X backend through the reference's own virtual factory

@@ -643,7 +643,8 @@ public:
             // the numbers, before the allocation is attempted: factor() / solve() then answer MI355X_KKT_FATAL with this message (no partial set-up, no
             // fallback).  MI355X_KKT_POOL_LIMIT_GIB caps what one handle may take (a GPU shared by several ranks or applications).
             size_t fr = 0, tot = 0;
-            (void)hipMemGetInfo(&fr, &tot);
+            const bool have_meminfo = hipMemGetInfo(&fr, &tot) == hipSuccess;      // (a failed query must not read as "0 bytes free": the fit check is then left to the allocation itself)
+            if (!have_meminfo) { (void)hipGetLastError(); fr = ~(size_t)0 >> 1; }
             const double gib = 1.0 / (1024.0 * 1024.0 * 1024.0);
             const double need = 8.0 * ((double)Sy.l_doubles + (double)Sy.cb_doubles + (double)Sy.wbuf_doubles + (double)Sy.minv_doubles + (double)Sy.cvec_doubles + (double)Sy.gpart_doubles) +
                                 12.0 * (double)Sy.nnz_a + 16.0 * (double)Sy.nnz_in + 12.0 * (double)Sy.rslot_idx.size() + 200.0 * (double)Sy.n;
@@ -1359,7 +1360,7 @@ public:
             !dalloc(&V.dinv, Sy.n) || !dalloc(&V.doff, Sy.n) || !dalloc(&V.ptype, Sy.n) || !dalloc(&V.lperm, Sy.n) ||
             !dalloc(&V.fstat, Sy.num_sn) || !dalloc(&V.xw, Sy.n) || !dalloc(&V.ybuf, Sy.n) || !dalloc(&V.zb, Sy.n) || !dalloc(&V.bw, Sy.n) || !dalloc(&V.xacc, Sy.n) || !dalloc(&V.cvec, (size_t)Sy.cvec_doubles) || !dalloc(&V.gpart, (size_t)Sy.gpart_doubles) ||
             !dalloc(&d_stats, 12) || !dalloc(&V.colfail, Sy.n) || !dalloc(&V.zpiv, Sy.n) || !dalloc(&V.cnorm, Sy.n) ||
-            !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_p, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
+            !dalloc(&V.sflag_d, Sy.num_sn) || !dalloc(&V.sflag_p, Sy.num_sn) || !dalloc(&V.sflag_s, 4 * (size_t)Sy.num_sn) || !dalloc(&V.tcnt, Sy.num_sn) || !dalloc(&V.apfail, Sy.num_sn) || !dalloc(&V.sepoch, 4)) return false;
         V.qstat = d_stats + 4;
         lap("device allocations");
         if (opt.scaling >= 3 && !d_user_scale) { HIPCHK(hipMalloc((void**)&d_user_scale, std::max<size_t>(Sy.n, 1) * sizeof(double))); allocs.push_back(d_user_scale); }
@@ -1720,24 +1721,27 @@ public:
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
         if (!drain_chain()) return false;
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
-        LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.sn_owner, Sy.num_sn, -2, d_stats);
+        LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.apfail, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());
         return true;
     }
 
     bool norestore_on = getenv("MI355X_KKT_RESTORE") == nullptr;      // (development knob: keep the safety copies of the pivot blocks in the optimistic schedule too)
     bool optimistic = false;                 // (set per factorisation: see launch_bucket)
-    bool optimistic_ok = true;               // no factorisation of this handle has needed a strict launch the optimistic schedule leaves out
+    bool optimistic_ok = true;               // the optimistic schedule may be tried (false while a back-off runs: see factor())
+    int  opt_backoff = 0, opt_wait = 0;      // after a fall-back: opt_wait factorisations on the full schedule, then one more optimistic try; every repeat doubles the wait (8 .. 256)
     hipGraphExec_t g_factor_full = nullptr;  // the schedule with every strict launch (g_factor: the optimistic one)
     bool factor(const double* dvals, bool reuse, FactorStats& st) {
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "factor: solver not set up (no device?)"; return false; }
         if (multi) return factor_dist(dvals, reuse, st);          // needs a communicator (set_comm_*), fails loudly otherwise
         static const bool opt_off = getenv("MI355X_KKT_NO_OPTIMISTIC") != nullptr;
+        if (!optimistic_ok && opt_wait > 0 && --opt_wait == 0) optimistic_ok = true;   // (one rejection early in an Ipopt run must not cost the optimistic schedule for the life of the structure)
         optimistic = V.fastpiv && !opt_off && !prof_on && optimistic_ok;
         if (!factor_once(dvals, reuse, st)) return false;
         if (optimistic && (h_stats[8] != 0 || h_stats[9] != 0)) { // some front was left for a strict launch that was not there / a pivot block without a safety copy was rejected: the full schedule, same values
-            optimistic = false; optimistic_ok = false;            // ... and from now on for this structure: a matrix family that needs the strict kernels once needs them again
+            optimistic = false; optimistic_ok = false;            // ... and for the next opt_wait factorisations: a matrix family that needs the strict kernels once tends to need them again
+            opt_backoff = opt_backoff == 0 ? 8 : std::min(256, 2 * opt_backoff); opt_wait = opt_backoff;
             if (opt.verbose) fprintf(stderr, h_stats[10] ? "[mi355x_kkt] factor: a wait of the data-flow launch over the small-front levels timed out (device shared?), running the full schedule\n"
                                                            : "[mi355x_kkt] factor: the optimistic schedule met a front for the strict kernels, running the full one\n");
             return factor_once(nullptr, true, st);
@@ -2174,8 +2178,8 @@ public:
     bool enqueue_stats() {
         // this rank counts its own subtrees and the replicated fronts whose range it is the first rank of => the sum over ranks is the inertia
         hipLaunchKernelGGL(k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
-        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, opt.rank, d_stats);
-        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.sn_owner, S->num_sn, -1, d_stats);
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.apfail, V.sn_owner, S->num_sn, opt.rank, d_stats);
+        hipLaunchKernelGGL(k_reduce_stats, dim3(1), dim3(256), 0, stream, V.fstat, V.apfail, V.sn_owner, S->num_sn, -1, d_stats);
         HIPCHK(hipGetLastError());
         return true;
     }

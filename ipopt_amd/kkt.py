@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
-    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_set_comm_callbacks", "mi355x_kkt_set_comm_range_callback", "mi355x_kkt_exchange_bytes", "mi355x_kkt_comm_plan", "mi355x_kkt_comm_info",
+    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_comm_shm_id", "mi355x_kkt_set_comm_shm", "mi355x_kkt_set_comm_callbacks", "mi355x_kkt_set_comm_range_callback", "mi355x_kkt_exchange_bytes", "mi355x_kkt_comm_plan", "mi355x_kkt_comm_info",
     "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_failed_pivots", "mi355x_kkt_delay_columns", "mi355x_kkt_set_delay_rounds", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
     "mi355x_kkt_pd_define", "mi355x_kkt_pd_put_data", "mi355x_kkt_pd_put", "mi355x_kkt_pd_get", "mi355x_kkt_pd_solve_once", "mi355x_kkt_pd_residual",
 ]
@@ -138,6 +138,8 @@ def load_library():
     lib.mi355x_kkt_pd_solve_once.argtypes = [vp, C.c_int, C.c_int, C.c_double, C.c_double]
     lib.mi355x_kkt_pd_residual.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp]
     lib.mi355x_kkt_set_comm_rccl.argtypes = [vp, vp]
+    lib.mi355x_kkt_comm_shm_id.argtypes = [vp, C.c_int]
+    lib.mi355x_kkt_set_comm_shm.argtypes = [vp, vp]
     lib.mi355x_kkt_set_comm_callbacks.argtypes = [vp, ALLREDUCE_FN, vp]
     lib.mi355x_kkt_set_comm_range_callback.argtypes = [vp, ALLREDUCE_RANGE_FN]
     lib.mi355x_kkt_exchange_bytes.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -327,6 +329,19 @@ class KKTSolver:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         if self.lib.mi355x_kkt_set_comm_rccl(self._h, buf) != 0:
             raise KKTError("set_comm_rccl: " + self.last_error())
+
+    @staticmethod
+    def comm_shm_id(nranks: int) -> bytes:
+        """rank 0: create the shared-memory segment of a host-staged communicator for ranks of one node (they may share a device)"""
+        buf = C.create_string_buffer(128)
+        if load_library().mi355x_kkt_comm_shm_id(buf, int(nranks)) != 0:
+            raise KKTError("comm_shm_id: shm_open / mmap failed")
+        return buf.raw
+
+    def set_comm_shm(self, shm_id: bytes):
+        buf = C.create_string_buffer(bytes(shm_id), 128)
+        if self.lib.mi355x_kkt_set_comm_shm(self._h, buf) != 0:
+            raise KKTError("set_comm_shm: " + self.last_error())
 
     def set_comm_callback(self, fn, fn_range=None):
         """fn(dptr: int, count: int, dtype: int (0 fp64, 1 int32), hip_stream: int) -> None; must leave the buffer summed over the ranks.

@@ -178,11 +178,16 @@ class CommKKT:
     after construction it is used exactly like a single-GPU KKTSolver (factor_device / solve_device2 / multi_solve).
     torch.distributed is only the bootstrap that carries the 128-byte ncclUniqueId from rank 0 to the other ranks."""
 
-    def __init__(self, rank, nranks, device, n, row, col, vals, dist, use_rccl=True, **opts):
+    def __init__(self, rank, nranks, device, n, row, col, vals, dist, use_rccl=True, use_shm=False, **opts):
         import torch
         self.s = _kkt.KKTSolver(device=device, nranks=nranks, rank=rank, **opts)
         self.s.initialize_structure(n, row, col, vals=vals)
-        if use_rccl:
+        if use_shm:
+            # the library's own host-staged communicator over POSIX shared memory (ranks of one node, which may share a device)
+            box = [_kkt.KKTSolver.comm_shm_id(nranks) if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.s.set_comm_shm(box[0])
+        elif use_rccl:
             box = [_kkt.KKTSolver.comm_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0)
             self.s.set_comm_rccl(box[0])

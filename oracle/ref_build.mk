@@ -80,7 +80,7 @@ $(OUT)/scalable.a: $(SCAL_OBJS)
 # --- the product's Ipopt adapter (B1), compiled against the reference headers where they lie.  The
 #     adapter SOURCE is product code (ipopt_amd/csrc/ipopt_adapter); only its build needs the reference. ---
 KKTLIB := ipopt_amd/lib
-ADAPTER_SRC := ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xPDSystemSolver.cpp
+ADAPTER_SRC := ipopt_amd/csrc/ipopt_adapter/IpMi355xCommBootstrap.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xPDSystemSolver.cpp
 $(OUT)/libmi355x_ipopt.so: $(ADAPTER_SRC) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h $(OUT)/libipopt_ref.so
 	$(CXX) -O2 -fPIC -shared -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter $(ADAPTER_SRC) -o $@ \
 	  -L$(OUT) -lipopt_ref -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib'
@@ -105,12 +105,13 @@ $(OUT)/ipopt_mi355x_driver: oracle/ref_driver.cpp $(OUT)/libipopt_ref.so $(OUT)/
 PATCH   := oracle/patches/linear_solver_mi355x.patch
 PSRC    := Algorithm/IpAlgBuilder.cpp Algorithm/LinearSolvers/IpLinearSolversRegOp.cpp Interfaces/IpTNLPAdapter.cpp
 POBJS   := $(OUT)/obj_patched/IpAlgBuilder.o $(OUT)/obj_patched/IpLinearSolversRegOp.o $(OUT)/obj_patched/IpTNLPAdapter.o \
-           $(OUT)/obj_patched/IpMi355xSolverInterface.o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o $(OUT)/obj_patched/IpMi355xPDSystemSolver.o
+           $(OUT)/obj_patched/IpMi355xSolverInterface.o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o $(OUT)/obj_patched/IpMi355xPDSystemSolver.o $(OUT)/obj_patched/IpMi355xCommBootstrap.o
 $(OUT)/obj_patched/.stamp: $(PATCH) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.cpp) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h
 	rm -rf $(OUT)/obj_patched $(OUT)/patched_src; mkdir -p $(OUT)/obj_patched $(OUT)/patched_src/src/Algorithm/LinearSolvers $(OUT)/patched_src/src/Interfaces
 	for f in $(PSRC); do cp $(REF)/src/$$f $(OUT)/patched_src/src/$$f; done
 	cd $(OUT)/patched_src && patch -p1 -s < $(CURDIR)/$(PATCH)
 	for f in $(PSRC); do $(CXX) $(CXXFLAGS_REF) -DIPOPT_HAS_MI355X $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c $(OUT)/patched_src/src/$$f -o $(OUT)/obj_patched/`basename $$f .cpp`.o || exit 1; done
+	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xCommBootstrap.cpp -o $(OUT)/obj_patched/IpMi355xCommBootstrap.o
 	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp -o $(OUT)/obj_patched/IpMi355xSolverInterface.o
 	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp -o $(OUT)/obj_patched/IpMi355xAugSystemSolver.o
 	$(CXX) $(CXXFLAGS_REF) $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter -c ipopt_amd/csrc/ipopt_adapter/IpMi355xPDSystemSolver.cpp -o $(OUT)/obj_patched/IpMi355xPDSystemSolver.o

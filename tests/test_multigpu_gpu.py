@@ -108,7 +108,7 @@ def _worker_comm(rank, world, port, case, subcube, ret):
     n, r, c, v, neg = case()
     K = kktgen.to_scipy(n, r, c, v)
     # RCCL refuses several ranks on one device, so the library gets the one collective it needs as a callback (gloo)
-    s = CommKKT(rank, world, 0, n, r, c, v, dist, use_rccl=False, subcube=subcube, **getattr(case, "opts", {})).s
+    s = CommKKT(rank, world, 0, n, r, c, v, dist, use_rccl=False, use_shm=os.environ.get("MI355X_TEST_COMM") == "shm", subcube=subcube, **getattr(case, "opts", {})).s
     out = []
     for rep in range(2):
         s.values()[:] = v
@@ -167,6 +167,32 @@ def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, c
         assert nsteps >= 2 and min(held) < ntop
     else:
         assert nsteps == 1 and held == [ntop] * world
+
+
+@pytest.mark.parametrize("world,subcube,case", [(2, 0, _case_grid), (3, 1, _case_grid), (4, 1, _case_band), (4, 1, _case_hostile)],
+                         ids=["2", "3-subcube", "4-subcube-band", "4-subcube-delayed-pivots"])
+def test_shared_memory_communicator_of_the_library(world, subcube, case, monkeypatch):
+    """mi355x_kkt_comm_shm_id / _set_comm_shm: the library's own host-staged communicator (POSIX shared memory, sums in rank order) behind the
+    same entry points -- what the Ipopt adapter's `mi355x_comm shm` uses when several Ipopt processes share one device (tests/test_e2e_multirank.py).
+    torch.distributed only carries the 128-byte segment name from rank 0 to the others."""
+    monkeypatch.setenv("MI355X_TEST_COMM", "shm")
+    monkeypatch.setenv("MI355X_KKT_SHM_TIMEOUT_S", "120")
+    monkeypatch.setenv("MI355X_KKT_SHM_SLOT_MIB", "0.25")          # several chunks per collective: the chunk loop is part of the test
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_comm, args=(rk, world, port, case, subcube, ret)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    out, neg, same, nsteps, ntop, held = ret.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert same                                  # rank-ordered sums: bitwise the same solution on every rank
+    for st, st2, nneg, res, lin, ntwo, nsmall, nedits in out:
+        assert st == 0 and st2 == 0 and nneg == neg and res <= 1e-12 and lin <= 1e-9
+        if case is _case_hostile:
+            assert nsmall == 0 and nedits >= 1
 
 
 def test_rccl_communicator_of_one_rank(monkeypatch):
