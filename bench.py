@@ -458,10 +458,11 @@ def main():
                 also[w2] = {"kkt_dim": n2, "ms_per_step": dt2 * 1e3, "GFLOP/s": (I2.flops_factor + NSOLVE * I2.flops_solve) / dt2 / 1e9,
                             "algorithmic_GBps": (I2.bytes_factor + NSOLVE * I2.bytes_solve) / dt2 / 1e9, "num_neg_ok": bool(st2[0] == 0 and st2[1] == neg2),
                             "scaled_residual": res2, "device_ms": {"factor": I2.time_factor_ms, "solve": I2.time_solve_ms}}
-                if w2 == "mbndry1_100" and not args.no_cpu_baseline:      # BASELINE.json configs[2]: its own CPU leg (the reference's PARDISO path on the same matrix)
+                if not args.no_cpu_baseline:      # every configuration carries its own CPU leg (the reference's PARDISO path on the same matrix)
                     cb2 = cpu_baseline(n2, r2, c2, v2, b2, x2, st2[1], NSOLVE)
                     also[w2]["cpu_baseline"] = {"ms_per_step": cb2["seconds_per_step"] * 1e3, "cores": cb2["cores"], "kind": cb2["kind"], "ms_per_step_by_threads": cb2["legs"],
                                                 "parity_vs_gpu": cb2["parity"], "speedup": cb2["seconds_per_step"] / dt2}
+                if w2 == "mbndry1_100":
                     also[w2]["what"] = "BASELINE.json configs[2]: the KKT system of the 4th boundary call of the reference's MBndryCntrl1 N = 100 run (tests/golden/mbndry1_100.kktrec)"
                 if w2 == "lukvle1_1e6":      # the maximum-product matching scaling (the job of MC64) on the device, per factorisation (scaling mode 5)
                     s2.set_scaling(5)

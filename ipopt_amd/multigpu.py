@@ -24,6 +24,8 @@ import numpy as np
 
 from . import kkt as _kkt
 
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 class _DevArray:
     """zero-copy view of library-owned device memory for torch (CUDA array interface v2)."""
@@ -315,15 +317,20 @@ def bench_main(args, rank, world, local):
 
     if os.environ.get("MI355X_KKT_BENCH_DRYRUN"):
         return bench_dry_run(args, rank, world)
+    # MI355X_KKT_BENCH_SHARED=1: all ranks on device 0 (a one-GPU box) -- gloo bootstrap, the library's shared-memory communicator instead of RCCL
+    # (which refuses two ranks on one device); kernels, partition and collective sequence are those of the N-GPU run, the timings are not
+    shared = bool(os.environ.get("MI355X_KKT_BENCH_SHARED"))
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
+    dist.init_process_group("gloo" if shared else "nccl", rank=rank, world_size=world)
     wl = "synth_1e6" if args.workload == "auto" else args.workload
     n, r, c, v, neg = B.make_workload(wl)
     K = kktgen.to_scipy(n, r, c, v)
     b = K @ np.ones(n)
     # the collectives (all-reduce of the top arena / top right-hand sides / solution, RCCL over xGMI) run inside the C library
     subcube = int(os.environ.get("MI355X_KKT_SUBCUBE", "1" if world > 2 else "0"))      # (two ranks: the two mappings coincide)
-    ck = CommKKT(rank, world, local, n, r, c, v, dist, use_rccl=not os.environ.get("MI355X_KKT_BENCH_GLOO"), subcube=subcube)
+    ck = CommKKT(rank, world, local, n, r, c, v, dist, use_rccl=not os.environ.get("MI355X_KKT_BENCH_GLOO"), use_shm=shared, subcube=subcube)
     s = ck.s
     I = s.info()
     dv = torch.tensor(v, dtype=torch.float64, device="cuda")
@@ -349,7 +356,7 @@ def bench_main(args, rank, world, local):
     for _ in range(args.steps):
         step()
     dist.barrier(); torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cpu" if shared else "cuda")
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     dt = float(el[0]) / args.steps
     own = s.symbolic(11, I.num_sn)
@@ -405,7 +412,54 @@ def bench_main(args, rank, world, local):
         pm = line["partition_model"]; ex = pm["exchange"]["predicted_ms_per_factorisation"]
         t1 = line["same_workload_1gpu"]["ms_per_step"]
         pm["predicted_speedup_with_exchange"] = {kk: t1 / (t1 / pm["predicted_speedup_bound"] + ms) for kk, ms in ex.items()}
+    # BASELINE configs[4]: an end-to-end Ipopt solve whose factorisations are shared by the N ranks -- one UNMODIFIED reference host process per
+    # rank (oracle/_ref/ipopt_mi355x_driver, device route), communicator set up by the adapter itself (mi355x_comm rccl; shm on a shared device)
+    if not getattr(args, "no_e2e", False):
+        del ck, s
+        e2e = e2e_multirank(rank, world, local, shared, dist)
+        if rank == 0:
+            line["e2e"] = e2e
     dist.barrier()
     if rank == 0:
         print(json.dumps(line))
     dist.destroy_process_group()
+
+
+def e2e_multirank(rank, world, local, shared, dist, problem="MBndryCntrl1", size=700, golden="mbndry1_700"):
+    """every rank runs the reference host on the configs[4] stand-in (MBndryCntrl1 N = 700: n = 492 800, m = 490 000, KKT dim 982 800) with the
+    MI355X device route; rank 0 reports iterations / objective / Ipopt's own timers of every rank next to the reference CPU run's golden summary"""
+    import subprocess
+    drv = os.path.join(_ROOT, "oracle", "_ref", "ipopt_mi355x_driver")
+    res = None
+    if os.path.exists(drv):
+        cmd = [drv, problem, str(size), "--solver", "mi355x-pd", "--quiet", "--set", "mi355x_nranks", str(world), "--set", "mi355x_rank", str(rank),
+               "--set", "mi355x_device", str(local), "--set", "mi355x_comm", "shm" if shared else "rccl", "--set", "mi355x_subcube", "yes" if world > 2 else "no"]
+        env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1", MI355X_KKT_SHM_TIMEOUT_S="120")
+        env.setdefault("MI355X_KKT_JOB_ID", "bench-" + os.environ.get("MASTER_PORT", "0") + "-" + os.environ.get("TORCHELASTIC_RUN_ID", "0"))
+        try:
+            t0 = time.perf_counter()
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp", env=env).stdout
+            j = json.loads(next(ln for ln in out.splitlines() if ln.startswith("DRIVER_SUMMARY"))[len("DRIVER_SUMMARY "):])
+            res = {k: j[k] for k in ("iterations", "objective", "status", "PDSystemSolverTotal", "LinearSystemFactorization", "LinearSystemBackSolve",
+                                     "LinearSystemSymbolicFactorization", "wall_total") if k in j}
+            res["process_wall_s"] = time.perf_counter() - t0
+        except Exception as e:      # a rank that fails must not take the bench line with it
+            res = {"error": str(e)[:200]}
+    allres = [None] * world
+    dist.all_gather_object(allres, res)
+    if rank != 0:
+        return None
+    if allres[0] is None:
+        return {"skipped": "oracle/_ref/ipopt_mi355x_driver not built"}
+    out = {"problem": f"ScalableProblems {problem} {size} (BASELINE configs[4] stand-in, KKT dim 982800)", "route": "mi355x-pd (device assembly + device-resident 8-block solver)",
+           "communicator": "shm (ranks share one device)" if shared else "rccl", "ranks": allres}
+    gpath = os.path.join(_ROOT, "tests", "golden", golden + ".summary")
+    if os.path.exists(gpath):
+        g = json.load(open(gpath))
+        out["reference_cpu_run"] = {"iterations": g.get("iterations"), "objective": g.get("objective")}
+        out["iterations_equal_on_every_rank"] = all(isinstance(r_, dict) and r_.get("iterations") == g.get("iterations") for r_ in allres)
+    ok = [r_ for r_ in allres if isinstance(r_, dict) and "PDSystemSolverTotal" in r_]
+    if ok:
+        out["PDSystemSolverTotal_max_over_ranks"] = max(r_["PDSystemSolverTotal"] for r_ in ok)
+        out["wall_total_max_over_ranks"] = max(r_["wall_total"] for r_ in ok)
+    return out

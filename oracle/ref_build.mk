@@ -81,7 +81,11 @@ $(OUT)/scalable.a: $(SCAL_OBJS)
 #     adapter SOURCE is product code (ipopt_amd/csrc/ipopt_adapter); only its build needs the reference. ---
 KKTLIB := ipopt_amd/lib
 ADAPTER_SRC := ipopt_amd/csrc/ipopt_adapter/IpMi355xCommBootstrap.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xSolverInterface.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xAugSystemSolver.cpp ipopt_amd/csrc/ipopt_adapter/IpMi355xPDSystemSolver.cpp
-$(OUT)/libmi355x_ipopt.so: $(ADAPTER_SRC) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h $(OUT)/libipopt_ref.so
+# route B2's struct layouts against the reference header: static_asserts, member by member -- the adapter build fails if either side drifts
+$(OUT)/ma97_layout_check.o: oracle/ma97_layout_check.cpp include/mi355x_ma97.h $(REF)/src/Algorithm/LinearSolvers/hsl_ma97d.h
+	@mkdir -p $(OUT)
+	$(CXX) -std=c++11 -Wall -Iinclude -I$(REF)/src/Algorithm/LinearSolvers -c $< -o $@
+$(OUT)/libmi355x_ipopt.so: $(ADAPTER_SRC) $(wildcard ipopt_amd/csrc/ipopt_adapter/*.hpp) include/mi355x_kkt.h $(OUT)/libipopt_ref.so $(OUT)/ma97_layout_check.o
 	$(CXX) -O2 -fPIC -shared -DHAVE_CONFIG_H -std=c++11 -w $(INCS) -Iinclude -Iipopt_amd/csrc/ipopt_adapter $(ADAPTER_SRC) -o $@ \
 	  -L$(OUT) -lipopt_ref -L$(KKTLIB) -lmi355x_kkt -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,'$$ORIGIN/../../ipopt_amd/lib'
 

@@ -16,7 +16,7 @@
 // (--set linear_solver ma97 --set hsllib .../libmi355x_kkt.so = route B2; --set linear_solver mi355x with the patched
 // library oracle/_ref/libipopt_ref_mi355x.so = route B1').
 //
-// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|mi355x-aug|mi355x-pd|stock] [--record file] [--max-records K]
+// usage: ref_driver <problem> <N> [--solver pardisomkl|mi355x|mi355x-aug|mi355x-pd|stock] [--record file] [--max-records K] [--skip-records K]
 //                   [--set name value]... [--optfile ipopt.opt] [--reoptimize] [--quiet]
 //   --reoptimize: after the first solve, set warm_start_same_structure=yes and call ReOptimizeNLP (second DRIVER_SUMMARY line)
 //   --then-bounds lo hi: (LukVl problems) after the first solve, optimise a SECOND instance of the problem with constraint bounds [lo, hi]
@@ -98,13 +98,13 @@ public:
 class RecordingSolverInterface: public SparseSymLinearSolverInterface
 {
 public:
-   RecordingSolverInterface(SmartPtr<SparseSymLinearSolverInterface> inner, const std::string& file, int max_records)
-      : inner_(inner), f_(NULL), dim_(0), nnz_(0), nrec_(0), max_records_(max_records), vals_(NULL)
+   RecordingSolverInterface(SmartPtr<SparseSymLinearSolverInterface> inner, const std::string& file, int max_records, int skip_records = 0)
+      : inner_(inner), f_(NULL), dim_(0), nnz_(0), nrec_(0), max_records_(max_records), ncalls_(0), skip_records_(skip_records), vals_(NULL)
    {
       f_ = fopen(file.c_str(), "wb");
       if( f_ ) fwrite("KKTREC1\n", 1, 8, f_);
    }
-   ~RecordingSolverInterface() { if( f_ ) fclose(f_); }
+   ~RecordingSolverInterface() { if( f_ ) fclose(f_); printf("RECORD_CALLS %d\n", ncalls_); }
    bool InitializeImpl(const OptionsList& options, const std::string& prefix)
    {
       return inner_->Initialize(Jnlst(), IpNLP(), IpData(), IpCq(), options, prefix);
@@ -131,7 +131,13 @@ public:
       // NB: some backends (MKL adapter) may overwrite their value array; copy before the call
       if( new_matrix && vals_ ) a.assign(vals_, vals_ + nnz_);
       ESymSolverStatus st = inner_->MultiSolve(new_matrix, ia, ja, nrhs, rhs_vals, check_NegEVals, numberOfNegEVals);
-      if( f_ && (max_records_ < 0 || nrec_ < max_records_) )
+      // --skip-records K: the first K calls are not stored (the LATE calls of a run -- Sigma spanning many decades, delta_c active -- are what
+      // is wanted); the first call that IS stored carries the matrix it was answered with even if that matrix is not new to the backend
+      if( skip_records_ > 0 && new_matrix ) last_a_ = a;
+      const bool store = f_ && ncalls_ >= skip_records_ && (max_records_ < 0 || nrec_ < max_records_);
+      ++ncalls_;
+      if( store && !new_matrix && nrec_ == 0 && skip_records_ > 0 ) { a = last_a_; new_matrix = true; }
+      if( store )
       {
          int hdr[8] = {1, dim_, nnz_, nrhs, new_matrix ? 1 : 0, check_NegEVals ? 1 : 0, numberOfNegEVals, (int) st};
          fwrite(hdr, sizeof(int), 8, f_);
@@ -152,7 +158,8 @@ private:
    SmartPtr<SparseSymLinearSolverInterface> inner_;
    FILE* f_;
    Index dim_, nnz_;
-   int nrec_, max_records_;
+   int nrec_, max_records_, ncalls_, skip_records_;
+   std::vector<Number> last_a_;
    Number* vals_;
 };
 
@@ -250,8 +257,8 @@ private:
 class DriverAlgBuilder: public AlgorithmBuilder
 {
 public:
-   DriverAlgBuilder(const std::string& solver, const std::string& record, int max_records, const std::string& record_pd = "")
-      : solver_(solver), record_(record), record_pd_(record_pd), max_records_(max_records) { }
+   DriverAlgBuilder(const std::string& solver, const std::string& record, int max_records, const std::string& record_pd = "", int skip_records = 0)
+      : solver_(solver), record_(record), record_pd_(record_pd), max_records_(max_records), skip_records_(skip_records) { }
    virtual SmartPtr<PDSystemSolver> PDSystemSolverFactory(const Journalist& jnlst, const OptionsList& options, const std::string& prefix)
    {
       SmartPtr<PDSystemSolver> pd = AlgorithmBuilder::PDSystemSolverFactory(jnlst, options, prefix);      // the reference's PDFullSpaceSolver
@@ -270,13 +277,13 @@ public:
       else if( solver_ == "mi355x" ) iface = new Mi355xSolverInterface();
 #endif
       else { fprintf(stderr, "unknown --solver %s\n", solver_.c_str()); exit(2); }
-      if( !record_.empty() ) iface = new RecordingSolverInterface(iface, record_, max_records_);
+      if( !record_.empty() ) iface = new RecordingSolverInterface(iface, record_, max_records_, skip_records_);
       SmartPtr<TSymScalingMethod> none;
       return new TSymLinearSolver(iface, none);
    }
 private:
    std::string solver_, record_, record_pd_;
-   int max_records_;
+   int max_records_, skip_records_;
 };
 
 static double wall(const TimedTask& t) { return t.TotalWallclockTime(); }
@@ -287,7 +294,7 @@ int main(int argc, char** argv)
    std::string problem = argv[1];
    int N = atoi(argv[2]);
    std::string solver = "pardisomkl", record, record_pd;
-   int max_records = -1;
+   int max_records = -1, skip_records = 0;
    bool quiet = false, reopt = false, then_bounds = false;
    double tb_lo = 0., tb_hi = 0.;
    std::string optfile;
@@ -299,6 +306,7 @@ int main(int argc, char** argv)
       else if( a == "--record" && i + 1 < argc ) record = argv[++i];
       else if( a == "--record-pd" && i + 1 < argc ) record_pd = argv[++i];
       else if( a == "--max-records" && i + 1 < argc ) max_records = atoi(argv[++i]);
+      else if( a == "--skip-records" && i + 1 < argc ) skip_records = atoi(argv[++i]);
       else if( a == "--set" && i + 2 < argc ) { sets.push_back(std::make_pair(std::string(argv[i + 1]), std::string(argv[i + 2]))); i += 2; }
       else if( a == "--quiet" ) quiet = true;
       else if( a == "--reoptimize" ) reopt = true;
@@ -369,7 +377,7 @@ int main(int argc, char** argv)
       builder = MakeMi355xPDSystemAlgorithmBuilder();
    }
 #endif
-   else builder = new DriverAlgBuilder(solver, record, max_records, record_pd);
+   else builder = new DriverAlgBuilder(solver, record, max_records, record_pd, skip_records);
    auto t0 = std::chrono::steady_clock::now();
    ApplicationReturnStatus status = app->OptimizeNLP(nlp, builder);
    double total = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

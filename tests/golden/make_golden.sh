@@ -12,6 +12,14 @@ set -e
 cd "$(dirname "$0")"
 D=../../oracle/_ref
 export MKL_NUM_THREADS=1 OMP_NUM_THREADS=1
+# tail <name> <problem> <N> <K>: the LAST K boundary calls of the run (late-barrier systems: Sigma spanning many decades, delta_c active --
+# IpPDPerturbationHandler.cpp:467-470) into <name>_late.kktrec; a first run counts the calls (RECORD_CALLS), the second skips all but the last K
+tail_rec() {
+  name=$1; p=$2; n=$3; k=$4
+  calls=$($D/ref_driver $p $n --record /dev/null --max-records 0 --quiet | grep RECORD_CALLS | awk '{print $2}')
+  $D/ref_driver $p $n --record ${name}_late.kktrec --skip-records $((calls - k)) --quiet > /dev/null
+  echo "${name}_late: calls $((calls - k + 1))..$calls of $calls"
+}
 run() {  # name problem N record?
   name=$1; p=$2; n=$3; rec=$4
   if [ "$rec" = rec ]; then $D/ref_driver $p $n --record $name.kktrec > /tmp/$name.log;
@@ -27,6 +35,10 @@ run mbndry1_8 MBndryCntrl1 8 rec
 # BASELINE.json configs[1] and [2]: iteration tables + the first four calls across the boundary (a full recording is 20 MB)
 run lukvle1_10000 LukVlE1 10000 rec4
 run mbndry1_100 MBndryCntrl1 100 rec4
+# ... and the LAST four calls of configs[1], configs[2] and of MBndryCntrl2 N = 100 (the problem whose factorisations delay pivots)
+tail_rec lukvle1_10000 LukVlE1 10000 4
+tail_rec mbndry1_100 MBndryCntrl1 100 4
+tail_rec mbndry2_100 MBndryCntrl2 100 4
 run lukvle1_1000000 LukVlE1 1000000 norec
 # more problem classes of examples/ScalableProblems (inequalities, other PDE controls, 3-D): iteration tables only
 run lukvli1_10000 LukVlI1 10000 norec
