@@ -269,7 +269,13 @@ const char* mi355x_kkt_last_error(mi355x_kkt_handle h);
  *       duplicates), 23 sn_class[num_sn] (kernel class of the front: 0 order <= 32, 1 <= 64, 2 <= 128, 3 the blocked path, order > 128),
  *       24 rslot_ptr[n + 1], 25 rslot_idx[rslot_ptr[n]], 26 rslot_col[rslot_ptr[n]] (the symmetric row view of the permuted pattern the equilibration
  *       sweeps and the device refinement gather over: for every row its entries of both triangles -- CSC slot and the other index -- by ascending other index).
- *       sn_parent (4) is the parent in the ASSEMBLY tree: a side child of an in-place chain link may hang on a lower link of that chain (finish_analysis 9b). */
+ *       sn_parent (4) is the parent in the ASSEMBLY tree: a side child of an in-place chain link may hang on a lower link of that chain (finish_analysis 9b).
+ *  27   the storage plan of the contribution blocks, 5 ints: {window of tree levels after which a dead block's space is written again (0: every block
+ *       resident), then as (low, high) 32-bit halves: doubles of all blocks if every one were resident, doubles of the blocks that are never reused};
+ *       info.cb_doubles is what the plan needs.  Blocks that only carry a contribution to their parent are RECYCLED over the level schedule where that
+ *       saves a quarter of the pool (MI355X_KKT_RECYCLE=0/1 forces it off / on) -- the workspace a multifrontal code keeps as a stack
+ *       (IpMumpsSolverInterface.cpp:151-177, ICNTL(14)), here with static addresses.
+ *  28   the offset (doubles, inside the contribution-block arena) of every front's block as (low, high) halves: 2 * num_sn ints. */
 int  mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t capacity);
 
 /* ---- measurement: device time per kernel kind (hip events around every launch of an eager, graph-less factor + one

@@ -467,6 +467,18 @@ int mi355x_kkt_get_symbolic(mi355x_kkt_handle h, int what, int* out, int64_t cap
     if (!h || !h->analysed || !out) return MI355X_KKT_FATAL;
     const Symbolic& S = h->sym;
     const avec<int>* v = nullptr;
+    if (what == 27) {      // the storage plan of the contribution blocks (symbolic.cpp step 12a): {window (0: every block resident), doubles of all blocks if resident, doubles never reused} as (lo, hi) halves
+        if (cap < 5) { h->err = "get_symbolic: buffer too small"; return MI355X_KKT_FATAL; }
+        out[0] = S.cb_window;
+        out[1] = (int)(S.cb_plain_doubles & 0xffffffffll); out[2] = (int)(S.cb_plain_doubles >> 32);
+        out[3] = (int)(S.cb_resident_doubles & 0xffffffffll); out[4] = (int)(S.cb_resident_doubles >> 32);
+        return MI355X_KKT_SUCCESS;
+    }
+    if (what == 28) {      // cb_off of every front as (low, high) 32-bit halves: 2 * num_sn ints (tests: no two blocks alive together share space)
+        if (cap < 2 * (int64_t)S.num_sn) { h->err = "get_symbolic: buffer too small"; return MI355X_KKT_FATAL; }
+        for (int s2 = 0; s2 < S.num_sn; ++s2) { out[2 * s2] = (int)(S.cb_off[s2] & 0xffffffffll); out[2 * s2 + 1] = (int)(S.cb_off[s2] >> 32); }
+        return MI355X_KKT_SUCCESS;
+    }
     switch (what) {
         case 0: v = &S.perm; break;        case 1: v = &S.sn_colptr; break;  case 2: v = &S.sn_rowptr; break;
         case 3: v = &S.sn_rows; break;     case 4: v = &S.sn_parent; break;  case 5: v = &S.sn_level; break;

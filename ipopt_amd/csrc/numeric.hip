@@ -47,8 +47,11 @@ enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_L
                   KK_BIG_SCHUR, KK_STATS, KK_SOLVE_PERM, KK_FWD_WAVE, KK_FWD_LDS, KK_FWD_BIG, KK_BWD_WAVE, KK_BWD_LDS, KK_BWD_BIG, KK_FWD_BIG_UPD, KK_BWD_BIG_DOT, KK_COUNT };
 #define DBGSTAMP(slot) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { V.dbg[2 * (slot)] = clock64(); V.dbg[2 * (slot) + 1] = wall_clock64(); } } while (0)
 #define DBGT(i) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) V.dbg[16 + (i)] = clock64(); } while (0)
-#define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); } while (0)
-#define LAUNCH_ON(kind, strm, ...) do { prof_begin(kind, strm); hipLaunchKernelGGL(__VA_ARGS__); prof_end(strm); } while (0)      // (a launch on the look-ahead stream: its events are recorded there)
+// (MI355X_KKT_LAUNCH_CHECK: development -- name the launch whose configuration the runtime refuses instead of the "invalid configuration argument" the next HIPCHK would report)
+static const bool g_launch_check = getenv("MI355X_KKT_LAUNCH_CHECK") != nullptr;
+#define LAUNCH_VERIFY(what) do { if (g_launch_check) { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) fprintf(stderr, "[mi355x_kkt] launch refused (%s): %s  @ line %d\n", hipGetErrorString(e_), what, __LINE__); } } while (0)
+#define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); LAUNCH_VERIFY(#__VA_ARGS__); } while (0)
+#define LAUNCH_ON(kind, strm, ...) do { prof_begin(kind, strm); hipLaunchKernelGGL(__VA_ARGS__); prof_end(strm); LAUNCH_VERIFY(#__VA_ARGS__); } while (0)      // (a launch on the look-ahead stream: its events are recorded there)
 
 static constexpr double BK_ALPHA = 0.6403882032022076;   // (1+sqrt(17))/8
 static constexpr double BK_ALPHA0 = 0.1;                 // a diagonal within this factor of its whole remaining column is taken as it comes (no partner search)
@@ -1621,6 +1624,7 @@ public:
         v2 = v2 && (size_t)maxch * ldi * sizeof(int) <= (size_t)158 * 1024 && ((nfronts >= 32 && maxch <= 6) || (asm2_wide && ncut == nfronts && cutmax <= 4 * ASM_CH));
         if (!v2) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
         const int ncols = (ncut == nfronts) ? std::min(mm, cutmax) : mm;      // (every front stops at its asmcut: no workgroups for the columns behind the largest of them)
+        if (ncols <= 0) return;                                               // (every front of the list has its whole block formed by its update: nothing to assemble -- a grid of 0 workgroups is refused by the runtime, met on the multi-rank schedule)
         LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble2, dim3((ncols + ASM_CH - 1) / ASM_CH, nfronts), dim3(256), (size_t)maxch * ldi * sizeof(int), stream, V, b0, top_mode, ldi, maxch);
     }
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
@@ -1698,6 +1702,10 @@ public:
                 const DfRun& R = df_runs[df_run_at[lv]];
                 LAUNCH(KK_FRONT_WAVE, k_front_df, dim3(std::min(R.nq, df_grid_cap)), dim3(64), 0, stream, V, d_dftab + R.tab0, R.nlev, R.nq);
                 lv = R.lv1; continue;
+            }
+            if (Sy.cb_window > 0 && lv % Sy.cb_window == 0) {      // recycled contribution blocks (symbolic.cpp step 12a): whatever earlier levels put on the look-ahead streams is
+                if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }      // through before a level >= lv may write into the space of a block they read
+                if (!drain_chain()) return false;
             }
             int lvl_fronts = 0, lvl_max = 0;
             for (int fc = 0; fc < FC_COUNT; ++fc) { const int nb = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1] - Sy.level_ptr[(size_t)lv * FC_COUNT + fc]; lvl_fronts += nb; lvl_max = std::max(lvl_max, nb); }

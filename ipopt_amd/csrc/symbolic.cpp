@@ -921,19 +921,91 @@ static bool finish_analysis(Symbolic& S, const SymbolicOptions& opt, const std::
         for (int s = 0; s < nsn; ++s) if (S.alias_child[s] < 0) loff += Mf(s) * K(s);
         S.l_doubles = loff;
         loff = 0;
-        for (int s = 0; s < nsn; ++s) {
-            const int64_t k = K(s), m = Mf(s), mu = m - k;
-            const int ac = S.alias_child[s];
-            if (ac < 0) {
-                S.panel_off[s] = loff; loff += m * k; S.sn_ldp[s] = (int)m;
-                S.cb_off[s] = coff; coff += mu * mu; S.sn_ldt[s] = (int)mu;
-            } else {        // children precede parents, so the child's placement is final
-                const int64_t ldc = S.sn_ldt[ac];
-                S.panel_off[s] = S.l_doubles + S.cb_off[ac]; S.sn_ldp[s] = (int)ldc;
-                S.cb_off[s] = S.cb_off[ac] + k * ldc + k; S.sn_ldt[s] = (int)ldc;
+        // ---- 12a. RECYCLING of the contribution blocks that only carry a contribution to their parent (round 6; what MUMPS' stack does, IpMumpsSolverInterface.cpp:151-177
+        //      ICNTL(14) sizes exactly that workspace).  The addresses stay STATIC (the factorisation remains one replayable launch sequence): the plan is made here, once,
+        //      over the LEVEL schedule.  A block of a BIG front that hosts no in-place chain is written at its front's level and dead once the front that extend-adds it (its
+        //      parent in the assembly tree) has been formed -- plus a WINDOW of levels, because launches of a level may still run on the look-ahead streams while the next
+        //      levels are enqueued: the numeric schedule joins those streams into the main one at every level that is a multiple of the window (numeric.hip, enqueue_factor),
+        //      so whatever was launched at level l has completed before anything of level >= l + window starts.  Blocks that host a chain hold that chain's panels (factor
+        //      storage) and stay; blocks of small fronts stay too (a few per cent of the pool; the data-flow launches over several levels tag them by epoch).  First fit over
+        //      the free list, blocks sorted by (level, size descending).  One GPU only (a rank's own subtrees report to the arena after ALL its levels).
+        //      MI355X_KKT_RECYCLE = 0 never / 1 always / unset: where it saves at least a quarter of the blocks and 1 GiB (synth_1e6: nothing to gain, 8 GiB, 4.7 of them hosts;
+        //      MBndryCntrl_3D 78: 68 -> ~35 GiB). ----
+        S.cb_window = 0; S.cb_resident_doubles = 0;
+        vector<char> recyc(nsn, 0);
+        int64_t plain_total = 0, cand_total = 0;
+        {
+            vector<char> host(nsn, 0);
+            for (int s = 0; s < nsn; ++s) if (S.alias_child[s] >= 0) host[S.alias_child[s]] = 1;
+            for (int s = 0; s < nsn; ++s) if (S.alias_child[s] < 0) {
+                const int64_t mu = Mf(s) - K(s);
+                plain_total += mu * mu;
+                if (!host[s] && S.sn_class[s] == FC_BIG && mu > 0 && S.sn_parent[s] >= 0) { recyc[s] = 1; cand_total += mu * mu; }
             }
         }
-        S.cb_doubles = coff;
+        int mode = -1;      // auto
+        if (const char* e = getenv("MI355X_KKT_RECYCLE")) mode = atoi(e) != 0 ? 1 : 0;
+        if (opt.nranks > 1 || getenv("MI355X_KKT_POOL_PIECE_MIB")) mode = 0;      // (pieces are cut between blocks that do not overlap)
+        const int WINDOW = 8;
+        vector<int64_t> roff(nsn, -1);
+        int64_t rpeak = 0;
+        if (mode != 0 && cand_total > 0) {
+            // the consuming level of a block: the level of the front whose child list holds it (the ASSEMBLY tree: a rehung side child is consumed where it was hung)
+            vector<int> cons(nsn, S.num_levels);
+            for (int p = 0; p < nsn; ++p) for (int q = S.child_ptr[p]; q < S.child_ptr[p + 1]; ++q) cons[S.child_idx[q]] = S.sn_level[p];
+            vector<int> order;
+            for (int s = 0; s < nsn; ++s) if (recyc[s]) order.push_back(s);
+            std::sort(order.begin(), order.end(), [&](int a, int b) {
+                if (S.sn_level[a] != S.sn_level[b]) return S.sn_level[a] < S.sn_level[b];
+                const int64_t ma = Mf(a) - K(a), mb = Mf(b) - K(b);
+                return ma != mb ? ma > mb : a < b; });
+            // live blocks ordered by the level from which their space may be written again; free list ordered by offset (coalesced)
+            std::multimap<int, std::pair<int64_t, int64_t>> live;      // free-from level -> (offset, size)
+            std::map<int64_t, int64_t> freel;                          // offset -> size
+            auto give_back = [&](int64_t off, int64_t sz) {
+                auto it = freel.lower_bound(off);
+                if (it != freel.begin()) { auto pr = std::prev(it); if (pr->first + pr->second == off) { off = pr->first; sz += pr->second; freel.erase(pr); } }
+                if (it != freel.end() && off + sz == it->first) { sz += it->second; freel.erase(it); }
+                freel[off] = sz;
+            };
+            for (int s : order) {
+                const int lv = S.sn_level[s];
+                while (!live.empty() && live.begin()->first <= lv) { give_back(live.begin()->second.first, live.begin()->second.second); live.erase(live.begin()); }
+                const int64_t mu = Mf(s) - K(s), need = mu * mu;
+                int64_t off = -1;
+                for (auto it = freel.begin(); it != freel.end(); ++it)
+                    if (it->second >= need) { off = it->first; const int64_t rest = it->second - need; freel.erase(it); if (rest > 0) freel[off + need] = rest; break; }
+                if (off < 0) {      // grow: a free tail is extended rather than skipped
+                    if (!freel.empty() && std::prev(freel.end())->first + std::prev(freel.end())->second == rpeak) { off = std::prev(freel.end())->first; freel.erase(std::prev(freel.end())); }
+                    else off = rpeak;
+                    rpeak = off + need;
+                }
+                roff[s] = off;
+                // written at level lv, read at level cons[s]; everything launched there has completed before level cons[s] + WINDOW starts being enqueued -- rounded up to the
+                // next join: free from the first multiple of WINDOW that is >= cons + 1 ... + WINDOW covers it (see enqueue_factor)
+                live.insert({std::min(cons[s], S.num_levels) + WINDOW + 1, {off, need}});
+            }
+            const int64_t saved = cand_total - rpeak;
+            if (mode == 1 || (4 * saved >= plain_total && 8 * saved >= (int64_t)1 << 30)) S.cb_window = WINDOW;
+        }
+        if (S.cb_window == 0) std::fill(recyc.begin(), recyc.end(), (char)0);
+        for (int s = 0; s < nsn; ++s) {
+            const int64_t k = K(s), m = Mf(s), mu = m - k;
+            if (S.alias_child[s] >= 0) continue;
+            S.panel_off[s] = loff; loff += m * k; S.sn_ldp[s] = (int)m; S.sn_ldt[s] = (int)mu;
+            if (!recyc[s]) { S.cb_off[s] = coff; coff += mu * mu; }
+        }
+        S.cb_resident_doubles = coff;
+        if (S.cb_window > 0) { for (int s = 0; s < nsn; ++s) if (recyc[s]) S.cb_off[s] = coff + roff[s]; coff += rpeak; }
+        for (int s = 0; s < nsn; ++s) {
+            const int ac = S.alias_child[s];
+            if (ac < 0) continue;
+            const int64_t k = K(s);        // children precede parents, so the child's placement is final
+            const int64_t ldc = S.sn_ldt[ac];
+            S.panel_off[s] = S.l_doubles + S.cb_off[ac]; S.sn_ldp[s] = (int)ldc;
+            S.cb_off[s] = S.cb_off[ac] + k * ldc + k; S.sn_ldt[s] = (int)ldc;
+        }
+        S.cb_doubles = coff; S.cb_plain_doubles = plain_total;
         // chain groups: up to `chain_group` consecutive links of an in-place chain (<= 256 columns, consecutive levels) are
         // ONE unit for the trailing update (a single rank-(sum k) update at the last link; the links before it only update
         // the group's own remaining columns) and for the triangular solves (one launch pair per group).

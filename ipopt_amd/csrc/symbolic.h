@@ -127,6 +127,8 @@ struct Symbolic {
     int num_gdepths = 1;
     // statistics
     int64_t nnz_l = 0, flops_factor = 0, sum_sn_rows = 0, cb_doubles = 0, l_doubles = 0;
+    int     cb_window = 0;                 // > 0: contribution blocks are RECYCLED over the level schedule (symbolic.cpp step 12a); the numeric schedule joins its side streams every cb_window levels
+    int64_t cb_resident_doubles = 0, cb_plain_doubles = 0;      // the part of cb_doubles that is never reused (chain hosts, small fronts); what cb_doubles would be with every block resident
     int num_rehung = 0;        // side children of chain links assembled further down their chain (SymbolicOptions::chain_purify)
     int maxfront = 0, maxsupernode = 0, num_big = 0;
     double time_analyse = 0;

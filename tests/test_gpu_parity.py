@@ -610,3 +610,36 @@ def test_fused_pivot_block_and_panel_solve_is_bitwise_identical(monkeypatch):
     for _ in range(3):
         x2 = b.copy(); s1.multi_solve(True, x2)
         assert np.array_equal(x1, x2)
+
+
+@pytest.mark.parametrize("source", ["mbndry3d_14", "grid40x36"])
+def test_recycled_contribution_blocks_give_bitwise_the_same_factorisation(source, monkeypatch):
+    """symbolic.cpp step 12a: contribution blocks that only carry a contribution to their parent share space over the level schedule.  Only ADDRESSES
+    change: inertia, pivot statistics and every bit of the solution must equal those of the layout with every block resident -- on the 3-D system
+    whose plan does reuse space (tests/test_symbolic.py checks that it does) and on a 2-D grid, twice each (the second factorisation finds the
+    space holding the first one's dead blocks)."""
+    if source == "mbndry3d_14":
+        n, r, c, v, neg = kktgen.recorded_kkt(os.path.join(os.path.dirname(__file__), "golden", "mbndry3d_14.kktrec"), which=0)
+    else:
+        n, r, c, v, neg = kktgen.grid_kkt(40, 36, dof=2, ncon=1, seed=8)
+    K = kktgen.to_scipy(n, r, c, v)
+    b = np.stack([K @ np.ones(n), np.random.default_rng(5).standard_normal(n)])
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("MI355X_KKT_RECYCLE", mode)
+        s = ipopt_amd.KKTSolver()
+        s.initialize_structure(n, r, c, vals=v)
+        assert (int(s.symbolic(27, 5)[0]) > 0) == (mode == "1")
+        xs = []
+        for rep in range(2):
+            s.values()[:] = v
+            x = b.copy()
+            assert s.multi_solve(True, x, True, neg) == kkt.SUCCESS
+            xs.append(x)
+        I = s.info()
+        out[mode] = (xs, s.number_of_neg_evals(), I.num_two, I.num_small, I.cb_doubles)
+        for k in range(2):
+            assert sres(K, xs[0][k], b[k]) <= RES_TOL
+    assert out["0"][1:4] == out["1"][1:4] and out["1"][4] <= out["0"][4]
+    for rep in range(2):
+        assert np.array_equal(out["0"][0][rep], out["1"][0][rep])

@@ -261,3 +261,23 @@ def test_rccl_two_ranks_on_the_one_device_or_a_clear_refusal():
         assert all(g[2] == 0 and g[3] <= 1e-12 for g in got), got
     else:
         assert all("nccl" in g[2].lower() or "rccl" in g[2].lower() for g in got), got
+
+
+def test_bench_line_of_two_ranks_at_configuration_size(tmp_path):
+    """`bench.py --gpus 2` on BASELINE configs[3] (synth_1e6) itself, the two ranks sharing cuda:0 (MI355X_KKT_BENCH_SHARED: gloo bootstrap, the library's
+    shared-memory communicator): the launcher, the distributed factor / solve at FULL size (round 6 found a launch of zero workgroups on this schedule that
+    no smaller test met), inertia + residual asserted inside the run, and the line's contract.  The numbers are not a scaling measurement."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI355X_KKT_BENCH_SHARED="1", MI355X_KKT_SHM_TIMEOUT_S="240")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-e2e"],
+                         capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-1500:] + out.stderr[-3000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["workload"] == "synth_1e6" and d["config"]["num_neg"] == 400000 and d["config"]["scaled_residual"] <= 1e-12
+    assert d["communicator"]["kind"] == "callbacks" and d["communicator"]["ranks_seen"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0

@@ -392,3 +392,57 @@ def test_row_view_lists_every_entry_of_both_triangles_by_ascending_other_index()
         assert (np.diff(oc) > 0).all()                                         # ascending other index, each once
         for q, o in zip(sl, oc):
             assert {int(arow[q]), int(acol[q])} == {i, int(o)}
+
+
+@pytest.mark.parametrize("source", ["mbndry3d_14", "grid40x36"])
+def test_recycled_contribution_blocks_never_share_space_while_both_are_alive(source, monkeypatch, golden_dir):
+    """Step 12a of the analysis (round 6): blocks that only carry a contribution to their parent are laid out over the LEVEL schedule -- a block is
+    written at its front's level, read at its assembly parent's level, and its space may be written again `window` + 1 levels later (the numeric
+    schedule joins its look-ahead streams every `window` levels).  Checked on the exported plan: (1) with the plan off every block has its own space;
+    (2) with it on, two blocks whose address ranges intersect have disjoint [born, consumed + window] level intervals, blocks that host an in-place
+    chain (factor storage) and blocks of small fronts intersect nothing; (3) the permutation, supernodes and row structures are those of the plain layout."""
+    import os
+    if source == "mbndry3d_14":
+        n, r, c, v, neg = kktgen.recorded_kkt(os.path.join(golden_dir, "mbndry3d_14.kktrec"), which=0)
+    else:
+        n, r, c, v, neg = kktgen.grid_kkt(40, 36, dof=2, ncon=1, seed=8)
+
+    def plan(mode):
+        monkeypatch.setenv("MI355X_KKT_RECYCLE", mode)
+        s = ipopt_amd.KKTSolver(device=-1)
+        s.initialize_structure(n, r, c, vals=v)
+        I = s.info(); N = I.num_sn
+        p = s.symbolic(27, 5).astype(np.int64)
+        o = s.symbolic(28, 2 * N).astype(np.int64)
+        off = (o[0::2] & 0xffffffff) | (o[1::2] << 32)
+        return s, I, int(p[0]), ((p[1] & 0xffffffff) | (p[2] << 32), (p[3] & 0xffffffff) | (p[4] << 32)), off
+
+    s0, I0, w0, (plain0, res0), off0 = plan("0")
+    s1, I1, w1, (plain1, res1), off1 = plan("1")
+    N = I0.num_sn
+    assert w0 == 0 and w1 > 0 and I0.cb_doubles == plain0 == plain1 and I1.cb_doubles <= I0.cb_doubles and res1 <= I1.cb_doubles
+    for sel, cnt in ((0, n), (1, N + 1), (2, N + 1), (4, N), (5, N), (17, N)):
+        assert np.array_equal(s0.symbolic(sel, cnt), s1.symbolic(sel, cnt))
+    colptr, rowptr = s1.symbolic(1, N + 1).astype(np.int64), s1.symbolic(2, N + 1).astype(np.int64)
+    parent, lev, alias, cls = s1.symbolic(4, N), s1.symbolic(5, N), s1.symbolic(17, N), s1.symbolic(23, N)
+    mu = np.diff(rowptr) - np.diff(colptr)
+    own = np.where((alias < 0) & (mu > 0))[0]
+    host = np.zeros(N, bool); host[alias[alias >= 0]] = True
+    born = lev[own]
+    dead = np.where(parent[own] >= 0, lev[np.maximum(parent[own], 0)], lev.max() + 1) + w1      # last level at which the space still belongs to the block
+    lo, hi = off1[own], off1[own] + mu[own].astype(np.int64) ** 2
+    order = np.argsort(lo, kind="stable")
+    shared = 0
+    for a_i, a in enumerate(order):
+        for b in order[a_i + 1:]:
+            if lo[b] >= hi[a]:
+                break
+            # the two ranges intersect: they may not be alive together, and neither may be a chain host or a small front's block
+            shared += 1
+            assert born[b] > dead[a] or born[a] > dead[b], (own[a], own[b])
+            assert not host[own[a]] and not host[own[b]] and cls[own[a]] == 3 and cls[own[b]] == 3
+    if source == "mbndry3d_14":
+        assert shared > 0 and I1.cb_doubles < I0.cb_doubles      # (3-D: the plan does reuse space; the 2-D grid keeps everything within the window)
+    # plain layout: nothing intersects
+    lo0 = off0[own]; o0 = np.argsort(lo0, kind="stable")
+    assert np.all(lo0[o0][1:] >= (lo0 + mu[own].astype(np.int64) ** 2)[o0][:-1])

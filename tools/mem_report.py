@@ -20,6 +20,9 @@ for wl in sys.argv[1:]:
            "analyse_s": I.time_analyse, "initialize_structure_wall_s": t_init, "cb_doubles": I.cb_doubles, "cb_GiB": I.cb_doubles * 8 / 2**30,
            "panels_GiB": float((m * k).sum() * 8 / 2**30), "cb_if_every_block_were_separate_GiB": float(((m - k) ** 2).sum() * 8 / 2**30),
            "device_total_GiB": total / 2**30, "device_used_by_setup_GiB": (free0 - free1) / 2**30}
+    pl = s.symbolic(27, 5).astype(np.int64)      # the storage plan of the contribution blocks (symbolic.cpp step 12a)
+    out["cb_plan"] = {"window_levels": int(pl[0]), "every_block_resident_GiB": float(((pl[1] & 0xffffffff) | (pl[2] << 32)) * 8 / 2**30),
+                      "never_reused_GiB": float(((pl[3] & 0xffffffff) | (pl[4] << 32)) * 8 / 2**30)}
     try:
         tf, ts = [], []
         for _ in range(3):
