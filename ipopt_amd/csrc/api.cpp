@@ -5,6 +5,7 @@
 #include "numeric.h"
 #include "matching_scaling.h"
 #include "comm_shm.h"
+#include "env_knobs.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -81,7 +82,8 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         so.index_base = h->opts.index_base; so.ordering = h->opts.ordering; so.matching = h->opts.matching;
         so.nd_leaf = h->opts.nd_leaf > 0 ? h->opts.nd_leaf : 32; so.nemin = h->opts.nemin > 0 ? h->opts.nemin : 8;
         so.max_sn_cols = h->opts.max_sn_cols > 1 ? (h->opts.max_sn_cols > 64 ? 64 : h->opts.max_sn_cols) : 64;   // 64: LDS budget of k_big_trsm (104 KiB at k = 65)
-        so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose; so.leaf_cols = h->opts.leaf_cols; so.tree_merge = h->opts.tree_merge; so.wide_panels = h->opts.wide_panels; so.chain_purify = getenv("MI355X_KKT_NO_PURIFY") ? 0 : 1; so.chain_group = h->opts.chain_group > 0 ? h->opts.chain_group : 4; so.solve_group = h->opts.solve_group; so.subcube = h->opts.subcube;
+        so.nranks = h->opts.nranks > 0 ? h->opts.nranks : 1; so.verbose = h->opts.verbose; so.leaf_cols = h->opts.leaf_cols; so.tree_merge = h->opts.tree_merge;
+        so.wide_panels = h->opts.wide_panels; so.chain_purify = knob_disabled("purify") ? 0 : 1; so.chain_group = h->opts.chain_group > 0 ? h->opts.chain_group : 4; so.solve_group = h->opts.solve_group; so.subcube = h->opts.subcube;
         // The device's first touch (runtime, context, code objects) and the pinned staging buffer do not depend on the analysis: the two run side by side.
         // HIP's "current device" belongs to the CALLING thread (a helper thread asking for it gets device 0 whatever the caller selected), and finding it
         // out initialises the runtime -- a good part of what is to be overlapped -- so the CALLER does the warm-up and the helper thread the analysis,

@@ -10,6 +10,7 @@
 // gives |s_i a_ij s_j| <= 1 everywhere and = 1 on the matching.  Host code like the symbolic analysis: it runs once when the
 // caller asks for it (MA97's "dynamic" policy computes it on demand and then reuses the factors).
 #include "matching_scaling.h"
+#include "env_knobs.h"
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -26,7 +27,7 @@ bool matching_scaling(int n, const int* ptr, const int* idx, const double* absva
 {
     // full symmetric pattern: column j holds the rows idx[ptr[j] .. ptr[j+1]) with |values| absval[...]
     const double INF = std::numeric_limits<double>::infinity();
-    const bool timing = getenv("MI355X_KKT_MATCH_TIMING") != nullptr;
+    const bool timing = knob_trace("matching");
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](const char* w) { if (timing) { const double t = now(); fprintf(stderr, "[match] %-12s %.3f s\n", w, t - t0); t0 = t; } };

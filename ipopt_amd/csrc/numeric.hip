@@ -35,6 +35,7 @@
 #include <string>
 #include <algorithm>
 #include "numeric.h"
+#include "env_knobs.h"
 #include "matching_scaling.h"
 
 namespace mi355x {
@@ -47,8 +48,9 @@ enum KernelKind { KK_GATHER_SCALE = 0, KK_FRONT_WAVE, KK_FRONT_LDS64, KK_FRONT_L
                   KK_BIG_SCHUR, KK_STATS, KK_SOLVE_PERM, KK_FWD_WAVE, KK_FWD_LDS, KK_FWD_BIG, KK_BWD_WAVE, KK_BWD_LDS, KK_BWD_BIG, KK_FWD_BIG_UPD, KK_BWD_BIG_DOT, KK_COUNT };
 #define DBGSTAMP(slot) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { V.dbg[2 * (slot)] = clock64(); V.dbg[2 * (slot) + 1] = wall_clock64(); } } while (0)
 #define DBGT(i) do { if (V.dbg && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) V.dbg[16 + (i)] = clock64(); } while (0)
-// (MI355X_KKT_LAUNCH_CHECK: development -- name the launch whose configuration the runtime refuses instead of the "invalid configuration argument" the next HIPCHK would report)
-static const bool g_launch_check = getenv("MI355X_KKT_LAUNCH_CHECK") != nullptr;
+// (MI355X_KKT_TRACE=launches: development -- name the launch whose configuration the runtime refuses instead of the "invalid configuration argument" the next HIPCHK would report)
+#include "env_knobs.h"
+static const bool g_launch_check = mi355x::knob_trace("launches");
 #define LAUNCH_VERIFY(what) do { if (g_launch_check) { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) fprintf(stderr, "[mi355x_kkt] launch refused (%s): %s  @ line %d\n", hipGetErrorString(e_), what, __LINE__); } } while (0)
 #define LAUNCH(kind, ...) do { prof_begin(kind); hipLaunchKernelGGL(__VA_ARGS__); prof_end(); LAUNCH_VERIFY(#__VA_ARGS__); } while (0)
 #define LAUNCH_ON(kind, strm, ...) do { prof_begin(kind, strm); hipLaunchKernelGGL(__VA_ARGS__); prof_end(strm); LAUNCH_VERIFY(#__VA_ARGS__); } while (0)      // (a launch on the look-ahead stream: its events are recorded there)
@@ -241,20 +243,12 @@ public:
     // grouped schedule (single GPU): per level the chain groups whose FIRST link sits there (entries = FrontMeta of the LAST link, sorted by
     // order, split at 1024 rows like the BIG buckets), launch geometry, look-ahead tiles
     bool grouped = false;
-    struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2, p1t, la3, nsplit; std::vector<hipEvent_t> evA, evB, evC, evD; };      // evC / evD: fork / join of the row blocks launched next to the pivot-row blocks (k_grp_rows); p1t: 64 x 64 tiles of a split front's part 1, la3: tiles of the fronts not split, nsplit: split fronts (among the large ones)
+    struct GrpSched { std::vector<int> g0, g1, split, nrb, tiles64, tiles, la1, la2, p1t, la3, nsplit; std::vector<hipEvent_t> evA, evB; };      // p1t: 64 x 64 tiles of a split front's part 1, la3: tiles of the fronts not split, nsplit: split fronts (among the large ones)
     GrpSched gs_single, gs_local;              // one-GPU schedule; multi-GPU: the rank's own subtrees
     std::vector<GrpSched> gs_stage;            // multi-GPU: the replicated fronts this rank holds, per exchange step (sn_gdepth)
     GrpSched* gs_cur = nullptr;                // ... the step launch_fronts is working on
     std::vector<hipEvent_t> la_evA, la_evB;
-    // chain look-ahead (single-GPU schedule, levels whose fronts are all pure in-place chain links): the critical path
-    //   pivot block (k_big_diag_reg) -> first row block of the panel (k_big_trsm, 1 workgroup) -> the NEXT link's 64 x 64 pivot
-    //   block (k_big_schur64, tile (0,0))
-    // stays on the main stream; the bulk of the panel solve and of the trailing update trails on `stream3` (the far part of
-    // a split group-end update on `stream2`), overlapped with the next link's latency-bound pivot block
-    hipStream_t stream3 = nullptr;
-    std::vector<char> lv_chain; bool chain_la = true; int chain_maxf = 64;
-    std::vector<hipEvent_t> chD, chLA, chN, chG1, chFar;
-    hipEvent_t ch_bulk_last = nullptr, ch_far_last = nullptr; bool ch_bulk_pending = false, ch_far_pending = false;
+    hipStream_t stream3 = nullptr;             // third stream: the side buckets of small fronts next to a level's main launches (enqueue_factor)
     hipStream_t stream2 = nullptr; bool la_pending = false; hipEvent_t la_last = nullptr; bool lookahead = true, la_any = false; int la_wgs = 1 << 20, la_min_nt = 8;
     std::vector<size_t> reg_lds;
     std::vector<int> mid_split; std::vector<size_t> mid_lds;   // per level: leading FC_LDS128 fronts of order <= 96 (6x6-tile kernel, 2 workgroups per CU) and their LDS need
@@ -379,7 +373,7 @@ public:
     }
     void make_subcomms() {
         destroy_subcomms();
-        if (comm_kind != 2 || !rccl.comm || !rccl.CommSplit || getenv("MI355X_KKT_NO_SUBCOMM")) return;
+        if (comm_kind != 2 || !rccl.comm || !rccl.CommSplit || knob_disabled("subcomm")) return;
         rccl.sub.assign(ndepth, nullptr);
         bool ok = true;
         for (int d = 0; d < ndepth; ++d) {
@@ -504,10 +498,9 @@ public:
         for (auto e : la_evB) if (e) (void)hipEventDestroy(e);
         la_evA.clear(); la_evB.clear();
         { std::vector<GrpSched*> all{&gs_single, &gs_local}; for (auto& g : gs_stage) all.push_back(&g);
-          for (GrpSched* g : all) { for (auto* v : {&g->evA, &g->evB, &g->evC, &g->evD}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); } } }
-        for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
+          for (GrpSched* g : all) { for (auto* v : {&g->evA, &g->evB}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); } } }
         for (auto* v : {&side_evF, &side_evJ}) { for (auto e : *v) if (e) (void)hipEventDestroy(e); v->clear(); }
-        ch_bulk_last = ch_far_last = la_last = nullptr; ch_bulk_pending = ch_far_pending = la_pending = false;
+        la_last = nullptr; la_pending = false;
         if (!keep) {
             if (stream3) { (void)hipStreamDestroy(stream3); stream3 = nullptr; }
             if (stream2) { (void)hipStreamDestroy(stream2); stream2 = nullptr; }
@@ -625,11 +618,9 @@ public:
             HIPCHK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, plo));
             HIPCHK(hipStreamCreateWithPriority(&stream3, hipStreamNonBlocking, (plo + phi) / 2));
         }
-        lookahead = getenv("MI355X_KKT_NO_LOOKAHEAD") == nullptr;
-        chain_la = getenv("MI355X_KKT_CHAIN_LA") != nullptr;      // default OFF: measured slower (DESIGN.md "measured design decisions")
-        if (const char* e = getenv("MI355X_KKT_CHAIN_LA_MAXF")) chain_maxf = std::max(1, atoi(e));
-        if (const char* e = getenv("MI355X_KKT_LA_WGS")) la_wgs = std::max(1, atoi(e));          // development knobs
-        if (const char* e = getenv("MI355X_KKT_LA_MIN_NT")) la_min_nt = std::max(3, atoi(e));
+        lookahead = !knob_disabled("lookahead");
+        la_wgs = (int)std::max(1ll, knob_int("la_wgs", la_wgs));          // development knobs
+        la_min_nt = (int)std::max(3ll, knob_int("la_min_nt", la_min_nt));
         if (!keep) {
             HIPCHK(hipEventCreate(&ev0)); HIPCHK(hipEventCreate(&ev1));
             if (opt.prewarmed_vals && opt.prewarmed_count >= std::max<size_t>(Sy.nnz_in, 1)) h_vals = (double*)opt.prewarmed_vals;       // (made while the analysis ran)
@@ -839,22 +830,21 @@ public:
         std::vector<ChainLink> chl; std::vector<ChainDesc> chd; std::vector<int> chwait, wgf, wgb;
         int ntailflags = 0, ndots = 0;
         chain_segs.clear(); in_seg.clear(); seg_at_lv0.assign(Sy.num_levels, -1); seg_at_lv1.assign(Sy.num_levels, -1);
-        chain_solve = getenv("MI355X_KKT_NO_CHAIN_SOLVE") == nullptr;
-        fuse_dt = getenv("MI355X_KKT_NO_FUSE_DT") == nullptr;
-        V.fastpiv = getenv("MI355X_KKT_NO_FASTPIV") == nullptr ? 1 : 0;
-        V.asm_pull = getenv("MI355X_KKT_NO_ASM_PULL") == nullptr ? 1 : 0;
-        if (const char* e = getenv("MI355X_KKT_GRP_RBW_MAX")) grp_rbw_max = std::max(1, atoi(e));
-        asm_v1 = getenv("MI355X_KKT_ASM_V1") != nullptr;      // (the one-wavefront-per-column assembly kernel of rounds 1-3)
-        V.fastu = 1e-4; if (const char* e = getenv("MI355X_KKT_FASTPIV_FLOOR")) V.fastu = atof(e);      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
-        if (const char* e = getenv("MI355X_KKT_FUSE_DT_MAXWG")) fuse_dt_maxwg = atoi(e);
-        pair_solve = getenv("MI355X_KKT_NO_PAIR_SOLVE") == nullptr && !multi;
+        chain_solve = !knob_disabled("chain_solve");
+        fuse_dt = !knob_disabled("fuse_dt");
+        V.fastpiv = !knob_disabled("fastpiv") ? 1 : 0;
+        V.asm_pull = !knob_disabled("asm_pull") ? 1 : 0;
+        grp_rbw_max = (int)std::max(1ll, knob_int("grp_rbw_max", grp_rbw_max));
+        V.fastu = 1e-4; { double fl; if (knob_tune("fastpiv_floor", &fl)) V.fastu = fl; }      // (0.01 up to r03a: 9 % of the synth_1e6 blocks then took the strict loop and set the pace of their level: 23.1 -> 22.0 ms)
+        fuse_dt_maxwg = (int)knob_int("fuse_dt_maxwg", fuse_dt_maxwg);
+        pair_solve = !knob_disabled("pair_solve") && !multi;
         wave_kmax.assign(Sy.num_levels, 0); wave_mmax.assign(Sy.num_levels, 0); wave_mmin.assign(Sy.num_levels, 1 << 30);
         for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_WAVE) {
             wave_kmax[Sy.sn_level[sn]] = std::max(wave_kmax[Sy.sn_level[sn]], Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
             wave_mmax[Sy.sn_level[sn]] = std::max(wave_mmax[Sy.sn_level[sn]], Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]);
             wave_mmin[Sy.sn_level[sn]] = std::min(wave_mmin[Sy.sn_level[sn]], Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]);
         }
-        if (const char* e = getenv("MI355X_KKT_CHAIN_SOLVE_MAXC")) chain_maxc = std::max(1, atoi(e));
+        chain_maxc = (int)std::max(1ll, knob_int("chain_solve_maxc", chain_maxc));
         if (!Sy.solve_group && chain_solve) {
             auto Kc = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
             auto Mr = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
@@ -958,7 +948,7 @@ public:
         }
         if (!upload(wgf, &V.chwg_f) || !upload(wgb, &V.chwg_b) || !upload(chwait, &V.chwait)) return false;
         V.strace = nullptr; V.strace_b = (int)wgf.size(); strace_n = 0;
-        if (getenv("MI355X_KKT_SOLVE_TRACE") && !wgf.empty()) {
+        if (knob_trace("solve") && !wgf.empty()) {
             strace_n = 4 * (wgf.size() + wgb.size());
             if (!dalloc(&V.strace, strace_n)) return false;
             strace_desc.clear();
@@ -990,7 +980,7 @@ public:
                 G.c0 = Sy.sn_colptr[l]; G.k = Sy.sn_colptr[l + 1] - G.c0; G.r0 = Sy.sn_rowptr[l]; G.m = Sy.sn_rowptr[l + 1] - G.r0;
                 G.ldp = Sy.sn_ldp[l]; G.ch0 = Sy.child_ptr[l]; G.ch1 = Sy.child_ptr[l + 1]; G.alias = Sy.alias_child[l] >= 0 ? 1 : 0;
                 G.t_off = CO(l); G.ldt = Sy.sn_ldt[l]; G.s = l; G.aq0 = Sy.acolptr[G.c0]; G.aq1 = Sy.acolptr[G.c0 + G.k]; G.bigidx = bigidx_of[l];
-                G.selfasm = ((!multi || aoff[l] < 0) && getenv("MI355X_KKT_NO_SELFASM") == nullptr && Sy.alias_child[l] >= 0 && Sy.child_ptr[l + 1] - Sy.child_ptr[l] == 1) ? 1 : 0;
+                G.selfasm = ((!multi || aoff[l] < 0) && !knob_disabled("selfasm") && Sy.alias_child[l] >= 0 && Sy.child_ptr[l + 1] - Sy.child_ptr[l] == 1) ? 1 : 0;
                 gt.push_back(G); gcols_of[sn] += G.k;
             }
         }
@@ -1036,7 +1026,7 @@ public:
                 const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
                 const int nt = (mu + 127) / 128; la_total += (long long)(nt - 2) * (nt - 1) / 2;
             }
-            const long long la_gate = getenv("MI355X_KKT_LA_MIN_TILES") ? atoll(getenv("MI355X_KKT_LA_MIN_TILES")) : 4000;     // (tests force 0)
+            const long long la_gate = knob_int("la_min_tiles", 4000);     // (tests force 0)
             if (la_total < la_gate || la_total == 0) { std::fill(split_of.begin(), split_of.end(), 0); std::fill(la_tiles2.begin(), la_tiles2.end(), 0);
                 for (int lv = 0; lv < Sy.num_levels; ++lv) la_tiles1[lv] = 0; }
             la_any = la_total >= la_gate && la_total > 0;
@@ -1059,7 +1049,7 @@ public:
                     }
                 tab_at[n] = at; return at;
             };
-            const bool xcd_aware = getenv("MI355X_KKT_NO_XCD_TILES") == nullptr;
+            const bool xcd_aware = !knob_disabled("xcd_tiles");
             for (int sn = 0; sn < Sy.num_sn; ++sn) if (xcd_aware && Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
                 const int mu = (Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]) - (Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]);
                 const int nt = (mu + 127) / 128;
@@ -1069,7 +1059,7 @@ public:
             }
         }
         if (!upload(tile_tab, &V.tile_tab)) return false;
-        const bool selfasm_on = getenv("MI355X_KKT_NO_SELFASM") == nullptr;
+        const bool selfasm_on = !knob_disabled("selfasm");
         lv_asm_skip.assign(Sy.num_levels, 0);
         if (!multi && selfasm_on)
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
@@ -1083,7 +1073,7 @@ public:
         // levels whose big fronts are ALL chain links that are not the last of their group: the (narrow) trailing updates ride in
         // the fused pivot-block + panel-solve launch
         lv_narrow_tiles.assign(Sy.num_levels, 0);
-        if (!multi && getenv("MI355X_KKT_NO_FUSE_UPD") == nullptr)
+        if (!multi && !knob_disabled("fuse_upd"))
             for (int lv = 0; lv < Sy.num_levels; ++lv) {
                 bool all = true; int cnt = 0, tl = 0;
                 for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1]; ++q) {
@@ -1093,27 +1083,8 @@ public:
                 }
                 lv_narrow_tiles[lv] = (cnt > 0 && all) ? tl : 0;
             }
-        lv_chain.assign(Sy.num_levels, 0);
-        if (!multi && selfasm_on && chain_la)
-            for (int lv = 0; lv < Sy.num_levels; ++lv) {
-                const int nbig = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1] - Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG];
-                const int nall = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_COUNT] - Sy.level_ptr[(size_t)lv * FC_COUNT];
-                int kmax = 0;
-                for (int q = Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG]; q < Sy.level_ptr[(size_t)lv * FC_COUNT + FC_BIG + 1]; ++q) kmax = std::max(kmax, Sy.sn_colptr[Sy.level_sn[q] + 1] - Sy.sn_colptr[Sy.level_sn[q]]);
-                lv_chain[lv] = (lv_asm_skip[lv] && nbig == nall && nbig <= chain_maxf && kmax <= 64) ? 1 : 0;
-            }
-        {
-            int nchain = 0;
-            for (int lv = 0; lv < Sy.num_levels; ++lv) nchain += lv_chain[lv];
-            if (nchain < 8) std::fill(lv_chain.begin(), lv_chain.end(), 0);      // not worth leaving the graph replay for
-            else la_any = true;                                                  // multi-stream schedule => eager launches (see factor())
-            chD.assign(Sy.num_levels, nullptr); chLA.assign(Sy.num_levels, nullptr); chN.assign(Sy.num_levels, nullptr); chG1.assign(Sy.num_levels, nullptr); chFar.assign(Sy.num_levels, nullptr);
-            for (int lv = 0; lv < Sy.num_levels; ++lv) if (lv_chain[lv])
-                for (auto* v : {&chD, &chLA, &chN, &chG1, &chFar}) HIPCHK(hipEventCreateWithFlags(&(*v)[lv], hipEventDisableTiming));
-            if (opt.verbose) fprintf(stderr, "[mi355x_kkt] chain look-ahead on %d of %d levels\n", nchain >= 8 ? nchain : 0, Sy.num_levels);
-        }
         // ---- grouped schedule: every chain group is factored at the level of its first link (k_grp_fused + update) ----
-        grouped = Sy.maxsupernode <= 64 && selfasm_on && getenv("MI355X_KKT_NO_GROUPED") == nullptr;
+        grouped = Sy.maxsupernode <= 64 && selfasm_on && !knob_disabled("grouped");
         {
             auto order_of = [&](int sn) { return Sy.sn_rowptr[sn + 1] - Sy.sn_rowptr[sn]; };
             auto cols_of = [&](int sn) { return Sy.sn_colptr[sn + 1] - Sy.sn_colptr[sn]; };
@@ -1121,7 +1092,7 @@ public:
             // in-place chain never crosses an ownership boundary -- symbolic.cpp only aliases fronts of one owner and one range of ranks -- so neither does a group)
             auto build_groups = [&](GrpSched& G, int which) -> bool {
                 for (auto* v : {&G.g0, &G.g1, &G.split, &G.nrb, &G.tiles64, &G.tiles, &G.la1, &G.la2, &G.p1t, &G.la3, &G.nsplit}) v->assign(Sy.num_levels, 0);
-                G.evA.assign(Sy.num_levels, nullptr); G.evB.assign(Sy.num_levels, nullptr); G.evC.assign(Sy.num_levels, nullptr); G.evD.assign(Sy.num_levels, nullptr);
+                G.evA.assign(Sy.num_levels, nullptr); G.evB.assign(Sy.num_levels, nullptr);
                 if (!grouped) return true;
                 std::vector<std::vector<int>> at(Sy.num_levels);
                 for (int sn = 0; sn < Sy.num_sn; ++sn) if (Sy.sn_class[sn] == FC_BIG && Sy.grp_rem[sn] == 0) {
@@ -1151,7 +1122,6 @@ public:
                     }
                     G.split[lv] = nsmall; G.g1[lv] = (int)lvl_list.size();
                     if (G.la2[lv] > 0) { HIPCHK(hipEventCreateWithFlags(&G.evA[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&G.evB[lv], hipEventDisableTiming)); }
-                    if (G.g1[lv] > G.g0[lv]) { HIPCHK(hipEventCreateWithFlags(&G.evC[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&G.evD[lv], hipEventDisableTiming)); }
                 }
                 if (opt.verbose) fprintf(stderr, "[mi355x_kkt] grouped schedule%s: %d chain groups factored in one launch each (tree levels >= %d)\n",
                                          which == 0 ? "" : (which == 1 ? " (own subtrees)" : " (replicated fronts of one exchange step)"), ng, Sy.grp_cut_level);
@@ -1168,7 +1138,7 @@ public:
             int nch = 0;
             for (int c = Sy.child_ptr[sn]; c < Sy.child_ptr[sn + 1]; ++c) if (Sy.child_idx[c] != Sy.alias_child[sn]) ++nch;
             const bool chain_only = Sy.alias_child[sn] >= 0 && nch == 0;      // (pure in-place link: nothing to assemble either way)
-            asm_fast_ok[q] = chain_only ? 1 : (Sy.alias_child[sn] < 0 ? (nch <= 6 ? std::max(nch, 1) : (asm2_wide ? std::min(nch, (int)ASM_MAXCH) : 0)) : 0);      // (the number of children the front brings to k_big_assemble2's row maps -- a front with more than ASM_MAXCH falls back to the column routine inside the kernel; 0: not for that kernel)
+            asm_fast_ok[q] = chain_only ? 1 : (Sy.alias_child[sn] < 0 ? (nch <= 6 ? std::max(nch, 1) : 0) : 0);      // (the number of children the front brings to k_big_assemble2's row maps -- a front with more than ASM_MAXCH falls back to the column routine inside the kernel; 0: not for that kernel)
         }
         // tfuse: the contribution block of a front is formed by its trailing update (T = sum of the children's contributions - L21 W21^T, written once) instead of
         // being assembled, read back and written again.  A front that is a unit of its own -- assembled (not in place on a child), its update one launch of
@@ -1178,8 +1148,8 @@ public:
         std::vector<char> tfuse_of(Sy.num_sn, 0);
         std::vector<int> asmcut_of(Sy.num_sn, 0);
         ntfuse = 0;
-        if (!multi && getenv("MI355X_KKT_NO_TFUSE") == nullptr) {
-            const bool wide = getenv("MI355X_KKT_TFUSE_SMALL") == nullptr && !chain_la;
+        if (!multi && !knob_disabled("tfuse")) {
+            const bool wide = true;
             for (int sn = 0; sn < Sy.num_sn; ++sn) {
                 if (Sy.sn_class[sn] != FC_BIG || Sy.grp_rem[sn] != 0) continue;      // (the last link of its group, or a front of its own)
                 int first = sn;
@@ -1262,7 +1232,7 @@ public:
             // link of the chain that starts at its leaf
             lc_levels = 0; lc_nchains = 0;
             std::vector<int> lcp, lcf; std::vector<LeafLink> lcl;
-            if (!multi && V.fastpiv && getenv("MI355X_KKT_NO_LEAFCHAIN") == nullptr) {
+            if (!multi && V.fastpiv && !knob_disabled("leafchain")) {
                 int L = 0;
                 for (; L < Sy.num_levels && L < 16; ++L) {
                     bool okl = true; int cnt = 0;
@@ -1370,9 +1340,9 @@ public:
         else if (opt.scaling == 2 && !d_user_scale) opt.scaling = 1;       // (user factors can only come through set_scaling)
         V.cb = V.L + Sy.l_doubles;          // one pool: panels of in-place chain fronts live inside the cb part
         V.arena = nullptr; V.top_rhs = nullptr; V.rank = opt.rank; V.dbg = nullptr;
-        if (getenv("MI355X_KKT_DEBUG_CLOCKS")) { if (!dalloc(&V.dbg, 128)) return false; }
+        if (knob_trace("clocks")) { if (!dalloc(&V.dbg, 128)) return false; }
         if (multi) { if (!dalloc(&V.arena, (size_t)arena_doubles) || !dalloc(&V.top_rhs, (size_t)toprhs_doubles)) return false; }
-        V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn; V.xcd_affine = getenv("MI355X_KKT_NO_XCD_AFFINE") ? 0 : 1;
+        V.pivtol = opt.pivtol; V.pivtol2 = std::max(opt.pivtol, opt.pivtolmax); V.small = opt.small; V.n = Sy.n; V.nnz_a = Sy.nnz_a; V.nsn = Sy.num_sn; V.xcd_affine = knob_disabled("xcd_affine") ? 0 : 1;
         // allow the large dynamic LDS sizes
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_reg<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_big_diag_reg<4, 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1381,10 +1351,8 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<64, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 6, true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)(k_front_reg<256, 8, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         // exact LDS need of the register-tiled front kernel per (level, class) bucket
         reg_lds.assign((size_t)Sy.num_levels * FC_COUNT, 0);
         for (int s = 0; s < Sy.num_sn; ++s) {
@@ -1399,7 +1367,6 @@ public:
         HIPCHK(hipFuncSetAttribute((const void*)k_big_trsm<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_diag_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_grp_fused, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        HIPCHK(hipFuncSetAttribute((const void*)k_grp_rows, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         HIPCHK(hipFuncSetAttribute((const void*)k_big_assemble2, hipFuncAttributeMaxDynamicSharedMemorySize, 158 * 1024));      // (+ 1.3 KB of static LDS: the per-child tables)
         // per (level, BIG) bucket: largest front order / pivot count (launch geometry)
         big_maxm.assign(Sy.num_levels, 0); big_maxk.assign(Sy.num_levels, 0); big_tiles.assign(Sy.num_levels, 0); big_tiles64.assign(Sy.num_levels, 0);
@@ -1441,7 +1408,6 @@ public:
     // one (level, class) bucket of fronts
     bool launch_bucket(int lv, int fc, int b0, int b1, int top_mode, int mm, int kk, int tiles, int tiles64) {
         const int nb = b1 - b0;
-        if (fc != FC_BIG && !drain_chain()) return false;        // (a level with small fronts is never a chain level)
         const size_t rl = reg_lds[(size_t)lv * FC_COUNT + fc];
         if (fc == FC_WAVE) {
             const bool sg = b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_WAVE];                            // single-GPU schedule: the bucket is sorted by order
@@ -1469,10 +1435,9 @@ public:
             // the fronts the static-order launch rejected -- 342 of them on synth_1e6 -- instead of the whole bucket: 18.21 against 18.16 ms.  The
             // 60-150 us of the strict launches are those fronts' own latency chains, not the workgroups that find nothing to do.)
             if (V.fastpiv) {      // fronts with <= 16 pivots: static-order path first; what it accepts is skipped by the launch behind it
-                if (nm > 0) { if (fast_occ & 1) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true, 4>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
-                              else LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode); }
-                if (nb - nm > 0) { if (fast_occ & 2) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true, 3>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
-                                   else LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode); }
+                // (<256, 6, true> cut to 128 VGPRs = 4 workgroups per CU: 2.24 -> 2.13 ms of front_lds128 on synth_1e6; the same cut of <256, 8, true> gained nothing and is gone)
+                if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6, true, 4>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, top_mode);
+                if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8, true>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, top_mode);
             }
             if (nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 6>), dim3(nm), dim3(256), mid_lds[lv], stream, V, b0, fl);
             if (nb - nm > 0) LAUNCH(KK_FRONT_LDS128, (k_front_reg<256, 8>), dim3(nb - nm), dim3(256), rl, stream, V, b0 + nm, fl);
@@ -1480,54 +1445,12 @@ public:
             const bool single = (b0 == S->level_ptr[(size_t)lv * FC_COUNT + FC_BIG]) && !multi;       // the single-GPU schedule
             if ((single || multi) && grouped && lv >= S->grp_cut_level) {
                 // the chain groups whose first link sits on this level, one launch each (the multi-GPU schedules have their own group lists)
-                if (!drain_chain()) return false;
                 if (!(single && lv_asm_skip[lv])) launch_assemble(mm, nb, b0, top_mode);
                 return launch_groups(lv, single ? gs_single : (top_mode ? *gs_cur : gs_local));
             }
             if (!single) { const bool sm = mm <= 640; return launch_big(lv, b0, sm ? b1 : b0, b1, top_mode, mm, kk, sm ? tiles64 : 0, sm ? 0 : tiles, false); }
             return launch_big(lv, b0, b0 + big_split[lv], b1, top_mode, mm, kk, part_tiles[0][lv], part_tiles[1][lv], true);
         }
-        return true;
-    }
-    // the big-front launches of one level: assembly, pivot blocks and TRSM over the whole list [b0, b1); the trailing update with
-    // 64 x 64 tiles / 256 threads on the fronts [b0, bs) of order <= 1024 (a handful of tiles, K = 16..64 each) and with
-    // 128 x 128 tiles / 1024 threads on [bs, b1)
-    bool drain_chain() {
-        if (ch_bulk_pending) { HIPCHK(hipStreamWaitEvent(stream, ch_bulk_last, 0)); ch_bulk_pending = false; }
-        if (ch_far_pending) { HIPCHK(hipStreamWaitEvent(stream, ch_far_last, 0)); ch_far_pending = false; }
-        return true;
-    }
-    // one level of pure chain links with look-ahead (see the member comment): [b0, bs) fronts of order <= 1024, [bs, b1) larger
-    bool launch_big_chain(int lv, int b0, int bs, int b1, int mm, int kk, int tiles_small, int tiles) {
-        const int nball = b1 - b0, nrb = (mm + 63) / 64;
-        if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
-        // ---- critical path (main stream) ----
-        hipLaunchKernelGGL(k_big_diag_reg<4>, dim3(nball), dim3(256), diag_lds_bytes(kk, 64), stream, V, b0);
-        HIPCHK(hipEventRecord(chD[lv], stream));
-        if (ch_bulk_pending) HIPCHK(hipStreamWaitEvent(stream, ch_bulk_last, 0));      // this panel's first row block was finalised by the previous level's bulk update
-        hipLaunchKernelGGL(k_big_trsm<false>, dim3(1, nball), dim3(256), trsm_lds(kk), stream, V, b0, 0);
-        hipLaunchKernelGGL(k_big_schur64, dim3(1, nball), dim3(256), 0, stream, V, b0, 1);
-        HIPCHK(hipEventRecord(chLA[lv], stream));
-        // ---- bulk (stream3): the rest of the panel solve, then the trailing update minus the block done above ----
-        HIPCHK(hipStreamWaitEvent(stream3, chD[lv], 0));
-        if (nrb > 1) hipLaunchKernelGGL(k_big_trsm<false>, dim3(nrb - 1, nball), dim3(256), trsm_lds(kk), stream3, V, b0, 1);
-        HIPCHK(hipStreamWaitEvent(stream3, chLA[lv], 0));
-        if (bs > b0 && tiles_small > 0) hipLaunchKernelGGL(k_big_schur64, dim3(tiles_small, bs - b0), dim3(256), 0, stream3, V, b0, 2);
-        if (b1 > bs) {
-            const int nb = b1 - bs;
-            if (la_full[lv] && ch_far_pending) { HIPCHK(hipStreamWaitEvent(stream3, ch_far_last, 0)); ch_far_pending = false; }   // a full update touches what the previous far part writes
-            if (la_tiles2[lv] > 0) {
-                hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(la_tiles1[lv]), nb), dim3(SCHUR_NT), 0, stream3, V, bs, 1, 0, 1);
-                HIPCHK(hipEventRecord(chG1[lv], stream3));
-                HIPCHK(hipStreamWaitEvent(stream2, chG1[lv], 0));
-                hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(std::min(la_tiles2[lv], la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, bs, 2, la_tiles2[lv], 0);
-                HIPCHK(hipEventRecord(chFar[lv], stream2));
-                ch_far_last = chFar[lv]; ch_far_pending = true;
-            } else if (tiles > 0) hipLaunchKernelGGL(k_big_schur, dim3(schur_grid(tiles), nb), dim3(SCHUR_NT), 0, stream3, V, bs, 0, 0, 1);
-        }
-        HIPCHK(hipEventRecord(chN[lv], stream3));
-        ch_bulk_last = chN[lv]; ch_bulk_pending = true;
-        HIPCHK(hipGetLastError());
         return true;
     }
     // the chain groups whose first link sits on level lv: pivot blocks + leading blocks, rows below, rank-(<= 256) updates
@@ -1539,23 +1462,8 @@ public:
             int rbw = 1;
             while (rbw < grp_rbw_max && (b1 - b0) * (4 + (G.nrb[lv] + rbw - 1) / rbw) > 256) rbw *= 2;
             const int nrbw = (G.nrb[lv] + rbw - 1) / rbw;
-            const int st = ((b1 - b0) * (4 + nrbw) <= 256 && !grp_nostage) ? 1 : 0;
+            const int st = ((b1 - b0) * (4 + nrbw) <= 256) ? 1 : 0;
             const size_t lds = std::max(diag_lds_bytes(64, 64), GRP_DB_BYTES + trsm_lds_bytes(64, st != 0));
-            // next to a part-2 update still running on the second stream: the pivot-row blocks first (4 workgroups per chain), the row blocks below in a second
-            // launch (see k_grp_fused) -- where that update is the longer of the two (grp_split_min: workgroups of the fused launch from which it pays)
-            const bool cut = la_pending && grp_split_min > 0 && (b1 - b0) * (4 + nrbw) >= grp_split_min && nrbw > 0;
-            // ... or the row blocks NEXT TO the pivot-row blocks, as a launch of the light kernel (k_grp_rows) on the third stream: an update workgroup shares a CU with those
-            const bool rows = la_pending && !multi && !prof_on && grp_rows_min > 0 && (b1 - b0) * (4 + nrbw) >= grp_rows_min && nrbw > 0 && G.evC[lv];
-            if (rows) {
-                HIPCHK(hipEventRecord(G.evC[lv], stream)); HIPCHK(hipStreamWaitEvent(stream3, G.evC[lv], 0));
-                LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4), dim3(256), lds, stream, V, b0, st, 1, 0);
-                hipLaunchKernelGGL(k_grp_rows, dim3(b1 - b0, G.nrb[lv]), dim3(256), trsm_lds_bytes(64, false), stream3, V, b0, 0, 1);
-                HIPCHK(hipEventRecord(G.evD[lv], stream3)); HIPCHK(hipStreamWaitEvent(stream, G.evD[lv], 0));
-            } else if (cut) {
-                const int nrb1 = G.nrb[lv];
-                LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4), dim3(256), lds, stream, V, b0, st, 1, 0);
-                LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, nrb1), dim3(256), lds, stream, V, b0, st, 1, 4);
-            } else
             LAUNCH(KK_BIG_DIAG, k_grp_fused, dim3(b1 - b0, 4 + nrbw), dim3(256), lds, stream, V, b0, st, rbw, 0);
         }
         if (bs > b0 && G.tiles64[lv] > 0) LAUNCH(KK_BIG_SCHUR, k_big_schur64, dim3(G.tiles64[lv], bs - b0), dim3(256), 0, stream, V, b0, 0);
@@ -1582,31 +1490,22 @@ public:
     // A handful of small fronts on a level whose bulk is elsewhere (synth_1e6: 3 fronts of order <= 128 next to 2 045 big ones; one front of order <= 64
     // next to 943 of order <= 128) is a launch of 1-3 workgroups running their strict pivot loops for 40-90 us with the chip idle.  The buckets of one level
     // are independent: in the eager (multi-stream) schedule such a bucket goes to the third stream, next to the level's main launches.
-    std::vector<hipEvent_t> side_evF, side_evJ; bool side_on = getenv("MI355X_KKT_NO_SIDE_SMALL") == nullptr; static constexpr int SIDE_MAX_FRONTS = 16;
+    std::vector<hipEvent_t> side_evF, side_evJ; bool side_on = !knob_disabled("side_small"); static constexpr int SIDE_MAX_FRONTS = 16;
     // runs of consecutive tree levels that hold nothing but one-wavefront fronts (order <= 32): one persistent data-flow launch each (k_front_df)
     struct DfRun { int lv0, lv1, tab0, nlev, nq; };
     std::vector<DfRun> df_runs; std::vector<int> df_run_at; const DfLevel* d_dftab = nullptr; int df_grid_cap = 0;
-    bool df_on = getenv("MI355X_KKT_NO_FRONT_DF") == nullptr;
+    bool df_on = !knob_disabled("front_df");
     int lc_levels = 0, lc_nchains = 0;      // leaf chains: the tree levels below lc_levels are lc_nchains chains of fronts of order <= 16 (k_leaf_chain)
-    bool p1_small_tiles = getenv("MI355X_KKT_NO_P1_SMALL") == nullptr;
+    bool p1_small_tiles = !knob_disabled("p1_small");
     // part 2 of the split updates (second stream, next to the following group's pivot chain): 128 x 128 tiles on 16 wavefronts, or quarter tiles on 4
     // wavefronts that fit on the CUs a k_grp_fused workgroup occupies (kernels_big.hip.inc: k_big_schur_q / _w)
-    int p2_kernel = getenv("MI355X_KKT_P2_KERNEL") ? atoi(getenv("MI355X_KKT_P2_KERNEL")) : 1;      // default: quarter tiles through LDS (synth_1e6 17.85 -> 17.70 ms, bitwise identical; 2 = straight from L2: 17.92)
-    int grp_split_min = getenv("MI355X_KKT_GRP_SPLIT") ? atoi(getenv("MI355X_KKT_GRP_SPLIT")) : 0;
-    int fast_occ = getenv("MI355X_KKT_FAST_OCC") ? atoi(getenv("MI355X_KKT_FAST_OCC")) : 1;      // bit 0: <256, 6, true> cut to 128 VGPRs (4 workgroups per CU: 2.24 -> 2.13 ms of front_lds128 on synth_1e6), bit 1: <256, 8, true> to 168 (no gain)
-    int grp_rows_min = getenv("MI355X_KKT_GRP_ROWS") ? atoi(getenv("MI355X_KKT_GRP_ROWS")) : 0;
-    bool grp_nostage = getenv("MI355X_KKT_GRP_NOSTAGE") != nullptr;      // (development: 110 KB instead of 143 KB of LDS per k_grp_fused workgroup -- room for a k_big_schur_q workgroup next to it)
     void launch_part2(int b0, int nb, int ntiles) {
         const int nvirt = ((ntiles + 7) / 8) * 32;
         const int wgs = (int)std::min<long long>(nvirt, 4ll * la_wgs);
-        if (p2_kernel == 1)      LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur_q, dim3(wgs, nb), dim3(256), 0, stream2, V, b0, ntiles);
-        else if (p2_kernel == 2) LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur_w, dim3(wgs, nb), dim3(256), 0, stream2, V, b0, ntiles);
-        else LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur, dim3(schur_grid(std::min(ntiles, la_wgs)), nb), dim3(SCHUR_NT), 0, stream2, V, b0, 2, ntiles, 0);
+        LAUNCH_ON(KK_BIG_SCHUR, stream2, k_big_schur_q, dim3(wgs, nb), dim3(256), 0, stream2, V, b0, ntiles);
     }
     std::vector<char> asm_fast_ok;          // per launch-list entry: the front can take k_big_assemble2's fast path (the number of children it pulls; 0: it cannot)
     std::vector<int> h_asmcut;              // per launch-list entry: FrontMeta::asmcut
-    bool asm2_wide = getenv("MI355X_KKT_ASM2_WIDE") != nullptr;      // (default off: measured on the MBndryCntrl_3D 50 system, big_assemble 7.16 -> 7.65 ms with the wide scope)
-    bool asm_v1 = false;
     // The column-chunk kernel pays where a level is MANY fronts of a few hundred rows (short columns: the one-wavefront-per-column kernel runs at the
     // latency of its load chain there) and every front can take its fast path (at most ASM_MAXCH children to pull, not an in-place link with other
     // children, no arena): measured 4.1 -> 2.0 ms per factorisation on synth_1e6, but 3.4 -> 8.7 ms on MBndryCntrl_3D 30, whose levels are a
@@ -1618,18 +1517,19 @@ public:
         // Round 5: a front whose contribution block is formed by its update (asmcut) has only its panel columns assembled; a launch of such fronts has no
         // workgroups behind the largest asmcut.  (MI355X_KKT_ASM2_WIDE: this kernel also for levels of a few dozen fronts with up to ASM_MAXCH = 16 children each
         // once only their panel columns are assembled -- the MBndryCntrl_3D family; measured slower there than the column kernel, 7.65 against 7.16 ms.)
-        bool v2 = !asm_v1 && !top_mode;
+        bool v2 = !top_mode;
         int maxch = 1, ncut = 0, cutmax = 0;
         for (int q = b0; q < b0 + nfronts && v2; ++q) { v2 = asm_fast_ok[q] != 0; maxch = std::max(maxch, (int)asm_fast_ok[q]); if (h_asmcut[q]) { ++ncut; cutmax = std::max(cutmax, h_asmcut[q] > 0 ? h_asmcut[q] : 0); } }
-        v2 = v2 && (size_t)maxch * ldi * sizeof(int) <= (size_t)158 * 1024 && ((nfronts >= 32 && maxch <= 6) || (asm2_wide && ncut == nfronts && cutmax <= 4 * ASM_CH));
+        v2 = v2 && (size_t)maxch * ldi * sizeof(int) <= (size_t)158 * 1024 && (nfronts >= 32 && maxch <= 6);
         if (!v2) { LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble, dim3((mm + 3) / 4, nfronts), dim3(256), 0, stream, V, b0, top_mode); return; }
         const int ncols = (ncut == nfronts) ? std::min(mm, cutmax) : mm;      // (every front stops at its asmcut: no workgroups for the columns behind the largest of them)
         if (ncols <= 0) return;                                               // (every front of the list has its whole block formed by its update: nothing to assemble -- a grid of 0 workgroups is refused by the runtime, met on the multi-rank schedule)
         LAUNCH(KK_BIG_ASSEMBLE, k_big_assemble2, dim3((ncols + ASM_CH - 1) / ASM_CH, nfronts), dim3(256), (size_t)maxch * ldi * sizeof(int), stream, V, b0, top_mode, ldi, maxch);
     }
+    // the big-front launches of one level: assembly, pivot blocks and TRSM over the whole list [b0, b1); the trailing update with
+    // 64 x 64 tiles / 256 threads on the fronts [b0, bs) of order <= 1024 (a handful of tiles, K = 16..64 each) and with
+    // 128 x 128 tiles / 1024 threads on [bs, b1)
     bool launch_big(int lv, int b0, int bs, int b1, int top_mode, int mm, int kk, int tiles_small, int tiles, bool single) {
-        if (single && lv_chain[lv] && !prof_on && !top_mode) return launch_big_chain(lv, b0, bs, b1, mm, kk, tiles_small, tiles);
-        if (!drain_chain()) return false;
         const int nball = b1 - b0;
         if (!(single && lv_asm_skip[lv])) launch_assemble(mm, nball, b0, top_mode);
         const int nrb = (mm + 63) / 64;
@@ -1674,8 +1574,7 @@ public:
         if (!fuse0) LAUNCH(KK_GATHER_SCALE, k_abs_rowview, dim3(grid1d(V.rslot_len)), dim3(256), 0, stream, V);
         if (opt.scaling >= 2) LAUNCH(KK_GATHER_SCALE, k_user_scale, dim3(grid1d(n)), dim3(256), 0, stream, V, (const double*)d_user_scale);     // 2: the caller's factors, 3: matching (computed just before)
         else if (opt.scaling) {
-            static const int lpr_env = getenv("MI355X_KKT_RUIZ_LPR") ? atoi(getenv("MI355X_KKT_RUIZ_LPR")) : 0;
-            const int lpr = lpr_env ? lpr_env : ((long long)V.rslot_len < 8ll * n ? 2 : 8);      // short rows (LukVl: ~5 entries): 2 lanes per row (measured 0.89 / 0.82 / 0.80 ms per factorisation at 8 / 4 / 2)
+            const int lpr = (long long)V.rslot_len < 8ll * n ? 2 : 8;      // short rows (LukVl: ~5 entries): 2 lanes per row (measured 0.89 / 0.82 / 0.80 ms per factorisation at 8 / 4 / 2)
             auto sweeps = [&](auto tag) {
                 constexpr int L = decltype(tag)::value;
                 if (fuse0) LAUNCH(KK_GATHER_SCALE, k_abs_rowview_sweep0<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, V.scale2);
@@ -1684,7 +1583,7 @@ public:
                 LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)V.scale, V.scale2, (double*)nullptr);
                 LAUNCH(KK_GATHER_SCALE, k_ruiz_sweep<L>, dim3(grid1d((long long)L * n)), dim3(256), 0, stream, V, (const double*)V.scale2, V.scale, V.cnorm);
             };
-            if (lpr == 2) sweeps(std::integral_constant<int, 2>()); else if (lpr == 4) sweeps(std::integral_constant<int, 4>()); else sweeps(std::integral_constant<int, 8>());
+            if (lpr == 2) sweeps(std::integral_constant<int, 2>()); else sweeps(std::integral_constant<int, 8>());
         } else LAUNCH(KK_GATHER_SCALE, k_fill, dim3(grid1d(n)), dim3(256), 0, stream, V.scale, 1.0, (long long)n);
         if (opt.scaling != 1) LAUNCH(KK_GATHER_SCALE, k_colnorm, dim3(grid1d(8ll * n)), dim3(256), 0, stream, V, opt.scaling ? 1 : 0);      // (Ruiz: ~1 by construction, written by the last sweep)
         if (opt.scaling) LAUNCH(KK_GATHER_SCALE, k_apply_scale, dim3(grid1d(Sy.nnz_a)), dim3(256), 0, stream, V);
@@ -1705,7 +1604,6 @@ public:
             }
             if (Sy.cb_window > 0 && lv % Sy.cb_window == 0) {      // recycled contribution blocks (symbolic.cpp step 12a): whatever earlier levels put on the look-ahead streams is
                 if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }      // through before a level >= lv may write into the space of a block they read
-                if (!drain_chain()) return false;
             }
             int lvl_fronts = 0, lvl_max = 0;
             for (int fc = 0; fc < FC_COUNT; ++fc) { const int nb = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1] - Sy.level_ptr[(size_t)lv * FC_COUNT + fc]; lvl_fronts += nb; lvl_max = std::max(lvl_max, nb); }
@@ -1714,7 +1612,7 @@ public:
                 const int b0 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc], b1 = Sy.level_ptr[(size_t)lv * FC_COUNT + fc + 1];
                 if (b1 == b0) continue;
                 // (the eager schedule only: a multi-stream hipGraph is what factor_once() avoids; not next to the three-stream chain look-ahead)
-                const bool side = side_on && la_any && !chain_la && !multi && fc != FC_BIG && b1 - b0 <= SIDE_MAX_FRONTS && lvl_max >= 8 * (b1 - b0) && lvl_fronts > b1 - b0;
+                const bool side = side_on && la_any && !multi && fc != FC_BIG && b1 - b0 <= SIDE_MAX_FRONTS && lvl_max >= 8 * (b1 - b0) && lvl_fronts > b1 - b0;
                 if (!side) { launch_bucket(lv, fc, b0, b1, 0, big_maxm[lv], big_maxk[lv], big_tiles[lv], big_tiles64[lv]); continue; }
                 if ((int)side_evF.size() < Sy.num_levels) { side_evF.resize(Sy.num_levels, nullptr); side_evJ.resize(Sy.num_levels, nullptr); }
                 if (!side_evF[lv]) { HIPCHK(hipEventCreateWithFlags(&side_evF[lv], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&side_evJ[lv], hipEventDisableTiming)); }
@@ -1727,14 +1625,13 @@ public:
             if (side_open) { HIPCHK(hipEventRecord(side_evJ[lv], stream3)); HIPCHK(hipStreamWaitEvent(stream, side_evJ[lv], 0)); }      // the level above reads what they wrote
         }
         if (la_pending) { HIPCHK(hipStreamWaitEvent(stream, la_last, 0)); la_pending = false; }
-        if (!drain_chain()) return false;
         LAUNCH(KK_STATS, k_zero_i32, dim3(1), dim3(64), 0, stream, d_stats, 4);
         LAUNCH(KK_STATS, k_reduce_stats, dim3(std::min(64, (Sy.num_sn + 255) / 256)), dim3(256), 0, stream, V.fstat, V.apfail, V.sn_owner, Sy.num_sn, -2, d_stats);
         HIPCHK(hipGetLastError());
         return true;
     }
 
-    bool norestore_on = getenv("MI355X_KKT_RESTORE") == nullptr;      // (development knob: keep the safety copies of the pivot blocks in the optimistic schedule too)
+    bool norestore_on = !knob_disabled("norestore");      // (development knob: keep the safety copies of the pivot blocks in the optimistic schedule too)
     bool optimistic = false;                 // (set per factorisation: see launch_bucket)
     bool optimistic_ok = true;               // the optimistic schedule may be tried (false while a back-off runs: see factor())
     int  opt_backoff = 0, opt_wait = 0;      // after a fall-back: opt_wait factorisations on the full schedule, then one more optimistic try; every repeat doubles the wait (8 .. 256)
@@ -1743,7 +1640,7 @@ public:
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "factor: solver not set up (no device?)"; return false; }
         if (multi) return factor_dist(dvals, reuse, st);          // needs a communicator (set_comm_*), fails loudly otherwise
-        static const bool opt_off = getenv("MI355X_KKT_NO_OPTIMISTIC") != nullptr;
+        static const bool opt_off = knob_disabled("optimistic");
         if (!optimistic_ok && opt_wait > 0 && --opt_wait == 0) optimistic_ok = true;   // (one rejection early in an Ipopt run must not cost the optimistic schedule for the life of the structure)
         optimistic = V.fastpiv && !opt_off && !prof_on && optimistic_ok;
         if (!factor_once(dvals, reuse, st)) return false;
@@ -1915,7 +1812,8 @@ public:
             if (V.strace) {
                 std::vector<unsigned long long> h(strace_n);
                 HIPCHK(hipMemcpy(h.data(), V.strace, strace_n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-                if (FILE* f = fopen(getenv("MI355X_KKT_SOLVE_TRACE"), "w")) {
+                std::string trace_path; knob_trace("solve", &trace_path);
+                if (FILE* f = fopen(trace_path.c_str(), "w")) {
                     for (size_t i = 0; i < strace_desc.size(); ++i)
                         fprintf(f, "%c %d %d %d %d %llu %llu %llu %llu\n", i < (size_t)V.strace_b ? 'F' : 'B', strace_desc[i].chain, strace_desc[i].w, strace_desc[i].nlinks, strace_desc[i].tail,
                                 h[4 * i], h[4 * i + 1], h[4 * i + 2], h[4 * i + 3]);

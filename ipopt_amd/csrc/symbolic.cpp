@@ -7,6 +7,7 @@
 // supernodal row structures, child->parent relative indices, A->front scatter map,
 // level schedule, storage offsets, multi-GPU subtree ownership.
 #include "symbolic.h"
+#include "env_knobs.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -109,7 +110,7 @@ void BlockCache::put(void* p, size_t bytes) noexcept
         else cache_release_range(C, off, len);
     }
 }
-BlockCache::Scope::Scope() { CacheState& C = cache_state(); std::lock_guard<std::mutex> lk(C.mu); ++C.scopes; if (C.scopes == 1 && !C.tried && getenv("MI355X_KKT_NO_BLOCKCACHE")) C.tried = true; }      // (development knob: no reservation => every block is malloc)
+BlockCache::Scope::Scope() { CacheState& C = cache_state(); std::lock_guard<std::mutex> lk(C.mu); ++C.scopes; if (C.scopes == 1 && !C.tried && knob_disabled("blockcache")) C.tried = true; }      // (development knob: no reservation => every block is malloc)
 BlockCache::Scope::~Scope()
 {
     CacheState& C = cache_state();
@@ -130,7 +131,14 @@ template <class T> using vector = avec<T>;       // every array of the analysis 
 
 
 // static-chunk parallel loop on std::thread (the analysis is the only multi-threaded host code; T <= 16)
-int analysis_threads() { unsigned h = std::thread::hardware_concurrency(); int t = h ? std::min((int)h, 32) : 1; const char* e = getenv("MI355X_KKT_THREADS"); if (e) t = atoi(e); return std::max(1, std::min(t, 256)); }      // default: up to 32 (measured on the 2 x 64-core host of the GPU box); MI355X_KKT_THREADS overrides
+// default: up to 32 threads (measured on the 2 x 64-core host of the GPU box); MI355X_KKT_THREADS overrides
+int analysis_threads()
+{
+    const unsigned h = std::thread::hardware_concurrency();
+    int t = h ? std::min((int)h, 32) : 1;
+    if (const char* e = getenv("MI355X_KKT_THREADS")) t = atoi(e);
+    return std::max(1, std::min(t, 256));
+}
 // The parallel loops of one analysis share a set of parked worker threads (PoolScope, opened by analyse / restructure_delays on the thread that runs the
 // analysis): a region costs a wake-up instead of creating and joining T threads -- ~0.8 ms per region at T = 32, some 40 regions per analysis.
 struct WorkerPool {
@@ -166,7 +174,7 @@ struct WorkerPool {
 thread_local WorkerPool* tl_pool = nullptr;
 struct PoolScope {
     WorkerPool* mine = nullptr;
-    explicit PoolScope(int T) { if (!tl_pool && T > 1 && getenv("MI355X_KKT_NO_POOL") == nullptr) { mine = new WorkerPool(T - 1); tl_pool = mine; } }
+    explicit PoolScope(int T) { if (!tl_pool && T > 1 && !knob_disabled("thread_pool")) { mine = new WorkerPool(T - 1); tl_pool = mine; } }
     ~PoolScope() { if (mine) { tl_pool = nullptr; delete mine; } }
 };
 template <class F> void parallel_chunks(long long n, int T, F fn) {
@@ -578,7 +586,6 @@ public:
                     if (touchesB) S.push_back(v); else A.push_back(v);
                 }
             }
-            if (getenv("MI355X_KKT_ND_DEBUG") && m > 20000) fprintf(stderr, "[nd] m=%d A=%zu B=%zu S=%zu nlev=%d level=%d\n", m, A.size(), B.size(), S.size(), nlev, bestl);
             if (A.empty() || B.empty() || (int)S.size() * 2 > m) { md.order(t.nodes, order.data() + t.start); return; }
             int sa = (int)A.size(), sb = (int)B.size();
             // separator last; inside S keep BFS order (dense clique anyway)
@@ -1014,7 +1021,7 @@ static bool finish_analysis(Symbolic& S, const SymbolicOptions& opt, const std::
         S.grp_pos.assign(nsn, 0); S.grp_rem.assign(nsn, 0);
         {   // the latency-bound top of the tree: the levels from which on no level has more than `maxch` BIG fronts
             int maxch = 8;
-            if (const char* e = getenv("MI355X_KKT_GRP_MAXCHAINS")) maxch = std::max(0, atoi(e));
+            maxch = (int)std::max(0ll, knob_int("grp_maxchains", maxch));
             vector<int> nbig(S.num_levels, 0);
             for (int s = 0; s < nsn; ++s) if (S.sn_class[s] == FC_BIG) nbig[S.sn_level[s]]++;
             S.grp_cut_level = S.num_levels;

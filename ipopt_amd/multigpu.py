@@ -195,7 +195,7 @@ class CommKKT:
             self.s.set_comm_rccl(box[0])
         else:
             fn, fn_range = gloo_allreduce_callback(torch, dist, nranks)
-            self.s.set_comm_callback(fn, fn_range if not os.environ.get("MI355X_KKT_NO_SUBCOMM") else None)
+            self.s.set_comm_callback(fn, fn_range if "subcomm" not in os.environ.get("MI355X_KKT_DISABLE", "").split(",") else None)
 
 
 def play_comm_plans(plans):
@@ -243,7 +243,7 @@ def bench_dry_run(args, rank, world):
     subcube = int(os.environ.get("MI355X_KKT_SUBCUBE", "1" if world > 2 else "0"))
     s = _kkt.KKTSolver(device=-1, nranks=world, rank=rank, subcube=subcube)
     s.initialize_structure(n, r, c, vals=v)
-    range_local = not bool(os.environ.get("MI355X_KKT_NO_SUBCOMM"))
+    range_local = "subcomm" not in os.environ.get("MI355X_KKT_DISABLE", "").split(",")
     mine = s.comm_plan(rank, range_local).tolist()
     box = [None] * world
     dist.all_gather_object(box, mine)
@@ -330,7 +330,7 @@ def bench_main(args, rank, world, local):
     b = K @ np.ones(n)
     # the collectives (all-reduce of the top arena / top right-hand sides / solution, RCCL over xGMI) run inside the C library
     subcube = int(os.environ.get("MI355X_KKT_SUBCUBE", "1" if world > 2 else "0"))      # (two ranks: the two mappings coincide)
-    ck = CommKKT(rank, world, local, n, r, c, v, dist, use_rccl=not os.environ.get("MI355X_KKT_BENCH_GLOO"), use_shm=shared, subcube=subcube)
+    ck = CommKKT(rank, world, local, n, r, c, v, dist, use_rccl=not shared, use_shm=shared, subcube=subcube)
     s = ck.s
     I = s.info()
     dv = torch.tensor(v, dtype=torch.float64, device="cuda")

@@ -84,7 +84,7 @@ def test_every_rank_issues_a_matching_sequence_of_collectives(nranks, subcube):
 
 @pytest.mark.parametrize("nranks", [2, 4, 8])
 def test_whole_communicator_fall_back_is_one_sum_per_step_on_every_rank(nranks):
-    """MI355X_KKT_NO_SUBCOMM / a failed ncclCommSplit: no splits, every rank issues the identical list (zeros for the squares of ranges it is not in)."""
+    """MI355X_KKT_DISABLE=subcomm / a failed ncclCommSplit: no splits, every rank issues the identical list (zeros for the squares of ranges it is not in)."""
     n, sym, plan = plans(nranks, 1, False)
     ref = [tuple(int(x) for x in rec) for rec in plan[0]]
     assert all(rec[0] != SPLIT and rec[2] == WHOLE for rec in ref)

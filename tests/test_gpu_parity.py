@@ -233,14 +233,14 @@ def test_lookahead_split_updates_are_exact_and_reproducible(monkeypatch, part1):
     """the two-stream look-ahead of the group-end trailing updates (normally only on very large fronts) forced onto a
     mid-size system: same inertia, converged solve, bitwise identical to the single-stream factorisation -- with part 1 (the first 256
     columns, on the main stream) in 64 x 64 tiles (k_big_schur_p1, the default where few tiles are in the launch) and in the 128 x 128 ones"""
-    if part1 == "tiles128": monkeypatch.setenv("MI355X_KKT_NO_P1_SMALL", "1")
+    if part1 == "tiles128": monkeypatch.setenv("MI355X_KKT_DISABLE", "p1_small")
     n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)        # fronts up to ~1 200 rows: several split updates
     K = kktgen.to_scipy(n, r, c, v)
     b = K @ np.ones(n)
-    monkeypatch.setenv("MI355X_KKT_NO_LOOKAHEAD", "1")
+    monkeypatch.setenv("MI355X_KKT_DISABLE", "lookahead")
     s0, st0, x0 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
-    monkeypatch.delenv("MI355X_KKT_NO_LOOKAHEAD")
-    monkeypatch.setenv("MI355X_KKT_LA_MIN_NT", "3"); monkeypatch.setenv("MI355X_KKT_LA_MIN_TILES", "0")
+    monkeypatch.delenv("MI355X_KKT_DISABLE")
+    monkeypatch.setenv("MI355X_KKT_TUNE", "la_min_nt=3,la_min_tiles=0")
     s1, st1, x1 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
     assert st0 == st1 == kkt.SUCCESS and s1.number_of_neg_evals() == neg
     assert sres(K, x1, b) <= RES_TOL
@@ -257,9 +257,9 @@ def test_leaf_chains_equal_the_level_by_level_schedule_bitwise(monkeypatch, n):
     nn, r, c, v, neg = kktgen.lukvl_like(n, seed=41)
     K = kktgen.to_scipy(nn, r, c, v)
     b = K @ np.linspace(1.0, 2.0, nn)
-    monkeypatch.setenv("MI355X_KKT_NO_LEAFCHAIN", "1")
+    monkeypatch.setenv("MI355X_KKT_DISABLE", "leafchain")
     s0, st0, x0 = gpu_factor_solve(nn, r, c, v, b, check=True, required=neg)
-    monkeypatch.delenv("MI355X_KKT_NO_LEAFCHAIN")
+    monkeypatch.delenv("MI355X_KKT_DISABLE")
     s1, st1, x1 = gpu_factor_solve(nn, r, c, v, b, check=True, required=neg)
     assert st0 == st1 == kkt.SUCCESS and s1.number_of_neg_evals() == s0.number_of_neg_evals() == neg
     assert np.array_equal(x0, x1)
@@ -334,23 +334,6 @@ def test_standalone_ruiz_scaling_of_a_triplet_matrix():
         mx = np.zeros(n); np.maximum.at(mx, r - 1, w); np.maximum.at(mx, c - 1, w)
         s = np.where(mx > 0, s / np.sqrt(np.where(mx > 0, mx, 1.0)), s)
     assert np.allclose(out, s, rtol=1e-14, atol=0)
-
-
-def test_chain_lookahead_schedule_is_bitwise_identical(monkeypatch):
-    """the three-stream look-ahead along the separator chains (pivot block / first panel rows / next pivot block on the
-    critical stream, bulk panel solve and trailing update trailing behind) must not change a single bit"""
-    n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)
-    K = kktgen.to_scipy(n, r, c, v)
-    b = K @ np.ones(n)
-    s0, st0, x0 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
-    monkeypatch.setenv("MI355X_KKT_CHAIN_LA", "1")       # (an option kept for the record: measured slower than the single-stream schedule, DESIGN.md)
-    s1, st1, x1 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
-    assert st0 == st1 == kkt.SUCCESS and s1.number_of_neg_evals() == neg
-    assert sres(K, x1, b) <= RES_TOL
-    assert np.array_equal(x0, x1)
-    for _ in range(3):                                   # repeated factorisations: no race between the streams
-        x2 = b.copy(); s1.multi_solve(True, x2)
-        assert np.array_equal(x1, x2)
 
 
 def test_matching_scaling_mode():
@@ -521,12 +504,12 @@ def test_sync_free_chain_sweeps_match_the_level_by_level_solves(monkeypatch):
     K = kktgen.to_scipy(n, r, c, v)
     rng = np.random.default_rng(4)
     B = [K @ np.ones(n), rng.standard_normal(n), K @ rng.standard_normal(n)]
-    monkeypatch.setenv("MI355X_KKT_NO_CHAIN_SOLVE", "1")
+    monkeypatch.setenv("MI355X_KKT_DISABLE", "chain_solve")
     s0, st0, _ = gpu_factor_solve(n, r, c, v, B[0], check=True, required=neg)
     X0 = []
     for b in B:
         x = b.copy(); s0.multi_solve(False, x); X0.append(x)
-    monkeypatch.delenv("MI355X_KKT_NO_CHAIN_SOLVE")
+    monkeypatch.delenv("MI355X_KKT_DISABLE")
     s1, st1, _ = gpu_factor_solve(n, r, c, v, B[0], check=True, required=neg)
     assert st0 == st1 == kkt.SUCCESS
     for b, x0 in zip(B, X0):
@@ -555,15 +538,15 @@ def test_data_flow_solve_sweeps_at_every_extent(monkeypatch, gen):
     rng = np.random.default_rng(9)
     B = [K @ np.ones(n), rng.standard_normal(n), K @ rng.standard_normal(n)]
     for refine in (0, 2):
-        monkeypatch.setenv("MI355X_KKT_NO_CHAIN_SOLVE", "1")
+        monkeypatch.setenv("MI355X_KKT_DISABLE", "chain_solve")
         s0, st0, _ = gpu_factor_solve(n, r, c, v, B[0], refine_steps=refine)
         assert st0 == kkt.SUCCESS
         X0 = []
         for b in B:
             x = b.copy(); s0.multi_solve(False, x); X0.append(x)
-        monkeypatch.delenv("MI355X_KKT_NO_CHAIN_SOLVE")
+        monkeypatch.delenv("MI355X_KKT_DISABLE")
         for maxc in ("1", "8", "128", "1000000"):
-            monkeypatch.setenv("MI355X_KKT_CHAIN_SOLVE_MAXC", maxc)
+            monkeypatch.setenv("MI355X_KKT_TUNE", "chain_solve_maxc=" + maxc)
             s1, st1, _ = gpu_factor_solve(n, r, c, v, B[0], refine_steps=refine)
             assert st1 == kkt.SUCCESS and s1.number_of_neg_evals() == s0.number_of_neg_evals()
             for b, x0 in zip(B, X0):
@@ -575,7 +558,7 @@ def test_data_flow_solve_sweeps_at_every_extent(monkeypatch, gen):
             s1.multi_solve(False, Xm)
             for j, x0 in enumerate(X0):
                 assert np.abs(Xm[j] - x0).max() <= 1e-9 * max(1.0, np.abs(x0).max())
-        monkeypatch.delenv("MI355X_KKT_CHAIN_SOLVE_MAXC")
+        monkeypatch.delenv("MI355X_KKT_TUNE")
 
 def test_short_lived_handles_on_recycled_device_memory():
     """many handles set up, used for a factorisation and two solves, and dropped in one process: each new handle is given device memory (and
@@ -601,9 +584,9 @@ def test_fused_pivot_block_and_panel_solve_is_bitwise_identical(monkeypatch):
     n, r, c, v, neg = kktgen.grid_kkt(110, 90, dof=3, ncon=2, seed=31)
     K = kktgen.to_scipy(n, r, c, v)
     b = K @ np.ones(n)
-    monkeypatch.setenv("MI355X_KKT_NO_FUSE_DT", "1")
+    monkeypatch.setenv("MI355X_KKT_DISABLE", "fuse_dt")
     s0, st0, x0 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
-    monkeypatch.delenv("MI355X_KKT_NO_FUSE_DT")
+    monkeypatch.delenv("MI355X_KKT_DISABLE")
     s1, st1, x1 = gpu_factor_solve(n, r, c, v, b, check=True, required=neg)
     assert st0 == st1 == kkt.SUCCESS and s0.info().num_two == s1.info().num_two
     assert np.array_equal(x0, x1)

@@ -147,7 +147,7 @@ def test_c_level_collectives_through_the_ordinary_entry_points(world, subcube, c
     if not range_local:
         if world < 3 or case is _case_band or case is _case_grid_device_matching:
             pytest.skip("the fall-back differs from the range-local exchange only with sub-ranges; one band case is enough")
-        monkeypatch.setenv("MI355X_KKT_NO_SUBCOMM", "1")
+        monkeypatch.setenv("MI355X_KKT_DISABLE", "subcomm")
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()

@@ -316,8 +316,8 @@ def test_side_children_of_chain_links_hang_down_the_chain(monkeypatch, golden_di
     n, r, c, v, neg = kktgen.recorded_kkt(os.path.join(golden_dir, "mbndry3d_14.kktrec"), which=0)
     syms = {}
     for off in (False, True):
-        if off: monkeypatch.setenv("MI355X_KKT_NO_PURIFY", "1")
-        else: monkeypatch.delenv("MI355X_KKT_NO_PURIFY", raising=False)
+        if off: monkeypatch.setenv("MI355X_KKT_DISABLE", "purify")
+        else: monkeypatch.delenv("MI355X_KKT_DISABLE", raising=False)
         s = ipopt_amd.KKTSolver()
         s.initialize_structure(n, r, c, vals=v)
         syms[off] = mirror.fetch(s)

@@ -1,5 +1,5 @@
 import sys, os, ctypes as C, numpy as np
-os.environ["MI355X_KKT_DEBUG_CLOCKS"] = "1"
+os.environ["MI355X_KKT_TRACE"] = "clocks"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ipopt_amd, bench
 wl = sys.argv[1] if len(sys.argv) > 1 else "grid_1e5"

@@ -7,8 +7,8 @@ z = np.load(sys.argv[1])
 n, r, c, vals, rhs, neg = int(z["n"]), z["r"], z["c"], z["vals"], z["rhs"], z["neg"]
 out = {}
 for mode in ("df", "nodf"):
-    if mode == "nodf": os.environ["MI355X_KKT_NO_FRONT_DF"] = "1"
-    else: os.environ.pop("MI355X_KKT_NO_FRONT_DF", None)
+    if mode == "nodf": os.environ["MI355X_KKT_DISABLE"] = "front_df"
+    else: os.environ.pop("MI355X_KKT_DISABLE", None)
     s = ipopt_amd.KKTSolver(); s.initialize_structure(n, r, c, vals=vals[0])
     res = []
     for i in range(len(vals)):

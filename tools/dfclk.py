@@ -1,5 +1,5 @@
 import sys, os, ctypes as C, numpy as np
-os.environ["MI355X_KKT_DEBUG_CLOCKS"] = "1"
+os.environ["MI355X_KKT_TRACE"] = "clocks"
 sys.path.insert(0, '/root/repo')
 import ipopt_amd, bench
 n, r, c, v, neg = bench.make_workload(sys.argv[1])

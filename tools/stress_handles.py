@@ -29,7 +29,7 @@ for it in range(int(sys.argv[1]) if len(sys.argv) > 1 else 40):
     if nanx or nanx2 or err > 1e-6 or I.num_neg != neg:
         bad += 1
         print(f"BAD it {it} n {n}: status {st} neg {I.num_neg}/{neg} two {I.num_two} zero {I.num_zero} nan {nanx} resolve-nan {nanx2} err {err:.2e} first idx {np.nonzero(np.isnan(x))[0][:6].tolist()}", flush=True)
-        for env in ({"MI355X_KKT_NO_CHAIN_SOLVE": "1"}, {"MI355X_KKT_NO_FASTPIV": "1"}, {}):
+        for env in ({"MI355X_KKT_DISABLE": "chain_solve"}, {"MI355X_KKT_DISABLE": "fastpiv"}, {}):
             st_, I_, y, y2 = run(n, r, c, v, b, **env)
             print(f"    retry {env}: nan {int(np.isnan(y).sum())} err {float(np.nanmax(np.abs(y - 1.0))):.2e} neg {I_.num_neg}", flush=True)
 print("stress done, bad =", bad)
