@@ -468,6 +468,7 @@ public:
     void release(bool keep = false) {
         DeviceGuard guard(dev);
         destroy_subcomms();                      // (the ranges follow the structure: split again after a restructure)
+        sctx_release();
         if (!keep) { if (rccl.comm && rccl.CommDestroy) { (void)rccl.CommDestroy(rccl.comm); rccl.comm = nullptr; }
                      comm_kind = 0; comm_range_fn = nullptr; }
         if (g_factor) { (void)hipGraphExecDestroy(g_factor); g_factor = nullptr; }
@@ -955,10 +956,11 @@ public:
             for (size_t i = 0; i < wgf.size(); ++i) { const ChainDesc& D = chd[wgf[i]]; strace_desc.push_back({wgf[i], (int)i - D.wg0f - chain_segs[0].wgf0 * 0, D.nlinks, D.tail}); }
             for (size_t i = 0; i < wgb.size(); ++i) { const ChainDesc& D = chd[wgb[i]]; strace_desc.push_back({wgb[i], (int)i - D.wg0b - D.nlinks * ((D.tail + 255) / 256), D.nlinks, D.tail}); }      // (dot workgroups: negative)
         }
-        if (!dalloc(&V.sflag_dot, (size_t)std::max(ndots, 1) * FLAG_STRIDE) || !dalloc(&V.dpart, (size_t)std::max(ndots, 1) * 64) ||
-            !dalloc(&V.sflag_t, (size_t)std::max(ntailflags, 1) * FLAG_STRIDE) || !dalloc(&V.sflag_b, std::max<size_t>(chl.size(), 1) * FLAG_STRIDE)) return false;
+        n_sflag_dot = (size_t)std::max(ndots, 1) * FLAG_STRIDE; n_dpart = (size_t)std::max(ndots, 1) * 64; n_sflag_t = (size_t)std::max(ntailflags, 1) * FLAG_STRIDE; n_sflag_b = std::max<size_t>(chl.size(), 1) * FLAG_STRIDE;
+        if (!dalloc(&V.sflag_dot, n_sflag_dot) || !dalloc(&V.dpart, n_dpart) || !dalloc(&V.sflag_t, n_sflag_t) || !dalloc(&V.sflag_b, n_sflag_b)) return false;
         {   // tagged solution entries of the segments' columns (indexed by column; + 64: a wavefront polls 64 entries from a link's first column)
             const size_t nt = chl.empty() ? 1 : (size_t)Sy.n + 64;
+            n_tag = nt;
             if (!dalloc(&V.ytag, nt) || !dalloc(&V.xtag, nt)) return false;
         }
         if (!upload(chl, &V.chlink) || !upload(chd, &V.chdesc)) return false;
@@ -1727,6 +1729,7 @@ public:
             for (int lv = lcs; lv < Sy.num_levels; ++lv) {
                 if (seg_at_lv0[lv] >= 0) {      // a run of pure chain levels: one sync-free launch for all of them
                     const ChainSeg& sg = chain_segs[seg_at_lv0[lv]];
+                    if (gate_on && !gate_entered) { if (gate_valid) HIPCHK(hipStreamWaitEvent(stream, gate_last, 0)); gate_entered = true; }      // (solve contexts: one chain section at a time)
                     LAUNCH(KK_FWD_BIG, k_fwd_chain, dim3(sg.nwg_f), dim3(320), 0, stream, V, sg.wgf0);
                     lv = sg.lv1; continue;
                 }
@@ -1751,6 +1754,7 @@ public:
                 if (seg_at_lv1[lv] >= 0) {
                     const ChainSeg& sg = chain_segs[seg_at_lv1[lv]];
                     LAUNCH(KK_BWD_BIG, k_bwd_chain, dim3(sg.nwg_b), dim3(320), 0, stream, V, sg.wgb0);
+                    if (gate_on && gate_mine) { HIPCHK(hipEventRecord(gate_mine, stream)); gate_last = gate_mine; gate_valid = true; }
                     lv = sg.lv0; continue;
                 }
                 for (int fc = 0; fc < FC_COUNT; ++fc) {
@@ -1779,31 +1783,145 @@ public:
         return true;
     }
 
+    // ---- several right-hand sides (MultiSolve with nrhs > 1, IpSparseSymLinearSolverInterface.hpp:190; the reference hands nrhs straight to ONE ma97_solve,
+    //      IpMa97SolverInterface.cpp:790,805): a single solve is a LATENCY chain (1.8 of the ~6 TB/s a stream of L could take), so the right-hand sides are not
+    //      solved one behind the other: up to SOLVE_CTX of them are in flight at once, each in a CONTEXT of its own -- its own stream, work vectors, message
+    //      tags, flags and epoch -- through the same kernels and the same launch sequence (the same bits per column as a solve on its own).  The panels of L that
+    //      one column's sweep has just pulled through L2 / the Infinity Cache are what the neighbouring columns' sweeps read next.  Context 0 is the solver's own
+    //      workspace and stream; the others are allocated at the first call that needs them (a caller with one right-hand side never pays for them). ----
+    static constexpr int SOLVE_CTX = 3;      // (streams of ONE priority share a hardware queue and are serialised by it: one context per priority level the runtime offers)
+    struct SolveCtx { hipStream_t strm = nullptr; hipEvent_t done = nullptr; hipGraphExec_t graph = nullptr;
+                      double *xw = nullptr, *cvec = nullptr, *bw = nullptr, *xacc = nullptr, *gpart = nullptr, *zb = nullptr, *ybuf = nullptr, *dpart = nullptr;
+                      int *sflag_t = nullptr, *sflag_dot = nullptr, *sflag_b = nullptr, *sepoch = nullptr; v2d *ytag = nullptr, *xtag = nullptr; };
+    SolveCtx sctx[SOLVE_CTX]; int nsctx = 1; hipEvent_t sctx_fork = nullptr;
+    int sctx_verdict = 0; bool sctx_tuning = false;      // 0: not measured for this structure yet, 1: contexts, 2: one after the other
+    // The data-flow sweeps over the top of the tree (k_fwd_chain / k_bwd_chain) are PERSISTENT launches whose workgroups wait for one another; the argument that
+    // a waiting workgroup never holds up the one it waits for (lower index = dispatched first) is an argument about ONE such launch on the device.  Two of them
+    // on two hardware queues did starve each other (measured, round 6: time-outs of the bounded waits as soon as the solver's own high-priority stream and a
+    // context's stream each had a sweep in flight; three contexts on streams of one priority share a hardware queue and were serialised by it).  So the
+    // contexts take turns through a GATE for their chain section -- from the first forward chain launch to the last backward one --, everything below it (the
+    // level launches of the bulk of the tree, which hold 2/3 of L) overlaps freely.  Needs eager launches: the gate is an event between streams.
+    bool gate_on = false, gate_valid = false, gate_entered = false; hipEvent_t gate_last = nullptr, gate_mine = nullptr; hipEvent_t gate_ev[SOLVE_CTX] = {nullptr, nullptr, nullptr};
+    size_t n_sflag_dot = 1, n_dpart = 1, n_sflag_t = 1, n_sflag_b = 1, n_tag = 1;      // element counts of the flag / tag arrays (set where they are allocated)
+    void sctx_release() {      // (the buffers are in `allocs`: release() frees them)
+        for (int c = 0; c < SOLVE_CTX; ++c) if (gate_ev[c]) { (void)hipEventDestroy(gate_ev[c]); gate_ev[c] = nullptr; }
+        gate_on = gate_valid = gate_entered = false; gate_last = gate_mine = nullptr; sctx_verdict = 0;
+        for (int c = 1; c < SOLVE_CTX; ++c) { if (sctx[c].graph) (void)hipGraphExecDestroy(sctx[c].graph); if (sctx[c].done) (void)hipEventDestroy(sctx[c].done);
+                                               if (sctx[c].strm) (void)hipStreamDestroy(sctx[c].strm); sctx[c] = SolveCtx(); }
+        if (sctx_fork) { (void)hipEventDestroy(sctx_fork); sctx_fork = nullptr; }
+        nsctx = 1;
+    }
+    bool sctx_ensure(int want) {
+        want = std::min(want, SOLVE_CTX);
+        const Symbolic& Sy = *S;
+        if (!sctx_fork) HIPCHK(hipEventCreateWithFlags(&sctx_fork, hipEventDisableTiming));
+        for (int c = 0; c < want; ++c) if (!gate_ev[c]) HIPCHK(hipEventCreateWithFlags(&gate_ev[c], hipEventDisableTiming));
+        for (int c = nsctx; c < want; ++c) {
+            SolveCtx& X = sctx[c];
+            { int plo = 0, phi = 0; (void)hipDeviceGetStreamPriorityRange(&plo, &phi);      // (numerically lower = higher priority; the solver's own stream has phi)
+              HIPCHK(hipStreamCreateWithPriority(&X.strm, hipStreamNonBlocking, c == 1 ? (plo + phi) / 2 : plo)); }
+            HIPCHK(hipEventCreateWithFlags(&X.done, hipEventDisableTiming));
+            if (!dalloc(&X.xw, Sy.n) || !dalloc(&X.ybuf, Sy.n) || !dalloc(&X.zb, Sy.n) || !dalloc(&X.bw, Sy.n) || !dalloc(&X.xacc, Sy.n) || !dalloc(&X.cvec, (size_t)Sy.cvec_doubles) ||
+                !dalloc(&X.gpart, (size_t)Sy.gpart_doubles) || !dalloc(&X.sflag_dot, n_sflag_dot) || !dalloc(&X.dpart, n_dpart) || !dalloc(&X.sflag_t, n_sflag_t) || !dalloc(&X.sflag_b, n_sflag_b) ||
+                !dalloc(&X.ytag, n_tag) || !dalloc(&X.xtag, n_tag) || !dalloc(&X.sepoch, 4)) return false;
+            HIPCHK(hipDeviceSynchronize());      // (dalloc's zero fills ran on the default stream)
+            nsctx = c + 1;
+        }
+        return true;
+    }
+    // the solver works in context c from here on (c = 0: back to its own workspace and stream); `saved` keeps what context 0 owns
+    struct SctxSaved { hipStream_t strm; hipGraphExec_t graph; SolveCtx w; };
+    void sctx_enter(int c, SctxSaved& sv) {
+        sv.strm = stream; sv.graph = g_solve;
+        sv.w.xw = V.xw; sv.w.cvec = V.cvec; sv.w.bw = V.bw; sv.w.xacc = V.xacc; sv.w.gpart = V.gpart; sv.w.zb = V.zb; sv.w.ybuf = V.ybuf; sv.w.dpart = V.dpart;
+        sv.w.sflag_t = V.sflag_t; sv.w.sflag_dot = V.sflag_dot; sv.w.sflag_b = V.sflag_b; sv.w.sepoch = V.sepoch; sv.w.ytag = V.ytag; sv.w.xtag = V.xtag;
+        const SolveCtx& X = sctx[c];
+        stream = X.strm; g_solve = X.graph;
+        V.xw = X.xw; V.cvec = X.cvec; V.bw = X.bw; V.xacc = X.xacc; V.gpart = X.gpart; V.zb = X.zb; V.ybuf = X.ybuf; V.dpart = X.dpart;
+        V.sflag_t = X.sflag_t; V.sflag_dot = X.sflag_dot; V.sflag_b = X.sflag_b; V.sepoch = X.sepoch; V.ytag = X.ytag; V.xtag = X.xtag;
+    }
+    void sctx_leave(int c, const SctxSaved& sv) {
+        sctx[c].graph = g_solve;          // (captured on first use)
+        stream = sv.strm; g_solve = sv.graph;
+        V.xw = sv.w.xw; V.cvec = sv.w.cvec; V.bw = sv.w.bw; V.xacc = sv.w.xacc; V.gpart = sv.w.gpart; V.zb = sv.w.zb; V.ybuf = sv.w.ybuf; V.dpart = sv.w.dpart;
+        V.sflag_t = sv.w.sflag_t; V.sflag_dot = sv.w.sflag_dot; V.sflag_b = sv.w.sflag_b; V.sepoch = sv.w.sepoch; V.ytag = sv.w.ytag; V.xtag = sv.w.xtag;
+    }
+    bool solve_one(const double* src, double* col) {      // one right-hand side in the CURRENT context (stream, V's work vectors, g_solve)
+        if (opt.use_graph) {
+            if (!g_solve) {
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+                bool ok = enqueue_solve_core();
+                hipError_t e = hipStreamEndCapture(stream, &g);
+                if (!ok) return false;
+                if (e != hipSuccess) { err_ = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return false; }
+                HIPCHK(hipGraphInstantiate(&g_solve, g, nullptr, nullptr, 0));
+                (void)hipGraphDestroy(g);
+            }
+            hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, src);
+            HIPCHK(hipGraphLaunch(g_solve, stream));
+            hipLaunchKernelGGL(k_store_sol, dim3(grid1d(S->n)), dim3(256), 0, stream, V, col);
+            return true;
+        }
+        return enqueue_solve(src, col);
+    }
     bool solve_device(int nrhs, const double* dsrc, int lds_, double* drhs, int ld, bool timed) {
         DeviceGuard guard(dev);
         if (!ready) { if (err_.empty()) err_ = "solve: solver not set up"; return false; }
         if (multi) return solve_dist(nrhs, dsrc, lds_, drhs, ld);
         if (timed) HIPCHK(hipEventRecord(ev0, stream));
-        for (int r = 0; r < nrhs; ++r) {
-            double* col = drhs + (size_t)r * ld;
-            const double* src = dsrc + (size_t)r * lds_;
-            if (opt.use_graph) {
-                if (!g_solve) {
-                    hipGraph_t g = nullptr;
-                    HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-                    bool ok = enqueue_solve_core();
-                    hipError_t e = hipStreamEndCapture(stream, &g);
-                    if (!ok) return false;
-                    if (e != hipSuccess) { err_ = std::string("hipStreamEndCapture: ") + hipGetErrorString(e); return false; }
-                    HIPCHK(hipGraphInstantiate(&g_solve, g, nullptr, nullptr, 0));
-                    (void)hipGraphDestroy(g);
-                    if (timed && r == 0) HIPCHK(hipEventRecord(ev0, stream));
+        int nctx = (nrhs > 1 && !prof_on && !V.strace && !knob_disabled("solve_ctx")) ? std::min(nrhs, SOLVE_CTX) : 1;
+        if (nctx > 1 && sctx_verdict == 0 && !sctx_tuning) {
+            // measured ONCE per structure, on scratch vectors: three right-hand sides one after the other against the same three through the contexts.  On a
+            // tree whose chain sweeps fill the device (synth_1e6: 5 290 spinning workgroups) the level launches of a second context starve next to them and the
+            // contexts LOSE (18.6 against 16.6 ms for eight right-hand sides); on a mid-size tree they win (grid_1e5: 2.2 against 3.5 ms).
+            double* scratch = nullptr;
+            HIPCHK(hipMalloc((void**)&scratch, 6 * (size_t)std::max(S->n, 1) * sizeof(double)));
+            HIPCHK(hipMemsetAsync(scratch, 0, 6 * (size_t)std::max(S->n, 1) * sizeof(double), stream));
+            sctx_tuning = true;
+            float t_seq = 0, t_ctx = 0; bool ok = true;
+            hipEvent_t e0 = nullptr, e1 = nullptr; HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            for (int mode = 0; mode < 2 && ok; ++mode) {
+                sctx_verdict = mode == 0 ? 2 : 1;
+                for (int rep = 0; rep < 2 && ok; ++rep) {      // (the first round warms the contexts up: allocation, graph capture)
+                    HIPCHK(hipEventRecord(e0, stream));
+                    ok = solve_device(3, scratch, S->n, scratch + 3 * (size_t)S->n, S->n, false);
+                    HIPCHK(hipEventRecord(e1, stream)); HIPCHK(hipStreamSynchronize(stream));
+                    if (ok) HIPCHK(hipEventElapsedTime(mode == 0 ? &t_seq : &t_ctx, e0, e1));
                 }
-                hipLaunchKernelGGL(k_load_rhs, dim3(grid1d(S->n)), dim3(256), 0, stream, V, src);
-                HIPCHK(hipGraphLaunch(g_solve, stream));
-                hipLaunchKernelGGL(k_store_sol, dim3(grid1d(S->n)), dim3(256), 0, stream, V, col);
-            } else if (!enqueue_solve(src, col)) return false;
+            }
+            (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipFree(scratch);
+            sctx_tuning = false;
+            if (!ok) { sctx_verdict = 0; return false; }
+            sctx_verdict = t_ctx < 0.9f * t_seq ? 1 : 2;
+            if (opt.verbose) fprintf(stderr, "[mi355x_kkt] solve contexts for nrhs > 1: three right-hand sides %.3f ms one after the other, %.3f ms through the contexts -> %s\n", t_seq, t_ctx, sctx_verdict == 1 ? "contexts" : "one after the other");
+            if (timed) HIPCHK(hipEventRecord(ev0, stream));
         }
+        if (sctx_verdict == 2 && !knob_int("solve_ctx_force", 0)) nctx = 1;
+        if (nctx > 1) {
+            if (!sctx_ensure(nctx)) return false;
+            HIPCHK(hipEventRecord(sctx_fork, stream));
+            for (int c = 1; c < nctx; ++c) HIPCHK(hipStreamWaitEvent(sctx[c].strm, sctx_fork, 0));
+            gate_on = true; gate_valid = false;
+            bool ok = true;
+            for (int r = 0; r < nrhs && ok; ++r) {
+                const int c = r % nctx;
+                double* col = drhs + (size_t)r * ld;
+                const double* src = dsrc + (size_t)r * lds_;
+                gate_mine = gate_ev[c]; gate_entered = false;
+                SctxSaved sv;
+                if (c > 0) sctx_enter(c, sv);
+                ok = enqueue_solve(src, col);          // eager: the gate of the chain sections is an event between the contexts' streams
+                if (c > 0) sctx_leave(c, sv);
+            }
+            gate_on = false; gate_mine = nullptr;
+            if (!ok) return false;
+            for (int c = 1; c < nctx; ++c) {
+                HIPCHK(hipEventRecord(sctx[c].done, sctx[c].strm)); HIPCHK(hipStreamWaitEvent(stream, sctx[c].done, 0));
+                if (!chain_segs.empty()) hipLaunchKernelGGL(k_merge_err, dim3(1), dim3(64), 0, stream, V.sepoch + 1, (const int*)(sctx[c].sepoch + 1));
+            }
+        } else
+            for (int r = 0; r < nrhs; ++r) if (!solve_one(dsrc + (size_t)r * lds_, drhs + (size_t)r * ld)) return false;
         if (timed) {
             HIPCHK(hipEventRecord(ev1, stream));
             if (!chain_segs.empty()) HIPCHK(hipMemcpyAsync(h_stats + 6, V.sepoch + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
