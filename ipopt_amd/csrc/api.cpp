@@ -35,6 +35,7 @@ struct mi355x_kkt_handle_s {
     int  zero_futile_events = 0;   // consecutive rounds driven by ZERO pivots alone that did not lower their number (latched at 2: see zero_delay_futile)
     bool zero_delay_futile = false;// a round driven by ZERO pivots alone did not lower their number: the matrix is singular (a dependent row is a zero pivot
                                    // wherever it is eliminated) -- later factorisations whose only complaint is zero pivots answer SINGULAR at once
+    std::thread reaper;            // destroys the structure a delayed-pivot edit replaced (80-90 ms of unmapping at n = 10^6) off the caller's path
     ShmComm* shm = nullptr;        // the shared-memory communicator of set_comm_shm (owned; the Numeric object only holds the callbacks' context)
     std::string err;
     std::vector<double> host_vals_nodev;   // plain host staging buffer handed out when no device exists (values only, never computed on)
@@ -66,7 +67,7 @@ int mi355x_kkt_create(mi355x_kkt_handle* h, const mi355x_kkt_options* opts)
 void mi355x_kkt_destroy(mi355x_kkt_handle h)
 {
     if (!h) return;
-    try { delete h->num; shm_comm_destroy(h->shm); delete h; } catch (...) {}
+    try { if (h->reaper.joinable()) h->reaper.join(); delete h->num; shm_comm_destroy(h->shm); delete h; } catch (...) {}
 }
 
 const char* mi355x_kkt_last_error(mi355x_kkt_handle h) { return h ? h->err.c_str() : "null handle"; }
@@ -76,6 +77,7 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
     if (!h) return MI355X_KKT_FATAL;
     try {
         h->analysed = false; h->numeric_ready = false; h->factored = false;
+        if (h->reaper.joinable()) h->reaper.join();
         delete h->num; h->num = nullptr;
         h->num_delayed = 0; h->num_restructures = 0; h->delay_count.clear(); h->delays_exhausted = false; h->zero_delay_futile = false; h->zero_futile_events = 0;
         SymbolicOptions& so = h->so; so = SymbolicOptions();
@@ -150,14 +152,23 @@ static bool apply_delays(mi355x_kkt_handle h, const std::vector<int>& marks_perm
     std::vector<int> hops(marks_perm.size());
     for (size_t q = 0; q < marks_perm.size(); ++q) hops[q] = 1 << std::min<int>(h->delay_count[h->sym.perm[marks_perm[q]]], 6);
     std::vector<char> acted;
+    const auto t_a = std::chrono::steady_clock::now();
     if (!restructure_delays(h->sym, h->so, marks_perm, hops, ns, moved, &acted)) return false;
+    const auto t_b = std::chrono::steady_clock::now();
     if (ns.nnz_l > 4 * h->base_nnz_l + 4000000) {      // the factor may grow, not explode: static pivoting from here on -- and no more edits are BUILT
         *moved = 0; h->delays_exhausted = true;         // (a complete host re-analysis each, 0.1-1 s at n = 10^6, only to be thrown away: ADVICE r04)
         if (h->opts.verbose) fprintf(stderr, "[mi355x_kkt] factor: the delayed-pivot edit would grow nnz(L) to %lld (> 4 x %lld + 4e6): static pivoting from here on\n", (long long)ns.nnz_l, (long long)h->base_nnz_l);
         return false;
     }
     for (size_t q = 0; q < marks_perm.size(); ++q) if (acted[q]) { unsigned char& c = h->delay_count[h->sym.perm[marks_perm[q]]]; if (c < 255) ++c; }
-    h->sym = std::move(ns);
+    {   // the old structure goes to a helper thread (joined before the next edit, before a new analysis and at destroy)
+        if (h->reaper.joinable()) h->reaper.join();
+        Symbolic* old = new Symbolic(std::move(h->sym));
+        h->sym = std::move(ns);
+        h->reaper = std::thread([old] { delete old; });
+    }
+    if (h->opts.verbose >= 2) fprintf(stderr, "[mi355x_kkt]   (delay) restructure_delays %.3f s, old structure dropped %.3f s\n", std::chrono::duration<double>(t_b - t_a).count(),
+                                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t_b).count());
     h->num_delayed += *moved; h->num_restructures++;
     return true;
 }

@@ -3,7 +3,7 @@
 //
 //   MI355X_KKT_DISABLE=name[,name...]   switches a KEPT fast path off, so that the tests can compare it bitwise with the plain path underneath:
 //       lookahead chain_solve fuse_dt fastpiv asm_pull pair_solve selfasm xcd_tiles xcd_affine fuse_upd grouped tfuse leafchain side_small
-//       front_df p1_small norestore optimistic subcomm blockcache thread_pool purify solve_ctx
+//       front_df p1_small norestore optimistic subcomm blockcache thread_pool purify solve_ctx keep_scale
 //   MI355X_KKT_TUNE=name=value[,...]    numeric thresholds of the schedule (defaults are the measured optima; tests force a path with them):
 //       la_wgs la_min_nt la_min_tiles grp_rbw_max grp_maxchains fuse_dt_maxwg chain_solve_maxc fastpiv_floor
 // Both are read when a handle is set up (analyse / restructure), `optimistic` at the first factorisation of the process.

@@ -1532,7 +1532,26 @@ bool restructure_delays(const Symbolic& C, const SymbolicOptions& opt, const std
             if (p < 0) { mk[j] = 0; continue; }                                             // a root front has nowhere to delay to
             int t = p;                                                                      // a column that failed before climbs several levels at once
             for (int h = target[j]; h > 1 && nat_parent(t) >= 0; --h) t = nat_parent(t);
-            target[j] = t; incount[t + 1]++; ++moved;
+            target[j] = t; ++moved;
+        }
+    }
+    // A target front that is FULL (max_sn_cols columns) would be cut in two by an arrival: a 64-column link of a separator chain that receives one column became a
+    // link of 64 and a link of ONE column -- a tree level of its own, pivot block + panel solve + rank-1 update over thousands of rows (round 5; measured in round 6: one
+    // edit of 100 random columns made the factorisation of a 2 * 10^5 grid 36 % slower, 4.36 -> 5.94 ms).  Inside a chain -- the parent is the next supernode, its
+    // front is this front's update rows -- the column may just as well wait one link further up, and further, until a link has room (the last link of a separator
+    // is rarely full): a longer delay, no front displaced, no fill (the chain is dense).  Nobody else changes front, which the delayed-pivot loop of the hostile test
+    // systems depends on (moving the boundary between two full links instead -- the link's own last column riding into the parent -- left forced pivots after 8 rounds).
+    {
+        const int maxcols = std::max(2, opt.max_sn_cols);
+        vector<int> load(nsn0);
+        for (int s = 0; s < nsn0; ++s) load[s] = C.sn_colptr[s + 1] - C.sn_colptr[s] - nmark[s];
+        // (... where the full front is LARGE -- 256 rows and more: there the one-column link is a level of ~100 us launches, and it pushes every ancestor one
+        //  level up, out of step with its siblings -- and the edit moves FEW columns, at most n / 64: an Ipopt run delays a handful per factorisation.  The hostile
+        //  systems of the tests -- order 800, hundreds of columns per round, every column moving four times -- needed a ninth and tenth round with the extra hops.)
+        for (int j = 0; j < n; ++j) if (mk[j]) {
+            int t = target[j];
+            for (int hop = 0; hop < 256 && moved <= n / 64 && load[t] >= maxcols && C.sn_rowptr[t + 1] - C.sn_rowptr[t] >= 256 && t + 1 < nsn0 && nat_parent(t) == t + 1; ++hop) ++t;
+            target[j] = t; load[t]++; incount[t + 1]++;
         }
     }
     if (moved_out) *moved_out = moved;

@@ -268,9 +268,16 @@ def test_leaf_chains_equal_the_level_by_level_schedule_bitwise(monkeypatch, n):
     assert oneg == neg and np.abs(x1 - xo).max() <= 1e-7 * max(1.0, np.abs(xo).max())
 
 
-def test_device_side_assembly_equals_host_assembly_bitwise():
+@pytest.mark.parametrize("keep", [False, True], ids=["scaling-recomputed", "scaling-kept-on-delta-only-retries"])
+def test_device_side_assembly_equals_host_assembly_bitwise(keep, monkeypatch):
     """mi355x_kkt_factor_assembled: values = scale * source + shift per segment, formed on the device, must
-    give the factorisation of the host-assembled values bit for bit; a delta-only refactorisation uploads nothing."""
+    give the factorisation of the host-assembled values bit for bit; a delta-only refactorisation uploads nothing.
+    Round 6: on such a retry -- nothing uploaded, the segment scales unchanged, only the shifts (delta_x, delta_c) new -- the Ruiz factors of the
+    last equilibration are KEPT (MA97 keeps its scaling until asked, IpMa97SolverInterface.cpp:725-771): same inertia, residual at rounding level,
+    the solution of the freshly equilibrated factorisation to 1e-9; a changed segment scale (W_factor 1 -> 0) equilibrates afresh and is bitwise
+    the host-assembled factorisation again.  MI355X_KKT_DISABLE=keep_scale: every factorisation equilibrates, every trial bitwise."""
+    if not keep:
+        monkeypatch.setenv("MI355X_KKT_DISABLE", "keep_scale")
     rng = np.random.default_rng(5)
     nx, m = 300, 120
     # K = [[H + Sigma + dx I, J^T], [J, -dc I]] in Ipopt's segment order  W | D_x | J_c | D_c
@@ -299,7 +306,13 @@ def test_device_side_assembly_equals_host_assembly_bitwise():
         x2 = b.copy(); st2 = s2.multi_solve(True, x2)
         assert st == st2 and neg == s2.number_of_neg_evals()
         if st == 0:
-            assert np.array_equal(x, x2)
+            kept = keep and (dx, dc, wf) in ((1e-4, 0.0, 1.0), (1e-2, 1e-8, 1.0))       # trials 2 and 3: only the shifts differ from the trial before
+            if kept:
+                K = kktgen.to_scipy(n, r, c, host_vals(dx, dc, wf))
+                assert not np.array_equal(x, x2)                                           # (the kept factors ARE other factors)
+                assert sres(K, x, b) <= RES_TOL and np.abs(x - x2).max() <= 1e-9 * np.abs(x2).max()
+            else:
+                assert np.array_equal(x, x2)
 
 
 def test_scaling_modes_and_factor_exchange():

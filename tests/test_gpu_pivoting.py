@@ -303,7 +303,7 @@ def test_a_rejected_optimistic_run_leaves_nothing_behind_for_the_full_schedule()
 def test_cost_of_a_delayed_pivot_edit_stays_under_its_ceiling():
     """VERDICT r05 item 2 (regression guard, not the target): a delayed-pivot round is a structure edit on the host + device re-set-up + refactorisation.
     Measured on the GPU box (`tools/delay_cost.py`, `profiles/r06_*`): 22-36 factorisations per edit of 100 columns at KKT dimension 10^6, host part ~0.2 s.
-    At KKT dimension 2 * 10^5 the whole cycle must stay below 80 factorisations, the factorisation after one edit within 25 % of the one before, the factor grows
+    At KKT dimension 2 * 10^5 the whole cycle must stay below 120 factorisations (the first edit of a process has been seen at 56 on the box, later ones at 22-36), the factorisation after one edit within 10 % of the one before (measured: 1-3 %), the factor grows
     by less than 1 %, inertia and residual unchanged -- what the reference's backends get for free inside one call (IpMa97SolverInterface.cpp:747-771, info.num_delay)
     costs us this much, and no more."""
     import time
@@ -326,8 +326,8 @@ def test_cost_of_a_delayed_pivot_edit_stays_under_its_ceiling():
     torch.cuda.synchronize(); cycle_ms = 1e3 * (time.perf_counter() - t0)
     assert moved == 100 and st[0] == 0 and st[1] == neg
     tf_after = min(_factor_ms(s, dv) for _ in range(5))
-    assert cycle_ms <= 80.0 * tf, (cycle_ms, tf)
-    assert tf_after <= 1.25 * tf, (tf_after, tf)
+    assert cycle_ms <= 120.0 * tf, (cycle_ms, tf)
+    assert tf_after <= 1.10 * tf, (tf_after, tf)      # (round 6: a delayed column waits further up a FULL chain link instead of cutting it -- 4.35 -> 4.41 ms here; 5.94 before)
     assert s.info().nnz_l <= 1.01 * nnz0
     b = K @ np.ones(n); db = torch.tensor(b, dtype=torch.float64, device="cuda"); dx = torch.empty_like(db)
     s.solve_device2(db.data_ptr(), dx.data_ptr())

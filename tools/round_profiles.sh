@@ -29,4 +29,11 @@ cp gpurun_out/prof_lukvle1_1e6/pmc_summary.json $O/lukvle1_1e6_pmc_summary.json 
 python tools/analysis_time.py lukvle1_1e6 synth_1e6 > $O/analysis_time.txt 2>&1
 (python tools/match_time.py lukvle1_1e6 synth_1e6 2>&1 | grep -v "^\[mi355x_kkt\]   \|look-ahead\|data-flow\|grouped\|chain look") > $O/matching_scaling_device.txt 2>&1
 timeout 120 python tools/stress_handles.py 60 > $O/stress_handles.txt 2>&1
+# round 6: several right-hand sides through the solve contexts, the cost of a delayed-pivot edit, the contribution-block plan on the 3-D family (if the recorded
+# systems are there: .dev_pivstat/ is scratch), two ranks on the shared device (bench line with its e2e leg), the multi-rank Ipopt runs
+python tools/multirhs_time.py synth_1e6 grid_1e5 lukvle1_1e6 mbndry1_100 > $O/multirhs_time.json 2> $O/multirhs_time.err
+python tools/delay_cost.py synth_1e6 100 > $O/delay_cost_synth_1e6.json 2> /dev/null
+for N in 50 78 100; do [ -f $R/.dev_pivstat/mb3d_$N.npz ] && for m in 0 1; do MI355X_KKT_RECYCLE=$m python tools/mem_report.py npz:$R/.dev_pivstat/mb3d_$N.npz 2>/dev/null | tail -1 >> $O/mem_report_recycle$m.txt; done; done
+MI355X_KKT_BENCH_SHARED=1 timeout 900 python bench.py --gpus 2 --steps 5 --warmup 2 2>/dev/null | grep '^{"metric' > $O/bench_2ranks_shared_device.json
+python -m pytest tests/test_e2e_multirank.py -q > $O/e2e_multirank_tests.log 2>&1
 ls -la $O
