@@ -64,3 +64,6 @@ MKL_NUM_THREADS=8 OMP_NUM_THREADS=8 run mbndry3d_50 MBndryCntrl_3D 50 norec
 # SURVEY 8(d)-5's 3-D instance itself: MBndryCntrl_3D N = 78 (n = 80^3 = 512 000, m = 78^3 = 474 552, KKT dimension 986 552; examples/ScalableProblems/solve_problem.cpp:56):
 # 16 iterations, 13 minutes on 8 MKL threads (PDSystemSolverTotal 727 s of the 775 s)
 MKL_NUM_THREADS=8 OMP_NUM_THREADS=8 run mbndry3d_78 MBndryCntrl_3D 78 norec
+# round 6: the same 3-D family at N = 100 (n = 102^3 = 1 061 208, m = 10^6, KKT dimension 2 060 000; fronts of up to 22 448 rows, 19.2 TFlop per factorisation with our
+# ordering): 16 iterations, 1 h 35 min on 6 MKL threads (PDSystemSolverTotal 5 281 s of 5 679 s) -- the instance the contribution-block recycling of round 6 makes room for
+MKL_NUM_THREADS=6 OMP_NUM_THREADS=6 run mbndry3d_100 MBndryCntrl_3D 100 norec

@@ -32,6 +32,7 @@ def run_driver(problem, n, solver="mi355x"):
                                             ("lukvli1_10000", "LukVlI1", 10000), ("lukvle5_10000", "LukVlE5", 10000), ("mbndry2_100", "MBndryCntrl2", 100),
                                             ("mdist1_100", "MDistCntrl1", 100), ("mbndry3d_12", "MBndryCntrl_3D", 12), ("mbndry3d_30", "MBndryCntrl_3D", 30), ("mbndry3d_50", "MBndryCntrl_3D", 50), ("mbndry1_300", "MBndryCntrl1", 300),
                                             ("mbndry1_700", "MBndryCntrl1", 700),       # BASELINE.json configs[4] stand-in (KKT dim 982 800)
+                                            ("mbndry3d_100", "MBndryCntrl_3D", 100),    # round 6: KKT dim 2 060 000, fronts up to 22 448 rows, 19.2 TFlop per factorisation; 109 GiB on the device with the contribution blocks recycled (182 without); the reference run behind the golden table took 1 h 35 min
                                             ("mbndry3d_78", "MBndryCntrl_3D", 78)])     # SURVEY 8(d)-5's 3-D instance (solve_problem.cpp:56): KKT dim 985 608, fronts up to 13 598 rows, 4.4 TFlop per factorisation, a 74 GiB factor + contribution-block pool
 def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_dir):
     gold = open(os.path.join(golden_dir, name + ".iters")).read().splitlines()
