@@ -481,6 +481,7 @@ public:
     // staging buffers handed out to the caller (values_buffer, assembly buffers), the device copy of the triplet values, the assembly
     // sources, the primal-dual workspace (it reads the triplet values and calls solve), the caller's scaling factors (original numbering)
     double* keep_tvals = nullptr;
+    double* kept_pool = nullptr; long long kept_pool_doubles = 0;      // the one-piece L | cb pool: survives a restructure (a delayed-pivot edit changes the layout by a fraction of a per cent: the 1 % of slack it is allocated with takes that), 40-80 ms of hipFree + hipMalloc at 9 GiB less per edit
     void release(bool keep = false) {
         DeviceGuard guard(dev);
         destroy_subcomms();                      // (the ranges follow the structure: split again after a restructure)
@@ -492,10 +493,12 @@ public:
         keep_tvals = nullptr;
         for (void* p : allocs) {
             if (keep && p == (void*)V.tvals) { keep_tvals = (double*)p; continue; }
+            if (keep && kept_pool && p == (void*)kept_pool) continue;      // (one-piece pool: handed to the next set-up, which reuses it if the new layout fits)
             if (keep && p == (void*)d_user_scale) continue;
             (void)hipFree(p);
         }
         allocs.clear();
+        if (!keep && kept_pool) { kept_pool = nullptr; kept_pool_doubles = 0; }      // (it was in allocs: freed above)
         if (keep && keep_tvals) allocs.push_back(keep_tvals);
         if (keep && d_user_scale) allocs.push_back(d_user_scale); else d_user_scale = nullptr;
         if (d_rhs) { (void)hipFree(d_rhs); d_rhs = nullptr; d_rhs_cap = 0; }
@@ -660,7 +663,7 @@ public:
             const double gib = 1.0 / (1024.0 * 1024.0 * 1024.0);
             const double need = 8.0 * ((double)Sy.l_doubles + (double)Sy.cb_doubles + (double)Sy.wbuf_doubles + (double)Sy.minv_doubles + (double)Sy.cvec_doubles + (double)Sy.gpart_doubles) +
                                 12.0 * (double)Sy.nnz_a + 16.0 * (double)Sy.nnz_in + 12.0 * (double)Sy.rslot_idx.size() + 200.0 * (double)Sy.n;
-            double cap = (double)fr;
+            double cap = (double)fr + (kept_pool ? 8.0 * (double)kept_pool_doubles : 0.0);      // (a restructure: the pool of the structure before the edit is still held, and will be reused or freed)
             if (const char* e = getenv("MI355X_KKT_POOL_LIMIT_GIB")) cap = std::min(cap, atof(e) / gib);
             if (need > cap) {
                 char msg[512];
@@ -696,10 +699,18 @@ public:
                 last_ok = b;
             }
             std::vector<char*> base(pool_cut.size(), nullptr);
+            if (kept_pool && (pool_cut.size() != 1 || total > kept_pool_doubles)) { (void)hipFree(kept_pool); kept_pool = nullptr; kept_pool_doubles = 0; }
             for (size_t i = 0; i < pool_cut.size(); ++i) {
                 const long long end = i + 1 < pool_cut.size() ? pool_cut[i + 1] : total;
                 double* pp = nullptr;
-                if (!dalloc(&pp, (size_t)std::max<long long>(end - pool_cut[i], 1))) return false;
+                if (pool_cut.size() == 1 && kept_pool) {      // the pool of the structure before the edit: reused, zeroed like a fresh one
+                    pp = kept_pool; allocs.push_back(pp);
+                    HIPCHK(hipMemsetAsync(pp, 0, (size_t)std::max<long long>(total, 1) * sizeof(double), stream));
+                } else if (pool_cut.size() == 1) {
+                    const long long cap = total + total / 100 + 1024;
+                    if (!dalloc(&pp, (size_t)cap)) return false;
+                    kept_pool = pp; kept_pool_doubles = cap;
+                } else if (!dalloc(&pp, (size_t)std::max<long long>(end - pool_cut[i], 1))) return false;
                 base[i] = (char*)pp;
                 pool_delta.push_back((long long)((base[i] - base[0]) / (ptrdiff_t)sizeof(double)) - pool_cut[i]);
             }

@@ -952,7 +952,7 @@ static bool finish_analysis(Symbolic& S, const SymbolicOptions& opt, const std::
         }
         int mode = -1;      // auto
         if (const char* e = getenv("MI355X_KKT_RECYCLE")) mode = atoi(e) != 0 ? 1 : 0;
-        if (opt.nranks > 1 || getenv("MI355X_KKT_POOL_PIECE_MIB")) mode = 0;      // (pieces are cut between blocks that do not overlap)
+        if (opt.nranks > 1 || getenv("MI355X_KKT_FORCE_MULTI") || getenv("MI355X_KKT_POOL_PIECE_MIB")) mode = 0;      // (the multi-rank schedule has no periodic join of its streams; pieces are cut between blocks that do not overlap)
         const int WINDOW = 8;
         vector<int64_t> roff(nsn, -1);
         int64_t rpeak = 0;
