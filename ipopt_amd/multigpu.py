@@ -438,7 +438,7 @@ def e2e_multirank(rank, world, local, shared, dist, problem="MBndryCntrl1", size
         env.setdefault("MI355X_KKT_JOB_ID", "bench-" + os.environ.get("MASTER_PORT", "0") + "-" + os.environ.get("TORCHELASTIC_RUN_ID", "0"))
         try:
             t0 = time.perf_counter()
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd="/tmp", env=env).stdout
+            out = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd="/tmp", env=env).stdout      # (a run takes seconds; a rank whose peers never arrive is killed here -- the bench line survives with an error entry)
             j = json.loads(next(ln for ln in out.splitlines() if ln.startswith("DRIVER_SUMMARY"))[len("DRIVER_SUMMARY "):])
             res = {k: j[k] for k in ("iterations", "objective", "status", "PDSystemSolverTotal", "LinearSystemFactorization", "LinearSystemBackSolve",
                                      "LinearSystemSymbolicFactorization", "wall_total") if k in j}
