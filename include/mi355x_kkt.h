@@ -330,6 +330,7 @@ int  mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn 
  *                          not arrive within MI355X_KKT_SHM_TIMEOUT_S (300) fails the call: never a hang.  The communicator in the adapter has the
  *                          reference's MPI_Init-inside-the-interface as its precedent (IpMumpsSolverInterface.cpp:58-75). */
 int  mi355x_kkt_comm_shm_id(void* out128, int nranks);
+void mi355x_kkt_comm_shm_discard(const void* id128);      /* rank 0: the id could not be handed to the other ranks after all -- unlink the segment nobody attached to */
 int  mi355x_kkt_set_comm_shm(mi355x_kkt_handle h, const void* id128);
 /* Range-local exchange.  A replicated front is held by a RANGE of ranks [rank_lo, rank_lo + nranks_in_range) and what it receives comes from
  * ranks of that range only, so its arena square (lower triangle, packed) and its top right-hand side are summed among those ranks alone:

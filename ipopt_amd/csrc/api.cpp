@@ -556,6 +556,7 @@ int mi355x_kkt_comm_shm_id(void* out128, int nranks)
     if (!out128) return MI355X_KKT_FATAL;
     try { std::string err; if (!shm_comm_create(nranks, out128, err)) { fprintf(stderr, "[mi355x_kkt] %s\n", err.c_str()); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
+void mi355x_kkt_comm_shm_discard(const void* id128) { try { shm_comm_discard(id128); } catch (...) {} }
 int mi355x_kkt_set_comm_shm(mi355x_kkt_handle h, const void* id128)
 {
     if (!h || !id128) return MI355X_KKT_FATAL;

@@ -159,6 +159,23 @@ ShmComm* shm_comm_attach(const void* id128, int rank, int nranks, std::string& e
     return c;
 }
 
+void shm_comm_discard(const void* id128)
+{
+    if (!id128) return;
+    char name[129];
+    std::memcpy(name, id128, 128); name[128] = 0;
+    if (std::strncmp(name, "/mi355x_kkt_", 12) != 0) return;
+    Mapping m;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_created.find(name);
+        if (it == g_created.end()) return;          // attached already (attach unlinks the name itself) or not ours
+        m = it->second; g_created.erase(it);
+    }
+    shm_unlink(name);
+    if (m.base) munmap(m.base, m.bytes);
+}
+
 void shm_comm_destroy(ShmComm* c)
 {
     if (!c) return;

@@ -17,6 +17,8 @@ bool shm_comm_create(int nranks, void* out128, std::string& err);
 // whatever happens later).  Returns nullptr + err on failure / time-out.
 ShmComm* shm_comm_attach(const void* id128, int rank, int nranks, std::string& err);
 void shm_comm_destroy(ShmComm* c);
+// rank 0, when the id could not be handed out after all (the rendez-vous file could not be written): unlink and unmap a segment nobody attached to
+void shm_comm_discard(const void* id128);
 // the two callbacks of include/mi355x_kkt.h (ctx = ShmComm*)
 int shm_comm_allreduce(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream);
 int shm_comm_allreduce_range(void* ctx, void* dptr, int64_t count, int dtype, void* hip_stream, int rank_lo, int nranks_in_range);

@@ -168,12 +168,14 @@ bool Mi355xCommBootstrap::Setup(mi355x_kkt_handle handle, const mi355x_kkt_optio
          {
             jnlst.Printf(J_ERROR, J_LINEAR_ALGEBRA, "mi355x: cannot write %s\n", tmp.c_str());
             if( fd >= 0 ) close(fd);
+            if( use_shm_ ) mi355x_kkt_comm_shm_discard(rec.id);
             return false;
          }
          close(fd);
          if( rename(tmp.c_str(), path.c_str()) != 0 )
          {
             (void) unlink(tmp.c_str());
+            if( use_shm_ ) mi355x_kkt_comm_shm_discard(rec.id);
             return false;
          }
       }

@@ -70,7 +70,7 @@ ABI_SYMBOLS = [
     "mi355x_kkt_get_info", "mi355x_kkt_last_error",
     "mi355x_kkt_get_symbolic", "mi355x_kkt_factor_local", "mi355x_kkt_top_arena", "mi355x_kkt_factor_top",
     "mi355x_kkt_solve_fwd_local", "mi355x_kkt_top_rhs", "mi355x_kkt_solve_top_and_bwd", "mi355x_kkt_profile",
-    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_comm_shm_id", "mi355x_kkt_set_comm_shm", "mi355x_kkt_set_comm_callbacks", "mi355x_kkt_set_comm_range_callback", "mi355x_kkt_exchange_bytes", "mi355x_kkt_comm_plan", "mi355x_kkt_comm_info",
+    "mi355x_kkt_comm_unique_id", "mi355x_kkt_set_comm_rccl", "mi355x_kkt_comm_shm_id", "mi355x_kkt_comm_shm_discard", "mi355x_kkt_set_comm_shm", "mi355x_kkt_set_comm_callbacks", "mi355x_kkt_set_comm_range_callback", "mi355x_kkt_exchange_bytes", "mi355x_kkt_comm_plan", "mi355x_kkt_comm_info",
     "mi355x_kkt_set_scaling", "mi355x_kkt_get_scaling", "mi355x_kkt_ruiz_scaling", "mi355x_kkt_matching_scaling", "mi355x_kkt_zero_pivots", "mi355x_kkt_failed_pivots", "mi355x_kkt_delay_columns", "mi355x_kkt_set_delay_rounds", "mi355x_kkt_assembly_define", "mi355x_kkt_assembly_buffer", "mi355x_kkt_assembly_upload", "mi355x_kkt_factor_assembled",
     "mi355x_kkt_pd_define", "mi355x_kkt_pd_put_data", "mi355x_kkt_pd_put", "mi355x_kkt_pd_get", "mi355x_kkt_pd_solve_once", "mi355x_kkt_pd_residual",
 ]

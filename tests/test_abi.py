@@ -138,3 +138,27 @@ def test_committed_bench_lines_keep_the_contract():
             for k in ("value", "unit", "cores", "kind", "sample"):
                 assert k in j["cpu_baseline"], (f, k)
             assert j["cpu_baseline"]["kind"] in ("reference", "port")
+
+
+def test_shared_memory_communicator_segment_is_created_and_discarded_without_a_device():
+    """mi355x_kkt_comm_shm_id (rank 0 of `mi355x_comm shm`) is host code: the POSIX segment appears under /dev/shm with a name of its own per call,
+    and mi355x_kkt_comm_shm_discard -- rank 0's way out when the id cannot be handed to the other ranks -- removes it again (nothing may be left behind:
+    /dev/shm is memory).  The collectives themselves need a device: tests/test_multigpu_gpu.py, tests/test_e2e_multirank.py."""
+    import ctypes as C
+    import os
+    lib = ipopt_amd.load_library()
+    lib.mi355x_kkt_comm_shm_discard.restype = None
+    ids = []
+    for _ in range(2):
+        buf = C.create_string_buffer(128)
+        assert lib.mi355x_kkt_comm_shm_id(buf, 2) == 0
+        name = buf.value.decode()
+        assert name.startswith("/mi355x_kkt_") and os.path.exists("/dev/shm" + name)
+        ids.append((buf, name))
+    assert ids[0][1] != ids[1][1]
+    for buf, name in ids:
+        lib.mi355x_kkt_comm_shm_discard(buf)
+        assert not os.path.exists("/dev/shm" + name)
+        lib.mi355x_kkt_comm_shm_discard(buf)          # idempotent
+    bad = C.create_string_buffer(128)
+    assert lib.mi355x_kkt_comm_shm_id(bad, 0) != 0 and lib.mi355x_kkt_comm_shm_id(bad, 65) != 0
