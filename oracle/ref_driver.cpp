@@ -32,10 +32,21 @@
 #include "IpSolveStatistics.hpp"
 #include "hs071_nlp.hpp"
 #include "LuksanVlcek1.hpp"
+#include "LuksanVlcek2.hpp"
+#include "LuksanVlcek3.hpp"
+#include "LuksanVlcek4.hpp"
 #include "LuksanVlcek5.hpp"
+#include "LuksanVlcek6.hpp"
+#include "LuksanVlcek7.hpp"
 #include "MittelmannBndryCntrlDiri.hpp"
 #include "MittelmannBndryCntrlDiri3D.hpp"
+#include "MittelmannBndryCntrlDiri3D_27.hpp"
+#include "MittelmannBndryCntrlDiri3Dsin.hpp"
+#include "MittelmannBndryCntrlNeum.hpp"
 #include "MittelmannDistCntrlDiri.hpp"
+#include "MittelmannDistCntrlNeumA.hpp"
+#include "MittelmannDistCntrlNeumB.hpp"
+#include "MittelmannParaCntrl.hpp"
 #ifdef WITH_MI355X
 #include "IpMi355xSolverInterface.hpp"
 #include "IpMi355xAugSystemSolver.hpp"
@@ -321,14 +332,29 @@ int main(int argc, char** argv)
    else
    {
       SmartPtr<RegisteredTNLP> r;
-      if( problem == "LukVlE1" ) r = new LuksanVlcek1(0, 0);
-      else if( problem == "LukVlI1" ) r = new LuksanVlcek1(-1., 0.);
-      else if( problem == "LukVlI1u" ) r = new LuksanVlcek1(-1., 1e20);      // the same with the upper constraint bound removed
-      else if( problem == "LukVlE5" ) r = new LuksanVlcek5(0, 0);
-      else if( problem == "MBndryCntrl1" ) r = new MittelmannBndryCntrlDiri1();
-      else if( problem == "MBndryCntrl2" ) r = new MittelmannBndryCntrlDiri2();
-      else if( problem == "MBndryCntrl_3D" ) r = new MittelmannBndryCntrlDiri3D();
-      else if( problem == "MDistCntrl1" ) r = new MittelmannDistCntrlDiri1();
+      // every problem class the reference's own driver registers (examples/ScalableProblems/solve_problem.cpp:28-91), under the same names
+#define PROB(name, ctor) else if( problem == #name ) r = new ctor
+      if( problem == "LukVlI1u" ) r = new LuksanVlcek1(-1., 1e20);      // (ours: LukVlI1 with the upper constraint bound removed)
+      PROB(LukVlE1, LuksanVlcek1(0, 0)); PROB(LukVlI1, LuksanVlcek1(-1., 0.));
+      PROB(LukVlE2, LuksanVlcek2(0, 0)); PROB(LukVlI2, LuksanVlcek2(-1., 0.));
+      PROB(LukVlE3, LuksanVlcek3(0, 0)); PROB(LukVlI3, LuksanVlcek3(-1., 0.));
+      PROB(LukVlE4, LuksanVlcek4(0, 0)); PROB(LukVlI4, LuksanVlcek4(-1., 0.));
+      PROB(LukVlE5, LuksanVlcek5(0, 0)); PROB(LukVlI5, LuksanVlcek5(-1., 0.));
+      PROB(LukVlE6, LuksanVlcek6(0, 0)); PROB(LukVlI6, LuksanVlcek6(-1., 0.));
+      PROB(LukVlE7, LuksanVlcek7(0, 0)); PROB(LukVlI7, LuksanVlcek7(-1., 0.));
+      PROB(MBndryCntrl1, MittelmannBndryCntrlDiri1()); PROB(MBndryCntrl2, MittelmannBndryCntrlDiri2());
+      PROB(MBndryCntrl3, MittelmannBndryCntrlDiri3()); PROB(MBndryCntrl4, MittelmannBndryCntrlDiri4());
+      PROB(MBndryCntrl_3D, MittelmannBndryCntrlDiri3D()); PROB(MBndryCntrl_3D_27, MittelmannBndryCntrlDiri3D_27());
+      PROB(MBndryCntrl_3D_27BT, MittelmannBndryCntrlDiri3D_27BT()); PROB(MBndryCntrl_3Dsin, MittelmannBndryCntrlDiri3Dsin());
+      PROB(MBndryCntrl5, MittelmannBndryCntrlNeum1()); PROB(MBndryCntrl6, MittelmannBndryCntrlNeum2());
+      PROB(MBndryCntrl7, MittelmannBndryCntrlNeum3()); PROB(MBndryCntrl8, MittelmannBndryCntrlNeum4());
+      PROB(MDistCntrl1, MittelmannDistCntrlDiri1()); PROB(MDistCntrl2, MittelmannDistCntrlDiri2());
+      PROB(MDistCntrl3, MittelmannDistCntrlDiri3()); PROB(MDistCntrl3a, MittelmannDistCntrlDiri3a());
+      PROB(MDistCntrl4, MittelmannDistCntrlNeumA1()); PROB(MDistCntrl5, MittelmannDistCntrlNeumA2()); PROB(MDistCntrl6a, MittelmannDistCntrlNeumA3());
+      PROB(MDistCntrl4a, MittelmannDistCntrlNeumB1()); PROB(MDistCntrl5a, MittelmannDistCntrlNeumB2()); PROB(MDistCntrl6, MittelmannDistCntrlNeumB3());
+      PROB(MPara5_1, MittelmannParaCntrlBase<MittelmannParaCntrl5_1>()); PROB(MPara5_2_1, MittelmannParaCntrlBase<MittelmannParaCntrl5_2_1>());
+      PROB(MPara5_2_2, MittelmannParaCntrlBase<MittelmannParaCntrl5_2_2>()); PROB(MPara5_2_3, MittelmannParaCntrlBase<MittelmannParaCntrl5_2_3>());
+#undef PROB
       else { fprintf(stderr, "unknown problem %s\n", problem.c_str()); return 2; }
       if( !r->InitializeProblem(N) ) { fprintf(stderr, "InitializeProblem(%d) failed\n", N); return 2; }
       tnlp = GetRawPtr(r);

@@ -67,3 +67,14 @@ MKL_NUM_THREADS=8 OMP_NUM_THREADS=8 run mbndry3d_78 MBndryCntrl_3D 78 norec
 # round 6: the same 3-D family at N = 100 (n = 102^3 = 1 061 208, m = 10^6, KKT dimension 2 060 000; fronts of up to 22 448 rows, 19.2 TFlop per factorisation with our
 # ordering): 16 iterations, 1 h 35 min on 6 MKL threads (PDSystemSolverTotal 5 281 s of 5 679 s) -- the instance the contribution-block recycling of round 6 makes room for
 MKL_NUM_THREADS=6 OMP_NUM_THREADS=6 run mbndry3d_100 MBndryCntrl_3D 100 norec
+# round 6: EVERY problem class the reference's own driver registers (examples/ScalableProblems/solve_problem.cpp:28-91) that its CPU run solves: iteration tables
+# only, 4 MKL threads, the whole sweep in four minutes.  (MPara5_1 and MPara5_2_1 at N = 40 end in "Maximum Number of Iterations Exceeded" and MPara5_2_2 in
+# "Error in step computation" with the reference's own MKL PARDISO path: no golden for those.  LukVl3 / LukVl4 want N + 2 divisible by 4.)
+export MKL_NUM_THREADS=4 OMP_NUM_THREADS=4
+for k in 2 6 7; do run lukvle${k}_10000 LukVlE$k 10000 norec; run lukvli${k}_10000 LukVlI$k 10000 norec; done
+for k in 3 4; do run lukvle${k}_9998 LukVlE$k 9998 norec; run lukvli${k}_9998 LukVlI$k 9998 norec; done
+run lukvli5_10000 LukVlI5 10000 norec
+for k in 3 4 5 6 7 8; do run mbndry${k}_100 MBndryCntrl$k 100 norec; done
+for k in 2 3 3a 4 5 6a 4a 5a 6; do run mdist${k}_100 MDistCntrl$k 100 norec; done
+run mbndry3d27_12 MBndryCntrl_3D_27 12 norec; run mbndry3d27bt_12 MBndryCntrl_3D_27BT 12 norec; run mbndry3dsin_12 MBndryCntrl_3Dsin 12 norec
+run mpara5_2_3_40 MPara5_2_3 40 norec

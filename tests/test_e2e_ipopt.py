@@ -54,6 +54,66 @@ def test_iteration_sequence_matches_reference_cpu_run(name, problem, n, golden_d
             assert abs(x - y) <= 1e-2 * max(x, y) + 1e-11, f"{a}   |   {b}"
 
 
+# Every problem class the reference's driver registers (examples/ScalableProblems/solve_problem.cpp:28-91) that its own CPU run solves: inequality variants (slacks),
+# Neumann boundary control, distributed control, the 27-point 3-D stencils, the parabolic control problem; goldens: tests/golden/make_golden.sh, round 6.
+SWEEP = ([(f"lukvl{v}{k}_10000", f"LukVl{v.upper()}{k}", 10000) for k in (2, 6, 7) for v in "ei"] + [(f"lukvl{v}{k}_9998", f"LukVl{v.upper()}{k}", 9998) for k in (3, 4) for v in "ei"]
+         + [("lukvli5_10000", "LukVlI5", 10000)] + [(f"mbndry{k}_100", f"MBndryCntrl{k}", 100) for k in (3, 4, 5, 6, 7, 8)]
+         + [(f"mdist{k}_100", f"MDistCntrl{k}", 100) for k in ("2", "3", "3a", "4", "5", "6a", "4a", "5a", "6")]
+         + [("mbndry3d27_12", "MBndryCntrl_3D_27", 12), ("mbndry3d27bt_12", "MBndryCntrl_3D_27BT", 12), ("mbndry3dsin_12", "MBndryCntrl_3Dsin", 12), ("mpara5_2_3_40", "MPara5_2_3", 40)])
+
+
+# Five of those classes do NOT print the reference's (MKL PARDISO) table with this backend -- nor would the reference with another of its own linear solvers:
+#   LukVlE4 / LukVlI4   the KKT matrix of iteration 1 is numerically singular: oracle/ldlt_oracle.c finds a zero pivot in it (u = 0.01), this backend answers
+#                       SYMSOLVER_SINGULAR and Ipopt regularises (lg(rg) = -4.0 in the table's second line); MKL PARDISO perturbs the pivot silently and reports
+#                       success (static pivoting, IpPardisoMKLSolverInterface.cpp:555 also hides a wrong inertia) -- the trajectories part there
+#   MDistCntrl5 / 5a, MBndryCntrl_3Dsin   line by line the reference's table until the late-barrier (lg(mu) = -8.6) resp. heavily regularised (lg(rg) = 4.4) systems:
+#                       from iteration 11-15 on the objective differs in the 7th digit (two direct solvers agree to ~1e-7 on such a system: bench.py's own
+#                       parity_vs_gpu line), then a line-search decision, then the count (49-50 / 39-40 / 48-61 against 48 / 39 / 48)
+# (tools/table_diff.py prints where a table is left).  They must still arrive where the reference arrives: same exit, objective to 1e-6.
+SOLVER_SENSITIVE = {"lukvle4_9998", "lukvli4_9998", "mdist5_100", "mdist5a_100", "mbndry3dsin_12"}
+
+
+def _driver_run(problem, n, solver):
+    env = dict(os.environ, MKL_NUM_THREADS="1", OMP_NUM_THREADS="1")
+    out = subprocess.run([DRIVER, problem, str(n), "--solver", solver], capture_output=True, text=True, timeout=900, cwd="/tmp", env=env).stdout
+    iters = []
+    for ln in out.splitlines():
+        f = ln.split()
+        if len(f) >= 10 and f[0].rstrip("r").isdigit() and ln.startswith(" "):
+            iters.append(" ".join([f[0], f[1], f[2], f[3], f[4], f[6], f[9]]))
+    summ = json.loads(next(ln for ln in out.splitlines() if ln.startswith("DRIVER_SUMMARY"))[len("DRIVER_SUMMARY "):])
+    return iters, summ, out
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("solver", ["mi355x", "mi355x-pd"], ids=["B1", "device-route"])
+@pytest.mark.parametrize("name,problem,n", [t for t in SWEEP if t[0] not in SOLVER_SENSITIVE], ids=[t[0] for t in SWEEP if t[0] not in SOLVER_SENSITIVE])
+def test_every_scalable_problem_class_reproduces_the_reference_iteration_table(name, problem, n, solver, golden_dir):
+    gold = open(os.path.join(golden_dir, name + ".iters")).read().splitlines()
+    gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
+    iters, summ, out = _driver_run(problem, n, solver)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    assert summ["iterations"] == gsum["iterations"], (summ["iterations"], gsum["iterations"])
+    assert abs(summ["objective"] - gsum["objective"]) <= 1e-8 * max(1.0, abs(gsum["objective"]))
+    _same_iterations(iters, gold)
+
+
+@pytest.mark.skipif(not os.path.exists(DRIVER), reason="oracle/_ref not built")
+@pytest.mark.parametrize("solver", ["mi355x", "mi355x-pd"], ids=["B1", "device-route"])
+@pytest.mark.parametrize("name,problem,n", [t for t in SWEEP if t[0] in SOLVER_SENSITIVE], ids=[t[0] for t in SWEEP if t[0] in SOLVER_SENSITIVE])
+def test_solver_sensitive_problem_classes_reach_the_reference_optimum(name, problem, n, solver, golden_dir):
+    gold = open(os.path.join(golden_dir, name + ".iters")).read().splitlines()
+    gsum = json.load(open(os.path.join(golden_dir, name + ".summary")))
+    iters, summ, out = _driver_run(problem, n, solver)
+    assert "EXIT: Optimal Solution Found." in out, out[-1500:]
+    assert summ["status"] == gsum["status"] == 0
+    assert abs(summ["objective"] - gsum["objective"]) <= 1e-6 * max(1.0, abs(gsum["objective"])), (summ["objective"], gsum["objective"])
+    if name.startswith("lukvl"):
+        assert iters[0] == gold[0] and iters[1].split()[5] == "-4.0" and gold[1].split()[5] == "-"      # the singular system of iteration 1: reported here, hidden there
+    else:
+        _same_iterations(iters[:10], gold[:10])      # the reference's table, line by line, for the first ten iterations
+
+
 HS071 = os.path.join(ROOT, "oracle", "_ref", "hs071_cpp")
 
 
