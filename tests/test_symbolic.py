@@ -446,3 +446,35 @@ def test_recycled_contribution_blocks_never_share_space_while_both_are_alive(sou
     # plain layout: nothing intersects
     lo0 = off0[own]; o0 = np.argsort(lo0, kind="stable")
     assert np.all(lo0[o0][1:] >= (lo0 + mu[own].astype(np.int64) ** 2)[o0][:-1])
+
+
+def test_a_delayed_column_waits_up_a_full_chain_link_instead_of_cutting_it():
+    """restructure_delays, round 6: a column delayed into a FULL (max_sn_cols = 64) link of a separator chain used to cut that link into 64 + 1 -- a one-column
+    link with launches of its own, and one more tree level for every ancestor, out of step with its siblings (one edit of 100 columns: 53 -> 57 levels and a
+    36 % slower factorisation at KKT dimension 2 * 10^5).  Now it waits further up the chain until a link has room: same number of supernodes, same number of
+    levels, no supernode above 64 columns, a valid permutation, and the column sits in a supernode ABOVE the one it left."""
+    n, r, c, v, neg = kktgen.grid_kkt(120, 100, dof=3, ncon=2, seed=77, sigma_exp=6.0)
+    s = ipopt_amd.KKTSolver(device=-1, delay_rounds=0)
+    s.initialize_structure(n, r, c, vals=v)
+    I0 = s.info(); N0 = I0.num_sn
+    colptr, rowptr, parent, perm = s.symbolic(1, N0 + 1), s.symbolic(2, N0 + 1), s.symbolic(4, N0), s.symbolic(0, n)
+    k = np.diff(colptr); m = np.diff(rowptr)
+    # links whose parent is the next supernode, FULL (64 columns) and a front of 256 rows and more: a column delayed out of such a link used to cut its parent
+    cand = [sn for sn in range(N0 - 1) if k[sn + 1] == 64 and m[sn + 1] >= 256 and parent[sn] == sn + 1]
+    assert len(cand) >= 8
+    rng = np.random.default_rng(3)
+    picks = rng.choice(cand, size=8, replace=False)
+    cols = np.array([perm[colptr[sn] + int(rng.integers(0, k[sn]))] for sn in picks]) + 1          # caller's numbering, 1-based
+    moved = s.delay_columns(cols)
+    I1 = s.info(); N1 = I1.num_sn
+    assert moved == 8 and N1 == N0 and I1.num_levels == I0.num_levels
+    colptr1, perm1 = s.symbolic(1, N1 + 1), s.symbolic(0, n)
+    assert np.diff(colptr1).max() <= 64 and sorted(perm1.tolist()) == list(range(n))
+    iperm1 = np.empty(n, dtype=np.int64); iperm1[perm1] = np.arange(n)
+    for sn, col in zip(picks, cols - 1):
+        sn_new = int(np.searchsorted(colptr1, iperm1[col], side="right") - 1)
+        assert sn_new > sn + 1                       # (the parent link was full: the column went further up)
+    # an edit that moves MANY columns (more than n / 64) keeps the old rule: fronts may be cut
+    many = rng.choice(n, size=n // 32, replace=False) + 1
+    s.delay_columns(many)
+    assert np.diff(s.symbolic(1, s.info().num_sn + 1)).max() <= 64
