@@ -157,10 +157,15 @@ def test_a_pool_that_does_not_fit_the_device_is_refused_with_the_numbers(monkeyp
     assert st == 0
 
 
-def test_eight_right_hand_sides_in_one_call_equal_eight_single_solves_bitwise():
-    """nrhs > 1 (what IpLowRankAugSystemSolver.cpp:435-487 and sIPOPT ask of MultiSolve): all columns go up in one batch, their sweeps run back to back with no
+@pytest.mark.parametrize("mode", ["measured-choice", "contexts", "one-after-the-other"])
+def test_eight_right_hand_sides_in_one_call_equal_eight_single_solves_bitwise(mode, monkeypatch):
+    """(round 6: up to three of the columns are in flight at once, each in a solve context of its own -- stream, work vectors, tags, flags, epoch --, the persistent chain
+    sweeps of the contexts taking turns; whether that is used is measured once per structure: all three ways must give the bits of single solves)
+    nrhs > 1 (what IpLowRankAugSystemSolver.cpp:435-487 and sIPOPT ask of MultiSolve): all columns go up in one batch, their sweeps run back to back with no
     host synchronisation in between, all solutions come down behind the last one -- and every column is bitwise the solution of a single solve, with a
     leading dimension larger than n as well (the C ABI's `ld`)."""
+    if mode == "contexts": monkeypatch.setenv("MI355X_KKT_TUNE", "solve_ctx_force=1")
+    if mode == "one-after-the-other": monkeypatch.setenv("MI355X_KKT_DISABLE", "solve_ctx")
     n, r, c, v, neg = kktgen.grid_kkt(48, 40, dof=3, ncon=2, seed=23)
     K = kktgen.to_scipy(n, r, c, v)
     rng = np.random.default_rng(5)
