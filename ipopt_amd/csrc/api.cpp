@@ -38,6 +38,7 @@ struct mi355x_kkt_handle_s {
     std::thread reaper;            // destroys the structure a delayed-pivot edit replaced (80-90 ms of unmapping at n = 10^6) off the caller's path
     ShmComm* shm = nullptr;        // the shared-memory communicator of set_comm_shm (owned; the Numeric object only holds the callbacks' context)
     std::string err;
+    std::string setup_err;         // why the device set-up of the last analyse() failed (no device; the pool does not fit ...): every later "not ready" answer repeats it
     std::vector<double> host_vals_nodev;   // plain host staging buffer handed out when no device exists (values only, never computed on)
 };
 
@@ -121,7 +122,8 @@ int mi355x_kkt_analyse(mi355x_kkt_handle h, int n, int nnz, const int* row, cons
         no.prewarmed_vals = pre; no.prewarmed_count = (size_t)(nnz > 0 ? nnz : 1);
         pg.taken = true;                       // (setup owns the buffer from here on, whether it succeeds or not)
         h->numeric_ready = h->num->setup(h->sym, no);
-        if (!h->numeric_ready) h->err = h->num->error();
+        h->setup_err = h->numeric_ready ? std::string() : h->num->error();
+        if (!h->numeric_ready) h->err = h->setup_err;
         if (h->opts.verbose >= 2) fprintf(stderr, "[mi355x_kkt]   device set-up done %.3f s after the call\n", wall_() - t_in);
         return MI355X_KKT_SUCCESS;
     } catch (const std::bad_alloc&) { h->err = "analyse: out of host memory"; return MI355X_KKT_FATAL; }
@@ -225,7 +227,7 @@ int mi355x_kkt_refactor(mi355x_kkt_handle h, int* num_neg, int* num_zero) { retu
 int mi355x_kkt_set_scaling(mi355x_kkt_handle h, int mode, const double* user_factors)
 {
     if (!h) return MI355X_KKT_FATAL;
-    if (!h->numeric_ready) { h->opts.scaling = mode == 2 ? 1 : mode; h->err = "set_scaling: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { h->opts.scaling = mode == 2 ? 1 : mode; h->err = std::string("set_scaling: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try { if (!h->num->set_scaling(mode, user_factors)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } h->opts.scaling = mode; h->stats_stale = true; return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
 int mi355x_kkt_get_scaling(mi355x_kkt_handle h, double* out)
@@ -329,7 +331,7 @@ int mi355x_kkt_delay_columns(mi355x_kkt_handle h, const int* cols, int count, in
 int mi355x_kkt_assembly_define(mi355x_kkt_handle h, int nseg, const int64_t* offset, const int64_t* length)
 {
     if (!h || !offset || !length) return MI355X_KKT_FATAL;
-    if (!h->numeric_ready) { h->err = "assembly_define: analyse() first (and a usable HIP device; no CPU fallback)"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { h->err = std::string("assembly_define: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try { if (!h->num->assembly_define(nseg, offset, length)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
 double* mi355x_kkt_assembly_buffer(mi355x_kkt_handle h, int seg)
@@ -345,7 +347,7 @@ int mi355x_kkt_assembly_upload(mi355x_kkt_handle h, int seg)
 int mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const double* shift, int* num_neg, int* num_zero)
 {
     if (!h || !scale || !shift) return MI355X_KKT_FATAL;
-    if (!h->analysed || !h->numeric_ready) { h->err = "factor_assembled: analyse() + a usable HIP device needed (no CPU fallback)"; return MI355X_KKT_FATAL; }
+    if (!h->analysed || !h->numeric_ready) { h->err = std::string("factor_assembled: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try {
         FactorStats st;
         if (!h->num->factor_assembled(scale, shift, st)) { h->err = h->num->error(); return MI355X_KKT_FATAL; }
@@ -359,7 +361,7 @@ int mi355x_kkt_factor_assembled(mi355x_kkt_handle h, const double* scale, const 
 
 #define PD_CALL(name, cond, call) \
     if (!h || !(cond)) return MI355X_KKT_FATAL; \
-    if (!h->analysed || !h->numeric_ready) { h->err = name ": analyse() + a usable HIP device needed (no CPU fallback)"; return MI355X_KKT_FATAL; } \
+    if (!h->analysed || !h->numeric_ready) { h->err = std::string(name ": no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; } \
     try { if (!h->num->call) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } \
     catch (...) { h->err = name ": unexpected exception"; return MI355X_KKT_FATAL; }
 int mi355x_kkt_pd_define(mi355x_kkt_handle h, const int32_t* dims8, const int32_t* ixl, const int32_t* ixu, const int32_t* isl, const int32_t* isu,
@@ -541,13 +543,13 @@ int mi355x_kkt_comm_unique_id(void* out128)
 int mi355x_kkt_set_comm_rccl(mi355x_kkt_handle h, const void* unique_id128)
 {
     if (!h || !unique_id128) return MI355X_KKT_FATAL;
-    if (!h->numeric_ready) { h->err = "set_comm_rccl: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { h->err = std::string("set_comm_rccl: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try { if (!h->num->set_comm_rccl(unique_id128)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
 int mi355x_kkt_set_comm_callbacks(mi355x_kkt_handle h, mi355x_kkt_allreduce_fn fn, void* ctx)
 {
     if (!h) return MI355X_KKT_FATAL;
-    if (!h->numeric_ready) { h->err = "set_comm_callbacks: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { h->err = std::string("set_comm_callbacks: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try { if (!h->num->set_comm_callback(fn, ctx)) { h->err = h->num->error(); return MI355X_KKT_FATAL; } return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
 /* the host-staged communicator over POSIX shared memory (comm_shm.cpp): ranks of ONE node, which may share a device */
@@ -560,7 +562,7 @@ void mi355x_kkt_comm_shm_discard(const void* id128) { try { shm_comm_discard(id1
 int mi355x_kkt_set_comm_shm(mi355x_kkt_handle h, const void* id128)
 {
     if (!h || !id128) return MI355X_KKT_FATAL;
-    if (!h->numeric_ready) { h->err = "set_comm_shm: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { h->err = std::string("set_comm_shm: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try {
         ShmComm* c = shm_comm_attach(id128, h->opts.rank, h->opts.nranks > 0 ? h->opts.nranks : 1, h->err);
         if (!c) return MI355X_KKT_FATAL;
@@ -572,7 +574,7 @@ int mi355x_kkt_set_comm_shm(mi355x_kkt_handle h, const void* id128)
 int mi355x_kkt_set_comm_range_callback(mi355x_kkt_handle h, mi355x_kkt_allreduce_range_fn fn)
 {
     if (!h) return MI355X_KKT_FATAL;
-    if (!h->numeric_ready) { h->err = "set_comm_range_callback: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { h->err = std::string("set_comm_range_callback: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try { return h->num->set_comm_range_callback(fn) ? MI355X_KKT_SUCCESS : MI355X_KKT_FATAL; } catch (...) { return MI355X_KKT_FATAL; }
 }
 /* host only: the collectives one rank issues (see include/mi355x_kkt.h) -- needs the analysis, not a device */
@@ -593,7 +595,7 @@ int mi355x_kkt_comm_plan(mi355x_kkt_handle h, int rank, int range_local, int* re
 int mi355x_kkt_comm_info(mi355x_kkt_handle h, int* kind, int* ranks_seen, int* range_local, int* exchange_steps)
 {
     if (!h) return MI355X_KKT_FATAL;
-    if (!h->numeric_ready) { h->err = "comm_info: analyse() first (and a usable HIP device)"; return MI355X_KKT_FATAL; }
+    if (!h->numeric_ready) { h->err = std::string("comm_info: no device set-up") + (h->setup_err.empty() ? " (analyse() first, and a usable HIP device; no CPU fallback)" : ": " + h->setup_err); return MI355X_KKT_FATAL; }
     try { h->num->comm_info(kind, ranks_seen, range_local, exchange_steps); return MI355X_KKT_SUCCESS; } catch (...) { return MI355X_KKT_FATAL; }
 }
 int mi355x_kkt_exchange_bytes(mi355x_kkt_handle h, int64_t* arena_bytes, int64_t* rhs_bytes)
