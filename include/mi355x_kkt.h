@@ -335,7 +335,7 @@ int  mi355x_kkt_set_comm_shm(mi355x_kkt_handle h, const void* id128);
 /* Range-local exchange.  A replicated front is held by a RANGE of ranks [rank_lo, rank_lo + nranks_in_range) and what it receives comes from
  * ranks of that range only, so its arena square (lower triangle, packed) and its top right-hand side are summed among those ranks alone:
  * with RCCL through one sub-communicator per exchange step (ncclCommSplit, created by _set_comm_rccl; without it -- or with
- * MI355X_KKT_NO_SUBCOMM -- every step is ONE all-reduce over the whole communicator, ranks outside a range contributing zeros), with a
+ * MI355X_KKT_DISABLE=subcomm -- every step is ONE all-reduce over the whole communicator, ranks outside a range contributing zeros), with a
  * callback communicator through this optional second callback (same contract as mi355x_kkt_allreduce_fn, plus the range; ctx is the one
  * given to _set_comm_callbacks; only ranks of the range call it).
  *   _exchange_bytes   bytes of all arena squares / all top right-hand sides of the current structure (what the exchange steps move) */
