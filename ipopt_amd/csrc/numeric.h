@@ -49,7 +49,7 @@ public:
     static constexpr int kNumKernelKinds = 18;
     bool   profile(int reps, double* ms, int* launches);
     bool   debug_pivots(double* dinv, double* doff, int* ptype, int* lperm);      // development aid: pivot data of the last factorisation, n entries each
-    bool   debug_clocks(unsigned long long* out128);        // development aid (MI355X_KKT_DEBUG_CLOCKS=1)   // per-kernel-kind device time (hip events), eager launches
+    bool   debug_clocks(unsigned long long* out128);        // development aid (MI355X_KKT_TRACE=clocks)   // per-kernel-kind device time (hip events), eager launches
     // multi-GPU pieces
     bool   factor_local(const double* dvals_or_null);
     bool   top_arena(double** dptr, int64_t* ndoubles);

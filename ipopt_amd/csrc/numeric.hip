@@ -2376,7 +2376,7 @@ public:
     }
     bool debug_clocks(unsigned long long* out) {
         DeviceGuard guard(dev);
-        if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_DEBUG_CLOCKS=1)"; return false; }
+        if (!V.dbg) { err_ = "debug clocks not enabled (MI355X_KKT_TRACE=clocks)"; return false; }
         HIPCHK(hipMemcpy(out, V.dbg, 128 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
 #ifdef MI355X_PIVSTAT
         unsigned long long ps[16]; HIPCHK(hipMemcpyFromSymbol(ps, HIP_SYMBOL(g_pivstat), sizeof ps));

@@ -1,4 +1,4 @@
-"""Reads the MI355X_KKT_SOLVE_TRACE file (4 wall-clock stamps per workgroup of the data-flow solve sweeps, 10 ns units) and prints, per chain:
+"""Reads the file of MI355X_KKT_TRACE=solve=<file> (4 wall-clock stamps per workgroup of the data-flow solve sweeps, 10 ns units) and prints, per chain:
 when its first link started waiting, when its rows had their start value, when the first / last link published, when the rows beyond were done."""
 import collections, sys
 rows = [l.split() for l in open(sys.argv[1])]
